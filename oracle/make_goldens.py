@@ -1,0 +1,286 @@
+"""TEST INFRASTRUCTURE -- fixture generator.  Runs ONLY in the build container: it imports the
+reference itself from /root/reference (through oracle/ref_harness.py stubs), runs it on seeded
+synthetic inputs with the deterministic weight generator of oracle/synth.py and writes small
+input/expected-output vectors to tests/golden/*.npz.  The reference's source never travels; the
+fixtures are data.
+
+    python oracle/make_goldens.py            # regenerates every fixture
+
+Fixtures (what pins what) are listed in tests/golden/README.md.
+"""
+import os
+import pickle
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import ref_harness as rh          # noqa: E402
+from oracle import synth                       # noqa: E402
+
+warnings.filterwarnings("ignore")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    p = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(p, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print("  %-34s %8.1f KB" % (name + ".npz", os.path.getsize(p) / 1024))
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+# ---------------------------------------------------------------------------------------------
+def clouds_for_knn(N, seed):
+    """3 clouds: hand-sized box with outliers, wrap-padded from 300 unique points, all-zero."""
+    g = rng(seed)
+    c = np.concatenate([g.uniform(-0.1, 0.1, (3, N, 2)), g.uniform(0.4, 0.5, (3, N, 1))], -1).astype(np.float32)
+    far = g.uniform(0, 1, (N,)) < 0.1
+    c[0, far, :2] = g.uniform(-0.5, 0.5, (int(far.sum()), 2)).astype(np.float32)
+    c[1] = c[1, np.resize(np.arange(300), N)]
+    c[2] = 0
+    return c
+
+
+def op_knn_group():
+    U = rh.ref_module("lib.utils.utils")
+    opt = rh.ref_opt(256)
+    pts = torch.from_numpy(clouds_for_knn(1024, 11))
+    x, ctr = U.group_points(pts.clone(), opt)                        # utils.py:134-163
+    # recover the index table exactly as the reference computes it (utils.py:140-151)
+    d = ((pts[:, :, :3].transpose(1, 2).unsqueeze(1) - pts[:, :512, :3].unsqueeze(-1)) ** 2).sum(2)
+    dist, idx = torch.topk(d, 64, 2, largest=False, sorted=False)
+    for jj in range(512):
+        idx[:, jj, :][dist[:, jj, :] > opt.ball_radius] = jj
+    save("op_group_points_l1", points=pts, idx_sorted=np.sort(idx.numpy(), -1).astype(np.int16),
+         grouped_sum=x.sum(-1), grouped_absmax=x.abs().amax(-1), centers=ctr, r2=np.float32(opt.ball_radius))
+    # level 2: [B,131,512] features, xyz in channels 0:3
+    g = rng(12)
+    feat = g.standard_normal((3, 131, 512)).astype(np.float32)
+    feat[:, :3] = clouds_for_knn(512, 13).transpose(0, 2, 1) * 3.0     # sft-modulated coordinates are O(0.3-1.5)
+    feat = torch.from_numpy(feat)
+    x2, ctr2 = U.group_points_2(feat.clone(), 512, 128, 64, opt.ball_radius2)   # utils.py:165-188
+    d = ((feat[:, 0:3, :].unsqueeze(1) - feat[:, 0:3, 0:128].transpose(1, 2).unsqueeze(-1)) ** 2).sum(2)
+    dist, idx = torch.topk(d, 64, 2, largest=False, sorted=False)
+    for jj in range(128):
+        idx[:, jj, :][dist[:, jj, :] > opt.ball_radius2] = jj
+    save("op_group_points_l2", feat=feat, idx_sorted=np.sort(idx.numpy(), -1).astype(np.int16),
+         grouped_sum=x2.sum(-1), grouped_absmax=x2.abs().amax(-1), centers=ctr2, r2=np.float32(opt.ball_radius2))
+
+
+def op_gather_sft_l2norm():
+    MU = rh.ref_module("lib.models.utils")
+    E = rh.ref_module("lib.models.networks.intaghand_encoder")
+    g = rng(21)
+    feat = torch.from_numpy(g.standard_normal((2, 5, 16, 16)).astype(np.float32))
+    ind = torch.from_numpy(g.integers(0, 256, (2, 7)))
+    save("op_gather_feat", feat=feat, ind=ind, out=MU._tranpose_and_gather_feat(feat, ind))
+    torch.manual_seed(0)
+    sft = E.SFTLayer(13, 6)
+    fea = torch.from_numpy(g.standard_normal((2, 13, 9)).astype(np.float32))
+    cond = torch.from_numpy(g.standard_normal((2, 9, 6)).astype(np.float32))
+    out = sft((fea, cond))
+    save("op_sft", fea=fea, cond=cond, out=out, **{"w_" + k: v for k, v in sft.state_dict().items()})
+    l2 = E.L2Norm(5, 10)
+    with torch.no_grad():
+        l2.weight.copy_(torch.from_numpy(g.uniform(5, 15, 5).astype(np.float32)))
+    save("op_l2norm", x=feat, weight=l2.weight, out=l2(feat))
+    hm = torch.from_numpy(g.standard_normal((3, 2, 16, 16)).astype(np.float32))
+    nms = E._nms(hm, 5)
+    i0 = E._topk(nms[:, :1], 1)[1]
+    i1 = E._topk(nms[:, 1:], 1)[1]
+    save("op_nms_topk", hm=hm, ind=torch.cat((i0, i1), 1))
+
+
+def op_decoder_blocks():
+    G = rh.ref_module("lib.models.networks.model_attn.gcn")
+    SA = rh.ref_module("lib.models.networks.model_attn.self_attn")
+    IA = rh.ref_module("lib.models.networks.model_attn.inter_attn")
+    z = np.load(os.path.join(OUT, "..", "..", "pdfnet_amd", "data", "gcn_core.npz"))
+    g = rng(31)
+    for V, Fd in ((63, 16), (126, 8), (252, 8)):
+        ip, ix, dt = z["L_left_%d_indptr" % V], z["L_left_%d_indices" % V], z["L_left_%d_data" % V]
+        D = np.zeros((V, V), np.float32)
+        D[np.repeat(np.arange(V), np.diff(ip)), ix] = dt
+        torch.manual_seed(V)
+        blk = G.GCN_ResBlock(Fd, Fd // 2, Fd // 2, D, 2, drop_out=0.0)         # gcn.py:72-110
+        for p in blk.parameters():
+            torch.nn.init.normal_(p, std=0.3)
+        x = torch.from_numpy(g.standard_normal((2, V, Fd)).astype(np.float32))
+        cheb = G.graph_conv_cheby(x, blk.fc1, blk.graph_L, K=2)                # gcn.py:34-69
+        save("op_gcn_block_V%d" % V, x=x, cheby_fc1=cheb, out=blk(x),
+             **{"w_" + k: v for k, v in blk.state_dict().items()})
+    torch.manual_seed(5)
+    sa = SA.SelfAttn(16, n_heads=4, hid_dim=16, dropout=0.0)                   # self_attn.py:36-85
+    ia = IA.inter_attn(16, n_heads=4, dropout=0.0)                             # inter_attn.py:38-125
+    for m in (sa, ia):
+        for p in m.parameters():
+            torch.nn.init.normal_(p, std=0.3)
+    x = torch.from_numpy(g.standard_normal((2, 63, 16)).astype(np.float32))
+    y = torch.from_numpy(g.standard_normal((2, 63, 16)).astype(np.float32))
+    save("op_self_attn", x=x, out=sa(x), **{"w_" + k: v for k, v in sa.state_dict().items()})
+    oL, oR = ia(x, y)
+    save("op_inter_attn", x=x, y=y, outL=oL, outR=oR, **{"w_" + k: v for k, v in ia.state_dict().items()})
+
+
+def op_mano():
+    """Reference ManoLayer (manolayer.py:257-334) driven by SYNTHETIC MANO-shaped constants written
+    to a temporary pickle (the MPI-licensed MANO_*.pkl are not redistributed)."""
+    ML = rh.ref_module("lib.models.networks.manolayer")
+    MM = rh.ref_module("lib.models.hand3d.Mano_model")
+    import scipy.sparse as sp
+    g = rng(41)
+    out = {}
+    for side in ("left", "right"):
+        c = synth.synthetic_mano_consts(side)
+        data = {
+            'hands_components': np.eye(45, dtype=np.float64), 'hands_mean': np.zeros(45),
+            'J_regressor': sp.csc_matrix(c['J_regressor'].numpy().astype(np.float64)),
+            'J': np.zeros((16, 3)), 'weights': c['weights'].numpy(), 'posedirs': c['posedirs'].numpy(),
+            'v_template': c['v_template'].numpy(), 'shapedirs': c['shapedirs'].numpy(),
+            'f': np.zeros((1538, 3), np.uint32),
+            'kintree_table': np.array([[4294967295, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14], list(range(16))]),
+        }
+        with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as f:
+            pickle.dump(data, f)
+        layer = ML.ManoLayer(f.name, center_idx=None, use_pca=False)
+        os.unlink(f.name)
+        rot = torch.from_numpy(g.standard_normal((4, 3)).astype(np.float32))
+        pose = torch.from_numpy((g.standard_normal((4, 45)) * 0.5).astype(np.float32))
+        shape = torch.from_numpy(g.standard_normal((4, 10)).astype(np.float32))
+        trans = torch.from_numpy(g.standard_normal((4, 3)).astype(np.float32) * 0.1)
+        v, j = layer(rot, pose, shape, trans=trans, side=side)
+        out.update({side + "_rot": rot, side + "_pose": pose, side + "_shape": shape, side + "_trans": trans,
+                    side + "_verts": v, side + "_joints": j})
+        # full_regressor (Mano_model.py:309-323) through the reference's own function
+        reg = MM.ManoModel.process_J_regressor(None, c['J_regressor'])
+        out[side + "_full_regressor_joints"] = torch.einsum('jv,bvc->bjc', reg, v)
+    save("op_mano_layer", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def surrogate_loss(res):
+    """Scalar touching every model output (defined identically in tests/util.py)."""
+    result, params, hand_list, other = res
+    t = 0
+    for h in ("left", "right"):
+        t = t + result['verts3d'][h].pow(2).mean() + (result['verts2d'][h] / 384).pow(2).mean()
+        t = t + params['scale'][h].pow(2).mean() + params['trans2d'][h].pow(2).mean() + params['root'][h].pow(2).mean()
+        t = t + hand_list[0]['verts3d'][h].pow(2).mean()
+    t = t + other['hms'].pow(2).mean() + other['mask'].pow(2).mean()
+    for k in ('hm', 'wh', 'params'):
+        t = t + other['ret'][k].pow(2).mean()
+    return t
+
+
+GRAD_KEYS = [
+    'encoder.resnet.conv1.weight', 'encoder.resnet.layer1.0.conv2.weight', 'encoder.resnet.layer2.0.downsample.0.weight',
+    'encoder.resnet.layer3.5.bn3.weight', 'encoder.resnet.layer4.2.conv3.weight', 'encoder.p2.weight', 'encoder.p3.weight',
+    'encoder.p5.bias', 'encoder.p4_l2.weight', 'encoder.feat.weight', 'encoder.feat_bn.bias', 'encoder.e_conv1.weight',
+    'encoder.pointnet_plus.sft0.SFT_scale_conv1.weight', 'encoder.pointnet_plus.netR_1.0.weight',
+    'encoder.pointnet_plus.netR_2.3.weight', 'encoder.pointnet_plus.netR_3.7.weight', 'encoder.pointnet_plus.sft2.SFT_shift_conv0.bias',
+    'encoder.center_feat_up0.weight', 'encoder.center_feat_up1.weight', 'encoder.sft.SFT_scale_conv0.weight',
+    'encoder.hm.0.weight', 'encoder.params.2.bias', 'encoder.hms_decoder.models.2.1.weight', 'encoder.dp_decoder.final_layer.1.weight',
+    'decoder.gf_layer_left.0.weight', 'decoder.dual_gcn.layers.0.position_embeddings.weight',
+    'decoder.dual_gcn.layers.0.graph_left.GCN_blocks.0.fc1.weight', 'decoder.dual_gcn.layers.1.graph_right.GCN_blocks.3.norm3.weight',
+    'decoder.dual_gcn.layers.2.attn.w_qs.weight', 'decoder.dual_gcn.layers.1.attn.L_self_attn_layer.ff.fc2.bias',
+    'decoder.unsample_layer.weight', 'decoder.coord_head.weight', 'decoder.avg_head.weight', 'decoder.root_head.bias',
+]
+
+
+def pack_outputs(res, ind):
+    result, params, hand_list, other = res
+    o = {}
+    for h in ("left", "right"):
+        o["verts3d_" + h] = result['verts3d'][h]
+        o["verts2d_" + h] = result['verts2d'][h]
+        o["scale_" + h] = params['scale'][h]
+        o["trans2d_" + h] = params['trans2d'][h]
+        o["root_" + h] = params['root'][h]
+        o["gcn_verts3d_" + h] = hand_list[0]['verts3d'][h]
+        o["mano_list_verts3d_" + h] = other['verts3d_MANO_list'][h][0]
+    B = ind.shape[0]
+    p = other['ret']['params'].reshape(B, 122, -1)
+    o["params_at_ind"] = torch.gather(p, 2, ind.unsqueeze(1).expand(B, 122, 2)).transpose(1, 2)   # [B,2,122]
+    o["hm"] = other['ret']['hm']
+    o["wh_crop"] = other['ret']['wh'][:, :, 8:24, 8:24]
+    for k in ("hms", "mask"):
+        t = other[k]
+        o[k + "_sum"] = t.double().sum().reshape(1)
+        o[k + "_abs_sum"] = t.double().abs().sum().reshape(1)
+        o[k + "_crop"] = t[:, :, 8:24, 8:24]
+    return o
+
+
+def e2e():
+    R, B = 256, 2
+    model = rh.build_ref_model(R)
+    sd = synth.det_state_dict(model.state_dict())
+    b = synth.to_torch(synth.synthetic_batch(B, R, seed=1, variant='mixed'))
+    args = lambda ind: (b['input'], b['choose'], b['cloud'], b['depth'], ind, b['K_new'], b['valid'])
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    # eval
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        res = model(*args(b['ind']))
+        o = pack_outputs(res, b['ind'])
+        res2 = model(*args(None))
+        hm = res2[3]['ret']['hm']
+        E = rh.ref_module("lib.models.networks.intaghand_encoder")
+        nms = E._nms(hm.clone(), 5)
+        pred = torch.cat((E._topk(nms[:, :1], 1)[1], E._topk(nms[:, 1:], 1)[1]), 1)
+        o["pred_ind"] = pred
+        o["pred_ind_verts3d_left"] = res2[0]['verts3d']['left']
+    save("e2e_eval_B2_R256", **o)
+    # train (BN batch stats, dropout 0) forward + surrogate-loss gradients
+    model.load_state_dict(sd)
+    model.train()
+    res = model(*args(b['ind']))
+    loss = surrogate_loss(res)
+    loss.backward()
+    o = pack_outputs(res, b['ind'])
+    o["loss"] = loss.detach().reshape(1)
+    named = dict(model.named_parameters())
+    for k in GRAD_KEYS:
+        gk = named[k].grad
+        o["gradnorm::" + k] = gk.double().norm().reshape(1)
+        o["gradhead::" + k] = gk.flatten()[:64]
+    nograd = sorted(k for k, p in named.items() if p.grad is None)
+    o["n_params_without_grad"] = np.array([len(nograd)])
+    new_sd = model.state_dict()
+    for k in ('encoder.resnet.bn1.running_mean', 'encoder.feat_bn.running_var', 'encoder.pointnet_plus.netR_1.1.running_mean',
+              'encoder.pointnet_plus.netR_3.7.running_var', 'mid_model.convs.2.2.running_mean', 'encoder.hms_decoder.models.3.3.running_var'):
+        o["stat::" + k] = new_sd[k]
+    save("e2e_train_B2_R256", **o)
+    with open(os.path.join(OUT, "params_without_grad.txt"), "w") as f:
+        f.write("\n".join(nograd) + "\n")
+    # state-dict manifest (names + shapes) and a digest of the generated weights
+    import hashlib
+    h = hashlib.sha256()
+    with open(os.path.join(OUT, "state_dict_manifest.txt"), "w") as f:
+        for k, v in sd.items():
+            f.write("%s %s %s\n" % (k, "x".join(map(str, v.shape)) or "scalar", str(v.dtype).replace("torch.", "")))
+            h.update(k.encode())
+            h.update(v.numpy().tobytes())
+        f.write("# sha256 %s\n" % h.hexdigest())
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["ops", "e2e"]
+    if "ops" in which:
+        op_knn_group()
+        op_gather_sft_l2norm()
+        op_decoder_blocks()
+        op_mano()
+    if "e2e" in which:
+        e2e()

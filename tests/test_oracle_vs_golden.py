@@ -1,0 +1,146 @@
+"""CPU: the oracle restatement (oracle/pdfnet_cpu.py) against fixtures generated from the
+reference itself (oracle/make_goldens.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pdfnet_cpu as O
+from oracle import synth
+from tests.util import gold, T, make_opt, pack_outputs, check_packed, surrogate_loss
+
+
+def test_group_points_level1():
+    g = gold("op_group_points_l1")
+    pts = T(g["points"])
+    idx = O.knn_ball_indices(pts, 512, 64, float(g["r2"]))
+    assert (np.sort(idx.numpy(), -1) == g["idx_sorted"]).all()          # bit-exact index sets
+    x, ctr = O.group_level1(pts, 512, 64, float(g["r2"]))
+    assert np.allclose(x.sum(-1).numpy(), g["grouped_sum"], atol=1e-5)
+    assert np.array_equal(x.abs().amax(-1).numpy(), g["grouped_absmax"])
+    assert np.array_equal(ctr.numpy(), g["centers"])
+
+
+def test_group_points_level2():
+    g = gold("op_group_points_l2")
+    f = T(g["feat"])
+    idx = O.knn_ball_indices(f[:, :3].transpose(1, 2), 128, 64, float(g["r2"]))
+    assert (np.sort(idx.numpy(), -1) == g["idx_sorted"]).all()
+    x, ctr = O.group_level2(f, 128, 64, float(g["r2"]))
+    assert np.allclose(x.sum(-1).numpy(), g["grouped_sum"], atol=1e-4)
+    assert np.array_equal(x.abs().amax(-1).numpy(), g["grouped_absmax"])
+    assert np.array_equal(ctr.numpy(), g["centers"])
+
+
+def test_gather_sft_l2norm_nms():
+    g = gold("op_gather_feat")
+    assert np.array_equal(O.gather_hw(T(g["feat"]), T(g["ind"])).numpy(), g["out"])
+    g = gold("op_sft")
+    m = O.SFTLayer(13, 6)
+    m.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w_")})
+    assert np.allclose(m(T(g["fea"]), T(g["cond"])).detach().numpy(), g["out"], atol=1e-6)
+    g = gold("op_l2norm")
+    m = O.L2Norm(5, 10)
+    m.weight.data = T(g["weight"])
+    assert np.allclose(m(T(g["x"])).detach().numpy(), g["out"], atol=1e-6)
+    g = gold("op_nms_topk")
+    assert np.array_equal(O.nms_topk_center(T(g["hm"])).numpy(), g["ind"])
+
+
+@pytest.mark.parametrize("V,Fd", [(63, 16), (126, 8), (252, 8)])
+def test_gcn_block(V, Fd):
+    g = gold("op_gcn_block_V%d" % V)
+    L = O.load_graph_constants()['L_left'][{63: 0, 126: 1, 252: 2}[V]]
+    blk = O.GCNResBlock(Fd, Fd // 2, L, 0.0)
+    blk.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w_")})
+    x = T(g["x"])
+    assert np.allclose(O.cheby_k2(x, blk.graph_L, blk.fc1).detach().numpy(), g["cheby_fc1"], atol=2e-5)
+    assert np.allclose(blk(x).detach().numpy(), g["out"], atol=2e-5)
+
+
+def test_attention_blocks():
+    g = gold("op_self_attn")
+    sa = O.SelfAttn(16, 4, 0.0)
+    sa.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w_")})
+    assert np.allclose(sa(T(g["x"])).detach().numpy(), g["out"], atol=2e-5)
+    g = gold("op_inter_attn")
+    ia = O.InterAttn(16, 4, 0.0)
+    ia.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w_")})
+    oL, oR = ia(T(g["x"]), T(g["y"]))
+    assert np.allclose(oL.detach().numpy(), g["outL"], atol=2e-5)
+    assert np.allclose(oR.detach().numpy(), g["outR"], atol=2e-5)
+
+
+def test_mano_layer():
+    g = gold("op_mano_layer")
+    for side in ("left", "right"):
+        c = synth.synthetic_mano_consts(side)
+        v, j = O.mano_lbs(c, T(g[side + "_rot"]), T(g[side + "_pose"]), T(g[side + "_shape"]),
+                          trans=T(g[side + "_trans"]), side=side)
+        assert np.allclose(v.numpy(), g[side + "_verts"], atol=2e-6)
+        assert np.allclose(j.numpy(), g[side + "_joints"], atol=2e-6)
+        reg = O.full_regressor(c['J_regressor'])
+        assert np.allclose(O.regress_joints(reg, v).numpy(), g[side + "_full_regressor_joints"], atol=2e-6)
+
+
+@pytest.fixture(scope="module")
+def model_and_batch():
+    torch.set_num_threads(8)
+    m = O.load_model_cpu(make_opt(256))
+    sd = synth.det_state_dict(m.state_dict())
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    b = synth.to_torch(synth.synthetic_batch(2, 256, seed=1, variant='mixed'))
+    return m, sd, b
+
+
+def test_state_dict_manifest(model_and_batch, golden_dir):
+    m, sd, _ = model_and_batch
+    import hashlib
+    import os
+    lines = open(os.path.join(golden_dir, "state_dict_manifest.txt")).read().strip().split("\n")
+    names = [l.split()[0] for l in lines if not l.startswith("#")]
+    assert names == list(m.state_dict().keys()) and len(names) == 1287
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.numpy().tobytes())
+    assert lines[-1].split()[-1] == h.hexdigest()          # generator reproduces the same bytes
+
+
+@pytest.mark.slow
+def test_e2e_eval(model_and_batch):
+    m, sd, b = model_and_batch
+    g = gold("e2e_eval_B2_R256")
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        res = m(b['input'], b['choose'], b['cloud'], b['depth'], b['ind'], b['K_new'], b['valid'])
+        check_packed(pack_outputs(res, b['ind']), g)
+        res2 = m(b['input'], b['choose'], b['cloud'], b['depth'], None, b['K_new'], b['valid'])
+    assert np.array_equal(res2[3]['ind'].numpy(), g["pred_ind"])          # predicted centres bit-exact
+    assert np.allclose(res2[0]['verts3d']['left'].numpy(), g["pred_ind_verts3d_left"], atol=1e-4)
+
+
+@pytest.mark.slow
+def test_e2e_train_and_grads(model_and_batch):
+    m, sd, b = model_and_batch
+    g = gold("e2e_train_B2_R256")
+    m.load_state_dict(sd)
+    m.train()
+    m.zero_grad()
+    res = m(b['input'], b['choose'], b['cloud'], b['depth'], b['ind'], b['K_new'], b['valid'])
+    check_packed(pack_outputs(res, b['ind']), g, abs_tol=1e-3, rel_tol=1e-4)
+    loss = surrogate_loss(res)
+    assert abs(loss.item() - float(g["loss"][0])) < 1e-4 * abs(float(g["loss"][0]))
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k, v in g.items():
+        if k.startswith("gradnorm::"):
+            n = named[k[10:]].grad.double().norm().item()
+            assert abs(n - float(v[0])) <= 1e-3 * float(v[0]) + 1e-9, (k, n, v)
+    assert sum(p.grad is None for p in named.values()) == int(g["n_params_without_grad"][0])
+    new = m.state_dict()
+    for k, v in g.items():
+        if k.startswith("stat::"):
+            assert np.allclose(new[k[6:]].numpy(), v, atol=1e-5)

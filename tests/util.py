@@ -1,0 +1,91 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import os
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def gold(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def make_opt(R=256, **over):
+    """The `opt` fields the model reads (reference lib/opts.py:221-239, heads :291-295)."""
+    o = types.SimpleNamespace(
+        depth=True, heads={'hm': 2, 'wh': 2, 'params': 122}, iterations=False,
+        PCA_SZ=63, knn_K=64, ball_radius=0.015, ball_radius2=0.04,
+        sample_num_level1=512, sample_num_level2=128, INPUT_FEATURE_NUM=3, SAMPLE_NUM=1024,
+        default_resolution=R, DECONV_DIMS=[256, 256, 256, 256], GCN_IN_DIM=[512, 256, 128],
+        GCN_OUT_DIM=[256, 128, 64], IMG_DIMS=[256, 128, 64], graph_k=2, graph_layer_num=4)
+    for k, v in over.items():
+        setattr(o, k, v)
+    return o
+
+
+def surrogate_loss(res):
+    """Scalar touching every model output (same definition as oracle/make_goldens.py)."""
+    result, params, hand_list, other = res
+    t = 0
+    for h in ("left", "right"):
+        t = t + result['verts3d'][h].pow(2).mean() + (result['verts2d'][h] / 384).pow(2).mean()
+        t = t + params['scale'][h].pow(2).mean() + params['trans2d'][h].pow(2).mean() + params['root'][h].pow(2).mean()
+        t = t + hand_list[0]['verts3d'][h].pow(2).mean()
+    t = t + other['hms'].pow(2).mean() + other['mask'].pow(2).mean()
+    for k in ('hm', 'wh', 'params'):
+        t = t + other['ret'][k].pow(2).mean()
+    return t
+
+
+def pack_outputs(res, ind):
+    result, params, hand_list, other = res
+    o = {}
+    for h in ("left", "right"):
+        o["verts3d_" + h] = result['verts3d'][h]
+        o["verts2d_" + h] = result['verts2d'][h]
+        o["scale_" + h] = params['scale'][h]
+        o["trans2d_" + h] = params['trans2d'][h]
+        o["root_" + h] = params['root'][h]
+        o["gcn_verts3d_" + h] = hand_list[0]['verts3d'][h]
+        o["mano_list_verts3d_" + h] = other['verts3d_MANO_list'][h][0]
+    B = ind.shape[0]
+    p = other['ret']['params'].reshape(B, 122, -1)
+    o["params_at_ind"] = torch.gather(p, 2, ind.unsqueeze(1).expand(B, 122, 2)).transpose(1, 2)
+    o["hm"] = other['ret']['hm']
+    o["wh_crop"] = other['ret']['wh'][:, :, 8:24, 8:24]
+    for k in ("hms", "mask"):
+        t = other[k]
+        o[k + "_sum"] = t.double().sum().reshape(1)
+        o[k + "_abs_sum"] = t.double().abs().sum().reshape(1)
+        o[k + "_crop"] = t[:, :, 8:24, 8:24]
+    return o
+
+
+# tolerances: SURVEY.md Appendix C noise floor (fp32 vs fp64 of the oracle itself)
+TOL_EVAL = {"verts3d": 1e-4, "scale": 1e-4, "trans2d": 1e-4, "root": 1e-4, "gcn_verts3d": 1e-4,
+            "mano_list_verts3d": 1e-4, "params_at_ind": 1e-4, "hm": 1e-4}
+
+
+def check_packed(got, exp, abs_tol=1e-4, rel_tol=1e-5, skip=()):
+    """got: dict of tensors, exp: dict of numpy arrays. verts2d/hms/mask use relative tolerance."""
+    bad = []
+    for k, e in exp.items():
+        if k not in got or k in skip:
+            continue
+        g = got[k].detach().cpu().double().numpy()
+        e = e.astype(np.float64)
+        d = np.abs(g - e).max()
+        lim = abs_tol + rel_tol * np.abs(e).max()
+        if k.startswith("verts2d") or k.startswith("hms") or k.startswith("mask"):
+            lim = abs_tol + 1e-5 * np.abs(e).max() * 10
+        if not d <= lim:
+            bad.append((k, d, lim))
+    assert not bad, bad
