@@ -1,0 +1,166 @@
+/* libpdfnet_hip.so -- C ABI of the MI355X-native (gfx950) PDFNet RGB-D two-hand hot path.
+ *
+ * Plain pointers and sizes only: every pointer is DEVICE memory (hipMalloc / a torch tensor's
+ * data_ptr()), `stream` is a hipStream_t passed as void*, nothing here allocates, synchronises or
+ * touches the default stream, so every call is hipGraph-capturable.  Return value: 0 on success,
+ * PDF_E_* (<0) for a rejected argument, or a positive hipError_t from the launch.
+ *
+ * Layout convention: activations are row-major [rows][channels] with an explicit row stride `ld*`
+ * in floats (NHWC for images: rows = n*H*W pixels).  Conv weights are [Cout][KH][KW][Cin] -- the
+ * channels_last storage of the reference's OIHW nn.Conv2d weight; ConvTranspose weights are
+ * [Cin][KH][KW][Cout] (channels_last storage of [Cin,Cout,KH,KW]).
+ *
+ * Each entry point names the reference interface (file:line under zijinxuxu/PDFNet @2024_08_07) it
+ * replaces.  The reference has no native op on this path (its one .cu, lib/utils/roi_align, is dead
+ * code), so the "FFI" a maintainer binds is these symbols via ctypes -- see INTEGRATION.md.
+ */
+#ifndef PDFNET_HIP_H
+#define PDFNET_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDF_E_BADARG (-1)
+#define PDF_E_WORKSPACE (-2)
+#define PDF_ACT_NONE 0
+#define PDF_ACT_RELU 1
+#define PDF_ACT_LRELU01 2
+
+/* ---- dense contractions: fp32 MFMA implicit GEMM (csrc/gemm.hip) ------------------------------ */
+
+/* y[M][N] = act(x[M][K] w[N][K]^T + bias).  nn.Linear / 1x1 nn.Conv2d call sites:
+ * model_attn/gcn.py:66 (cl(x)), self_attn.py:66-68,79, intaghand_encoder.py:48-103 (netR_*), :213-218 (SFT convs). */
+int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
+                   int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream);
+/* dW[N][K] (+)= dy[M][N]^T x[M][K]; ws >= pdf_wgrad_workspace_floats(M,N,K) floats. (autograd of the above) */
+int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+                          int M, int N, int K, int ldx, int lddy, int accumulate, void* stream);
+long pdf_wgrad_workspace_floats(int M, int NI, int NJ);
+
+/* nn.Conv2d forward on NHWC: lib/models/networks/resnet.py:202-218 (trunk), intaghand_encoder.py:602 (p2),
+ * :617 (feat), :621 (e_conv1), :627-628 (center_feat_up0/1), :675-693 (heads), :270-316 (decoders). */
+int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                   int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                   int stride, int pad, int OH, int OW, int ldy, int act, void* stream);
+/* dx from dy; wT = [Cin][KH][KW][Cout] (pdf_transpose_atb(w, Cout, KH*KW, Cin)); caller zero-fills dx when stride > kernel */
+int pdf_conv2d_bwd_data(const float* dy, const float* wT, float* dx,
+                        int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                        int stride, int pad, int OH, int OW, int lddy, void* stream);
+int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+                          int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                          int stride, int pad, int OH, int OW, int lddy, int accumulate, void* stream);
+
+/* nn.ConvTranspose2d (pyramid laterals p3/p4/p5, intaghand_encoder.py:603-605,721-729).
+ * fwd weight repack wP: kernel==stride: [KH*KW*Cout][Cin] = pdf_transpose_atb(w, Cin, 1, KH*KW*Cout);
+ *                       otherwise:      [Cout][KH][KW][Cin] = pdf_transpose_atb(w, Cin, KH*KW, Cout). */
+int pdf_deconv2d_fwd(const float* x, const float* wP, const float* bias, float* y,
+                     int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                     int stride, int pad, int OH, int OW, int ldy, void* stream);
+int pdf_deconv2d_bwd_data(const float* dy, const float* w, float* dx,
+                          int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                          int stride, int pad, int OH, int OW, int lddy, void* stream);
+int pdf_deconv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+                            int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                            int stride, int pad, int OH, int OW, int lddy, int accumulate, void* stream);
+/* in [A][T][B] -> out [B][T][A] */
+int pdf_transpose_atb(const float* in, float* out, int A, int T, int B, void* stream);
+/* C[b][m][n] (+)= sum_{r<RB} sum_k A[b,r][m][k] B[b,r][k][n], element strides (0 = broadcast).
+ * Small matmuls: avg_head / unsample_layer (intaghand_decoder.py:205,224), full_regressor (Mano_model.py:309-323). */
+int pdf_bmm_strided(const float* A, const float* B, float* C, int batch, int M, int N, int K, int RB,
+                    long sab, long sar, long sam, long sak, long sbb, long sbr, long sbk, long sbn,
+                    long scb, long scm, long scn, int beta, void* stream);
+
+/* ---- PointNet++ set abstraction (csrc/pointops.hip) ------------------------------------------ */
+
+/* group_points / group_points_2 (lib/utils/utils.py:134-163, :165-188): centroids = first S points,
+ * kNN(K) on squared distances + ball mask (d2 > r2 -> centroid's own index) + gather + centre-subtract
+ * of channels 0:3, one launch.  pts [Bc][N][ldp] (xyz = channels 0:3, C channels), idx [Bc][S][K] int32,
+ * grouped [Bc][S][K][ldg] (channels C..ldg-1 zero-filled) or NULL. */
+int pdf_knn_ball_group(const float* pts, int ldp, int C, int Bc, int N, int S, int K, float r2,
+                       int* idx, float* grouped, int ldg, void* stream);
+/* autograd of the gather (values only; indices carry no gradient): dpts must be zero-filled */
+int pdf_group_bwd(const float* dg, int ldg, const int* idx, float* dpts, int ldd, int C,
+                  int Bc, int N, int S, int K, void* stream);
+/* _tranpose_and_gather_feat (lib/models/utils.py:22-26) on an NHWC map: out[b][m][:] = feat[b][ind'[b][m]][:],
+ * ind' = pyramid index of intaghand_encoder.py:125-126 when shift > 0.  ind is int64 [B][>=M] with batch stride. */
+int pdf_gather_rows(const float* feat, int ldf, int C, long HW, const long* ind, long ind_bstride,
+                    int B, int M, int R, int shift, float* out, int ldo, void* stream);
+int pdf_scatter_rows_add(const float* dout, int ldo, int C, long HW, const long* ind, long ind_bstride,
+                         int B, int M, int R, int shift, float* dfeat, int ldf, void* stream);
+/* nn.MaxPool2d((1,K)) / ((S2,1)) of netR_1/2/3 (intaghand_encoder.py:62,82,100): x [R][K][ldx] -> y [R][ldy], arg [R][C] */
+int pdf_maxk_fwd(const float* x, int ldx, int C, long R, int K, float* y, int ldy, int* arg, void* stream);
+int pdf_maxk_bwd(const float* dy, int ldy, const int* arg, int C, long R, int K, float* dx, int ldx, void* stream);
+
+/* ---- normalisation (csrc/norm.hip) ------------------------------------------------------------ */
+
+/* nn.BatchNorm2d/1d in train mode (+ optional residual add and ReLU): resnet.py:100-122, intaghand_encoder.py:48-103,
+ * :618 (feat_bn, momentum 0.01), :192-198, :304-306.  ws >= pdf_bn_workspace_floats(C,R). */
+long pdf_bn_workspace_floats(int C, long R);
+int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps,
+                     const float* res, int ldr, int relu, float* y, int ldy,
+                     float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, void* stream);
+int pdf_bn_eval_fwd(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
+                    const float* running_mean, const float* running_var, float eps,
+                    const float* res, int ldr, int relu, float* y, int ldy, float* scale, float* shift, void* stream);
+/* ws >= pdf_bn_workspace_floats(C,R) + 3*C */
+int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy, int relu, const float* x, int ldx,
+                     const float* save_mean, const float* save_rstd, const float* gamma, int C, long R,
+                     float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
+                     float* ws, void* stream);
+/* out[c] (+)= sum_r g[r][c] (bias gradients); ws >= pdf_bn_workspace_floats(C,R) */
+int pdf_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, void* stream);
+/* nn.LayerNorm(eps=1e-6): gcn.py:92-97, self_attn.py:58, inter_attn.py:66-67, intaghand_decoder.py:139-142 */
+int pdf_layernorm_fwd(const float* x, int ldx, int F, long R, const float* gamma, const float* beta, float eps,
+                      float* y, int ldy, float* mean, float* rstd, void* stream);
+int pdf_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, int F, long R, const float* gamma,
+                      const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, void* stream);
+/* L2Norm.forward (intaghand_encoder.py:318-334) */
+int pdf_l2norm_fwd(const float* x, int ldx, int C, long R, const float* w, float eps, float* y, int ldy, float* norm, void* stream);
+int pdf_l2norm_bwd(const float* dy, int lddy, const float* x, int ldx, int C, long R, const float* w, float eps,
+                   const float* norm, float* dx, int lddx, float* dw, void* stream);
+
+/* ---- elementwise / spatial (csrc/elementwise.hip) --------------------------------------------- */
+int pdf_act_fwd(const float* x, int ldx, float* y, int ldy, int C, long R, int act, void* stream);
+int pdf_act_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, int C, long R, int act, void* stream);
+/* SFTLayer.forward modulation fea*(scale+1)+shift (intaghand_encoder.py:219) */
+int pdf_sft_fwd(const float* fea, int ldf, const float* scale, int lds, const float* shift, int ldh,
+                float* out, int ldo, int C, long R, void* stream);
+int pdf_sft_bwd(const float* g, int ldg, const float* fea, int ldf, const float* scale, int lds,
+                float* dfea, int lddf, float* dscale, int ldds, int C, long R, void* stream);
+/* nn.Dropout(p) with a stateless (seed, index) mask: the same call is its own backward (gcn.py:96, self_attn.py:51-52) */
+int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream);
+/* resnet.maxpool (resnet.py:206) */
+int pdf_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* arg, void* stream);
+int pdf_maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, void* stream);
+/* nn.Upsample(scale_factor=2, bilinear, align_corners=True) (intaghand_encoder.py:287-302) */
+int pdf_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);
+int pdf_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream);
+/* torch.optim.Adam step (main.py:63) over one flat buffer; corr = device [1-b1^t, 1-b2^t] */
+int pdf_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                  const float* corr, float grad_scale, void* stream);
+
+/* ---- mesh decoder (csrc/graph.hip) ------------------------------------------------------------ */
+/* graph_conv_cheby, K=2 (model_attn/gcn.py:34-69): out[b][v][2f]=x, out[b][v][2f+1]=(Lx); L as ELL [V][Wd] */
+int pdf_cheby2_fwd(const float* x, int ldx, int B, int V, int F, const int* col, const float* val, int Wd,
+                   float* out, int ldo, void* stream);
+int pdf_cheby2_bwd(const float* d, int ldd, int B, int V, int F, const int* colT, const float* valT, int Wd,
+                   float* dx, int lddx, void* stream);
+/* multi-head softmax attention (self_attn.py:63-76, inter_attn.py:82-105); stat [B][H][V][2], dvec [B][H][V] */
+int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld, int B, int V, int H, int dh,
+                 float pdrop, unsigned long long seed, float* out, int ldo, float* stat, void* stream);
+int pdf_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* o, const float* dout, int ldo,
+                 const float* stat, int B, int V, int H, int dh, float pdrop, unsigned long long seed,
+                 float* dq, float* dk, float* dv, int lddq, float* dvec, void* stream);
+
+/* ---- MANO (csrc/mano.hip) --------------------------------------------------------------------- */
+/* ManoLayer.forward, use_pca=False (lib/models/networks/manolayer.py:257-334): axis-angle root [B][3], pose [B][45],
+ * shape [B][10], trans [B][3] or NULL -> verts [B][778][3], joints [B][21][3]; center_idx < 0 = None. */
+int pdf_mano_lbs_fwd(const float* root_aa, const float* pose_aa, const float* shape, const float* trans,
+                     const float* v_template, const float* shapedirs, const float* posedirs, const float* J_reg,
+                     const float* weights, int B, int left_side, int center_idx, float* verts, float* joints, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+// Streaming elementwise / spatial kernels (all HBM-bound, channel axis contiguous):
+// activations, SFT modulation, dropout, 3x3/s2 max-pool, bilinear x2 (align_corners), fused Adam.
+#include "common.h"
+
+#define GRID_STRIDE(i, total) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (total); i += (long)gridDim.x * blockDim.x)
+
+// act: 1 relu, 2 leaky-relu(0.1)
+__global__ void act_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int C, long total, int act) {
+    GRID_STRIDE(i, total) {
+        long r = i / C; int c = (int)(i - r * C);
+        float v = x[r * ldx + c];
+        y[r * ldy + c] = act == 1 ? fmaxf(v, 0.f) : (v > 0.f ? v : 0.1f * v);
+    }
+}
+PDF_API int pdf_act_fwd(const float* x, int ldx, float* y, int ldy, int C, long R, int act, hipStream_t s) {
+    if (R * C <= 0) return 0;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, y, ldy, C, R * C, act);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx = dy * act'(.) using the activation OUTPUT y (sign(y) == sign(pre-activation) for both)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                               float* __restrict__ dx, int lddx, int C, long total, int act) {
+    GRID_STRIDE(i, total) {
+        long r = i / C; int c = (int)(i - r * C);
+        float g = dy[r * lddy + c];
+        bool pos = y[r * ldy + c] > 0.f;
+        dx[r * lddx + c] = pos ? g : (act == 1 ? 0.f : 0.1f * g);
+    }
+}
+PDF_API int pdf_act_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, int C, long R, int act, hipStream_t s) {
+    if (R * C <= 0) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, C, R * C, act);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// out = fea * (scale + 1) + shift      (SFTLayer.forward, intaghand_encoder.py:213-219)
+__global__ void sft_fwd_kernel(const float* __restrict__ fea, int ldf, const float* __restrict__ scale, int lds_, const float* __restrict__ shift, int ldh,
+                               float* __restrict__ out, int ldo, int C, long total) {
+    GRID_STRIDE(i, total) {
+        long r = i / C; int c = (int)(i - r * C);
+        out[r * ldo + c] = fea[r * ldf + c] * (scale[r * lds_ + c] + 1.f) + shift[r * ldh + c];
+    }
+}
+PDF_API int pdf_sft_fwd(const float* fea, int ldf, const float* scale, int lds_, const float* shift, int ldh,
+                        float* out, int ldo, int C, long R, hipStream_t s) {
+    if (R * C <= 0) return 0;
+    hipLaunchKernelGGL(sft_fwd_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, fea, ldf, scale, lds_, shift, ldh, out, ldo, C, R * C);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// dfea = g*(scale+1); dscale = g*fea; (dshift = g: caller aliases)
+__global__ void sft_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ fea, int ldf, const float* __restrict__ scale, int lds_,
+                               float* __restrict__ dfea, int lddf, float* __restrict__ dscale, int ldds, int C, long total) {
+    GRID_STRIDE(i, total) {
+        long r = i / C; int c = (int)(i - r * C);
+        float gv = g[r * ldg + c];
+        dfea[r * lddf + c] = gv * (scale[r * lds_ + c] + 1.f);
+        dscale[r * ldds + c] = gv * fea[r * ldf + c];
+    }
+}
+PDF_API int pdf_sft_bwd(const float* g, int ldg, const float* fea, int ldf, const float* scale, int lds_,
+                        float* dfea, int lddf, float* dscale, int ldds, int C, long R, hipStream_t s) {
+    if (R * C <= 0) return 0;
+    hipLaunchKernelGGL(sft_bwd_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, g, ldg, fea, ldf, scale, lds_, dfea, lddf, dscale, ldds, C, R * C);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// dropout with a stateless mask: keep iff u(seed, i) >= p ; y = x * keep / (1-p).  Same call serves
+// forward and backward (the mask is a pure function of seed and element index).
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p, unsigned long long seed) {
+    const float sc = 1.f / (1.f - p);
+    GRID_STRIDE(i, n) y[i] = pdf_uniform(seed, (unsigned long long)i) >= p ? x[i] * sc : 0.f;
+}
+PDF_API int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long seed, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, p, seed);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(3, stride 2, pad 1) on NHWC (resnet.maxpool, intaghand_encoder.py:716)
+__global__ void maxpool3s2_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int OH, int OW,
+                                      float* __restrict__ y, unsigned char* __restrict__ arg, long total) {
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C); long p = i / C;
+        int ox = (int)(p % OW); p /= OW;
+        int oy = (int)(p % OH); int n = (int)(p / OH);
+        float best = -INFINITY; int bi = 0;
+        for (int ky = 0; ky < 3; ++ky) {
+            int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                float v = x[(((long)n * H + iy) * W + ix) * C + c];
+                if (v > best) { best = v; bi = ky * 3 + kx; }
+            }
+        }
+        y[i] = best; arg[i] = (unsigned char)bi;
+    }
+}
+PDF_API int pdf_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* arg, hipStream_t s) {
+    int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    long total = (long)N * OH * OW * C;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, N, H, W, C, OH, OW, y, arg, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// dx must be zero-filled; windows overlap so scatter with atomics
+__global__ void maxpool3s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, int N, int H, int W, int C,
+                                      int OH, int OW, float* __restrict__ dx, long total) {
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C); long p = i / C;
+        int ox = (int)(p % OW); p /= OW;
+        int oy = (int)(p % OH); int n = (int)(p / OH);
+        int a = arg[i];
+        int iy = oy * 2 - 1 + a / 3, ix = ox * 2 - 1 + a % 3;
+        atomicAdd(&dx[(((long)n * H + iy) * W + ix) * C + c], dy[i]);
+    }
+}
+PDF_API int pdf_maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, hipStream_t s) {
+    int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    long total = (long)N * OH * OW * C;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, arg, N, H, W, C, OH, OW, dx, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) on NHWC (intaghand_encoder.py:281-302)
+__device__ __forceinline__ void up2_coords(int o, int in_sz, int out_sz, int& i0, int& i1, float& w1) {
+    float src = out_sz > 1 ? (float)o * ((float)(in_sz - 1) / (float)(out_sz - 1)) : 0.f;
+    i0 = (int)src;
+    if (i0 > in_sz - 1) i0 = in_sz - 1;
+    i1 = i0 + 1 < in_sz ? i0 + 1 : i0;
+    w1 = src - (float)i0;
+}
+__global__ void up2_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, float* __restrict__ y, long total) {
+    const int OH = 2 * H, OW = 2 * W;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C); long p = i / C;
+        int ox = (int)(p % OW); p /= OW;
+        int oy = (int)(p % OH); int n = (int)(p / OH);
+        int y0, y1, x0, x1; float wy, wx;
+        up2_coords(oy, H, OH, y0, y1, wy);
+        up2_coords(ox, W, OW, x0, x1, wx);
+        const float* b = x + (long)n * H * W * C + c;
+        float v00 = b[((long)y0 * W + x0) * C], v01 = b[((long)y0 * W + x1) * C];
+        float v10 = b[((long)y1 * W + x0) * C], v11 = b[((long)y1 * W + x1) * C];
+        // same association as ATen's upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+        y[i] = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+    }
+}
+PDF_API int pdf_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, hipStream_t s) {
+    long total = (long)N * 4 * H * W * C;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(up2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, N, H, W, C, y, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// dx zero-filled by caller
+__global__ void up2_bwd_kernel(const float* __restrict__ dy, int N, int H, int W, int C, float* __restrict__ dx, long total) {
+    const int OH = 2 * H, OW = 2 * W;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C); long p = i / C;
+        int ox = (int)(p % OW); p /= OW;
+        int oy = (int)(p % OH); int n = (int)(p / OH);
+        int y0, y1, x0, x1; float wy, wx;
+        up2_coords(oy, H, OH, y0, y1, wy);
+        up2_coords(ox, W, OW, x0, x1, wx);
+        float g = dy[i];
+        float* b = dx + (long)n * H * W * C + c;
+        atomicAdd(&b[((long)y0 * W + x0) * C], g * (1.f - wy) * (1.f - wx));
+        atomicAdd(&b[((long)y0 * W + x1) * C], g * (1.f - wy) * wx);
+        atomicAdd(&b[((long)y1 * W + x0) * C], g * wy * (1.f - wx));
+        atomicAdd(&b[((long)y1 * W + x1) * C], g * wy * wx);
+    }
+}
+PDF_API int pdf_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, hipStream_t s) {
+    long total = (long)N * 4 * H * W * C;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, N, H, W, C, dx, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics, main.py:63) over one flat fp32 buffer.
+// step_size / bias corrections are read from a 2-float device buffer so the launch is graph-replayable.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                            float lr, float b1, float b2, float eps, const float* __restrict__ corr /*[bc1, bc2]*/, float grad_scale) {
+    const float bc1 = corr[0], bc2 = corr[1];
+    const float step = lr / bc1;
+    const float rs2 = 1.f / sqrtf(bc2);
+    GRID_STRIDE(i, n) {
+        float gv = g[i] * grad_scale;
+        float mv = b1 * m[i] + (1.f - b1) * gv;
+        float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mv; v[i] = vv;
+        p[i] -= step * mv / (sqrtf(vv) * rs2 + eps);
+    }
+}
+PDF_API int pdf_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                          const float* corr, float grad_scale, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, corr, grad_scale);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}

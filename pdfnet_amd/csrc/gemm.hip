@@ -1,0 +1,680 @@
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit-GEMM kernels for gfx950.
+//
+// Every dense contraction of the PDFNet hot path is one of two kernels:
+//   igemm_nt : C[m][n] = act( sum_{t,c} A[pos(m,t)][c] * B[n][wt[t]*Cin + c] + bias[n] )
+//              A is an NHWC image gathered through a tap table (conv / transposed-conv parity
+//              class / strided backward-data) or plain rows (Linear, 1x1 conv);  B is K-major.
+//   wgemm_tn : dW[i][wt[t]*Cq + c] = sum_m P[m][i] * Q[pos(m,t)][c]      (weight gradients,
+//              reduction over pixels, split over M into slabs that reduce_slabs() sums).
+// Tiles are 64-wide-wavefront shaped: 256 threads = 4 waves, each wave owns (BM/WM)x(BN/WN) made of
+// 32x32 MFMA tiles; K-step 16 staged through LDS with a register prefetch of the next tile.
+// fp32-input MFMA is bit-for-bit an fmaf chain (guide: FP32-input MFMA), so results are exact fp32.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MAX_TAPS 64
+
+struct IGemm {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, Cin;
+    int lda, ldb;
+    int H, W, QH, QW, sy, sx, T;
+    int plain_in, plain_out;
+    int OH, OW, osy, osx, ooy, oox, ldc;
+    int ps_cout, ps_kw;
+    int act;                                  // 0 none, 1 relu, 2 leaky-relu(0.1)
+    short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
+};
+
+__device__ __forceinline__ void xcd_tile(int bid, int nblk, int ntn, int& tm, int& tn) {
+    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous chunk of the
+    // tile list so the n-tiles that re-read one A panel hit the same L2 (guide T1, bijective form)
+    int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    tn = lin % ntn;
+    tm = lin / ntn;
+}
+
+template <int BM, int BN, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
+    constexpr int BK = 16, LD = BK + 1;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RA = BM / 64, RB = BN / 64;
+    __shared__ float As[2][BM * LD];
+    __shared__ float Bs[2][BN * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    int tmi, tni;
+    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
+    const int m0 = tmi * BM, n0 = tni * BN;
+
+    const int lrow = tid >> 2, kq = (tid & 3) * 4;
+    long abase[RA]; int iy0[RA], ix0[RA]; bool aval[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        int r = m0 + lrow + i * 64;
+        aval[i] = r < g.M;
+        if (g.plain_in) {
+            abase[i] = (long)r * g.lda; iy0[i] = 0; ix0[i] = 0;
+        } else {
+            int hw = g.QH * g.QW;
+            int ni = r / hw, rem = r - ni * hw;
+            int qy = rem / g.QW, qx = rem - qy * g.QW;
+            iy0[i] = qy * g.sy; ix0[i] = qx * g.sx;
+            abase[i] = (long)ni * g.H * g.W * g.lda;
+        }
+    }
+    long bbase[RB]; bool bval[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        int n = n0 + lrow + i * 64;
+        bval[i] = n < g.N;
+        bbase[i] = (long)n * g.ldb;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (g.K + BK - 1) / BK;
+    const int tpt = FAST ? g.Cin / BK : 1;   // k-tiles per tap
+
+    float4 ra[RA], rb[RB];
+    auto gload = [&](int kt) {
+        if (FAST) {
+            int t = kt / tpt;
+            int ci0 = (kt - t * tpt) * BK + kq;
+            int ddy = g.dy[t], ddx = g.dx[t];
+            int wofs = g.wt[t] * g.Cin + ci0;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g.plain_in) {
+                    if (aval[i]) v = *reinterpret_cast<const float4*>(g.A + abase[i] + kt * BK + kq);
+                } else {
+                    int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
+                    if (aval[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                        v = *reinterpret_cast<const float4*>(g.A + abase[i] + ((long)iy * g.W + ix) * g.lda + ci0);
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bval[i]) v = *reinterpret_cast<const float4*>(g.B + bbase[i] + wofs);
+                rb[i] = v;
+            }
+        } else {
+            float tmpa[RA][4], tmpb[RB][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = kt * BK + kq + j;
+                bool kin = k < g.K;
+                int t = kin ? k / g.Cin : 0;
+                int ci = k - t * g.Cin;
+                int ddy = g.dy[t], ddx = g.dx[t];
+                int wofs = g.wt[t] * g.Cin + ci;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    float v = 0.f;
+                    if (kin && aval[i]) {
+                        if (g.plain_in) v = g.A[abase[i] + k];
+                        else {
+                            int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
+                            if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                                v = g.A[abase[i] + ((long)iy * g.W + ix) * g.lda + ci];
+                        }
+                    }
+                    tmpa[i][j] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < RB; ++i) tmpb[i][j] = (kin && bval[i]) ? g.B[bbase[i] + wofs] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = make_float4(tmpa[i][0], tmpa[i][1], tmpa[i][2], tmpa[i][3]);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) rb[i] = make_float4(tmpb[i][0], tmpb[i][1], tmpb[i][2], tmpb[i][3]);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            float* p = &As[buf][(lrow + i * 64) * LD + kq];
+            p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            float* p = &Bs[buf][(lrow + i * 64) * LD + kq];
+            p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w;
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5);
+    const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* as = As[cur];
+        const float* bs = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[arow + i * 32 * LD + kk * 2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[brow + j * 32 * LD + kk * 2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        const bool cok = col < g.N;
+        int co = col, padd_y = 0, padd_x = 0;
+        if (g.ps_cout > 0) {
+            int tap = col / g.ps_cout;
+            co = col - tap * g.ps_cout;
+            padd_y = tap / g.ps_kw;
+            padd_x = tap - padd_y * g.ps_kw;
+        }
+        const float bv = (g.bias != nullptr && cok) ? g.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (cok && row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+                    long o;
+                    if (g.plain_out) o = (long)row * g.ldc + co;
+                    else {
+                        int hw = g.QH * g.QW;
+                        int ni = row / hw, rem = row - ni * hw;
+                        int qy = rem / g.QW, qx = rem - qy * g.QW;
+                        int oy = qy * g.osy + g.ooy + padd_y, ox = qx * g.osx + g.oox + padd_x;
+                        o = (((long)ni * g.OH + oy) * g.OW + ox) * g.ldc + co;
+                    }
+                    g.C[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct WGemm {
+    const float* P; const float* Q; float* slab;
+    int M, NI, Cq, T;
+    int ldp, ldq, ldw;
+    int H, W, QH, QW, sy, sx;
+    int plain_q;
+    int rows_per_split;
+    short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
+};
+
+template <int BI, int BJ, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
+    constexpr int BK = 16;
+    constexpr int TM = BI / WM / 32, TN = BJ / WN / 32;
+    constexpr int TPR_P = BI / 4, TPR_Q = BJ / 4;        // threads per LDS row
+    constexpr int RP = BK / (256 / TPR_P), RQ = BK / (256 / TPR_Q);
+    __shared__ __attribute__((aligned(16))) float Ps[2][BK * BI];
+    __shared__ __attribute__((aligned(16))) float Qs[2][BK * BJ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int NJ = g.T * g.Cq;
+    const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
+    int ti, tj;
+    xcd_tile(blockIdx.x, nti * ntj, ntj, ti, tj);
+    const int i0 = ti * BI, j0 = tj * BJ;
+    const int ms = blockIdx.y * g.rows_per_split;
+    const int me = min(g.M, ms + g.rows_per_split);
+
+    const int pr = tid / TPR_P, pc = (tid % TPR_P) * 4;
+    const int qr = tid / TPR_Q, qc = (tid % TPR_Q) * 4;
+    // this thread's Q columns j0+qc..+3 -> (tap, channel); fixed for the whole reduction
+    int qt[4], qch[4]; bool qok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int j = j0 + qc + e;
+        qok[e] = j < NJ;
+        int t = qok[e] ? j / g.Cq : 0;
+        qt[e] = t; qch[e] = j - t * g.Cq;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 rp[RP], rq[RQ];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            int m = mb + pr + i * (256 / TPR_P);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < me) {
+                const float* p = g.P + (long)m * g.ldp + i0 + pc;
+                if (FAST) { if (i0 + pc < g.NI) v = *reinterpret_cast<const float4*>(p); }
+                else {
+                    if (i0 + pc + 0 < g.NI) v.x = p[0];
+                    if (i0 + pc + 1 < g.NI) v.y = p[1];
+                    if (i0 + pc + 2 < g.NI) v.z = p[2];
+                    if (i0 + pc + 3 < g.NI) v.w = p[3];
+                }
+            }
+            rp[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) {
+            int m = mb + qr + i * (256 / TPR_Q);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < me) {
+                if (g.plain_q) {
+                    const float* p = g.Q + (long)m * g.ldq;
+                    if (FAST) { if (qok[0]) v = *reinterpret_cast<const float4*>(p + qch[0]); }
+                    else {
+                        if (qok[0]) v.x = p[qch[0]];
+                        if (qok[1]) v.y = p[qch[1]];
+                        if (qok[2]) v.z = p[qch[2]];
+                        if (qok[3]) v.w = p[qch[3]];
+                    }
+                } else {
+                    int hw = g.QH * g.QW;
+                    int ni = m / hw, rem = m - ni * hw;
+                    int qy = rem / g.QW, qx = rem - qy * g.QW;
+                    const float* img = g.Q + (long)ni * g.H * g.W * g.ldq;
+                    if (FAST) {
+                        int iy = qy * g.sy + g.dy[qt[0]], ix = qx * g.sx + g.dx[qt[0]];
+                        if (qok[0] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                            v = *reinterpret_cast<const float4*>(img + ((long)iy * g.W + ix) * g.ldq + qch[0]);
+                    } else {
+                        float e4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            int iy = qy * g.sy + g.dy[qt[e]], ix = qx * g.sx + g.dx[qt[e]];
+                            e4[e] = (qok[e] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                                        ? img[((long)iy * g.W + ix) * g.ldq + qch[e]] : 0.f;
+                        }
+                        v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                    }
+                }
+            }
+            rq[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RP; ++i)
+            *reinterpret_cast<float4*>(&Ps[buf][(pr + i * (256 / TPR_P)) * BI + pc]) = rp[i];
+#pragma unroll
+        for (int i = 0; i < RQ; ++i)
+            *reinterpret_cast<float4*>(&Qs[buf][(qr + i * (256 / TPR_Q)) * BJ + qc]) = rq[i];
+    };
+
+    if (ms < me) {
+        gload(ms);
+        lstore(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    const int aoff = (lane >> 5) * BI + wm * TM * 32 + (lane & 31);
+    const int boff = (lane >> 5) * BJ + wn * TN * 32 + (lane & 31);
+    for (int mb = ms; mb < me; mb += BK) {
+        const bool more = mb + BK < me;
+        if (more) gload(mb + BK);
+        const float* ps = Ps[cur];
+        const float* qs = Qs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ps[aoff + kk * 2 * BI + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = qs[boff + kk * 2 * BJ + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* out = g.slab + (long)blockIdx.y * g.NI * g.ldw;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (col >= NJ) continue;
+        const int t = col / g.Cq;
+        const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.NI) out[(long)row * g.ldw + wcol] = acc[i][j][r];
+            }
+    }
+}
+
+__global__ void reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, long n, int splits, int accumulate) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = accumulate ? out[i] : 0.f;
+        for (int z = 0; z < splits; ++z) s += slab[(long)z * n + i];
+        out[i] = s;
+    }
+}
+
+// in [A][T][B] -> out [B][T][A]   (weight repacks: OHWI <-> IHWO, Linear W <-> W^T)
+__global__ void transpose_atb(const float* __restrict__ in, float* __restrict__ out, int A, int T, int B) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        int a = a0 + r, b = b0 + threadIdx.x;
+        tile[r][threadIdx.x] = (a < A && b < B) ? in[((long)a * T + t) * B + b] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        int b = b0 + r, a = a0 + threadIdx.x;
+        if (a < A && b < B) out[((long)b * T + t) * A + a] = tile[threadIdx.x][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int launch_igemm(IGemm& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
+    const bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
+    // tile choice: wide tiles when there are enough of them to fill 256 CUs, else smaller ones
+    long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+    if (g.N > 64 && t128 >= 192) {
+        int nb = (int)t128;
+        if (fast) hipLaunchKernelGGL((igemm_nt<128, 128, 2, 2, true>), dim3(nb), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((igemm_nt<128, 128, 2, 2, false>), dim3(nb), dim3(256), 0, s, g);
+    } else if (g.N <= 64 && (long)cdiv(g.M, 128) >= 192) {
+        int nb = cdiv(g.M, 128) * cdiv(g.N, 64);
+        if (fast) hipLaunchKernelGGL((igemm_nt<128, 64, 4, 1, true>), dim3(nb), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((igemm_nt<128, 64, 4, 1, false>), dim3(nb), dim3(256), 0, s, g);
+    } else {
+        int nb = cdiv(g.M, 64) * cdiv(g.N, 64);
+        if (fast) hipLaunchKernelGGL((igemm_nt<64, 64, 2, 2, true>), dim3(nb), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((igemm_nt<64, 64, 2, 2, false>), dim3(nb), dim3(256), 0, s, g);
+    }
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+static void conv_taps(IGemm& g, int KH, int KW, int pad, int dil) {
+    g.T = KH * KW;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+            int t = ky * KW + kx;
+            g.dy[t] = (short)(ky * dil - pad); g.dx[t] = (short)(kx * dil - pad); g.wt[t] = (short)t;
+        }
+}
+
+// Linear / 1x1: y[M][N] = act(x[M][K] w[N][K]^T + b).  Reference: nn.Linear / 1x1 nn.Conv2d call sites
+// (e.g. model_attn/gcn.py:66, intaghand_encoder.py:48-103 netR_*, :205-219 SFT convs).
+PDF_API int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
+                           int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) {
+    IGemm g = {};
+    g.A = x; g.B = w; g.C = y; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.Cin = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldy;
+    g.T = 1; g.plain_in = 1; g.plain_out = 1; g.act = act;
+    g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
+    return launch_igemm(g, s);
+}
+
+// Conv2d forward on NHWC.  w is [Cout][KH][KW][Cin] (the channels_last storage of an OIHW weight).
+// Replaces nn.Conv2d.forward at intaghand_encoder.py:711-772,790-791 and resnet.py:202-218.
+PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                           int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                           int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s) {
+    if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    IGemm g = {};
+    g.A = x; g.B = w; g.C = y; g.bias = bias;
+    g.M = N * OH * OW; g.N = Cout; g.K = KH * KW * Cin; g.Cin = Cin; g.lda = ldx; g.ldb = KH * KW * Cin; g.ldc = ldy;
+    g.H = H; g.W = W; g.QH = OH; g.QW = OW; g.sy = stride; g.sx = stride;
+    conv_taps(g, KH, KW, pad, 1);
+    g.plain_in = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
+    g.plain_out = 1; g.act = act;
+    return launch_igemm(g, s);
+}
+
+// Conv2d backward-data: dx[N,H,W,Cin] from dy[N,OH,OW,Cout] and wT = [Cin][KH][KW][Cout]
+// (pdf_transpose_atb of the forward weight).  One launch per input-parity class so a stride-s conv
+// never multiplies zeros.  dx must be zero-filled by the caller when stride > kernel (1x1 s2).
+PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* wT, float* dx,
+                                int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
+    if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            IGemm g = {};
+            g.A = dy; g.B = wT; g.C = dx; g.bias = nullptr;
+            g.N = Cin; g.Cin = Cout; g.lda = lddy; g.ldb = KH * KW * Cout; g.ldc = lddx;
+            g.H = OH; g.W = OW;
+            g.QH = (H - py + stride - 1) / stride; g.QW = (W - px + stride - 1) / stride;
+            if (g.QH <= 0 || g.QW <= 0) continue;
+            g.M = N * g.QH * g.QW;
+            g.sy = 1; g.sx = 1;
+            // input row iy = qy*stride + py; contributing taps: (iy + pad - ky) % stride == 0, oy = (iy+pad-ky)/stride
+            int T = 0;
+            for (int ky = 0; ky < KH; ++ky) {
+                if ((py + pad - ky) % stride != 0) continue;
+                for (int kx = 0; kx < KW; ++kx) {
+                    if ((px + pad - kx) % stride != 0) continue;
+                    // oy = qy + (py + pad - ky)/stride  (exact division, may be negative)
+                    int ny = py + pad - ky, nx = px + pad - kx;
+                    g.dy[T] = (short)(ny >= 0 ? ny / stride : -((-ny) / stride));
+                    g.dx[T] = (short)(nx >= 0 ? nx / stride : -((-nx) / stride));
+                    g.wt[T] = (short)(ky * KW + kx);
+                    ++T;
+                }
+            }
+            if (T == 0) continue;
+            g.T = T; g.K = T * Cout;
+            g.plain_in = 0; g.plain_out = 0;
+            g.OH = H; g.OW = W; g.osy = stride; g.osx = stride; g.ooy = py; g.oox = px;
+            if (stride == 1) { g.plain_out = 1; if (KH == 1 && KW == 1 && pad == 0) g.plain_in = 1; }
+            int rc = launch_igemm(g, s);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int accumulate, hipStream_t s) {
+    const int NJ = g.T * g.Cq;
+    if (g.M <= 0 || g.NI <= 0 || NJ <= 0) return 0;
+    const bool fast = (g.NI % 4 == 0) && (g.Cq % 4 == 0) && (g.ldp % 4 == 0) && (g.ldq % 4 == 0) &&
+                      aligned16(g.P) && aligned16(g.Q);
+    const bool small = (g.NI <= 64 || NJ <= 64);
+    const int BI = small ? 64 : 128, BJ = small ? 64 : 128;
+    long tiles = (long)cdiv(g.NI, BI) * cdiv(NJ, BJ);
+    int splits = (int)((1024 + tiles - 1) / tiles);
+    int max_by_rows = cdiv(g.M, 512);
+    if (splits > max_by_rows) splits = max_by_rows;
+    long per = (long)g.NI * g.ldw;
+    if ((long)splits * per > ws_floats) splits = (int)(ws_floats / per);
+    if (splits < 1) return PDF_E_WORKSPACE;
+    int rps = cdiv(cdiv(g.M, splits), 16) * 16;
+    splits = cdiv(g.M, rps);
+    g.rows_per_split = rps;
+    g.slab = ws;
+    dim3 grid((unsigned)tiles, (unsigned)splits);
+    if (small) {
+        if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);
+    } else {
+        if (fast) hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, false>), grid, dim3(256), 0, s, g);
+    }
+    PDF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_slabs, dim3(grid_for(per)), dim3(256), 0, s, ws, out, per, splits, accumulate);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Workspace (floats) the weight-gradient entry points need at most for an [NI][NJ] gradient over M rows.
+PDF_API long pdf_wgrad_workspace_floats(int M, int NI, int NJ) {
+    const bool small = (NI <= 64 || NJ <= 64);
+    const int B = small ? 64 : 128;
+    long tiles = (long)cdiv(NI, B) * cdiv(NJ, B);
+    int splits = (int)((1024 + tiles - 1) / tiles);
+    int max_by_rows = cdiv(M, 512);
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
+    return (long)splits * NI * NJ;
+}
+
+// dW[N][K] (+)= dy[M][N]^T x[M][K]   (Linear / 1x1 weight gradient)
+PDF_API int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+                                  int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) {
+    WGemm g = {};
+    g.P = dy; g.Q = x; g.M = M; g.NI = N; g.Cq = K; g.T = 1; g.ldp = lddy; g.ldq = ldx; g.ldw = K;
+    g.plain_q = 1; g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
+    g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
+    return launch_wgemm(g, dw, ws, ws_floats, accumulate, s);
+}
+
+// dW[Cout][KH][KW][Cin] (+)= sum over output pixels dy[m][co] * x[pos(m,tap)][ci]
+PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+                                  int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                                  int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
+    if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    WGemm g = {};
+    g.P = dy; g.Q = x; g.M = N * OH * OW; g.NI = Cout; g.Cq = Cin; g.T = KH * KW;
+    g.ldp = lddy; g.ldq = ldx; g.ldw = KH * KW * Cin;
+    g.H = H; g.W = W; g.QH = OH; g.QW = OW; g.sy = stride; g.sx = stride;
+    g.plain_q = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+            int t = ky * KW + kx;
+            g.dy[t] = (short)(ky - pad); g.dx[t] = (short)(kx - pad); g.wt[t] = (short)t;
+        }
+    return launch_wgemm(g, dw, ws, ws_floats, accumulate, s);
+}
+
+// ConvTranspose2d forward on NHWC: y[n, iy*s - pad + ky, ix*s - pad + kx, co] += x[n,iy,ix,ci] w[ci][co][ky][kx].
+// wP = [Cout][KH][KW][Cin] repack of the weight (pdf_transpose_atb of its [Cin][KH][KW][Cout] storage).
+// kernel == stride (p4/p5, intaghand_encoder.py:604-605): ONE plain GEMM + pixel-shuffle epilogue;
+// otherwise (p3: k4 s2 p1, :603) one launch per output-parity class.
+PDF_API int pdf_deconv2d_fwd(const float* x, const float* wP, const float* bias, float* y,
+                             int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                             int stride, int pad, int OH, int OW, int ldy, hipStream_t s) {
+    if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    if (KH == stride && KW == stride && pad == 0) {
+        IGemm g = {};
+        g.A = x; g.B = wP; g.C = y; g.bias = bias;
+        g.M = N * H * W; g.N = KH * KW * Cout; g.K = Cin; g.Cin = Cin; g.lda = ldx; g.ldc = ldy;
+        // B rows: n = (tap, co) -> wP[co][tap][ci]: not a uniform row stride, so B is addressed as
+        // [tap*Cout + co] rows of a [KH*KW][Cout][Cin] repack -- caller passes that layout (see host).
+        g.ldb = Cin;
+        g.T = 1; g.plain_in = 1; g.plain_out = 0; g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
+        g.H = H; g.W = W; g.QH = H; g.QW = W; g.sy = 1; g.sx = 1;
+        g.OH = OH; g.OW = OW; g.osy = stride; g.osx = stride; g.ooy = 0; g.oox = 0;
+        g.ps_cout = Cout; g.ps_kw = KW;
+        return launch_igemm(g, s);
+    }
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            IGemm g = {};
+            g.A = x; g.B = wP; g.C = y; g.bias = bias;
+            g.N = Cout; g.Cin = Cin; g.lda = ldx; g.ldb = KH * KW * Cin; g.ldc = ldy;
+            g.H = H; g.W = W;
+            g.QH = (OH - py + stride - 1) / stride; g.QW = (OW - px + stride - 1) / stride;
+            if (g.QH <= 0 || g.QW <= 0) continue;
+            g.M = N * g.QH * g.QW;
+            g.sy = 1; g.sx = 1;
+            int T = 0;
+            for (int ky = 0; ky < KH; ++ky) {
+                if ((py + pad - ky) % stride != 0) continue;
+                for (int kx = 0; kx < KW; ++kx) {
+                    if ((px + pad - kx) % stride != 0) continue;
+                    int ny = py + pad - ky, nx = px + pad - kx;      // iy = qy + ny/stride
+                    g.dy[T] = (short)(ny >= 0 ? ny / stride : -((-ny) / stride));
+                    g.dx[T] = (short)(nx >= 0 ? nx / stride : -((-nx) / stride));
+                    g.wt[T] = (short)(ky * KW + kx);
+                    ++T;
+                }
+            }
+            if (T == 0) return PDF_E_BADARG;      // would need a bias-only fill; not used by PDFNet
+            g.T = T; g.K = T * Cin;
+            g.plain_in = 0; g.plain_out = 0;
+            g.OH = OH; g.OW = OW; g.osy = stride; g.osx = stride; g.ooy = py; g.oox = px;
+            int rc = launch_igemm(g, s);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+// ConvTranspose2d backward-data: dx[n,iy,ix,ci] = sum dy[n, iy*s-pad+ky, ix*s-pad+kx, co] w[ci][ky][kx][co]
+// -- a plain strided conv over dy with the weight in its natural [Cin][KH][KW][Cout] storage.
+PDF_API int pdf_deconv2d_bwd_data(const float* dy, const float* w, float* dx,
+                                  int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                  int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
+    if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    IGemm g = {};
+    g.A = dy; g.B = w; g.C = dx; g.bias = nullptr;
+    g.M = N * H * W; g.N = Cin; g.K = KH * KW * Cout; g.Cin = Cout; g.lda = lddy; g.ldb = KH * KW * Cout; g.ldc = lddx;
+    g.H = OH; g.W = OW; g.QH = H; g.QW = W; g.sy = stride; g.sx = stride;
+    conv_taps(g, KH, KW, pad, 1);
+    g.plain_in = 0; g.plain_out = 1;
+    return launch_igemm(g, s);
+}
+
+// ConvTranspose2d weight gradient in the natural [Cin][KH][KW][Cout] storage.
+PDF_API int pdf_deconv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+                                    int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                                    int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
+    if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    WGemm g = {};
+    g.P = x; g.Q = dy; g.M = N * H * W; g.NI = Cin; g.Cq = Cout; g.T = KH * KW;
+    g.ldp = ldx; g.ldq = lddy; g.ldw = KH * KW * Cout;
+    g.H = OH; g.W = OW; g.QH = H; g.QW = W; g.sy = stride; g.sx = stride; g.plain_q = 0;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+            int t = ky * KW + kx;
+            g.dy[t] = (short)(ky - pad); g.dx[t] = (short)(kx - pad); g.wt[t] = (short)t;
+        }
+    return launch_wgemm(g, dw, ws, ws_floats, accumulate, s);
+}
+
+PDF_API int pdf_transpose_atb(const float* in, float* out, int A, int T, int B, hipStream_t s) {
+    if (A <= 0 || T <= 0 || B <= 0) return 0;
+    dim3 grid(cdiv(B, 32), cdiv(A, 32), T);
+    hipLaunchKernelGGL(transpose_atb, grid, dim3(32, 8), 0, s, in, out, A, T, B);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,397 @@
+// Normalisation kernels on row-major [rows][channels] (NHWC) activations: BatchNorm (train/eval,
+// fused ReLU / residual), LayerNorm, L2Norm.  All HBM-bound: each is a column- or row-reduction plus
+// one streaming pass; channels are the contiguous axis so every access is coalesced.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d / BatchNorm1d over rows.  Statistics are accumulated as shifted sums
+// sum(x - x0), sum((x - x0)^2) (x0 = first row) in fp32 per thread, combined in fp64.
+#define BN_CT 64   // channels per block
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int ldx, int C, long R, long rows_per_chunk,
+                                                         float* __restrict__ part /*[chunks][C][2]*/) {
+    __shared__ float s1[4][BN_CT], s2[4][BN_CT];
+    const int tx = threadIdx.x & (BN_CT - 1), ty = threadIdx.x / BN_CT;
+    const int c = blockIdx.x * BN_CT + tx;
+    const long r0 = blockIdx.y * rows_per_chunk;
+    const long r1 = min(R, r0 + rows_per_chunk);
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+        const float sh = x[c];
+        for (long r = r0 + ty; r < r1; r += 4) {
+            float v = x[r * ldx + c] - sh;
+            a += v; b += v * v;
+        }
+    }
+    s1[ty][tx] = a; s2[ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        a = s1[0][tx] + s1[1][tx] + s1[2][tx] + s1[3][tx];
+        b = s2[0][tx] + s2[1][tx] + s2[2][tx] + s2[3][tx];
+        part[((long)blockIdx.y * C + c) * 2 + 0] = a;
+        part[((long)blockIdx.y * C + c) * 2 + 1] = b;
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int chunks, const float* __restrict__ x, int C, long R,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                   float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < chunks; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    const double n = (double)R;
+    const double dm = a / n;
+    double var = b / n - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const double mean = dm + (double)x[c];
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_rstd[c] = rstd;
+    if (running_mean != nullptr) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        const double unb = R > 1 ? var * n / (n - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+}
+
+__global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                     float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// y = act(scale*x + shift (+ res))
+__global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ res, int ldr,
+                                                           float* __restrict__ y, int ldy, int C, long total, int relu) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        float v = x[r * ldx + c] * scale[c] + shift[c];
+        if (res != nullptr) v += res[r * ldr + c];
+        if (relu) v = fmaxf(v, 0.f);
+        y[r * ldy + c] = v;
+    }
+}
+
+// Training forward.  ws: >= pdf_bn_workspace_floats(C, R) floats.  scale/shift [C] are outputs the
+// caller keeps for backward-free reuse; save_mean/save_rstd [C] feed the backward.
+PDF_API long pdf_bn_workspace_floats(int C, long R) {
+    long chunks = (R + 255) / 256; if (chunks > 512) chunks = 512; if (chunks < 1) chunks = 1;
+    return chunks * C * 2;
+}
+
+PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps,
+                             const float* res, int ldr, int relu, float* y, int ldy,
+                             float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, hipStream_t s) {
+    if (R <= 0 || C <= 0) return 0;
+    long chunks = (R + 255) / 256; if (chunks > 512) chunks = 512; if (chunks < 1) chunks = 1;
+    long rpc = (R + chunks - 1) / chunks;
+    chunks = (R + rpc - 1) / rpc;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws);
+    PDF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, ws, (int)chunks, x, C, R, gamma, beta,
+                       running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+    PDF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+PDF_API int pdf_bn_eval_fwd(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
+                            const float* running_mean, const float* running_var, float eps,
+                            const float* res, int ldr, int relu, float* y, int ldy, float* scale, float* shift, hipStream_t s) {
+    if (R <= 0 || C <= 0) return 0;
+    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, C, gamma, beta, running_mean, running_var, eps, scale, shift);
+    PDF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward partials: sum(g), sum(g * xhat) with g = dy * (y > 0 if relu)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int relu,
+                                                             const float* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, int C, long R, long rows_per_chunk,
+                                                             float* __restrict__ part) {
+    __shared__ float s1[4][BN_CT], s2[4][BN_CT];
+    const int tx = threadIdx.x & (BN_CT - 1), ty = threadIdx.x / BN_CT;
+    const int c = blockIdx.x * BN_CT + tx;
+    const long r0 = blockIdx.y * rows_per_chunk;
+    const long r1 = min(R, r0 + rows_per_chunk);
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+        const float m = mean[c], rs = rstd[c];
+        for (long r = r0 + ty; r < r1; r += 4) {
+            float g = dy[r * lddy + c];
+            if (relu && !(y[r * ldy + c] > 0.f)) g = 0.f;
+            a += g; b += g * (x[r * ldx + c] - m) * rs;
+        }
+    }
+    s1[ty][tx] = a; s2[ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        part[((long)blockIdx.y * C + c) * 2 + 0] = s1[0][tx] + s1[1][tx] + s1[2][tx] + s1[3][tx];
+        part[((long)blockIdx.y * C + c) * 2 + 1] = s2[0][tx] + s2[1][tx] + s2[2][tx] + s2[3][tx];
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, long R, const float* __restrict__ gamma,
+                                       const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                       float* __restrict__ coef /*[3][C]: a, c1, c2*/) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < chunks; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    if (accumulate) { dbeta[c] += (float)a; dgamma[c] += (float)b; }
+    else { dbeta[c] = (float)a; dgamma[c] = (float)b; }
+    coef[c] = gamma[c] * rstd[c];
+    coef[C + c] = (float)(a / (double)R);
+    coef[2 * C + c] = (float)(b / (double)R);
+}
+
+// dx = a * (g - c1 - xhat * c2);  dres = g (optional)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int relu,
+                                                           const float* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ coef, int C, long total,
+                                                           float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddr) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        float g = dy[r * lddy + c];
+        if (relu && !(y[r * ldy + c] > 0.f)) g = 0.f;
+        if (dres != nullptr) dres[r * lddr + c] = g;
+        const float xh = (x[r * ldx + c] - mean[c]) * rstd[c];
+        dx[r * lddx + c] = coef[c] * (g - coef[C + c] - xh * coef[2 * C + c]);
+    }
+}
+
+// ws: pdf_bn_workspace_floats(C,R) + 3*C floats
+PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy, int relu, const float* x, int ldx,
+                             const float* save_mean, const float* save_rstd, const float* gamma, int C, long R,
+                             float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
+                             float* ws, hipStream_t s) {
+    if (R <= 0 || C <= 0) return 0;
+    long chunks = (R + 255) / 256; if (chunks > 512) chunks = 512; if (chunks < 1) chunks = 1;
+    long rpc = (R + chunks - 1) / chunks;
+    chunks = (R + rpc - 1) / rpc;
+    float* coef = ws + pdf_bn_workspace_floats(C, R);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
+                       save_mean, save_rstd, C, R, rpc, ws);
+    PDF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, ws, (int)chunks, C, R, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
+    PDF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef, C, R * C,
+                       dx, lddx, dres, lddr);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// column sums: out[c] (+)= sum_r g[r][c]   (conv / linear bias gradients), optional relu mask by y
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0;
+    for (int k = 0; k < chunks; ++k) a += part[((long)k * C + c) * 2];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)a;
+}
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, int ldg, int C, long R, long rows_per_chunk, float* __restrict__ part) {
+    __shared__ float s1[4][BN_CT];
+    const int tx = threadIdx.x & (BN_CT - 1), ty = threadIdx.x / BN_CT;
+    const int c = blockIdx.x * BN_CT + tx;
+    const long r0 = blockIdx.y * rows_per_chunk;
+    const long r1 = min(R, r0 + rows_per_chunk);
+    float a = 0.f;
+    if (c < C) for (long r = r0 + ty; r < r1; r += 4) a += g[r * ldg + c];
+    s1[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && c < C) part[((long)blockIdx.y * C + c) * 2] = s1[0][tx] + s1[1][tx] + s1[2][tx] + s1[3][tx];
+}
+
+PDF_API int pdf_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s) {
+    if (R <= 0 || C <= 0) return 0;
+    long chunks = (R + 255) / 256; if (chunks > 512) chunks = 512; if (chunks < 1) chunks = 1;
+    long rpc = (R + chunks - 1) / chunks;
+    chunks = (R + rpc - 1) / rpc;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, g, ldg, C, R, rpc, ws);
+    PDF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, ws, (int)chunks, C, out, accumulate);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last axis (F <= 1024), one wave per row (nn.LayerNorm(eps=1e-6) in model_attn/*).
+#define LN_MAXV 16
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, int F, long R, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
+                                                            float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = w0; r < R; r += nw) {
+        float v[LN_MAXV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = lane + 64 * i;
+            v[i] = c < F ? x[r * ldx + c] : 0.f;
+            sum += v[i];
+        }
+        const float mu = wave_sum(sum) / (float)F;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = lane + 64 * i;
+            float d = c < F ? v[i] - mu : 0.f;
+            sq += d * d;
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)F + eps);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = lane + 64 * i;
+            if (c < F) y[r * ldy + c] = (v[i] - mu) * rs * gamma[c] + beta[c];
+        }
+        if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    }
+}
+
+PDF_API int pdf_layernorm_fwd(const float* x, int ldx, int F, long R, const float* gamma, const float* beta, float eps,
+                              float* y, int ldy, float* mean, float* rstd, hipStream_t s) {
+    if (F > 64 * LN_MAXV) return PDF_E_BADARG;
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(R * 64)), dim3(256), 0, s, x, ldx, F, R, gamma, beta, eps, y, ldy, mean, rstd);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma; dgamma += sum dy*xhat; dbeta += sum dy
+// (dgamma/dbeta accumulated with one atomic per channel per block; caller zero-fills or accumulates)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx, int F, long R,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ dx, int lddx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sg[64 * LN_MAXV], sb[64 * LN_MAXV];
+    for (int i = threadIdx.x; i < F; i += 256) { sg[i] = 0.f; sb[i] = 0.f; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    float ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+    for (long r = w0; r < R; r += nw) {
+        const float mu = mean[r], rs = rstd[r];
+        float g[LN_MAXV], xh[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = lane + 64 * i;
+            float d = 0.f, h = 0.f;
+            if (c < F) {
+                d = dy[r * lddy + c];
+                h = (x[r * ldx + c] - mu) * rs;
+                ag[i] += d * h; ab[i] += d;
+                d *= gamma[c];
+            }
+            g[i] = d; xh[i] = h;
+            s1 += d; s2 += d * h;
+        }
+        s1 = wave_sum(s1) / (float)F;
+        s2 = wave_sum(s2) / (float)F;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = lane + 64 * i;
+            if (c < F) dx[r * lddx + c] = rs * (g[i] - s1 - xh[i] * s2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        int c = lane + 64 * i;
+        if (c < F) { atomicAdd(&sg[c], ag[i]); atomicAdd(&sb[c], ab[i]); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < F; i += 256) {
+        if (dgamma != nullptr) atomicAdd(&dgamma[i], sg[i]);
+        if (dbeta != nullptr) atomicAdd(&dbeta[i], sb[i]);
+    }
+}
+
+PDF_API int pdf_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, int F, long R, const float* gamma,
+                              const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, hipStream_t s) {
+    if (F > 64 * LN_MAXV) return PDF_E_BADARG;
+    if (R <= 0) return 0;
+    int grid = grid_for(R * 64, 256, 512);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, F, R, gamma, mean, rstd, dx, lddx, dgamma, dbeta);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2Norm (intaghand_encoder.py:318-334): y = w[c] * x / (sqrt(sum_c x^2) + 1e-10), one wave per pixel.
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int ldx, int C, long R, const float* __restrict__ w,
+                                                         float eps, float* __restrict__ y, int ldy, float* __restrict__ norm) {
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = w0; r < R; r += nw) {
+        float sq = 0.f;
+        for (int c = lane; c < C; c += 64) { float v = x[r * ldx + c]; sq += v * v; }
+        const float n = sqrtf(wave_sum(sq)) + eps;
+        for (int c = lane; c < C; c += 64) y[r * ldy + c] = w[c] * (x[r * ldx + c] / n);
+        if (lane == 0) norm[r] = n;
+    }
+}
+
+PDF_API int pdf_l2norm_fwd(const float* x, int ldx, int C, long R, const float* w, float eps, float* y, int ldy, float* norm, hipStream_t s) {
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid_for(R * 64)), dim3(256), 0, s, x, ldx, C, R, w, eps, y, ldy, norm);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx_j = w_j g_j / n - x_j * (sum_c w_c g_c x_c) / (n^2 * (n - eps));  dw_c += sum_r g_c x_c / n
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx, int C, long R,
+                                                         const float* __restrict__ w, float eps, const float* __restrict__ norm,
+                                                         float* __restrict__ dx, int lddx, float* __restrict__ dw) {
+    extern __shared__ float sw[];
+    for (int i = threadIdx.x; i < C; i += 256) sw[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = w0; r < R; r += nw) {
+        const float n = norm[r];
+        float dot = 0.f;
+        for (int c = lane; c < C; c += 64) dot += w[c] * dy[r * lddy + c] * x[r * ldx + c];
+        dot = wave_sum(dot);
+        const float nn = n - eps;
+        const float k = nn > 0.f ? dot / (n * n * nn) : 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float g = dy[r * lddy + c], xv = x[r * ldx + c];
+            dx[r * lddx + c] = w[c] * g / n - xv * k;
+            atomicAdd(&sw[c], g * xv / n);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&dw[i], sw[i]);
+}
+
+PDF_API int pdf_l2norm_bwd(const float* dy, int lddy, const float* x, int ldx, int C, long R, const float* w, float eps,
+                           const float* norm, float* dx, int lddx, float* dw, hipStream_t s) {
+    if (R <= 0) return 0;
+    int grid = grid_for(R * 64, 256, 512);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid), dim3(256), C * sizeof(float), s, dy, lddy, x, ldx, C, R, w, eps, norm, dx, lddx, dw);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,269 @@
+// PointNet++ set-abstraction data movement for gfx950: kNN(K) + ball mask + grouping in ONE launch,
+// row gathers/scatters on NHWC maps, and the max-over-neighbours pool.  All HBM-bound: coalesced
+// row reads, the cloud staged once per 16 centroids in LDS, wavefront ballots for the selection.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// knn_ball_group: replaces group_points / group_points_2 (reference lib/utils/utils.py:134-188):
+//   centroids = first S points; K smallest squared distances; neighbours with d2 > r2 replaced by the
+//   centroid's own index (utils.py:149-151,176-179); gather all C features, subtract the centre from
+//   channels 0:3 (utils.py:160,186).  Distances use the reference's operation order
+//   ((dx*dx + dy*dy) + dz*dz) with no fma contraction so the selected index SETS are bit-exact.
+// One wave per centroid: each lane keeps N/64 keys in registers; the K-th smallest key is found by a
+// 31-step bitwise search with wave-wide counts (no sort, no [S][N] distance matrix in memory).
+template <int NPL>   // points per lane = N / 64
+__global__ __launch_bounds__(256) void knn_ball_group_kernel(
+    const float* __restrict__ pts, int ldp, int C, int N, int S, int K, float r2,
+    int* __restrict__ idx_out, float* __restrict__ grouped, int ldg) {
+    extern __shared__ float smem[];
+    float* sx = smem;            // [N]
+    float* sy = sx + N;
+    float* sz = sy + N;
+    int* sidx = reinterpret_cast<int*>(sz + N);   // [4 waves][K]
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* cloud = pts + (long)b * N * ldp;
+    for (int j = tid; j < N; j += 256) {
+        sx[j] = cloud[(long)j * ldp + 0];
+        sy[j] = cloud[(long)j * ldp + 1];
+        sz[j] = cloud[(long)j * ldp + 2];
+    }
+    __syncthreads();
+    int* widx = sidx + wave * K;
+    const uint32_t r2bits = __float_as_uint(r2);
+    for (int cc = 0; cc < 4; ++cc) {
+        const int s = blockIdx.x * 16 + wave * 4 + cc;      // wave-uniform
+        if (s >= S) break;
+        const float cx = sx[s], cy = sy[s], cz = sz[s];
+        uint32_t key[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            int j = lane + 64 * i;
+            float dx = __fsub_rn(sx[j], cx), dy = __fsub_rn(sy[j], cy), dz = __fsub_rn(sz[j], cz);
+            float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            key[i] = __float_as_uint(d);                    // d >= 0: uint order == float order
+        }
+        uint32_t thr = 0;
+        for (int bit = 30; bit >= 0; --bit) {
+            uint32_t cand = thr | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) c += key[i] < cand ? 1 : 0;
+            c = wave_sum_i(c);
+            if (c < K) thr = cand;                          // K-th smallest key is >= cand
+        }
+        // compaction: everything below the threshold, then ties in increasing point index
+        int base = 0;
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            bool sel = key[i] < thr;
+            unsigned long long m = __ballot(sel);
+            if (sel) {
+                int pos = base + __popcll(m & lt_mask);
+                widx[pos] = key[i] > r2bits ? s : lane + 64 * i;
+            }
+            base += __popcll(m);
+        }
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            bool sel = key[i] == thr;
+            unsigned long long m = __ballot(sel);
+            if (sel) {
+                int pos = base + __popcll(m & lt_mask);
+                if (pos < K) widx[pos] = key[i] > r2bits ? s : lane + 64 * i;
+            }
+            base += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // NB: widx is wave-private LDS; LDS ops of one wave complete in order
+        const long orow = ((long)b * S + s) * K;
+        for (int k = lane; k < K; k += 64) idx_out[orow + k] = widx[k];
+        if (grouped != nullptr) {
+            if (ldg <= 16) {
+                // few channels: one neighbour per lane, whole padded row from one lane
+                for (int k = lane; k < K; k += 64) {
+                    int j = widx[k];
+                    float* o = grouped + (orow + k) * ldg;
+                    const float* p = cloud + (long)j * ldp;
+                    for (int c = 0; c < ldg; ++c) {
+                        float v = 0.f;
+                        if (c < C) v = p[c];
+                        if (c == 0) v = __fsub_rn(v, cx); else if (c == 1) v = __fsub_rn(v, cy); else if (c == 2) v = __fsub_rn(v, cz);
+                        if (c >= C) v = 0.f;
+                        o[c] = v;
+                    }
+                }
+            } else {
+                for (int k = 0; k < K; ++k) {
+                    int j = widx[k];
+                    const float* p = cloud + (long)j * ldp;
+                    float* o = grouped + (orow + k) * ldg;
+                    for (int c = lane; c < ldg; c += 64) {
+                        float v = c < C ? p[c] : 0.f;
+                        if (c == 0) v = __fsub_rn(v, cx); else if (c == 1) v = __fsub_rn(v, cy); else if (c == 2) v = __fsub_rn(v, cz);
+                        o[c] = v;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+PDF_API int pdf_knn_ball_group(const float* pts, int ldp, int C, int Bc, int N, int S, int K, float r2,
+                               int* idx, float* grouped, int ldg, hipStream_t s) {
+    if (N % 64 != 0 || N > 1024 || K > N || K < 1 || S > N || C < 3 || ldp < C || (grouped && ldg < C)) return PDF_E_BADARG;
+    dim3 grid(cdiv(S, 16), Bc);
+    size_t smem = (size_t)3 * N * sizeof(float) + (size_t)4 * K * sizeof(int);
+#define KNN_CASE(NPL_) case NPL_: hipLaunchKernelGGL(knn_ball_group_kernel<NPL_>, grid, dim3(256), smem, s, pts, ldp, C, N, S, K, r2, idx, grouped, ldg); break;
+    switch (N / 64) {
+        KNN_CASE(1) KNN_CASE(2) KNN_CASE(4) KNN_CASE(8) KNN_CASE(16)
+        default: return PDF_E_BADARG;
+    }
+#undef KNN_CASE
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of the grouping gather: dpts (zero-filled by caller) [Bc][N][ldd]
+//   dpts[b][idx[b,s,k]][c] += dg[b,s,k,c];  dpts[b][s][c<3] -= sum_k dg[b,s,k,c]
+__global__ __launch_bounds__(256) void group_bwd_kernel(const float* __restrict__ dg, int ldg, const int* __restrict__ idx,
+                                                        float* __restrict__ dpts, int ldd, int C, int N, int S, int K, long total_rows) {
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long row = w0; row < total_rows; row += nw) {       // row = b*S + s
+        const long b = row / S;
+        const int s = (int)(row - b * S);
+        float* base = dpts + b * N * ldd;
+        float csum = 0.f;                                    // lanes 0..2: centre gradient
+        for (int k = 0; k < K; ++k) {
+            const int j = idx[row * K + k];
+            const float* g = dg + (row * K + k) * ldg;
+            for (int c = lane; c < C; c += 64) {
+                float v = g[c];
+                atomicAdd(base + (long)j * ldd + c, v);
+                if (c < 3) csum += v;
+            }
+        }
+        if (lane < 3) atomicAdd(base + (long)s * ldd + lane, -csum);
+    }
+}
+
+PDF_API int pdf_group_bwd(const float* dg, int ldg, const int* idx, float* dpts, int ldd, int C,
+                          int Bc, int N, int S, int K, hipStream_t s) {
+    long rows = (long)Bc * S;
+    hipLaunchKernelGGL(group_bwd_kernel, dim3(grid_for(rows * 64)), dim3(256), 0, s, dg, ldg, idx, dpts, ldd, C, N, S, K, rows);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather_rows: replaces _tranpose_and_gather_feat (lib/models/utils.py:22-26) without the full-map
+// permute: feat is already NHWC, so a gathered pixel is one contiguous row.
+// shift > 0 applies the pyramid index math of intaghand_encoder.py:125-126:
+//   ind' = (ind / R >> shift) * (R >> shift) + (ind % R >> shift)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ feat, int ldf, int C, long HW,
+                                                          const long* __restrict__ ind, long ind_bstride, int M, int R, int shift,
+                                                          float* __restrict__ out, int ldo, long total) {
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = w0; r < total; r += nw) {                  // r = b*M + m
+        const long b = r / M;
+        long i = ind[b * ind_bstride + (r - b * M)];
+        if (shift > 0) {
+            long y = i / R, x = i - y * R;
+            i = (y >> shift) * (R >> shift) + (x >> shift);
+        }
+        const float* p = feat + (b * HW + i) * ldf;
+        float* o = out + r * ldo;
+        for (int c = lane; c < ldo; c += 64) o[c] = c < C ? p[c] : 0.f;
+    }
+}
+
+PDF_API int pdf_gather_rows(const float* feat, int ldf, int C, long HW, const long* ind, long ind_bstride,
+                            int B, int M, int R, int shift, float* out, int ldo, hipStream_t s) {
+    long total = (long)B * M;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total * 64)), dim3(256), 0, s, feat, ldf, C, HW, ind, ind_bstride, M, R, shift, out, ldo, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// dfeat (zero-filled by caller) [B][HW][ldf] += rows of dout
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dout, int ldo, int C, long HW,
+                                                           const long* __restrict__ ind, long ind_bstride, int M, int R, int shift,
+                                                           float* __restrict__ dfeat, int ldf, long total) {
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = w0; r < total; r += nw) {
+        const long b = r / M;
+        long i = ind[b * ind_bstride + (r - b * M)];
+        if (shift > 0) {
+            long y = i / R, x = i - y * R;
+            i = (y >> shift) * (R >> shift) + (x >> shift);
+        }
+        float* p = dfeat + (b * HW + i) * ldf;
+        const float* o = dout + r * ldo;
+        for (int c = lane; c < C; c += 64) atomicAdd(p + c, o[c]);
+    }
+}
+
+PDF_API int pdf_scatter_rows_add(const float* dout, int ldo, int C, long HW, const long* ind, long ind_bstride,
+                                 int B, int M, int R, int shift, float* dfeat, int ldf, hipStream_t s) {
+    long total = (long)B * M;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(total * 64)), dim3(256), 0, s, dout, ldo, C, HW, ind, ind_bstride, M, R, shift, dfeat, ldf, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// max over the K axis of [R][K][ld] rows (nn.MaxPool2d((1,K)) / ((S2,1)), intaghand_encoder.py:62,82,100)
+__global__ __launch_bounds__(256) void maxk_fwd_kernel(const float* __restrict__ x, int ldx, int C, int K,
+                                                       float* __restrict__ y, int ldy, int* __restrict__ arg, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        const float* p = x + r * K * ldx + c;
+        float best = p[0];
+        int bi = 0;
+        for (int k = 1; k < K; ++k) {
+            float v = p[(long)k * ldx];
+            if (v > best) { best = v; bi = k; }
+        }
+        y[r * ldy + c] = best;
+        arg[r * C + c] = bi;
+    }
+}
+
+PDF_API int pdf_maxk_fwd(const float* x, int ldx, int C, long R, int K, float* y, int ldy, int* arg, hipStream_t s) {
+    long total = R * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(maxk_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, ldx, C, K, y, ldy, arg, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx[r][k][c] = (k == arg[r][c]) ? dy[r][c] : 0   (writes every element of dx's C columns)
+__global__ __launch_bounds__(256) void maxk_bwd_kernel(const float* __restrict__ dy, int ldy, const int* __restrict__ arg,
+                                                       int C, int K, float* __restrict__ dx, int ldx, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long rk = i / C;
+        const int c = (int)(i - rk * C);
+        const long r = rk / K;
+        const int k = (int)(rk - r * K);
+        dx[rk * ldx + c] = (arg[r * C + c] == k) ? dy[r * ldy + c] : 0.f;
+    }
+}
+
+PDF_API int pdf_maxk_bwd(const float* dy, int ldy, const int* arg, int C, long R, int K, float* dx, int ldx, hipStream_t s) {
+    long total = R * K * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(maxk_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, ldy, arg, C, K, dx, ldx, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}

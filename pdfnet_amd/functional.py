@@ -1,0 +1,640 @@
+"""Autograd shells around the C-ABI kernels (libpdfnet_hip.so).  PyTorch here is plumbing only:
+device memory, the current stream and the autograd tape; every computation below is a HIP kernel.
+
+Activation layout: 4-D maps are logical NCHW tensors in torch.channels_last memory (physically NHWC,
+rows = pixels, channels contiguous); everything else is row-major [..., channels].
+"""
+import torch
+from torch.autograd import Function
+
+from . import hip
+from .hip import ptr, stream
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+CL = torch.channels_last
+
+
+def _L():
+    return hip.lib()
+
+
+def cl(x):
+    """4-D tensor -> channels_last-contiguous (no copy if it already is)."""
+    return x.contiguous(memory_format=CL)
+
+
+def _rows(x):
+    """(R, C) of a row-major / channels_last tensor."""
+    if x.dim() == 4:
+        return x.shape[0] * x.shape[2] * x.shape[3], x.shape[1]
+    return x.numel() // x.shape[-1], x.shape[-1]
+
+
+def _canon(x):
+    return cl(x) if x.dim() == 4 else x.contiguous()
+
+
+def _zeros_cl(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev, memory_format=CL).zero_()
+
+
+def _ws(nfloats, dev):
+    return torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=dev)
+
+
+def _wgrad_ws(M, NI, NJ, dev):
+    n = _L().pdf_wgrad_workspace_floats(M, NI, NJ)
+    return _ws(n, dev), n
+
+
+def _colsum(g, C, R, ldg):
+    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    ws = _ws(_L().pdf_bn_workspace_floats(C, R), g.device)
+    _L().pdf_colsum(ptr(g), ldg, C, R, ptr(out), 0, ptr(ws), stream())
+    return out
+
+
+def _act_bwd(dy, y, act):
+    R, C = _rows(y)
+    g = torch.empty_like(y)
+    _L().pdf_act_bwd(ptr(dy), C, ptr(y), C, ptr(g), C, C, R, act, stream())
+    return g
+
+
+# ----------------------------------------------------------------------------------------------
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act):
+        hip.require_gpu(x, w)
+        x, w = cl(x), cl(w)
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = w.shape
+        OH = (H + 2 * pad - KH) // stride + 1
+        OW = (W + 2 * pad - KW) // stride + 1
+        y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
+        _L().pdf_conv2d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream())
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.cfg = (stride, pad, act, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, has_b = ctx.cfg
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = w.shape
+        OH, OW = dy.shape[2], dy.shape[3]
+        g = cl(dy)
+        if act:
+            g = _act_bwd(g, y, act)
+        dx = dw = db = None
+        L = _L()
+        if ctx.needs_input_grad[0]:
+            wT = torch.empty(Cin * KH * KW * Cout, dtype=torch.float32, device=x.device)
+            L.pdf_transpose_atb(ptr(w), ptr(wT), Cout, KH * KW, Cin, stream())
+            if stride > KH:
+                dx = torch.zeros_like(x)
+            else:
+                dx = torch.empty_like(x)
+            L.pdf_conv2d_bwd_data(ptr(g), ptr(wT), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws, n = _wgrad_ws(N * OH * OW, Cout, KH * KW * Cin, x.device)
+            L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(dw), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, 0, stream())
+        if has_b and ctx.needs_input_grad[2]:
+            db = _colsum(g, Cout, N * OH * OW, Cout)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE):
+    return _Conv2d.apply(x, w, b, stride, pad, act)
+
+
+class _Deconv2d(Function):
+    """nn.ConvTranspose2d; w logical [Cin, Cout, KH, KW] in channels_last storage."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad):
+        hip.require_gpu(x, w)
+        x, w = cl(x), cl(w)
+        N, Cin, H, W = x.shape
+        _, Cout, KH, KW = w.shape
+        OH = (H - 1) * stride - 2 * pad + KH
+        OW = (W - 1) * stride - 2 * pad + KW
+        L = _L()
+        wP = torch.empty(w.numel(), dtype=torch.float32, device=x.device)
+        if KH == stride and KW == stride and pad == 0:
+            L.pdf_transpose_atb(ptr(w), ptr(wP), Cin, 1, KH * KW * Cout, stream())
+        else:
+            L.pdf_transpose_atb(ptr(w), ptr(wP), Cin, KH * KW, Cout, stream())
+        y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
+        L.pdf_deconv2d_fwd(ptr(x), ptr(wP), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_b = ctx.cfg
+        N, Cin, H, W = x.shape
+        _, Cout, KH, KW = w.shape
+        OH, OW = dy.shape[2], dy.shape[3]
+        g = cl(dy)
+        L = _L()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.pdf_deconv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
+            L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(dw), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, 0, stream())
+        if has_b and ctx.needs_input_grad[2]:
+            db = _colsum(g, Cout, N * OH * OW, Cout)
+        return dx, dw, db, None, None
+
+
+def deconv2d(x, w, b=None, stride=1, pad=0):
+    return _Deconv2d.apply(x, w, b, stride, pad)
+
+
+class _Linear(Function):
+    """y[..., N] = act(x[..., K] w[N, K]^T + b)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        hip.require_gpu(x, w)
+        x, w = x.contiguous(), w.contiguous()
+        K = x.shape[-1]
+        M = x.numel() // K
+        Nn = w.shape[0]
+        y = torch.empty(x.shape[:-1] + (Nn,), dtype=torch.float32, device=x.device)
+        _L().pdf_linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), M, Nn, K, K, K, Nn, act, stream())
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.cfg = (act, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        act, has_b = ctx.cfg
+        K = x.shape[-1]
+        M = x.numel() // K
+        Nn = w.shape[0]
+        g = dy.contiguous()
+        if act:
+            g = _act_bwd(g, y, act)
+        L = _L()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wT = torch.empty(K * Nn, dtype=torch.float32, device=x.device)
+            L.pdf_transpose_atb(ptr(w), ptr(wT), Nn, 1, K, stream())
+            dx = torch.empty_like(x)
+            L.pdf_linear_fwd(ptr(g), ptr(wT), None, ptr(dx), M, K, Nn, Nn, Nn, K, 0, stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws, n = _wgrad_ws(M, Nn, K, x.device)
+            L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(dw), ptr(ws), n, M, Nn, K, K, Nn, 0, stream())
+        if has_b and ctx.needs_input_grad[2]:
+            db = _colsum(g, Nn, M, Nn)
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, act=ACT_NONE):
+    return _Linear.apply(x, w, b, act)
+
+
+# ----------------------------------------------------------------------------------------------
+class _BatchNorm(Function):
+    """y = [relu]( BN(x) [+ res] ) over rows; x 4-D channels_last or [..., C]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, res, training, momentum, eps, relu):
+        hip.require_gpu(x)
+        x = _canon(x)
+        res = _canon(res) if res is not None else None
+        R, C = _rows(x)
+        y = torch.empty_like(x)
+        dev = x.device
+        scale = torch.empty(C, device=dev)
+        shift = torch.empty(C, device=dev)
+        L = _L()
+        if training:
+            mean = torch.empty(C, device=dev)
+            rstd = torch.empty(C, device=dev)
+            ws = _ws(L.pdf_bn_workspace_floats(C, R), dev)
+            L.pdf_bn_train_fwd(ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
+                               ptr(res), C, int(relu), ptr(y), C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
+            ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
+        else:
+            L.pdf_bn_eval_fwd(ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps,
+                              ptr(res), C, int(relu), ptr(y), C, ptr(scale), ptr(shift), stream())
+            ctx.save_for_backward(x, gamma, None, None, y if relu else None)
+        ctx.cfg = (training, relu, res is not None, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        training, relu, has_res, eps = ctx.cfg
+        if not training:
+            raise RuntimeError("pdfnet_amd: BatchNorm backward in eval mode is not implemented")
+        R, C = _rows(x)
+        g = _canon(dy)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dgamma = torch.empty(C, device=x.device)
+        dbeta = torch.empty(C, device=x.device)
+        L = _L()
+        ws = _ws(L.pdf_bn_workspace_floats(C, R) + 3 * C, x.device)
+        L.pdf_bn_train_bwd(ptr(g), C, ptr(y), C, int(relu), ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), C, R,
+                           ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), 0, ptr(ws), stream())
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False, res=None):
+    return _BatchNorm.apply(x, gamma, beta, rmean, rvar, res, training, momentum, eps, relu)
+
+
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        hip.require_gpu(x)
+        x = _canon(x)
+        R, C = _rows(x)
+        y = torch.empty_like(x)
+        _L().pdf_act_fwd(ptr(x), C, ptr(y), C, C, R, act, stream())
+        ctx.save_for_backward(y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return _act_bwd(_canon(dy), y, ctx.act), None
+
+
+def relu(x):
+    return _Act.apply(x, ACT_RELU)
+
+
+class _MaxPool3s2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = cl(x)
+        N, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, OH, OW), device=x.device, memory_format=CL)
+        arg = torch.empty(y.numel(), dtype=torch.uint8, device=x.device)
+        _L().pdf_maxpool3s2_fwd(ptr(x), N, H, W, C, ptr(y), ptr(arg), stream())
+        ctx.save_for_backward(arg)
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        dx = _zeros_cl((N, C, H, W), dy.device)
+        _L().pdf_maxpool3s2_bwd(ptr(cl(dy)), ptr(arg), N, H, W, C, ptr(dx), stream())
+        return dx
+
+
+def maxpool3s2(x):
+    return _MaxPool3s2.apply(x)
+
+
+class _Up2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = cl(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, 2 * H, 2 * W), device=x.device, memory_format=CL)
+        _L().pdf_upsample2x_fwd(ptr(x), N, H, W, C, ptr(y), stream())
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = ctx.shape
+        dx = _zeros_cl((N, C, H, W), dy.device)
+        _L().pdf_upsample2x_bwd(ptr(cl(dy)), N, H, W, C, ptr(dx), stream())
+        return dx
+
+
+def upsample2x(x):
+    return _Up2.apply(x)
+
+
+class _L2Norm(Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        x = cl(x)
+        R, C = _rows(x)
+        y = torch.empty_like(x)
+        norm = torch.empty(R, device=x.device)
+        _L().pdf_l2norm_fwd(ptr(x), C, C, R, ptr(w), eps, ptr(y), C, ptr(norm), stream())
+        ctx.save_for_backward(x, w, norm)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, norm = ctx.saved_tensors
+        R, C = _rows(x)
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        _L().pdf_l2norm_bwd(ptr(cl(dy)), C, ptr(x), C, C, R, ptr(w), ctx.eps, ptr(norm), ptr(dx), C, ptr(dw), stream())
+        return dx, dw, None
+
+
+def l2norm(x, w, eps=1e-10):
+    return _L2Norm.apply(x, w, eps)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        hip.require_gpu(x)
+        x = x.contiguous()
+        R, Fd = _rows(x)
+        y = torch.empty_like(x)
+        mean = torch.empty(R, device=x.device)
+        rstd = torch.empty(R, device=x.device)
+        _L().pdf_layernorm_fwd(ptr(x), Fd, Fd, R, ptr(gamma), ptr(beta), eps, ptr(y), Fd, ptr(mean), ptr(rstd), stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        R, Fd = _rows(x)
+        dx = torch.empty_like(x)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        _L().pdf_layernorm_bwd(ptr(dy.contiguous()), Fd, ptr(x), Fd, Fd, R, ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), Fd, ptr(dg), ptr(db), stream())
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _L().pdf_dropout(ptr(x), ptr(y), x.numel(), p, seed, stream())
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _L().pdf_dropout(ptr(dy), ptr(dx), dy.numel(), p, seed, stream())
+        return dx, None, None
+
+
+_seed_state = [0x5DEECE66D]
+
+
+def next_seed():
+    """Host-side counter; each dropout site of each step gets a distinct mask stream."""
+    _seed_state[0] = (_seed_state[0] * 6364136223846793005 + 1442695040888963407) & ((1 << 63) - 1)
+    return _seed_state[0]
+
+
+def manual_seed(s):
+    _seed_state[0] = (int(s) * 2654435761 + 12345) & ((1 << 63) - 1)
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, float(p), next_seed())
+
+
+# ----------------------------------------------------------------------------------------------
+class _SFTModulate(Function):
+    """fea * (scale + 1) + shift   on [..., C] rows."""
+
+    @staticmethod
+    def forward(ctx, fea, scale, shift):
+        fea, scale, shift = fea.contiguous(), scale.contiguous(), shift.contiguous()
+        R, C = _rows(fea)
+        out = torch.empty_like(fea)
+        _L().pdf_sft_fwd(ptr(fea), C, ptr(scale), C, ptr(shift), C, ptr(out), C, C, R, stream())
+        ctx.save_for_backward(fea, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fea, scale = ctx.saved_tensors
+        g = g.contiguous()
+        R, C = _rows(fea)
+        dfea = torch.empty_like(fea)
+        dscale = torch.empty_like(fea)
+        _L().pdf_sft_bwd(ptr(g), C, ptr(fea), C, ptr(scale), C, ptr(dfea), C, ptr(dscale), C, C, R, stream())
+        return dfea, dscale, g
+
+
+def sft_modulate(fea, scale, shift):
+    return _SFTModulate.apply(fea, scale, shift)
+
+
+class _GatherRows(Function):
+    """feat 4-D channels_last [B,C,H,W]; ind int64 [B,M] -> [B,M,ldo] (channels >= C zero)."""
+
+    @staticmethod
+    def forward(ctx, feat, ind, R, shift, ldo):
+        hip.require_gpu(feat, ind)
+        feat = cl(feat)
+        B, C, H, W = feat.shape
+        M = ind.shape[1]
+        assert ind.dtype == torch.int64 and ind.stride(1) == 1
+        out = torch.empty((B, M, ldo), device=feat.device)
+        _L().pdf_gather_rows(ptr(feat), C, C, H * W, ptr(ind), ind.stride(0), B, M, R, shift, ptr(out), ldo, stream())
+        ctx.save_for_backward(ind)
+        ctx.cfg = (B, C, H, W, M, R, shift, ldo)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ind,) = ctx.saved_tensors
+        B, C, H, W, M, R, shift, ldo = ctx.cfg
+        dfeat = _zeros_cl((B, C, H, W), g.device)
+        _L().pdf_scatter_rows_add(ptr(g.contiguous()), ldo, C, H * W, ptr(ind), ind.stride(0), B, M, R, shift, ptr(dfeat), C, stream())
+        return dfeat, None, None, None, None
+
+
+def gather_rows(feat, ind, R=1, shift=0, ldo=None):
+    return _GatherRows.apply(feat, ind, R, shift, ldo or feat.shape[1])
+
+
+class _KnnGroup(Function):
+    """pts [Bc,N,ldp] rows (C real channels, xyz first) -> grouped [Bc,S,K,ldg], idx [Bc,S,K] int32."""
+
+    @staticmethod
+    def forward(ctx, pts, C, S, K, r2, ldg):
+        hip.require_gpu(pts)
+        pts = pts.contiguous()
+        Bc, N, ldp = pts.shape
+        idx = torch.empty((Bc, S, K), dtype=torch.int32, device=pts.device)
+        g = torch.empty((Bc, S, K, ldg), device=pts.device)
+        _L().pdf_knn_ball_group(ptr(pts), ldp, C, Bc, N, S, K, r2, ptr(idx), ptr(g), ldg, stream())
+        ctx.save_for_backward(idx)
+        ctx.cfg = (Bc, N, ldp, C, S, K, ldg)
+        ctx.mark_non_differentiable(idx)
+        return g, idx
+
+    @staticmethod
+    def backward(ctx, dg, _):
+        (idx,) = ctx.saved_tensors
+        Bc, N, ldp, C, S, K, ldg = ctx.cfg
+        dpts = torch.zeros((Bc, N, ldp), device=dg.device)
+        _L().pdf_group_bwd(ptr(dg.contiguous()), ldg, ptr(idx), ptr(dpts), ldp, C, Bc, N, S, K, stream())
+        return dpts, None, None, None, None, None
+
+
+def knn_ball_group(pts, C, S, K, r2, ldg):
+    return _KnnGroup.apply(pts, C, S, K, float(r2), ldg)
+
+
+class _MaxK(Function):
+    """x [R, K, C] -> max over K -> [R, C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        R, K, C = x.shape
+        y = torch.empty((R, C), device=x.device)
+        arg = torch.empty((R, C), dtype=torch.int32, device=x.device)
+        _L().pdf_maxk_fwd(ptr(x), C, C, R, K, ptr(y), C, ptr(arg), stream())
+        ctx.save_for_backward(arg)
+        ctx.cfg = (R, K, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        R, K, C = ctx.cfg
+        dx = torch.empty((R, K, C), device=dy.device)
+        _L().pdf_maxk_bwd(ptr(dy.contiguous()), C, ptr(arg), C, R, K, ptr(dx), C, stream())
+        return dx
+
+
+def max_over_k(x):
+    return _MaxK.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+class _Cheby2(Function):
+    """x [B,V,F] -> [B,V,2F] = interleave(x, L x); ell = (col, val, colT, valT, width)."""
+
+    @staticmethod
+    def forward(ctx, x, col, val, colT, valT):
+        hip.require_gpu(x)
+        x = x.contiguous()
+        B, V, Fd = x.shape
+        Wd = col.shape[1]
+        out = torch.empty((B, V, 2 * Fd), device=x.device)
+        _L().pdf_cheby2_fwd(ptr(x), Fd, B, V, Fd, ptr(col), ptr(val), Wd, ptr(out), 2 * Fd, stream())
+        ctx.save_for_backward(colT, valT)
+        ctx.cfg = (B, V, Fd)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        colT, valT = ctx.saved_tensors
+        B, V, Fd = ctx.cfg
+        dx = torch.empty((B, V, Fd), device=d.device)
+        _L().pdf_cheby2_bwd(ptr(d.contiguous()), 2 * Fd, B, V, Fd, ptr(colT), ptr(valT), colT.shape[1], ptr(dx), Fd, stream())
+        return dx, None, None, None, None
+
+
+def cheby2(x, ell):
+    return _Cheby2.apply(x, *ell)
+
+
+class _Attention(Function):
+    """softmax(q k^T / sqrt(dh)) v, heads = contiguous dh slices of the last axis; q,k,v [B,V,F]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, pdrop, seed):
+        hip.require_gpu(q, k, v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, V, Fd = q.shape
+        dh = Fd // heads
+        out = torch.empty_like(q)
+        stat = torch.empty((B, heads, V, 2), device=q.device)
+        _L().pdf_attn_fwd(ptr(q), ptr(k), ptr(v), Fd, B, V, heads, dh, pdrop, seed, ptr(out), Fd, ptr(stat), stream())
+        ctx.save_for_backward(q, k, v, out, stat)
+        ctx.cfg = (heads, pdrop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, out, stat = ctx.saved_tensors
+        heads, pdrop, seed = ctx.cfg
+        B, V, Fd = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        dvec = torch.empty((B, heads, V), device=q.device)
+        _L().pdf_attn_bwd(ptr(q), ptr(k), ptr(v), Fd, ptr(out), ptr(do.contiguous()), Fd, ptr(stat), B, V, heads, Fd // heads,
+                          pdrop, seed, ptr(dq), ptr(dk), ptr(dv), Fd, ptr(dvec), stream())
+        return dq, dk, dv, None, None, None
+
+
+def attention(q, k, v, heads, pdrop=0.0, training=False):
+    p = float(pdrop) if training else 0.0
+    return _Attention.apply(q, k, v, heads, p, next_seed() if p > 0 else 0)
+
+
+# ----------------------------------------------------------------------------------------------
+def mano_lbs(consts, root_aa, pose_aa, shape, trans=None, side='left', center_idx=None):
+    """ManoLayer.forward (manolayer.py:257-334, use_pca=False). Forward only (the training loss uses
+    the joint regressor, not LBS -- SURVEY.md 0.5)."""
+    hip.require_gpu(root_aa)
+    B = root_aa.shape[0]
+    verts = torch.empty((B, 778, 3), device=root_aa.device)
+    joints = torch.empty((B, 21, 3), device=root_aa.device)
+    _L().pdf_mano_lbs_fwd(ptr(root_aa.contiguous()), ptr(pose_aa.contiguous()), ptr(shape.contiguous()),
+                          ptr(trans.contiguous()) if trans is not None else None,
+                          ptr(consts['v_template']), ptr(consts['shapedirs']), ptr(consts['posedirs']),
+                          ptr(consts['J_regressor']), ptr(consts['weights']), B, int(side == 'left'),
+                          -1 if center_idx is None else int(center_idx), ptr(verts), ptr(joints), stream())
+    return verts, joints
+
+
+class _RegressJoints(Function):
+    """joints[b] = reg[J,778] @ verts[b]  (full_regressor, Mano_model.py:309-323; simplified.py:431-434)."""
+
+    @staticmethod
+    def forward(ctx, reg, verts):
+        verts = verts.contiguous()
+        B, Vn, _ = verts.shape
+        J = reg.shape[0]
+        out = torch.empty((B, J, 3), device=verts.device)
+        _L().pdf_bmm_strided(ptr(reg), ptr(verts), ptr(out), B, J, 3, Vn, 1,
+                             0, 0, Vn, 1, Vn * 3, 0, 3, 1, J * 3, 3, 1, 0, stream())
+        ctx.save_for_backward(reg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (reg,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, J, _ = g.shape
+        Vn = reg.shape[1]
+        dv = torch.empty((B, Vn, 3), device=g.device)
+        # dv[b][v][c] = sum_j reg[j][v] g[b][j][c]
+        _L().pdf_bmm_strided(ptr(reg), ptr(g), ptr(dv), B, Vn, 3, J, 1,
+                             0, 0, 1, Vn, J * 3, 0, 3, 1, Vn * 3, 3, 1, 0, stream())
+        return None, dv
+
+
+def regress_joints(reg, verts):
+    return _RegressJoints.apply(reg, verts)

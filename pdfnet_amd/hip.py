@@ -1,0 +1,90 @@
+"""ctypes binding of libpdfnet_hip.so -- the drop-in C-ABI boundary (include/pdfnet_hip.h).
+
+The product path has NO fallback: if the library is missing, import fails loudly; if a call returns
+non-zero, a RuntimeError is raised (the reference's only native op calls exit(-1) on a launch error,
+lib/utils/roi_align/src/cuda/crop_and_resize_kernel.cu:186-191 -- we raise instead).
+torch is used only for device memory (tensor.data_ptr()) and the current HIP stream handle.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdfnet_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "pdfnet_hip.h")
+
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
+       "unsigned long long": ctypes.c_ulonglong}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every `int|long pdf_*(...)` prototype in the header."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|long)\s+(pdf_\w+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        types = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            if "*" in a:
+                types.append(ctypes.c_void_p)
+            else:
+                base = a.rsplit(" ", 1)[0]
+                types.append(_CT[base])
+        protos[name] = (_CT[ret], types)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "pdfnet_amd: %s is missing -- build it with `python -m pdfnet_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback." % LIB_PATH)
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(self.cdll, name)          # AttributeError if the .so does not export it
+            fn.restype = ret
+            fn.argtypes = args
+
+    def __getattr__(self, name):
+        fn = getattr(self.cdll, name)
+        is_status = self.protos[name][0] is ctypes.c_int
+
+        def call(*args):
+            rc = fn(*args)
+            if is_status and rc != 0:
+                raise RuntimeError("libpdfnet_hip: %s failed with code %d" % (name, rc))
+            return rc
+        setattr(self, name, call)
+        return call
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def stream():
+    """hipStream_t of torch's current stream (launches are captured when that stream is capturing)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pdfnet_amd ops run only on the GPU (HIP); got a %s tensor. "
+                               "There is no CPU fallback in the product path." % t.device)

@@ -1,0 +1,401 @@
+"""GPU parity of every C-ABI kernel (called through pdfnet_amd.functional -> ctypes -> libpdfnet_hip.so)
+against a plain PyTorch fp32 CPU reference of the same op (or the oracle for the point / MANO ops)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from tests.util import gold, T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from pdfnet_amd import functional as F
+    return F
+
+
+def dev(t):
+    return t.cuda()
+
+
+def close(a, b, atol, rtol=1e-5, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    lim = atol + rtol * b.abs().max().item()
+    assert err <= lim, "%s: max err %.3e > %.3e (max|ref|=%.3e)" % (what, err, lim, b.abs().max().item())
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("M,K,N,act,bias", [
+    (2016, 512, 256, 0, True), (300, 131, 128, 1, True), (64, 252, 778, 0, False), (8064, 64, 3, 0, True),
+    (1000, 16, 64, 2, True), (37, 1024, 509, 0, True), (32768, 64, 64, 1, False), (40000, 256, 128, 0, True), (5, 3, 3, 2, True)])
+def test_linear(F, M, K, N, act, bias):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    ref = TF.linear(xr, wr, br)
+    ref = TF.relu(ref) if act == 1 else (TF.leaky_relu(ref, 0.1) if act == 2 else ref)
+    gy = rnd(M, N, seed=4)
+    ref.backward(gy)
+    xd, wd = dev(x).requires_grad_(), dev(w).requires_grad_()
+    bd = dev(b).requires_grad_() if bias else None
+    out = F.linear(xd, wd, bd, act)
+    out.backward(dev(gy))
+    tol = 2e-5 * max(1.0, K ** 0.5 / 8)
+    close(out, ref, tol, what="linear fwd")
+    close(xd.grad, xr.grad, tol * 4, what="linear dx")
+    close(wd.grad, wr.grad, 2e-5 * max(1.0, M ** 0.5 / 4), rtol=2e-5, what="linear dw")
+    if bias:
+        close(bd.grad, br.grad, 2e-5 * max(1.0, M ** 0.5 / 4), rtol=2e-5, what="linear db")
+
+
+CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, act, bias
+    (2, 3, 32, 32, 64, 7, 2, 3, 0, False), (2, 3, 17, 19, 3, 3, 1, 1, 1, False), (2, 64, 16, 16, 64, 3, 1, 1, 0, False),
+    (2, 128, 13, 13, 128, 3, 2, 1, 0, False), (2, 256, 16, 16, 128, 1, 2, 0, 0, False), (2, 64, 16, 16, 256, 1, 1, 0, 0, False),
+    (3, 32, 9, 11, 48, 3, 1, 1, 1, True), (1, 256, 64, 64, 256, 3, 1, 1, 1, True), (2, 256, 8, 8, 122, 1, 1, 0, 0, True),
+    (4, 1024, 16, 16, 256, 3, 1, 1, 0, False)]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv2d(F, cfg):
+    N, Cin, H, W, Cout, k, s, p, act, bias = cfg
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    b = rnd(Cout, seed=3) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    ref = TF.conv2d(xr, wr, br, s, p)
+    if act:
+        ref = TF.relu(ref)
+    gy = rnd(*ref.shape, seed=4)
+    ref.backward(gy)
+    xd = dev(x).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wd = dev(w).contiguous(memory_format=torch.channels_last).requires_grad_()
+    bd = dev(b).requires_grad_() if bias else None
+    out = F.conv2d(xd, wd, bd, s, p, act)
+    assert out.shape == ref.shape
+    out.backward(dev(gy))
+    K = Cin * k * k
+    close(out, ref, 3e-5 * max(1, K ** 0.5 / 16), what="conv fwd")
+    close(xd.grad, xr.grad, 1e-4, rtol=2e-5, what="conv dx")
+    close(wd.grad, wr.grad, 5e-5 * max(1, (N * H * W) ** 0.5 / 16), rtol=5e-5, what="conv dw")
+    if bias:
+        close(bd.grad, br.grad, 1e-4, rtol=5e-5, what="conv db")
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 8, 8, 16, 4, 2, 1), (2, 6, 5, 7, 10, 4, 2, 1), (2, 64, 4, 4, 32, 4, 4, 0),
+                                 (2, 128, 2, 2, 256, 8, 8, 0), (3, 512, 32, 32, 256, 4, 2, 1)])
+def test_deconv2d(F, cfg):
+    N, Cin, H, W, Cout, k, s, p = cfg
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cin, Cout, k, k, seed=2, scale=Cin ** -0.5)
+    b = rnd(Cout, seed=3)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = TF.conv_transpose2d(xr, wr, br, s, p)
+    gy = rnd(*ref.shape, seed=4)
+    ref.backward(gy)
+    xd = dev(x).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wd = dev(w).contiguous(memory_format=torch.channels_last).requires_grad_()
+    bd = dev(b).requires_grad_()
+    out = F.deconv2d(xd, wd, bd, s, p)
+    assert out.shape == ref.shape
+    out.backward(dev(gy))
+    close(out, ref, 5e-5, what="deconv fwd")
+    close(xd.grad, xr.grad, 2e-4, rtol=2e-5, what="deconv dx")
+    close(wd.grad, wr.grad, 2e-4, rtol=5e-5, what="deconv dw")
+    close(bd.grad, br.grad, 2e-4, rtol=5e-5, what="deconv db")
+
+
+@pytest.mark.parametrize("shape,relu,res", [((4, 64, 9, 9), True, False), ((2, 256, 8, 8), True, True), ((3, 3, 5, 5), False, False),
+                                            ((700, 130), True, False), ((2, 128, 31, 33), False, True)])
+def test_batchnorm(F, shape, relu, res):
+    C = shape[1]
+    x = rnd(*shape, seed=1) * 2 + 0.5
+    r = rnd(*shape, seed=5) if res else None
+    g, b = torch.rand(C) + 0.5, rnd(C, seed=2)
+    rm0, rv0 = rnd(C, seed=3), torch.rand(C) + 0.5
+    for training in (True, False):
+        xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+        rr = r.clone().requires_grad_() if res else None
+        rm, rv = rm0.clone(), rv0.clone()
+        ref = TF.batch_norm(xr, rm, rv, gr, br, training, 0.1, 1e-5)
+        if res:
+            ref = ref + rr
+        if relu:
+            ref = TF.relu(ref)
+        xd, gd, bd = dev(x).requires_grad_(), dev(g).requires_grad_(), dev(b).requires_grad_()
+        if len(shape) == 4:
+            xd = dev(x).contiguous(memory_format=torch.channels_last).requires_grad_()
+        rd = dev(r).requires_grad_() if res else None
+        rmd, rvd = dev(rm0.clone()), dev(rv0.clone())
+        out = F.batch_norm(xd, gd, bd, rmd, rvd, training, 0.1, 1e-5, relu, rd)
+        close(out, ref, 2e-5, what="bn fwd train=%s" % training)
+        if training:
+            close(rmd, rm, 1e-5, what="running_mean")
+            close(rvd, rv, 1e-5, what="running_var")
+            gy = rnd(*shape, seed=4)
+            ref.backward(gy)
+            out.backward(dev(gy))
+            close(xd.grad, xr.grad, 5e-5, rtol=5e-5, what="bn dx")
+            close(gd.grad, gr.grad, 2e-4, rtol=5e-5, what="bn dgamma")
+            close(bd.grad, br.grad, 2e-4, rtol=5e-5, what="bn dbeta")
+            if res:
+                close(rd.grad, rr.grad, 1e-6, what="bn dres")
+
+
+def test_pool_upsample_relu(F):
+    x = rnd(2, 16, 13, 14, seed=1)
+    xr = x.clone().requires_grad_()
+    ref = TF.max_pool2d(xr, 3, 2, 1)
+    gy = rnd(*ref.shape, seed=2)
+    ref.backward(gy)
+    xd = dev(x).requires_grad_()
+    out = F.maxpool3s2(xd)
+    out.backward(dev(gy))
+    close(out, ref, 0, what="maxpool")
+    close(xd.grad, xr.grad, 1e-6, what="maxpool dx")
+    xr = x.clone().requires_grad_()
+    ref = TF.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=True)
+    gy = rnd(*ref.shape, seed=3)
+    ref.backward(gy)
+    xd = dev(x).requires_grad_()
+    out = F.upsample2x(xd)
+    out.backward(dev(gy))
+    close(out, ref, 2e-6, what="upsample")
+    close(xd.grad, xr.grad, 1e-5, what="upsample dx")
+    xd = dev(x).requires_grad_()
+    out = F.relu(xd)
+    out.backward(dev(gy[:, :, :13, :14].contiguous()))
+    close(out, TF.relu(x), 0, what="relu")
+    close(xd.grad, gy[:, :, :13, :14] * (x > 0), 0, what="relu dx")
+
+
+def test_l2norm_layernorm(F):
+    x = rnd(2, 256, 7, 9, seed=1)
+    w = torch.rand(256) * 10 + 5
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    n = xr.pow(2).sum(1, keepdim=True).sqrt() + 1e-10
+    ref = wr.view(1, -1, 1, 1) * (xr / n)
+    gy = rnd(*x.shape, seed=2)
+    ref.backward(gy)
+    xd, wd = dev(x).requires_grad_(), dev(w).requires_grad_()
+    out = F.l2norm(xd, wd)
+    out.backward(dev(gy))
+    close(out, ref, 1e-5, what="l2norm")
+    close(xd.grad, xr.grad, 1e-5, rtol=1e-5, what="l2norm dx")
+    close(wd.grad, wr.grad, 2e-5, rtol=1e-5, what="l2norm dw")
+    for Fd in (509, 512, 64, 16):
+        x = rnd(3, 63, Fd, seed=3) * 3 + 1
+        g, b = torch.rand(Fd) + 0.5, rnd(Fd, seed=4)
+        xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+        ref = TF.layer_norm(xr, (Fd,), gr, br, 1e-6)
+        gy = rnd(*x.shape, seed=5)
+        ref.backward(gy)
+        xd, gd, bd = dev(x).requires_grad_(), dev(g).requires_grad_(), dev(b).requires_grad_()
+        out = F.layer_norm(xd, gd, bd, 1e-6)
+        out.backward(dev(gy))
+        close(out, ref, 1e-5, what="ln")
+        close(xd.grad, xr.grad, 2e-5, rtol=1e-5, what="ln dx")
+        close(gd.grad, gr.grad, 5e-5, rtol=1e-5, what="ln dgamma")
+        close(bd.grad, br.grad, 5e-5, rtol=1e-5, what="ln dbeta")
+
+
+def _check_group(F, pts_rows, C, S, K, r2, ldg, gold_idx_sorted, ref_grouped):
+    """pts_rows [B,N,C] (xyz first). ref_grouped [B,C,S,K] from the oracle."""
+    from oracle import pdfnet_cpu as O
+    pd = dev(pts_rows).requires_grad_()
+    g, idx = F.knn_ball_group(pd, C, S, K, r2, ldg)
+    idx_s = np.sort(idx.cpu().numpy(), -1)
+    # exact-tie handling: rows whose K-th and (K+1)-th smallest distances are equal may pick either
+    xyz = pts_rows[:, :, :3]
+    d2 = ((xyz.unsqueeze(1) - xyz[:, :S].unsqueeze(2)) ** 2)
+    d2 = d2[..., 0] + d2[..., 1] + d2[..., 2]
+    srt = torch.sort(d2, dim=2)[0]
+    tie = (srt[:, :, K - 1] == srt[:, :, K]).numpy() if d2.shape[2] > K else np.zeros(idx_s.shape[:2], bool)
+    same = (idx_s == gold_idx_sorted).all(-1)
+    assert same[~tie].all(), "index sets differ on %d tie-free centroids" % int((~same[~tie]).sum())
+    # grouped features: permutation-invariant comparison (sum / max over K)
+    # (on exact ties -- duplicated points -- either duplicate may be picked: there only xyz is comparable)
+    gg = g[..., :C].permute(0, 3, 1, 2).detach().cpu()
+    nt = torch.from_numpy(~tie).unsqueeze(1)                                    # [B,1,S]
+    ds, dm = (gg.sum(-1) - ref_grouped.sum(-1)).abs(), (gg.abs().amax(-1) - ref_grouped.abs().amax(-1)).abs()
+    assert (ds * nt).max() <= 1e-4 and (dm * nt).max() == 0
+    assert ds[:, :3].max() <= 1e-4 and dm[:, :3].max() == 0
+    if ldg > C:
+        assert (g[..., C:] == 0).all()
+    return pd, g, idx
+
+
+def test_knn_ball_group_level1(F):
+    from oracle import pdfnet_cpu as O
+    gd = gold("op_group_points_l1")
+    pts = T(gd["points"])
+    ref, _ = O.group_level1(pts, 512, 64, float(gd["r2"]))
+    pd, g, idx = _check_group(F, pts, 3, 512, 64, float(gd["r2"]), 16, gd["idx_sorted"].astype(np.int64), ref)
+    # backward vs autograd of the oracle gather with the kernel's own indices
+    gy = rnd(*g.shape, seed=3)
+    gy[..., 3:] = 0
+    g.backward(dev(gy))
+    pr = pts.clone().requires_grad_()
+    ii = idx.cpu().long()
+    gath = torch.gather(pr, 1, ii.reshape(3, -1, 1).expand(-1, -1, 3)).view(3, 512, 64, 3) - pr[:, :512].unsqueeze(2)
+    (gath * gy[..., :3]).sum().backward()
+    close(pd.grad, pr.grad, 1e-4, what="group bwd")
+
+
+def test_knn_ball_group_level2(F):
+    from oracle import pdfnet_cpu as O
+    gd = gold("op_group_points_l2")
+    feat = T(gd["feat"])                                   # [B,131,512]
+    ref, _ = O.group_level2(feat, 128, 64, float(gd["r2"]))
+    rows = feat.transpose(1, 2).contiguous()
+    pd, g, idx = _check_group(F, rows, 131, 128, 64, float(gd["r2"]), 144, gd["idx_sorted"].astype(np.int64), ref)
+    gy = rnd(*g.shape, seed=3)
+    g.backward(dev(gy))
+    pr = rows.clone().requires_grad_()
+    ii = idx.cpu().long()
+    gath = torch.gather(pr, 1, ii.reshape(3, -1, 1).expand(-1, -1, 131)).view(3, 128, 64, 131)
+    gath = torch.cat([gath[..., :3] - pr[:, :128, :3].unsqueeze(2), gath[..., 3:]], -1)
+    (gath * gy[..., :131]).sum().backward()
+    close(pd.grad, pr.grad, 2e-4, what="group2 bwd")
+
+
+def test_gather_rows_maxk_sft(F):
+    from oracle import pdfnet_cpu as O
+    gd = gold("op_gather_feat")
+    out = F.gather_rows(dev(T(gd["feat"])), dev(T(gd["ind"])))
+    close(out, T(gd["out"]), 0, what="gather golden")
+    feat = rnd(2, 64, 32, 32, seed=1)
+    R = 64
+    choose = torch.randint(0, R * R, (2, 100))
+    fr = feat.clone().requires_grad_()
+    c2 = (choose // R // 2) * (R // 2) + choose % R // 2
+    ref = O.gather_hw(fr, c2[:, :40])
+    gy = rnd(2, 40, 64, seed=2)
+    ref.backward(gy)
+    fd = dev(feat).requires_grad_()
+    out = F.gather_rows(fd, dev(choose)[:, :40], R=R, shift=1)
+    out.backward(dev(gy))
+    close(out, ref, 0, what="gather pyramid")
+    close(fd.grad, fr.grad, 1e-5, what="gather bwd")
+    x = rnd(50, 64, 24, seed=3)
+    xr = x.clone().requires_grad_()
+    ref = xr.max(1)[0]
+    gy = rnd(50, 24, seed=4)
+    ref.backward(gy)
+    xd = dev(x).requires_grad_()
+    out = F.max_over_k(xd)
+    out.backward(dev(gy))
+    close(out, ref, 0, what="maxk")
+    close(xd.grad, xr.grad, 0, what="maxk bwd")
+    a, b, c = rnd(7, 9, 13, seed=5), rnd(7, 9, 13, seed=6), rnd(7, 9, 13, seed=7)
+    ar, br, cr = (t.clone().requires_grad_() for t in (a, b, c))
+    ref = ar * (br + 1) + cr
+    gy = rnd(7, 9, 13, seed=8)
+    ref.backward(gy)
+    ad, bd, cd = (dev(t).requires_grad_() for t in (a, b, c))
+    out = F.sft_modulate(ad, bd, cd)
+    out.backward(dev(gy))
+    close(out, ref, 1e-6, what="sft")
+    for u, v in ((ad, ar), (bd, br), (cd, cr)):
+        close(u.grad, v.grad, 1e-6, what="sft bwd")
+
+
+def _ell(D):
+    V = D.shape[0]
+    Wd = int((D != 0).sum(1).max())
+    col = torch.zeros(V, Wd, dtype=torch.int32)
+    val = torch.zeros(V, Wd)
+    for v in range(V):
+        nz = torch.nonzero(D[v]).flatten()
+        col[v, :len(nz)] = nz.int()
+        val[v, :len(nz)] = D[v, nz]
+    return col, val
+
+
+def test_cheby_attention(F):
+    from oracle import pdfnet_cpu as O
+    Ls = O.load_graph_constants()['L_right']
+    for D, Fd in zip(Ls, (32, 16, 8)):
+        V = D.shape[0]
+        col, val = _ell(D)
+        colT, valT = _ell(D.t().contiguous())
+        x = rnd(3, V, Fd, seed=1)
+        xr = x.clone().requires_grad_()
+        ref = torch.stack((xr, torch.einsum('vw,bwf->bvf', D, xr)), -1).flatten(2)
+        gy = rnd(3, V, 2 * Fd, seed=2)
+        ref.backward(gy)
+        xd = dev(x).requires_grad_()
+        out = F.cheby2(xd, tuple(dev(t) for t in (col, val, colT, valT)))
+        out.backward(dev(gy))
+        close(out, ref, 1e-5, what="cheby")
+        close(xd.grad, xr.grad, 1e-5, what="cheby bwd")
+    for V, Fd in ((63, 256), (126, 128), (252, 64), (63, 16)):
+        q, k, v = rnd(2, V, Fd, seed=3), rnd(2, V, Fd, seed=4), rnd(2, V, Fd, seed=5)
+        qr, kr, vr = (t.clone().requires_grad_() for t in (q, k, v))
+        ref = O.mha(qr, kr, vr, 4, lambda a: a)
+        gy = rnd(2, V, Fd, seed=6)
+        ref.backward(gy)
+        qd, kd, vd = (dev(t).requires_grad_() for t in (q, k, v))
+        out = F.attention(qd, kd, vd, 4)
+        out.backward(dev(gy))
+        close(out, ref, 2e-5, what="attn")
+        for u, w_ in ((qd, qr), (kd, kr), (vd, vr)):
+            close(u.grad, w_.grad, 5e-5, rtol=2e-5, what="attn bwd")
+    # dropout: keep-rate and backward uses the same mask
+    x = dev(torch.ones(1 << 20)).requires_grad_()
+    y = F.dropout(x, 0.05, True)
+    keep = (y > 0).float().mean().item()
+    assert abs(keep - 0.95) < 2e-3 and abs(y.max().item() - 1 / 0.95) < 1e-6
+    y.sum().backward()
+    assert torch.equal(x.grad > 0, y > 0)
+    qd = dev(q).requires_grad_()
+    o1 = F.attention(qd, dev(k), dev(v), 4, 0.3, True)
+    assert torch.isfinite(o1).all()
+
+
+def test_mano_regressor(F):
+    from oracle import pdfnet_cpu as O
+    from oracle import synth
+    gd = gold("op_mano_layer")
+    for side in ("left", "right"):
+        c = synth.synthetic_mano_consts(side)
+        cd = {k: dev(v.contiguous()) for k, v in c.items()}
+        v, j = F.mano_lbs(cd, dev(T(gd[side + "_rot"])), dev(T(gd[side + "_pose"])), dev(T(gd[side + "_shape"])),
+                          trans=dev(T(gd[side + "_trans"])), side=side)
+        close(v, T(gd[side + "_verts"]), 5e-6, what="mano verts " + side)
+        close(j, T(gd[side + "_joints"]), 5e-6, what="mano joints " + side)
+        reg = O.full_regressor(c['J_regressor'])
+        vd = v.clone().requires_grad_()
+        jr = F.regress_joints(dev(reg), vd)
+        close(jr, T(gd[side + "_full_regressor_joints"]), 5e-6, what="regressor")
+        gy = rnd(*jr.shape, seed=1)
+        jr.backward(dev(gy))
+        close(vd.grad, torch.einsum('jv,bjc->bvc', reg, gy), 1e-6, what="regressor bwd")
+        v2, j2 = F.mano_lbs(cd, dev(T(gd[side + "_rot"])), dev(T(gd[side + "_pose"])), dev(T(gd[side + "_shape"])), side=side, center_idx=9)
+        vo, jo = O.mano_lbs(c, T(gd[side + "_rot"]), T(gd[side + "_pose"]), T(gd[side + "_shape"]), side=side, center_idx=9)
+        close(v2, vo, 5e-6, what="mano centered")
+        close(j2, jo, 5e-6, what="mano centered joints")
+
+
+def test_adam(F):
+    from pdfnet_amd import hip
+    p0, g = rnd(10000, seed=1), rnd(10000, seed=2)
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=1e-4)
+    pd, m, v = dev(p0.clone()), dev(torch.zeros(10000)), dev(torch.zeros(10000))
+    for step in range(1, 4):
+        pr.grad = g * step
+        opt.step()
+        corr = dev(torch.tensor([1 - 0.9 ** step, 1 - 0.999 ** step]))
+        hip.lib().pdf_adam_step(hip.ptr(pd), hip.ptr(dev(g * step)), hip.ptr(m), hip.ptr(v), 10000, 1e-4, 0.9, 0.999, 1e-8,
+                                hip.ptr(corr), 1.0, hip.stream())
+    close(pd, pr, 1e-7, what="adam")
