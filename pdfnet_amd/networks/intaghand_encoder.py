@@ -1,0 +1,266 @@
+"""MI355X-native counterpart of the reference's lib/models/networks/intaghand_encoder.py:
+ResNet-50 RGB trunk + pyramid fusion + PointNet++ set abstraction on the depth cloud + SFT fusion.
+
+Same module tree / state_dict keys as the reference `ResNetSimple` (intaghand_encoder.py:567-819) and
+`resnet_mid` (:822-881); every op is a HIP kernel through pdfnet_amd.functional.  Internally all maps are
+NHWC (channels_last) and point features are row-major [cloud, point, channel].
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from .layers import (BatchNorm, Conv2d, ConvTranspose2d, Linear, PointConv, Slot, kaiming_normal_, small_normal_)
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+class Bottleneck(nn.Module):
+    """ResNet v1.5 bottleneck, stride on conv2 (reference twin lib/models/networks/resnet.py:76-122)."""
+
+    def __init__(self, cin, width, stride, down):
+        super().__init__()
+        self.conv1 = Conv2d(cin, width, 1, bias=False)
+        self.bn1 = BatchNorm(width)
+        self.conv2 = Conv2d(width, width, 3, stride, 1, bias=False)
+        self.bn2 = BatchNorm(width)
+        self.conv3 = Conv2d(width, width * 4, 1, bias=False)
+        self.bn3 = BatchNorm(width * 4)
+        self.downsample = None
+        if down:
+            self.downsample = nn.Sequential(Conv2d(cin, width * 4, 1, stride, 0, bias=False), BatchNorm(width * 4))
+
+    def forward(self, x):
+        y = self.bn1(self.conv1(x), relu=True)
+        y = self.bn2(self.conv2(y), relu=True)
+        y = self.conv3(y)
+        sc = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        return self.bn3(y, relu=True, res=sc)          # relu(bn3(y) + shortcut) in one pass
+
+
+class ResNet50(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = BatchNorm(64)
+        cin = 64
+        for li, (width, n, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)], 1):
+            blocks = []
+            for b in range(n):
+                blocks.append(Bottleneck(cin, width, stride if b == 0 else 1, b == 0))
+                cin = width * 4
+            setattr(self, "layer%d" % li, nn.Sequential(*blocks))
+        self.fc = Linear(2048, 1000)               # key parity only (never on the path)
+        for m in self.modules():                   # torchvision init
+            if isinstance(m, Conv2d):
+                nn.init.kaiming_normal_(m.weight.data, mode='fan_out', nonlinearity='relu')
+
+
+class L2Norm(nn.Module):
+    def __init__(self, c, scale):
+        super().__init__()
+        self.weight = nn.Parameter(torch.full((c,), float(scale)))
+
+    def forward(self, x):
+        return F.l2norm(x, self.weight, 1e-10)
+
+
+class SFTLayer(nn.Module):
+    """intaghand_encoder.py:205-219 on rows: fea [.., P, Cf], cond [.., P, Cc] -> [.., P, Cf]."""
+
+    def __init__(self, c_fea, c_cond):
+        super().__init__()
+        self.SFT_scale_conv0 = PointConv(c_cond, c_cond)
+        self.SFT_scale_conv1 = PointConv(c_cond, c_fea)
+        self.SFT_shift_conv0 = PointConv(c_cond, c_cond)
+        self.SFT_shift_conv1 = PointConv(c_cond, c_fea)
+
+    def forward(self, fea, cond):
+        scale = self.SFT_scale_conv1(self.SFT_scale_conv0(cond, F.ACT_LRELU))
+        shift = self.SFT_shift_conv1(self.SFT_shift_conv0(cond, F.ACT_LRELU))
+        return F.sft_modulate(fea, scale, shift)
+
+
+def _sa_mlp(cin, dims):
+    mods = []
+    for d in dims:
+        mods += [PointConv(cin, d), BatchNorm(d), Slot()]
+        cin = d
+    return mods + [Slot()]          # index 9 = the reference's MaxPool2d slot
+
+
+class PointNet_Plus(nn.Module):
+    """intaghand_encoder.py:32-159.  One call per hand (BN batch statistics are per hand, :805-806)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.sft0, self.sft1, self.sft2 = SFTLayer(3, 3), SFTLayer(131, 64), SFTLayer(259, 256)
+        self.netR_1 = nn.Sequential(*_sa_mlp(opt.INPUT_FEATURE_NUM, [64, 64, 128]))
+        self.netR_2 = nn.Sequential(*_sa_mlp(131, [128, 128, 256]))
+        self.netR_3 = nn.Sequential(*_sa_mlp(259, [512, 512, 1024]))
+        self.netR_FC = nn.Sequential(Linear(1024, 1024), BatchNorm(1024), Slot(), Linear(1024, 512), BatchNorm(512), Slot(),
+                                     Linear(512, opt.PCA_SZ))          # constructed, unused (:155)
+
+    @staticmethod
+    def _mlp(seq, x):
+        x = x.reshape(-1, x.shape[-1])            # point rows [cloud*centroid*neighbour, channel]
+        for i in (0, 3, 6):
+            x = seq[i + 1](seq[i](x), relu=True)
+        return x
+
+    def forward(self, cloud, emb, choose):
+        o = self.opt
+        R, S1, S2, K = o.default_resolution, o.sample_num_level1, o.sample_num_level2, o.knn_K
+        B = cloud.shape[0]
+        pts = self.sft0(cloud, F.gather_rows(emb[0], choose))                              # [B,1024,3]   (:120-122)
+        g1, _ = F.knn_ball_group(pts, 3, S1, K, o.ball_radius, _pad16(3))                  # [B,S1,K,16]  (:123)
+        x = F.max_over_k(self._mlp(self.netR_1, g1).view(B * S1, K, 128))                  # [B*S1,128]   (:132)
+        e1 = F.gather_rows(emb[1], choose[:, :S1], R, 1)                                   # [B,S1,64]    (:125-127)
+        x = torch.cat((pts[:, :S1], x.view(B, S1, 128)), 2)                                # [B,S1,131]   (:134)
+        x = self.sft1(x, e1)                                                               #              (:137)
+        g2, _ = F.knn_ball_group(x, 131, S2, K, o.ball_radius2, _pad16(131))               # [B,S2,K,144] (:139)
+        y = F.max_over_k(self._mlp(self.netR_2, g2).view(B * S2, K, 256))                  # [B*S2,256]
+        e2 = F.gather_rows(emb[2], choose[:, :S2], R, 2)                                   # [B,S2,256]   (:126,128)
+        y = torch.cat((x[:, :S2, :3], y.view(B, S2, 256)), 2)                              # [B,S2,259]
+        y = self.sft2(y, e2)                                                               #              (:147)
+        y = torch.nn.functional.pad(y, (0, _pad16(259) - 259))
+        y = F.max_over_k(self._mlp(self.netR_3, y).view(B, S2, 1024))                      # [B,1024]     (:152)
+        return y.view(B, 1, 1024)
+
+
+class ResNetSimple_decoder(nn.Module):
+    """intaghand_encoder.py:270-316: 1x1 then 3 x [bilinear x2 -> conv3x3 -> ReLU -> BN] (conv->ReLU->BN order)."""
+
+    def __init__(self, out_dim, up_scale):
+        super().__init__()
+        self.models = nn.ModuleList([nn.Sequential(Conv2d(2048, 128, 1, bias=False), Slot(), BatchNorm(128))])
+        for _ in range(3):
+            self.models.append(nn.Sequential(Slot(), Conv2d(128, 128, 3, 1, 1, bias=False), Slot(), BatchNorm(128)))
+        self.up_scale = up_scale
+        if up_scale:
+            self.final_layer = nn.Sequential(Slot(), Conv2d(128, out_dim, 1), Slot())
+        else:
+            self.final_layer = nn.Sequential(Conv2d(128, out_dim, 1))
+        kaiming_normal_(self)
+
+    def forward(self, x):
+        fmaps = []
+        x = self.models[0][2](self.models[0][0](x, F.ACT_RELU))
+        fmaps.append(x)
+        for m in list(self.models)[1:]:
+            x = m[3](m[1](F.upsample2x(x), F.ACT_RELU))
+            fmaps.append(x)
+        if self.up_scale:
+            x = F.upsample2x(self.final_layer[1](F.upsample2x(x)))
+        else:
+            x = self.final_layer[0](x)
+        return x, fmaps
+
+
+def _fc_head(dout):
+    return nn.Sequential(Linear(1024, 512), BatchNorm(512), Slot(), Linear(512, 256), BatchNorm(256), Slot(), Linear(256, dout))
+
+
+def nms_top1_centers(hm):
+    """Centre pick of the test path (intaghand_encoder.py:349-367,750-758): 5x5 max-pool NMS on the raw
+    logits, top-1 per channel.  Decode is SURVEY 8(f) row 3 ("next"); until it has its own kernel this
+    runs on aten ops (eval/demo only, never in the train step)."""
+    h = hm.detach().contiguous()
+    keep = (torch.nn.functional.max_pool2d(h, 5, 1, 2) == h).float()
+    h = h * keep
+    B = h.shape[0]
+    return torch.cat([torch.topk(h[:, c].reshape(B, -1), 1)[1] for c in (0, 1)], dim=1)
+
+
+class ResNetSimple(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.resnet = ResNet50()
+        self.p2 = Conv2d(256, 256, 3, 1, 1)
+        self.p3 = ConvTranspose2d(512, 256, 4, 2, 1)
+        self.p4 = ConvTranspose2d(1024, 256, 4, 4, 0)
+        self.p5 = ConvTranspose2d(2048, 256, 8, 8, 0)
+        self.p2_l2, self.p3_l2, self.p4_l2, self.p5_l2 = (L2Norm(256, 10) for _ in range(4))
+        self.feat = Conv2d(1024, 256, 3, 1, 1, bias=False)
+        self.feat_bn = BatchNorm(256, momentum=0.01)
+        self.e_conv1 = Conv2d(3, 3, 3, 1, 1, bias=False)
+        self.pointnet_plus = PointNet_Plus(opt)
+        self.hms_decoder = ResNetSimple_decoder(42, False)
+        self.center_feat_up0 = Conv2d(256, 512, 3, 1, 1, bias=False)
+        self.center_feat_up1 = Conv2d(512, 1024, 3, 1, 1, bias=False)
+        self.mano_head, self.joint_head_l, self.joint_head_r = _fc_head(122), _fc_head(66), _fc_head(66)   # unused (:811)
+        for m in (self.mano_head, self.joint_head_l, self.joint_head_r):
+            small_normal_(m)
+        self.sft = SFTLayer(1024, 1024)
+        for head in sorted(opt.heads):
+            fc = nn.Sequential(Conv2d(256, 256, 3, 1, 1), Slot(), Conv2d(256, opt.heads[head], 1))
+            if 'hm' in head:
+                fc[2].bias.data.fill_(-4.59)                   # :690
+            else:
+                small_normal_(fc)
+            setattr(self, head, fc)
+        self.dp_decoder = ResNetSimple_decoder(2, True)
+
+    def forward(self, img, ind, choose, cloud):
+        if choose is None or cloud is None:
+            raise NotImplementedError(
+                "pdfnet_amd: clouds must be supplied (the reference's CPU depth2pcl branch, "
+                "intaghand_encoder.py:779-784, is SURVEY 8(f) row 2 and not built yet)")
+        r = self.resnet
+        img = F.cl(img)
+        emb0 = self.e_conv1(img, F.ACT_RELU)                                              # :711
+        emb1 = r.bn1(r.conv1(img), relu=True)                                             # :712-715
+        x4 = r.layer1(F.maxpool3s2(emb1))
+        x3 = r.layer2(x4)
+        x2 = r.layer3(x3)
+        x1 = r.layer4(x2)
+        pyr = torch.cat([self.p2_l2(self.p2(x4)), self.p3_l2(self.p3(x3)),
+                         self.p4_l2(self.p4(x2)), self.p5_l2(self.p5(x1))], 1)            # NHWC channel concat
+        x0 = self.feat_bn(self.feat(pyr), relu=True)                                      # :740-744
+        ret = {}
+        for head in self.opt.heads:                                                        # :749-772
+            if 'hm' in ret and ind is None:
+                ind = nms_top1_centers(ret['hm'])
+            fc = getattr(self, head)
+            ret[head] = fc[2](fc[0](x0, F.ACT_RELU))
+        hms, hms_f = self.hms_decoder(x1)
+        mask, dp_f = self.dp_decoder(x1)
+        center = F.gather_rows(self.center_feat_up1(self.center_feat_up0(x0)), ind)        # [B,2,1024]  (:790-792)
+        emb = [emb0, emb1, x0]
+        fl = self.pointnet_plus(cloud[:, 0], emb, choose[:, 0])                            # :805
+        fr = self.pointnet_plus(cloud[:, 1], emb, choose[:, 1])                            # :806
+        fuse = self.sft(torch.cat((fl, fr), 1), center)                                    # [B,2,1024]  (:807-809)
+        return hms, mask, ret, [fuse, x2, x3, x4], hms_f, dp_f, ind
+
+
+class resnet_mid(nn.Module):
+    """intaghand_encoder.py:822-881: conv1x1 -> ReLU -> BN on cat(hms_f, dp_f[, img_f]).  Its fmaps are
+    only shape-asserted downstream (DualGraph.py:69-72) but its BN running statistics are live state."""
+
+    def __init__(self, out_dims):
+        super().__init__()
+        self.convs = nn.ModuleList()
+        for i, od in enumerate(out_dims):
+            cin = 256 + (0 if i == 0 else [2048, 1024, 512, 256][i])
+            bn = BatchNorm(od)
+            self.convs.append(nn.Sequential(Conv2d(cin, od, 1, bias=False), Slot(), bn))
+        self.global_feature_dim = 1024
+        self.fmaps_dim = out_dims
+
+    def get_info(self):
+        return {'global_feature_dim': self.global_feature_dim, 'fmaps_dim': self.fmaps_dim}
+
+    def forward(self, img_f, hms_f, dp_f):
+        fmaps = []
+        for i, conv in enumerate(self.convs):
+            parts = [hms_f[i], dp_f[i]] + ([img_f[i]] if i > 0 else [])
+            fmaps.append(conv[2](conv[0](torch.cat(parts, 1), F.ACT_RELU)))
+        return img_f[0][:, 0], img_f[0][:, 1], fmaps
+
+
+def load_encoder(opt):
+    """intaghand_encoder.py:1064-1087."""
+    return ResNetSimple(opt), resnet_mid(opt.DECONV_DIMS)

@@ -1,0 +1,41 @@
+"""MI355X-native counterpart of lib/models/networks/intaghand_model.py: `HandNET_GCN` and the factory
+`load_model_intag(opt)` with the reference's forward signature, return structure and state_dict keys, so
+it drops into `ModleWithLoss` (lib/trains/base_trainer.py:24-78) / demo.py:202 unchanged.
+"""
+import torch.nn as nn
+
+from .intaghand_decoder import load_decoder
+from .intaghand_encoder import load_encoder
+
+
+class HandNET_GCN(nn.Module):
+    def __init__(self, encoder, mid_model, decoder, run_mid_model=True):
+        super().__init__()
+        self.encoder = encoder
+        self.mid_model = mid_model
+        self.decoder = decoder
+        # mid_model's fmaps are dead downstream but its BatchNorm running statistics are
+        # state the reference updates every step; keep it on by default for state parity.
+        self.run_mid_model = run_mid_model
+
+    def forward(self, img, choose, cloud, depth, ind, K_new, valid):
+        hms, mask, ret, img_fmaps, hms_fmaps, dp_fmaps, ind = self.encoder(img, ind, choose, cloud)
+        if self.run_mid_model:
+            gl, gr, _ = self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)
+        else:
+            gl, gr = img_fmaps[0][:, 0], img_fmaps[0][:, 1]
+        result, paramsDict, handDictList, otherInfo = self.decoder(gl, gr)
+        otherInfo['hms'] = hms
+        otherInfo['mask'] = mask
+        otherInfo['ret'] = ret
+        otherInfo['ind'] = ind
+        otherInfo['converter_left'] = self.decoder.converter['left']
+        otherInfo['converter_right'] = self.decoder.converter['right']
+        return result, paramsDict, handDictList, otherInfo
+
+
+def load_model_intag(opt):
+    """Reads the same `opt` fields as the reference factory (intaghand_model.py:49-67)."""
+    encoder, mid_model = load_encoder(opt)
+    decoder = load_decoder(opt, mid_model.get_info())
+    return HandNET_GCN(encoder, mid_model, decoder)

@@ -1,0 +1,61 @@
+"""CPU (-m "not gpu"): host logic of the product package -- the C-ABI library loads and exports every
+symbol include/pdfnet_hip.h declares, the module tree has the reference's state_dict keys, and the product
+refuses to compute without a GPU (no CPU fallback)."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from tests.util import make_opt, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from pdfnet_amd import hip
+    protos = hip.parse_header(os.path.join(ROOT, "include", "pdfnet_hip.h"))
+    assert len(protos) >= 40
+    cdll = ctypes.CDLL(hip.LIB_PATH)
+    for name in protos:
+        assert hasattr(cdll, name), name
+    # and nothing is exported that the header does not declare
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", hip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("pdf_")}
+    assert exported == set(protos), exported ^ set(protos)
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    m = load_model_intag(make_opt(256))
+    lines = [l.split() for l in open(os.path.join(golden_dir, "state_dict_manifest.txt")) if not l.startswith("#")]
+    sd = m.state_dict()
+    assert [l[0] for l in lines] == list(sd.keys())
+    for name, shape, dtype in lines:
+        want = tuple(int(s) for s in shape.split("x")) if shape != "scalar" else ()
+        assert tuple(sd[name].shape) == want, name
+        assert str(sd[name].dtype) == "torch." + dtype, name
+    assert sum(v.numel() for v in sd.values()) == 100435929
+    for attr in ("encoder", "mid_model", "decoder"):
+        assert hasattr(m, attr)
+    # graph tables are non-persistent, like the reference's graph_L (model_attn/gcn.py:79-86)
+    assert not any("ell_" in k or "graph_L" in k for k in sd)
+
+
+def test_product_has_no_cpu_fallback():
+    from pdfnet_amd import functional as F
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.linear(torch.zeros(4, 16), torch.zeros(8, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.conv2d(torch.zeros(1, 16, 4, 4), torch.zeros(8, 16, 3, 3))
+
+
+def test_product_does_not_import_oracle():
+    import re
+    bad = []
+    for root, _, files in os.walk(os.path.join(ROOT, "pdfnet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) or "/root/reference" in src:
+                    bad.append(f)
+    assert not bad, bad

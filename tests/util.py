@@ -85,7 +85,7 @@ def check_packed(got, exp, abs_tol=1e-4, rel_tol=1e-5, skip=()):
         d = np.abs(g - e).max()
         lim = abs_tol + rel_tol * np.abs(e).max()
         if k.startswith("verts2d") or k.startswith("hms") or k.startswith("mask"):
-            lim = abs_tol + 1e-5 * np.abs(e).max() * 10
+            lim = abs_tol + 5 * rel_tol * np.abs(e).max()      # pixel-scaled outputs: relative
         if not d <= lim:
             bad.append((k, d, lim))
     assert not bad, bad
