@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train-step images/s @ 256x256 RGB-D, B=32 per GPU, fp32 (BASELINE.json configs[2]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = model forward + CtdetLoss + backward + gradient all-reduce (N>1) + Adam, on a synthetic batch that
+is already resident in HBM.  Rank 0 prints ONE JSON line (contract in the task description) that also carries
+  roofline     : fp32-MFMA roofline of the dominant kernel family (the implicit-GEMM kernels), measured live
+                 with events on the launch stream in an extra instrumented step after the timed region;
+  cpu_baseline : the CPU oracle (oracle/pdfnet_cpu.py) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md:42
+ALGO_GFLOP_PER_IMG_STEP_DENSE = 358.0  # 119.46 GF/img forward x3 (reference formulation)
+
+
+def make_opt(R):
+    import types
+    return types.SimpleNamespace(
+        depth=True, heads={'hm': 2, 'wh': 2, 'params': 122}, iterations=False, PCA_SZ=63, knn_K=64,
+        ball_radius=0.015, ball_radius2=0.04, sample_num_level1=512, sample_num_level2=128, INPUT_FEATURE_NUM=3,
+        SAMPLE_NUM=1024, default_resolution=R, DECONV_DIMS=[256, 256, 256, 256], GCN_IN_DIM=[512, 256, 128],
+        GCN_OUT_DIM=[256, 128, 64], IMG_DIMS=[256, 128, 64], graph_k=2, graph_layer_num=4,
+        size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+
+
+class GemmProfiler:
+    """Wraps the GEMM-family C-ABI entry points with start/stop events on the current stream and counts the
+    algorithmic FLOPs (2*M*N*K of the contraction each call performs) from the call's own arguments."""
+    NAMES = ('pdf_linear_fwd', 'pdf_linear_bwd_weight', 'pdf_conv2d_fwd', 'pdf_conv2d_bwd_data', 'pdf_conv2d_bwd_weight',
+             'pdf_deconv2d_fwd', 'pdf_deconv2d_bwd_data', 'pdf_deconv2d_bwd_weight')
+
+    def __init__(self):
+        from pdfnet_amd import hip
+        self.lib = hip.lib()
+        self.records = []
+        self.saved = {}
+
+    @staticmethod
+    def flops(name, a):
+        if name == 'pdf_linear_fwd':
+            return 2.0 * a[4] * a[5] * a[6]
+        if name == 'pdf_linear_bwd_weight':
+            return 2.0 * a[5] * a[6] * a[7]
+        # conv family: (..., N, H, W, Cin, ld, Cout, KH, KW, stride, pad, OH, OW, ...)
+        off = {'pdf_conv2d_fwd': 4, 'pdf_conv2d_bwd_data': 3, 'pdf_conv2d_bwd_weight': 5,
+               'pdf_deconv2d_fwd': 4, 'pdf_deconv2d_bwd_data': 3, 'pdf_deconv2d_bwd_weight': 5}[name]
+        N, H, W, Cin, _, Cout, KH, KW, stride, pad, OH, OW = a[off:off + 12]
+        if name.startswith('pdf_conv2d'):
+            return 2.0 * N * OH * OW * Cout * Cin * KH * KW
+        return 2.0 * N * H * W * Cin * Cout * KH * KW          # transposed conv: per input pixel
+
+    def __enter__(self):
+        for n in self.NAMES:
+            fn = getattr(self.lib, n)                           # materialises the bound wrapper
+            self.saved[n] = fn
+
+            def wrapped(*a, _fn=fn, _n=n):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _fn(*a)
+                e1.record()
+                self.records.append((_n, self.flops(_n, a), e0, e1))
+                return r
+            setattr(self.lib, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for n, fn in self.saved.items():
+            setattr(self.lib, n, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        per = {}
+        for n, fl, e0, e1 in self.records:
+            d = per.setdefault(n, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += fl
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        return per
+
+
+def cpu_baseline(R, threads):
+    """The CPU oracle on a bounded sample of the same workload: B=2, one timed train step
+    (forward + surrogate loss + backward + torch Adam) after one warm-up."""
+    from oracle import pdfnet_cpu as O
+    from oracle import synth
+    from tests.util import surrogate_loss
+    torch.set_num_threads(threads)
+    B = 2
+    o = O.load_model_cpu(make_opt(R))
+    opt = torch.optim.Adam(o.parameters(), lr=1e-4)
+    b = synth.to_torch(synth.synthetic_batch(B, R, seed=1))
+    o.train()
+    times = []
+    for _ in range(2):
+        t0 = time.time()
+        opt.zero_grad()
+        res = o(b['input'], b['choose'], b['cloud'], b['depth'], b['ind'], b['K_new'], b['valid'])
+        surrogate_loss(res).backward()
+        opt.step()
+        times.append(time.time() - t0)
+    return {"value": round(B / times[-1], 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "CPU oracle (oracle/pdfnet_cpu.py, PyTorch fp32), B=%d %dx%d RGB-D, 1 train step "
+                      "(fwd + surrogate loss + bwd + Adam) after 1 warm-up, %.1f s" % (B, R, R, times[-1])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (BASELINE config 3: 32)')
+    ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from pdfnet_amd import functional as F
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch, to_device
+    from pdfnet_amd.trains.base_trainer import Trainer, init_distributed
+    from pdfnet_amd.trains.simplified import CtdetLoss
+
+    rank, local, world = init_distributed()
+    assert world == args.gpus or (world == 1 and args.gpus == 1), "launch with torch.distributed.run for --gpus > 1"
+    dev = torch.device('cuda', local)
+    R, B = args.res, args.batch
+    opt = make_opt(R)
+    torch.manual_seed(0)
+    F.manual_seed(1234 + rank)
+    model = load_model_intag(opt).to(dev)
+    consts = synthetic_loss_constants()
+    loss = CtdetLoss(opt, consts).to(dev)
+    trainer = Trainer(opt, model, loss, lr=1e-4, use_graph=not args.no_graph)
+    if world > 1:
+        dist.broadcast(trainer.optimizer.flat_p, 0)            # identical replicas (DDP constructor semantics)
+    batch = to_device(synthetic_train_batch(B, R, seed=1 + rank, consts=consts), dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(batch)
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        last = trainer.train_step(batch)
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(last)
+    assert loss_val == loss_val, "loss is NaN"
+
+    out = {
+        "metric": "train-step images/sec @256x256 RGB-D B=32", "value": round(world * B * args.steps / dt, 2),
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2]: B=%d/GPU full RGB-D pyramid fusion + PointNet++ + GCN decoder fwd + CtdetLoss + bwd + Adam, "
+                               "fp32, %dx%d" % (B, R, R), "global_batch": world * B, "parallelism": "dp%d" % world,
+                   "launch": "eager" if args.no_graph else "hipGraph(fwd+loss+bwd) + fused Adam", "final_loss": round(loss_val, 4)},
+    }
+    if rank == 0 and not args.no_roofline:
+        # instrumented eager step: events around every implicit-GEMM entry point on the launch stream
+        trainer.use_graph = False
+        with GemmProfiler() as prof:
+            trainer.train_step(batch)
+        per = prof.summary()
+        calls = sum(v[0] for v in per.values())
+        flops = sum(v[1] for v in per.values())
+        secs = sum(v[2] for v in per.values())
+        out["roofline"] = {
+            "bound": "mfma", "achieved": round(flops / secs / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "igemm_nt / wgemm_tn (fp32 MFMA implicit GEMM family, csrc/gemm.hip)",
+            "launches_per_step": calls, "algorithmic_gflop_per_step": round(flops / 1e9, 1),
+            "gemm_ms_per_step": round(secs * 1e3, 2),
+            "per_entry_point": {k: {"calls": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
+                                    "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(per.items())},
+            "step_level": {"algorithmic_gflop_per_img_reference_formulation": ALGO_GFLOP_PER_IMG_STEP_DENSE,
+                           "tflops_at_measured_rate": round(ALGO_GFLOP_PER_IMG_STEP_DENSE * out["value"] / world / 1e3, 2)},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(R, max(1, (os.cpu_count() or 2) // 2))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,8 +128,9 @@ int pdf_sft_fwd(const float* fea, int ldf, const float* scale, int lds, const fl
                 float* out, int ldo, int C, long R, void* stream);
 int pdf_sft_bwd(const float* g, int ldg, const float* fea, int ldf, const float* scale, int lds,
                 float* dfea, int lddf, float* dscale, int ldds, int C, long R, void* stream);
-/* nn.Dropout(p) with a stateless (seed, index) mask: the same call is its own backward (gcn.py:96, self_attn.py:51-52) */
-int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream);
+/* nn.Dropout(p) with a stateless (seed, index) mask: the same call is its own backward (gcn.py:96, self_attn.py:51-52).
+ * step: optional DEVICE counter mixed into the seed so a replayed hipGraph draws a fresh mask every step. */
+int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long seed, const unsigned long long* step, void* stream);
 /* resnet.maxpool (resnet.py:206) */
 int pdf_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* arg, void* stream);
 int pdf_maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, void* stream);
@@ -148,9 +149,9 @@ int pdf_cheby2_bwd(const float* d, int ldd, int B, int V, int F, const int* colT
                    float* dx, int lddx, void* stream);
 /* multi-head softmax attention (self_attn.py:63-76, inter_attn.py:82-105); stat [B][H][V][2], dvec [B][H][V] */
 int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld, int B, int V, int H, int dh,
-                 float pdrop, unsigned long long seed, float* out, int ldo, float* stat, void* stream);
+                 float pdrop, unsigned long long seed, const unsigned long long* step, float* out, int ldo, float* stat, void* stream);
 int pdf_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* o, const float* dout, int ldo,
-                 const float* stat, int B, int V, int H, int dh, float pdrop, unsigned long long seed,
+                 const float* stat, int B, int V, int H, int dh, float pdrop, unsigned long long seed, const unsigned long long* step,
                  float* dq, float* dk, float* dv, int lddq, float* dvec, void* stream);
 
 /* ---- MANO (csrc/mano.hip) --------------------------------------------------------------------- */

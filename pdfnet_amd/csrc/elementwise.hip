@@ -71,13 +71,15 @@ PDF_API int pdf_sft_bwd(const float* g, int ldg, const float* fea, int ldf, cons
 
 // dropout with a stateless mask: keep iff u(seed, i) >= p ; y = x * keep / (1-p).  Same call serves
 // forward and backward (the mask is a pure function of seed and element index).
-__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p, unsigned long long seed) {
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p, unsigned long long seed,
+                               const unsigned long long* __restrict__ step) {
     const float sc = 1.f / (1.f - p);
+    if (step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;      // per-step stream under hipGraph replay
     GRID_STRIDE(i, n) y[i] = pdf_uniform(seed, (unsigned long long)i) >= p ? x[i] * sc : 0.f;
 }
-PDF_API int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long seed, hipStream_t s) {
+PDF_API int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long seed, const unsigned long long* step, hipStream_t s) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, p, seed);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, p, seed, step);
     PDF_LAUNCH_CHECK();
     return 0;
 }

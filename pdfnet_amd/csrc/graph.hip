@@ -56,8 +56,9 @@ PDF_API int pdf_cheby2_bwd(const float* d, int ldd, int B, int V, int F, const i
 // Dropout on the attention matrix (dropout1) uses the stateless mask of common.h.
 template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
-                                                       int V, int H, float inv_norm, float pdrop, unsigned long long seed,
+                                                       int V, int H, float inv_norm, float pdrop, unsigned long long seed, const unsigned long long* __restrict__ step,
                                                        float* __restrict__ out, int ldo, float* __restrict__ stat /*[B][H][V][2] = max, sumexp*/) {
+    if (step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;
     extern __shared__ float sm[];
     float* sk = sm;              // [V][DH]
     float* sv = sm + V * DH;
@@ -102,12 +103,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 }
 
 PDF_API int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld, int B, int V, int H, int dh,
-                         float pdrop, unsigned long long seed, float* out, int ldo, float* stat, hipStream_t s) {
+                         float pdrop, unsigned long long seed, const unsigned long long* step, float* out, int ldo, float* stat, hipStream_t s) {
     size_t smem = (size_t)2 * V * dh * sizeof(float);
     if (smem > 64 * 1024) return PDF_E_BADARG;
     float inv_norm = 1.f / sqrtf((float)dh);
     dim3 grid(B * H);
-#define ATT_CASE(D) case D: hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, V, H, inv_norm, pdrop, seed, out, ldo, stat); break;
+#define ATT_CASE(D) case D: hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, V, H, inv_norm, pdrop, seed, step, out, ldo, stat); break;
     switch (dh) { ATT_CASE(4) ATT_CASE(16) ATT_CASE(32) ATT_CASE(64) default: return PDF_E_BADARG; }
 #undef ATT_CASE
     PDF_LAUNCH_CHECK();
@@ -119,8 +120,9 @@ PDF_API int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld,
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
                                                          const float* __restrict__ o, const float* __restrict__ dout, int ldo,
-                                                         const float* __restrict__ stat, int V, int H, float inv_norm, float pdrop, unsigned long long seed,
+                                                         const float* __restrict__ stat, int V, int H, float inv_norm, float pdrop, unsigned long long seed, const unsigned long long* __restrict__ step,
                                                          float* __restrict__ dq, int lddq, float* __restrict__ dvec /*[B][H][V] D_i*/) {
+    if (step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;
     extern __shared__ float sm[];
     float* sk = sm;
     float* sv = sm + V * DH;
@@ -166,8 +168,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
                                                           const float* __restrict__ dout, int ldo, const float* __restrict__ stat,
-                                                          const float* __restrict__ dvec, int V, int H, float inv_norm, float pdrop, unsigned long long seed,
+                                                          const float* __restrict__ dvec, int V, int H, float inv_norm, float pdrop, unsigned long long seed, const unsigned long long* __restrict__ step,
                                                           float* __restrict__ dk, float* __restrict__ dv, int lddk) {
+    if (step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;
     extern __shared__ float sm[];
     float* sq = sm;              // [V][DH]
     float* sg = sm + V * DH;     // dO
@@ -209,15 +212,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
 }
 
 PDF_API int pdf_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* o, const float* dout, int ldo,
-                         const float* stat, int B, int V, int H, int dh, float pdrop, unsigned long long seed,
+                         const float* stat, int B, int V, int H, int dh, float pdrop, unsigned long long seed, const unsigned long long* step,
                          float* dq, float* dk, float* dv, int lddq, float* dvec, hipStream_t s) {
     size_t smem = (size_t)2 * V * dh * sizeof(float);
     if (smem > 64 * 1024) return PDF_E_BADARG;
     float inv_norm = 1.f / sqrtf((float)dh);
     dim3 grid(B * H);
 #define ATT_CASE(D) case D: \
-        hipLaunchKernelGGL(attn_bwd_q_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, o, dout, ldo, stat, V, H, inv_norm, pdrop, seed, dq, lddq, dvec); \
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, dout, ldo, stat, dvec, V, H, inv_norm, pdrop, seed, dk, dv, lddq); break;
+        hipLaunchKernelGGL(attn_bwd_q_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, o, dout, ldo, stat, V, H, inv_norm, pdrop, seed, step, dq, lddq, dvec); \
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, dout, ldo, stat, dvec, V, H, inv_norm, pdrop, seed, step, dk, dv, lddq); break;
     switch (dh) { ATT_CASE(4) ATT_CASE(16) ATT_CASE(32) ATT_CASE(64) default: return PDF_E_BADARG; }
 #undef ATT_CASE
     PDF_LAUNCH_CHECK();

@@ -386,7 +386,7 @@ class _Dropout(Function):
     def forward(ctx, x, p, seed):
         x = x.contiguous()
         y = torch.empty_like(x)
-        _L().pdf_dropout(ptr(x), ptr(y), x.numel(), p, seed, stream())
+        _L().pdf_dropout(ptr(x), ptr(y), x.numel(), p, seed, ptr(step_counter(x.device)), stream())
         ctx.cfg = (p, seed)
         return y
 
@@ -395,7 +395,7 @@ class _Dropout(Function):
         p, seed = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
-        _L().pdf_dropout(ptr(dy), ptr(dx), dy.numel(), p, seed, stream())
+        _L().pdf_dropout(ptr(dy), ptr(dx), dy.numel(), p, seed, ptr(step_counter(dy.device)), stream())
         return dx, None, None
 
 
@@ -406,6 +406,18 @@ def next_seed():
     """Host-side counter; each dropout site of each step gets a distinct mask stream."""
     _seed_state[0] = (_seed_state[0] * 6364136223846793005 + 1442695040888963407) & ((1 << 63) - 1)
     return _seed_state[0]
+
+
+_step_counters = {}
+
+
+def step_counter(dev):
+    """Device-resident step counter mixed into every dropout seed.  The trainer increments it inside the
+    captured step, so hipGraph replays draw fresh masks although the host-side seeds are baked in."""
+    key = str(dev)
+    if key not in _step_counters:
+        _step_counters[key] = torch.zeros(1, dtype=torch.int64, device=dev)
+    return _step_counters[key]
 
 
 def manual_seed(s):
@@ -571,7 +583,7 @@ class _Attention(Function):
         dh = Fd // heads
         out = torch.empty_like(q)
         stat = torch.empty((B, heads, V, 2), device=q.device)
-        _L().pdf_attn_fwd(ptr(q), ptr(k), ptr(v), Fd, B, V, heads, dh, pdrop, seed, ptr(out), Fd, ptr(stat), stream())
+        _L().pdf_attn_fwd(ptr(q), ptr(k), ptr(v), Fd, B, V, heads, dh, pdrop, seed, ptr(step_counter(q.device)), ptr(out), Fd, ptr(stat), stream())
         ctx.save_for_backward(q, k, v, out, stat)
         ctx.cfg = (heads, pdrop, seed)
         return out
@@ -584,7 +596,7 @@ class _Attention(Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         dvec = torch.empty((B, heads, V), device=q.device)
         _L().pdf_attn_bwd(ptr(q), ptr(k), ptr(v), Fd, ptr(out), ptr(do.contiguous()), Fd, ptr(stat), B, V, heads, Fd // heads,
-                          pdrop, seed, ptr(dq), ptr(dk), ptr(dv), Fd, ptr(dvec), stream())
+                          pdrop, seed, ptr(step_counter(q.device)), ptr(dq), ptr(dk), ptr(dv), Fd, ptr(dvec), stream())
         return dq, dk, dv, None, None, None
 
 

@@ -53,17 +53,25 @@ def load_graph_constants():
 
 
 class GCN_vert_convert:
-    """intaghand_decoder.py:32-43 (index tensors follow the data's device)."""
+    """intaghand_decoder.py:32-43.  The index tables are (non-persistent) buffers of the decoder module so they
+    move with .cuda()/.to() and no host->device copy happens inside a captured step."""
 
-    def __init__(self, graph_perm, graph_perm_reverse):
-        self.graph_perm = graph_perm
-        self.graph_perm_reverse = graph_perm_reverse
+    def __init__(self, owner, hand):
+        self._owner, self._hand = owner, hand
+
+    @property
+    def graph_perm(self):
+        return getattr(self._owner, 'graph_perm_' + self._hand)
+
+    @property
+    def graph_perm_reverse(self):
+        return getattr(self._owner, 'graph_perm_reverse_' + self._hand)
 
     def vert_to_GCN(self, x):
-        return x[:, self.graph_perm.to(x.device)]
+        return x[:, self.graph_perm]
 
     def GCN_to_vert(self, x):
-        return x[:, self.graph_perm_reverse.to(x.device)]
+        return x[:, self.graph_perm_reverse]
 
 
 class GCN_ResBlock(nn.Module):
@@ -224,7 +232,10 @@ class decoder(nn.Module):
         super().__init__()
         g = load_graph_constants()
         self.register_buffer('dense_coor', g['dense_coor'].clone())
-        self.converter = {h: GCN_vert_convert(g['perm_' + h], g['perm_rev_' + h]) for h in ('left', 'right')}
+        for h in ('left', 'right'):
+            self.register_buffer('graph_perm_' + h, g['perm_' + h].clone(), persistent=False)
+            self.register_buffer('graph_perm_reverse_' + h, g['perm_rev_' + h].clone(), persistent=False)
+        self.converter = {h: GCN_vert_convert(self, h) for h in ('left', 'right')}
         cin, cout = opt.GCN_IN_DIM, opt.GCN_OUT_DIM
         layers = []
         for i, V in enumerate((63, 126, 252)):
