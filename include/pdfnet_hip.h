@@ -87,6 +87,11 @@ int pdf_gather_rows(const float* feat, int ldf, int C, long HW, const long* ind,
                     int B, int M, int R, int shift, float* out, int ldo, void* stream);
 int pdf_scatter_rows_add(const float* dout, int ldo, int C, long HW, const long* ind, long ind_bstride,
                          int B, int M, int R, int shift, float* dfeat, int ldf, void* stream);
+/* 5x5 / 3x3 windows around the centre pixels for the exact sparse evaluation of center_feat_up0 -> center_feat_up1 ->
+ * _tranpose_and_gather_feat (intaghand_encoder.py:790-792).  buf is [B*M][win][win][C], win = 2r+1.
+ * mode 0: buf = windows of feat (zero outside); 1: feat += buf (backward); 2: buf = inside-image ? src : 0. */
+int pdf_window_op(float* feat, int ldf, int C, int H, int W, const long* ind, long ind_bstride,
+                  int B, int M, int r, float* buf, const float* src, int mode, void* stream);
 /* nn.MaxPool2d((1,K)) / ((S2,1)) of netR_1/2/3 (intaghand_encoder.py:62,82,100): x [R][K][ldx] -> y [R][ldy], arg [R][C] */
 int pdf_maxk_fwd(const float* x, int ldx, int C, long R, int K, float* y, int ldy, int* arg, void* stream);
 int pdf_maxk_bwd(const float* dy, int ldy, const int* arg, int C, long R, int K, float* dx, int ldx, void* stream);

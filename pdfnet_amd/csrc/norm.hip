@@ -32,15 +32,33 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
+
+// sum the per-chunk partials part[chunk][C][2] for channel c: 64 channels x 4 chunk-lanes per block
+// (a serial 512-iteration loop per channel was latency-bound: ~50 us for a kernel that moves a few KB)
+#define FIN_TX 64
+#define FIN_TY 4
+__device__ __forceinline__ void reduce_chunks(const float* __restrict__ part, int chunks, int C, int c, int ty,
+                                              double (&s1)[FIN_TY][FIN_TX], double (&s2)[FIN_TY][FIN_TX], double& a, double& b) {
+    a = 0.0; b = 0.0;
+    if (c < C)
+        for (int k = ty; k < chunks; k += FIN_TY) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    const int tx = threadIdx.x;
+    s1[ty][tx] = a; s2[ty][tx] = b;
+    __syncthreads();
+    a = 0.0; b = 0.0;
+    for (int j = 0; j < FIN_TY; ++j) { a += s1[j][tx]; b += s2[j][tx]; }
+}
+
 __global__ void bn_finalize_kernel(const float* __restrict__ part, int chunks, const float* __restrict__ x, int C, long R,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
                                    float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                    float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < chunks; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    __shared__ double s1[FIN_TY][FIN_TX], s2[FIN_TY][FIN_TX];
+    const int c = blockIdx.x * FIN_TX + threadIdx.x;
+    double a, b;
+    reduce_chunks(part, chunks, C, c, threadIdx.y, s1, s2, a, b);
+    if (c >= C || threadIdx.y != 0) return;
     const double n = (double)R;
     const double dm = a / n;
     double var = b / n - dm * dm;
@@ -85,8 +103,16 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
 
 // Training forward.  ws: >= pdf_bn_workspace_floats(C, R) floats.  scale/shift [C] are outputs the
 // caller keeps for backward-free reuse; save_mean/save_rstd [C] feed the backward.
+static long bn_chunks(int C, long R) {
+    long want = 1024 / ((C + BN_CT - 1) / BN_CT);          // ~1024 blocks over (channel tiles x chunks)
+    if (want > 256) want = 256;
+    long by_rows = (R + 63) / 64;                           // at least 64 rows per chunk
+    if (want > by_rows) want = by_rows;
+    if (want < 1) want = 1;
+    return want;
+}
 PDF_API long pdf_bn_workspace_floats(int C, long R) {
-    long chunks = (R + 255) / 256; if (chunks > 512) chunks = 512; if (chunks < 1) chunks = 1;
+    long chunks = bn_chunks(C, R);
     return chunks * C * 2;
 }
 
@@ -95,12 +121,12 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
                              const float* res, int ldr, int relu, float* y, int ldy,
                              float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, hipStream_t s) {
     if (R <= 0 || C <= 0) return 0;
-    long chunks = (R + 255) / 256; if (chunks > 512) chunks = 512; if (chunks < 1) chunks = 1;
+    long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
     hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, ws, (int)chunks, x, C, R, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, x, C, R, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
     PDF_LAUNCH_CHECK();
     hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
@@ -149,10 +175,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, long R, const float* __restrict__ gamma,
                                        const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                        float* __restrict__ coef /*[3][C]: a, c1, c2*/) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < chunks; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    __shared__ double s1[FIN_TY][FIN_TX], s2[FIN_TY][FIN_TX];
+    const int c = blockIdx.x * FIN_TX + threadIdx.x;
+    double a, b;
+    reduce_chunks(part, chunks, C, c, threadIdx.y, s1, s2, a, b);
+    if (c >= C || threadIdx.y != 0) return;
     if (accumulate) { dbeta[c] += (float)a; dgamma[c] += (float)b; }
     else { dbeta[c] = (float)a; dgamma[c] = (float)b; }
     coef[c] = gamma[c] * rstd[c];
@@ -182,14 +209,14 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
                              float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
                              float* ws, hipStream_t s) {
     if (R <= 0 || C <= 0) return 0;
-    long chunks = (R + 255) / 256; if (chunks > 512) chunks = 512; if (chunks < 1) chunks = 1;
+    long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
     float* coef = ws + pdf_bn_workspace_floats(C, R);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
                        save_mean, save_rstd, C, R, rpc, ws);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, ws, (int)chunks, C, R, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, R, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
     PDF_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef, C, R * C,
                        dx, lddx, dres, lddr);
@@ -199,10 +226,11 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
 
 // column sums: out[c] (+)= sum_r g[r][c]   (conv / linear bias gradients), optional relu mask by y
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0;
-    for (int k = 0; k < chunks; ++k) a += part[((long)k * C + c) * 2];
+    __shared__ double s1[FIN_TY][FIN_TX], s2[FIN_TY][FIN_TX];
+    const int c = blockIdx.x * FIN_TX + threadIdx.x;
+    double a, b;
+    reduce_chunks(part, chunks, C, c, threadIdx.y, s1, s2, a, b);
+    if (c >= C || threadIdx.y != 0) return;
     out[c] = (accumulate ? out[c] : 0.f) + (float)a;
 }
 
@@ -216,17 +244,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (c < C) for (long r = r0 + ty; r < r1; r += 4) a += g[r * ldg + c];
     s1[ty][tx] = a;
     __syncthreads();
-    if (ty == 0 && c < C) part[((long)blockIdx.y * C + c) * 2] = s1[0][tx] + s1[1][tx] + s1[2][tx] + s1[3][tx];
+    if (ty == 0 && c < C) {
+        part[((long)blockIdx.y * C + c) * 2] = s1[0][tx] + s1[1][tx] + s1[2][tx] + s1[3][tx];
+        part[((long)blockIdx.y * C + c) * 2 + 1] = 0.f;
+    }
 }
 
 PDF_API int pdf_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s) {
     if (R <= 0 || C <= 0) return 0;
-    long chunks = (R + 255) / 256; if (chunks > 512) chunks = 512; if (chunks < 1) chunks = 1;
+    long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, g, ldg, C, R, rpc, ws);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, ws, (int)chunks, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, out, accumulate);
     PDF_LAUNCH_CHECK();
     return 0;
 }

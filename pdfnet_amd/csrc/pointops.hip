@@ -267,3 +267,46 @@ PDF_API int pdf_maxk_bwd(const float* dy, int ldy, const int* arg, int C, long R
     PDF_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Window gathers for the exact sparse evaluation of center_feat_up0 -> center_feat_up1 -> gather
+// (reference intaghand_encoder.py:790-792 computes two full 3x3 convolutions, 48.3 GFLOP/img, and keeps
+// 2 pixels per sample).  out[(b*M+m)][wy][wx][:] = feat[b][cy-r+wy][cx-r+wx][:] (zero outside the map),
+// (cy, cx) = divmod(ind[b][m], W).  mode 0: gather; mode 1: scatter-add of `buf` into feat (backward);
+// mode 2: in-place-safe mask: y = inside ? x : 0 on a [.., win, win, C] patch tensor (the 3x3 up0 patch must
+// be ZERO where it falls outside the image -- conv padding pads up0, it does not convolve the padding).
+__global__ __launch_bounds__(256) void window_kernel(float* __restrict__ feat, int ldf, int C, int H, int W,
+                                                     const long* __restrict__ ind, long ind_bstride, int M, int r,
+                                                     float* __restrict__ buf, const float* __restrict__ src, int mode, long total) {
+    const int lane = threadIdx.x & 63;
+    const int win = 2 * r + 1;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long p = w0; p < total; p += nw) {                  // p = ((b*M + m)*win + wy)*win + wx
+        long q = p;
+        const int wx = (int)(q % win); q /= win;
+        const int wy = (int)(q % win); q /= win;
+        const long b = q / M;
+        const long i = ind[b * ind_bstride + (q - b * M)];
+        const int y = (int)(i / W) - r + wy, x = (int)(i % W) - r + wx;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        float* row = buf + p * C;
+        if (mode == 2) {
+            const float* s = src + p * C;
+            for (int c = lane; c < C; c += 64) row[c] = in ? s[c] : 0.f;
+        } else {
+            float* f = feat + ((b * H + y) * (long)W + x) * ldf;
+            if (mode == 0) { for (int c = lane; c < C; c += 64) row[c] = in ? f[c] : 0.f; }
+            else if (in) { for (int c = lane; c < C; c += 64) atomicAdd(f + c, row[c]); }
+        }
+    }
+}
+
+PDF_API int pdf_window_op(float* feat, int ldf, int C, int H, int W, const long* ind, long ind_bstride,
+                          int B, int M, int r, float* buf, const float* src, int mode, hipStream_t s) {
+    long total = (long)B * M * (2 * r + 1) * (2 * r + 1);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(window_kernel, dim3(grid_for(total * 64)), dim3(256), 0, s, feat, ldf, C, H, W, ind, ind_bstride, M, r, buf, src, mode, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}

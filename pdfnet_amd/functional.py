@@ -487,6 +487,59 @@ def gather_rows(feat, ind, R=1, shift=0, ldo=None):
     return _GatherRows.apply(feat, ind, R, shift, ldo or feat.shape[1])
 
 
+class _WindowGather(Function):
+    """feat [B,C,H,W] channels_last, ind [B,M] -> windows [B*M, C, win, win] (channels_last), zero outside."""
+
+    @staticmethod
+    def forward(ctx, feat, ind, r):
+        hip.require_gpu(feat, ind)
+        feat = cl(feat)
+        B, C, H, W = feat.shape
+        M, win = ind.shape[1], 2 * r + 1
+        out = torch.empty((B * M, C, win, win), device=feat.device, memory_format=CL)
+        _L().pdf_window_op(ptr(feat), C, C, H, W, ptr(ind), ind.stride(0), B, M, r, ptr(out), None, 0, stream())
+        ctx.save_for_backward(ind)
+        ctx.cfg = (B, C, H, W, M, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ind,) = ctx.saved_tensors
+        B, C, H, W, M, r = ctx.cfg
+        dfeat = _zeros_cl((B, C, H, W), g.device)
+        _L().pdf_window_op(ptr(dfeat), C, C, H, W, ptr(ind), ind.stride(0), B, M, r, ptr(cl(g)), None, 1, stream())
+        return dfeat, None, None
+
+
+class _WindowMask(Function):
+    """x [B*M, C, win, win]: zero the window positions that fall outside the H x W map (its own backward)."""
+
+    @staticmethod
+    def forward(ctx, x, ind, H, W, r):
+        x = cl(x)
+        C = x.shape[1]
+        B, M = ind.shape
+        y = torch.empty_like(x)
+        _L().pdf_window_op(None, C, C, H, W, ptr(ind), ind.stride(0), B, M, r, ptr(y), ptr(x), 2, stream())
+        ctx.save_for_backward(ind)
+        ctx.cfg = (H, W, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (ind,) = ctx.saved_tensors
+        H, W, r = ctx.cfg
+        return _WindowMask.apply(g, ind, H, W, r), None, None, None, None
+
+
+def window_gather(feat, ind, r):
+    return _WindowGather.apply(feat, ind, r)
+
+
+def window_mask(x, ind, H, W, r):
+    return _WindowMask.apply(x, ind, H, W, r)
+
+
 class _KnnGroup(Function):
     """pts [Bc,N,ldp] rows (C real channels, xyz first) -> grouped [Bc,S,K,ldg], idx [Bc,S,K] int32."""
 

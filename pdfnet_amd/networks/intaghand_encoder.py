@@ -203,6 +203,23 @@ class ResNetSimple(nn.Module):
                 small_normal_(fc)
             setattr(self, head, fc)
         self.dp_decoder = ResNetSimple_decoder(2, True)
+        self.dense_center = False
+
+    def center_features(self, x0, ind):
+        """center_feat_up0 -> center_feat_up1 -> gather at the 2 centre pixels (:790-792).
+        sparse (default): exact evaluation on the 5x5 window of x0 around each centre -- up0 on the 3x3
+        neighbourhood (zeroed where it leaves the map, because up1's padding pads up0 with zeros), then up1
+        at the centre: 0.06 instead of 48.3 GFLOP/img, same values.
+        dense: the reference formulation (two full 3x3 convolutions, then keep 2 pixels)."""
+        if self.dense_center:
+            return F.gather_rows(self.center_feat_up1(self.center_feat_up0(x0)), ind)
+        B, _, H, W = x0.shape
+        up0, up1 = self.center_feat_up0, self.center_feat_up1
+        win = F.window_gather(x0, ind, 2)                                                  # [B*2,256,5,5]
+        u0 = F.conv2d(win, up0.weight, None, 1, 0)                                         # [B*2,512,3,3] (valid conv)
+        u0 = F.window_mask(u0, ind, H, W, 1)
+        u1 = F.conv2d(u0, up1.weight, None, 1, 0)                                          # [B*2,1024,1,1]
+        return u1.reshape(B, 2, 1024)
 
     def forward(self, img, ind, choose, cloud):
         if choose is None or cloud is None:
@@ -228,7 +245,7 @@ class ResNetSimple(nn.Module):
             ret[head] = fc[2](fc[0](x0, F.ACT_RELU))
         hms, hms_f = self.hms_decoder(x1)
         mask, dp_f = self.dp_decoder(x1)
-        center = F.gather_rows(self.center_feat_up1(self.center_feat_up0(x0)), ind)        # [B,2,1024]  (:790-792)
+        center = self.center_features(x0, ind)                                             # [B,2,1024]  (:790-792)
         emb = [emb0, emb1, x0]
         fl = self.pointnet_plus(cloud[:, 0], emb, choose[:, 0])                            # :805
         fr = self.pointnet_plus(cloud[:, 1], emb, choose[:, 1])                            # :806

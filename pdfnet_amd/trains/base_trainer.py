@@ -41,20 +41,22 @@ class FlatAdam:
         dev = self.params[0].device
         assert dev.type == 'cuda', "FlatAdam: parameters must be on the GPU (no CPU fallback)"
         self.lr, self.betas, self.eps = lr, betas, eps
-        n = sum(p.numel() for p in self.params)
+        ALIGN = 64                                     # every tensor starts on a 256-byte boundary: the GEMM fast
+        offs, n = [], 0                                # path needs 16-byte aligned operands (float4 loads)
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = n
-        self.flat_p = torch.empty(n, device=dev)
+        self.flat_p = torch.zeros(n, device=dev)
         self.flat_g = torch.zeros(n, device=dev)
         self.flat_m = torch.zeros(n, device=dev)
         self.flat_v = torch.zeros(n, device=dev)
-        o = 0
-        for p in self.params:
+        for p, o in zip(self.params, offs):
             k = p.numel()
             view = self.flat_p[o:o + k].as_strided(p.shape, p.stride())      # keeps e.g. channels_last storage
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_g[o:o + k].as_strided(p.shape, p.stride())
-            o += k
         self.step_t = torch.zeros(1, device=dev)                             # device-side step count (graph-safe)
         self.corr = torch.ones(2, device=dev)
         self._b = torch.tensor(betas, device=dev)
