@@ -197,8 +197,12 @@ def main():
             "gemm_ms_per_step": round(secs * 1e3, 2),
             "per_entry_point": {k: {"calls": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
                                     "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(per.items())},
-            "step_level": {"algorithmic_gflop_per_img_reference_formulation": ALGO_GFLOP_PER_IMG_STEP_DENSE,
-                           "tflops_at_measured_rate": round(ALGO_GFLOP_PER_IMG_STEP_DENSE * out["value"] / world / 1e3, 2)},
+            "formulation": "executed contraction = exact sparse centre features (SURVEY 8a6): ~214 GFLOP/img/step; "
+                           "reference formulation (dense centre convs) = 358 GFLOP/img/step",
+            "step_level": {"gflop_per_img_step_reference_formulation": ALGO_GFLOP_PER_IMG_STEP_DENSE,
+                           "tflops_reference_formulation": round(ALGO_GFLOP_PER_IMG_STEP_DENSE * out["value"] / world / 1e3, 2),
+                           "gflop_per_img_step_executed": round(flops / 1e9 / B, 1),
+                           "tflops_executed": round(flops / 1e9 / B * out["value"] / world / 1e3, 2)},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, max(1, (os.cpu_count() or 2) // 2))

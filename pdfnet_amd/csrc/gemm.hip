@@ -84,15 +84,17 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = (g.K + BK - 1) / BK;
-    const int tpt = FAST ? g.Cin / BK : 1;   // k-tiles per tap
 
     float4 ra[RA], rb[RB];
+    // tap state of the NEXT tile to load (tiles are loaded strictly in order): no per-tile division and the
+    // tap table (scalar loads that share lgkmcnt with the LDS traffic) is read only when the tap changes
+    int nt_tap = 0, nt_ci = 0, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * g.Cin;
     auto gload = [&](int kt) {
         if (FAST) {
-            int t = kt / tpt;
-            int ci0 = (kt - t * tpt) * BK + kq;
-            int ddy = g.dy[t], ddx = g.dx[t];
-            int wofs = g.wt[t] * g.Cin + ci0;
+            const int ci0 = nt_ci + kq;
+            const int wofs = wbase + ci0;
+            nt_ci += BK;
+            const bool tap_done = nt_ci >= g.Cin;
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -111,6 +113,10 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
                 if (bval[i]) v = *reinterpret_cast<const float4*>(g.B + bbase[i] + wofs);
                 rb[i] = v;
             }
+            if (tap_done && nt_tap + 1 < g.T) {
+                ++nt_tap; nt_ci = 0;
+                ddy = g.dy[nt_tap]; ddx = g.dx[nt_tap]; wbase = g.wt[nt_tap] * g.Cin;
+            }
         } else {
             float tmpa[RA][4], tmpb[RB][4];
 #pragma unroll
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
                 bool kin = k < g.K;
                 int t = kin ? k / g.Cin : 0;
                 int ci = k - t * g.Cin;
-                int ddy = g.dy[t], ddx = g.dx[t];
+                const int gdy = g.dy[t], gdx = g.dx[t];
                 int wofs = g.wt[t] * g.Cin + ci;
 #pragma unroll
                 for (int i = 0; i < RA; ++i) {
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
                     if (kin && aval[i]) {
                         if (g.plain_in) v = g.A[abase[i] + k];
                         else {
-                            int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
+                            int iy = iy0[i] + gdy, ix = ix0[i] + gdx;
                             if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
                                 v = g.A[abase[i] + ((long)iy * g.W + ix) * g.lda + ci];
                         }
@@ -230,6 +236,7 @@ struct WGemm {
     int H, W, QH, QW, sy, sx;
     int plain_q;
     int rows_per_split;
+    int beta;                                 // single-split launches write dW directly: dW = beta*dW + acc
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
 
@@ -273,6 +280,17 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float4 rp[RP], rq[RQ];
+    // (image, qy, qx) of each Q row this thread loads, advanced by BK rows per step -- no divisions in the loop
+    int q_ni[RQ], q_y[RQ], q_x[RQ];
+#pragma unroll
+    for (int i = 0; i < RQ; ++i) {
+        int m = ms + qr + i * (256 / TPR_Q);
+        int hw = g.QH * g.QW;
+        q_ni[i] = m / hw;
+        int rem = m - q_ni[i] * hw;
+        q_y[i] = rem / g.QW;
+        q_x[i] = rem - q_y[i] * g.QW;
+    }
     auto gload = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
@@ -305,10 +323,8 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
                         if (qok[3]) v.w = p[qch[3]];
                     }
                 } else {
-                    int hw = g.QH * g.QW;
-                    int ni = m / hw, rem = m - ni * hw;
-                    int qy = rem / g.QW, qx = rem - qy * g.QW;
-                    const float* img = g.Q + (long)ni * g.H * g.W * g.ldq;
+                    const int qy = q_y[i], qx = q_x[i];
+                    const float* img = g.Q + (long)q_ni[i] * g.H * g.W * g.ldq;
                     if (FAST) {
                         int iy = qy * g.sy + g.dy[qt[0]], ix = qx * g.sx + g.dx[qt[0]];
                         if (qok[0] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
@@ -326,6 +342,11 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
                 }
             }
             rq[i] = v;
+            q_x[i] += BK;
+            while (q_x[i] >= g.QW) {
+                q_x[i] -= g.QW;
+                if (++q_y[i] == g.QH) { q_y[i] = 0; ++q_ni[i]; }
+            }
         }
     };
     auto lstore = [&](int buf) {
@@ -380,7 +401,10 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.NI) out[(long)row * g.ldw + wcol] = acc[i][j][r];
+                if (row < g.NI) {
+                    float* o = out + (long)row * g.ldw + wcol;
+                    *o = g.beta ? *o + acc[i][j][r] : acc[i][j][r];
+                }
             }
     }
 }
@@ -527,11 +551,12 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     if (splits > max_by_rows) splits = max_by_rows;
     long per = (long)g.NI * g.ldw;
     if ((long)splits * per > ws_floats) splits = (int)(ws_floats / per);
-    if (splits < 1) return PDF_E_WORKSPACE;
+    if (splits < 1) splits = 1;
     int rps = cdiv(cdiv(g.M, splits), 16) * 16;
     splits = cdiv(g.M, rps);
     g.rows_per_split = rps;
-    g.slab = ws;
+    g.slab = splits == 1 ? out : ws;          // one split: no slab round trip, no reduce launch
+    g.beta = splits == 1 ? accumulate : 0;
     dim3 grid((unsigned)tiles, (unsigned)splits);
     if (small) {
         if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
@@ -541,8 +566,10 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         else hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, false>), grid, dim3(256), 0, s, g);
     }
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_slabs, dim3(grid_for(per)), dim3(256), 0, s, ws, out, per, splits, accumulate);
-    PDF_LAUNCH_CHECK();
+    if (splits > 1) {
+        hipLaunchKernelGGL(reduce_slabs, dim3(grid_for(per)), dim3(256), 0, s, ws, out, per, splits, accumulate);
+        PDF_LAUNCH_CHECK();
+    }
     return 0;
 }
 

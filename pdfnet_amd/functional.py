@@ -47,6 +47,22 @@ def _wgrad_ws(M, NI, NJ, dev):
     return _ws(n, dev), n
 
 
+def _main_grad(param, like):
+    """The trainer's flat gradient view of `param` if gradients may be accumulated into it directly
+    (FlatAdam tags its parameters): skips autograd's separate `grad += dw` pass and the dw allocation."""
+    if param is None or not getattr(param, '_pdf_main_grad', False):
+        return None
+    g = param.grad
+    if g is None or g.shape != like.shape or g.stride() != like.stride():
+        return None
+    return g
+
+
+def _colsum_into(g, C, R, ldg, out):
+    ws = _ws(_L().pdf_bn_workspace_floats(C, R), g.device)
+    _L().pdf_colsum(ptr(g), ldg, C, R, ptr(out), 1, ptr(ws), stream())
+
+
 def _colsum(g, C, R, ldg):
     out = torch.empty(C, dtype=torch.float32, device=g.device)
     ws = _ws(_L().pdf_bn_workspace_floats(C, R), g.device)
@@ -66,6 +82,7 @@ class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, act):
         hip.require_gpu(x, w)
+        w_in = w
         x, w = cl(x), cl(w)
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = w.shape
@@ -75,6 +92,7 @@ class _Conv2d(Function):
         _L().pdf_conv2d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream())
         ctx.save_for_backward(x, w, y if act else None)
         ctx.cfg = (stride, pad, act, b is not None)
+        ctx.params = (w_in, b)
         return y
 
     @staticmethod
@@ -97,12 +115,19 @@ class _Conv2d(Function):
             else:
                 dx = torch.empty_like(x)
             L.pdf_conv2d_bwd_data(ptr(g), ptr(wT), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+        w_par, b_par = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            mg = _main_grad(w_par, w)
+            dw = torch.empty_like(w) if mg is None else None
             ws, n = _wgrad_ws(N * OH * OW, Cout, KH * KW * Cin, x.device)
-            L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(dw), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, 0, stream())
+            L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+                                    stride, pad, OH, OW, Cout, int(mg is not None), stream())
         if has_b and ctx.needs_input_grad[2]:
-            db = _colsum(g, Cout, N * OH * OW, Cout)
+            mg = _main_grad(b_par, b_par)
+            if mg is None:
+                db = _colsum(g, Cout, N * OH * OW, Cout)
+            else:
+                _colsum_into(g, Cout, N * OH * OW, Cout, mg)
         return dx, dw, db, None, None, None
 
 
@@ -116,6 +141,7 @@ class _Deconv2d(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad):
         hip.require_gpu(x, w)
+        w_in = w
         x, w = cl(x), cl(w)
         N, Cin, H, W = x.shape
         _, Cout, KH, KW = w.shape
@@ -131,6 +157,7 @@ class _Deconv2d(Function):
         L.pdf_deconv2d_fwd(ptr(x), ptr(wP), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, b is not None)
+        ctx.params = (w_in, b)
         return y
 
     @staticmethod
@@ -146,12 +173,19 @@ class _Deconv2d(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.pdf_deconv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+        w_par, b_par = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            mg = _main_grad(w_par, w)
+            dw = torch.empty_like(w) if mg is None else None
             ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
-            L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(dw), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, 0, stream())
+            L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+                                      stride, pad, OH, OW, Cout, int(mg is not None), stream())
         if has_b and ctx.needs_input_grad[2]:
-            db = _colsum(g, Cout, N * OH * OW, Cout)
+            mg = _main_grad(b_par, b_par)
+            if mg is None:
+                db = _colsum(g, Cout, N * OH * OW, Cout)
+            else:
+                _colsum_into(g, Cout, N * OH * OW, Cout, mg)
         return dx, dw, db, None, None
 
 
@@ -165,6 +199,7 @@ class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, act):
         hip.require_gpu(x, w)
+        w_in = w
         x, w = x.contiguous(), w.contiguous()
         K = x.shape[-1]
         M = x.numel() // K
@@ -173,6 +208,7 @@ class _Linear(Function):
         _L().pdf_linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), M, Nn, K, K, K, Nn, act, stream())
         ctx.save_for_backward(x, w, y if act else None)
         ctx.cfg = (act, b is not None)
+        ctx.params = (w_in, b)
         return y
 
     @staticmethod
@@ -192,12 +228,18 @@ class _Linear(Function):
             L.pdf_transpose_atb(ptr(w), ptr(wT), Nn, 1, K, stream())
             dx = torch.empty_like(x)
             L.pdf_linear_fwd(ptr(g), ptr(wT), None, ptr(dx), M, K, Nn, Nn, Nn, K, 0, stream())
+        w_par, b_par = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            mg = _main_grad(w_par, w)
+            dw = torch.empty_like(w) if mg is None else None
             ws, n = _wgrad_ws(M, Nn, K, x.device)
-            L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(dw), ptr(ws), n, M, Nn, K, K, Nn, 0, stream())
+            L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, M, Nn, K, K, Nn, int(mg is not None), stream())
         if has_b and ctx.needs_input_grad[2]:
-            db = _colsum(g, Nn, M, Nn)
+            mg = _main_grad(b_par, b_par)
+            if mg is None:
+                db = _colsum(g, Nn, M, Nn)
+            else:
+                _colsum_into(g, Nn, M, Nn, mg)
         return dx, dw, db, None
 
 
@@ -232,6 +274,7 @@ class _BatchNorm(Function):
                               ptr(res), C, int(relu), ptr(y), C, ptr(scale), ptr(shift), stream())
             ctx.save_for_backward(x, gamma, None, None, y if relu else None)
         ctx.cfg = (training, relu, res is not None, eps)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -244,12 +287,17 @@ class _BatchNorm(Function):
         g = _canon(dy)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        dgamma = torch.empty(C, device=x.device)
-        dbeta = torch.empty(C, device=x.device)
+        g_par, b_par = ctx.params
+        mg_g, mg_b = _main_grad(g_par, g_par), _main_grad(b_par, b_par)
+        direct = mg_g is not None and mg_b is not None
+        dgamma = mg_g if direct else torch.empty(C, device=x.device)
+        dbeta = mg_b if direct else torch.empty(C, device=x.device)
         L = _L()
         ws = _ws(L.pdf_bn_workspace_floats(C, R) + 3 * C, x.device)
         L.pdf_bn_train_bwd(ptr(g), C, ptr(y), C, int(relu), ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), C, R,
-                           ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), 0, ptr(ws), stream())
+                           ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream())
+        if direct:
+            dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
@@ -364,6 +412,7 @@ class _LayerNorm(Function):
         rstd = torch.empty(R, device=x.device)
         _L().pdf_layernorm_fwd(ptr(x), Fd, Fd, R, ptr(gamma), ptr(beta), eps, ptr(y), Fd, ptr(mean), ptr(rstd), stream())
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -371,9 +420,14 @@ class _LayerNorm(Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         R, Fd = _rows(x)
         dx = torch.empty_like(x)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
+        g_par, b_par = ctx.params
+        mg_g, mg_b = _main_grad(g_par, g_par), _main_grad(b_par, b_par)
+        direct = mg_g is not None and mg_b is not None
+        dg = mg_g if direct else torch.zeros_like(gamma)
+        db = mg_b if direct else torch.zeros_like(gamma)
         _L().pdf_layernorm_bwd(ptr(dy.contiguous()), Fd, ptr(x), Fd, Fd, R, ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), Fd, ptr(dg), ptr(db), stream())
+        if direct:
+            dg = db = None
         return dx, dg, db, None
 
 

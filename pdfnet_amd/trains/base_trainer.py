@@ -57,6 +57,7 @@ class FlatAdam:
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_g[o:o + k].as_strided(p.shape, p.stride())
+            p._pdf_main_grad = True                   # HIP backward kernels accumulate straight into this view
         self.step_t = torch.zeros(1, device=dev)                             # device-side step count (graph-safe)
         self.corr = torch.ones(2, device=dev)
         self._b = torch.tensor(betas, device=dev)
