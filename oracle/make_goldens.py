@@ -305,6 +305,69 @@ def e2e_fp64_oracle():
     save("e2e_train_fp64_oracle", **out)
 
 
+
+def synthetic_model_outputs(B, R, seed):
+    """Model-output-shaped tensors for the loss parity fixture (same generator in tests/util.py)."""
+    g = rng(seed)
+    f = lambda *sh, sc=1.0: torch.from_numpy((g.standard_normal(sh) * sc).astype(np.float32))
+    result = {'verts3d': {h: f(B, 778, 3, sc=0.05) for h in ('left', 'right')},
+              'verts2d': {h: f(B, 778, 2, sc=30.0) + R / 2 for h in ('left', 'right')}}
+    params = {'scale': {h: f(B, sc=0.3) for h in ('left', 'right')}, 'trans2d': {h: f(B, 2, sc=0.3) for h in ('left', 'right')},
+              'root': {h: f(B, 3, sc=3.0) for h in ('left', 'right')}}
+    hand = [{'verts3d': {h: f(B, 252, 3, sc=0.05) for h in ('left', 'right')},
+             'verts2d': {h: f(B, 252, 2, sc=30.0) + R / 2 for h in ('left', 'right')}}]
+    other = {'hms': f(B, 42, R // 4, R // 4, sc=0.3), 'mask': f(B, 2, R, R, sc=0.5),
+             'ret': {'hm': f(B, 2, R // 4, R // 4) - 2.0, 'wh': f(B, 2, R // 4, R // 4), 'params': f(B, 122, R // 4, R // 4)}}
+    return result, params, hand, other
+
+
+def loss_golden():
+    """Reference CtdetLoss.forward (lib/trains/simplified.py:364-655) on a synthetic batch + synthetic model outputs.
+    The render object is a light stand-in exposing exactly what the live branch touches (full_regressor, faces,
+    get_uv_root_3d, get_Landmarks_new bound from the reference's own ManoRender class; constants are the synthetic
+    MANO-shaped ones of pdfnet_amd/synthetic.py so no MPI-licensed data enters the fixture)."""
+    import types
+    rh.install_stubs()
+    S = rh.ref_module("lib.trains.simplified")
+    MR = rh.ref_module("lib.models.hand3d.Mano_render")
+    D = rh.ref_module("lib.models.networks.intaghand_decoder")
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch
+    R, B = 256, 3
+    consts = synthetic_loss_constants()
+    opt = rh.ref_opt(R, reproj_loss=True, photometric_loss=False, bone_loss=True, dataset='H2O', num_stacks=1, center_weight=200.0,
+                     reproj_weight=1.0, bone_dir_weight=200.0, down_ratio=4, off=False,
+                     perceptual_loss=False, gcn_decoder=False, discrepancy=False)
+    render = types.SimpleNamespace(
+        lhm_path=os.path.join(rh.REF_ROOT, "lib/models/hand3d/mano_core/MANO_LEFT.pkl"),
+        rhm_path=os.path.join(rh.REF_ROOT, "lib/models/hand3d/mano_core/MANO_RIGHT.pkl"),
+        MANO_L=types.SimpleNamespace(full_regressor=consts['full_regressor_left'], faces=consts['faces_left'].numpy()),
+        MANO_R=types.SimpleNamespace(full_regressor=consts['full_regressor_right'], faces=consts['faces_right'].numpy()),
+        input_res=R, opt=opt)
+    render.get_uv_root_3d = types.MethodType(MR.ManoRender.get_uv_root_3d, render)
+    render.get_Landmarks_new = types.MethodType(MR.ManoRender.get_Landmarks_new, render)
+    crit = S.CtdetLoss(opt, render)
+    z = np.load(os.path.join(OUT, "..", "..", "pdfnet_amd", "data", "gcn_core.npz"))
+    conv = {h: D.GCN_vert_convert(vertex_num=778, graph_perm_reverse=z['graph_perm_reverse_' + h], graph_perm=list(z['graph_perm_' + h]))
+            for h in ('left', 'right')}
+    batch = synthetic_train_batch(B, R, seed=5, consts=consts)
+    batch['valid'][1, 1] = 0.0
+    batch['file_id'] = torch.tensor([1, 2, 3])               # % 100 != 0: no debug dumps (simplified.py:527-529)
+    out = {}
+    for epoch in (0, 25):                                      # alpha = 0 / 1 (simplified.py:610)
+        result, params, hand, other = synthetic_model_outputs(B, R, 9)
+        other['converter_left'], other['converter_right'] = conv['left'], conv['right']
+        loss, stats, _, _ = crit(result, params, hand, other, batch, 'train', epoch)
+        out["loss_e%d" % epoch] = loss
+        for k, v in stats.items():
+            out["stat_e%d::%s" % (epoch, k)] = torch.as_tensor(v).reshape(-1)
+    result, params, hand, other = synthetic_model_outputs(B, R, 9)
+    other['converter_left'], other['converter_right'] = conv['left'], conv['right']
+    tup = crit(result, params, hand, other, batch, 'test', 0)
+    for i, t in enumerate(tup):
+        out["test%d" % i] = t
+    save("loss_ctdet_B3_R256", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["ops", "e2e"]
@@ -317,3 +380,5 @@ if __name__ == "__main__":
         e2e()
     if "e2e64" in which or "e2e" in which:
         e2e_fp64_oracle()
+    if "loss" in which or "e2e" in which:
+        loss_golden()

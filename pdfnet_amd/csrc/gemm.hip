@@ -547,7 +547,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     const int BI = small ? 64 : 128, BJ = small ? 64 : 128;
     long tiles = (long)cdiv(g.NI, BI) * cdiv(NJ, BJ);
     int splits = (int)((1024 + tiles - 1) / tiles);
-    int max_by_rows = cdiv(g.M, 512);
+    int max_by_rows = cdiv(g.M, 128);          // >= 128 rows (8 K-steps) per split: small-M gradients still fill the chip
     if (splits > max_by_rows) splits = max_by_rows;
     long per = (long)g.NI * g.ldw;
     if ((long)splits * per > ws_floats) splits = (int)(ws_floats / per);
@@ -579,7 +579,7 @@ PDF_API long pdf_wgrad_workspace_floats(int M, int NI, int NJ) {
     const int B = small ? 64 : 128;
     long tiles = (long)cdiv(NI, B) * cdiv(NJ, B);
     int splits = (int)((1024 + tiles - 1) / tiles);
-    int max_by_rows = cdiv(M, 512);
+    int max_by_rows = cdiv(M, 128);
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
     return (long)splits * NI * NJ;

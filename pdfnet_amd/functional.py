@@ -11,6 +11,46 @@ from . import hip
 from .hip import ptr, stream
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+import os as _os
+USE_SIDE_STREAMS = _os.environ.get("PDFNET_SIDE_STREAMS", "1") != "0"
+_side = {}
+
+
+def _record(obj, stream_):
+    if torch.is_tensor(obj):
+        obj.record_stream(stream_)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _record(o, stream_)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _record(o, stream_)
+
+
+def parallel(*fns):
+    """Run independent branches (left/right hand sub-networks, sibling decoders) on separate HIP streams.
+    Their kernels are launch-bound and fill a fraction of the 256 CUs each; forked streams let them overlap, and
+    inside a captured step the fork/join becomes parallel branches of the hipGraph.  Autograd replays every
+    node's backward on the stream its forward ran on, so the backward overlaps the same way."""
+    if not USE_SIDE_STREAMS or len(fns) == 1:
+        return [f() for f in fns]
+    cur = torch.cuda.current_stream()
+    key = (cur.device_index if hasattr(cur, 'device_index') else torch.cuda.current_device())
+    pool = _side.setdefault(key, [])
+    while len(pool) < len(fns) - 1:
+        pool.append(torch.cuda.Stream())
+    streams = [cur] + pool[:len(fns) - 1]
+    for s_ in streams[1:]:
+        s_.wait_stream(cur)
+    out = []
+    for f, s_ in zip(fns, streams):
+        with torch.cuda.stream(s_):
+            out.append(f())
+    for r, s_ in zip(out[1:], streams[1:]):
+        cur.wait_stream(s_)
+        _record(r, cur)                     # produced on a side stream, consumed on the main one
+    return out
+
 CL = torch.channels_last
 
 

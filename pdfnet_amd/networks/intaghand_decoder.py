@@ -156,8 +156,8 @@ class inter_attn(nn.Module):
         self.ffL, self.ffR = MLP_res_block(d, d, drop), MLP_res_block(d, d, drop)
         xavier_(self)
 
-    def forward(self, Lf, Rf):
-        Lf, Rf = self.L_self_attn_layer(Lf), self.R_self_attn_layer(Rf)
+    def forward(self, Lf0, Rf0):
+        Lf, Rf = F.parallel(lambda: self.L_self_attn_layer(Lf0), lambda: self.R_self_attn_layer(Rf0))
         l2, r2 = self.layer_norm1(Lf), self.layer_norm2(Rf)
         B = l2.shape[0]
         both = torch.cat((l2, r2), 0)                                   # shared projections: one GEMM for both hands
@@ -203,7 +203,8 @@ class DualGraphLayer(nn.Module):
 
     def forward(self, Lf, Rf):
         pe = self.position_embeddings.weight.unsqueeze(0)
-        return self.attn(self.graph_left(Lf + pe), self.graph_right(Rf + pe))
+        Lg, Rg = F.parallel(lambda: self.graph_left(Lf + pe), lambda: self.graph_right(Rf + pe))
+        return self.attn(Lg, Rg)
 
 
 class DualGraph(nn.Module):

@@ -243,8 +243,7 @@ class ResNetSimple(nn.Module):
                 ind = nms_top1_centers(ret['hm'])
             fc = getattr(self, head)
             ret[head] = fc[2](fc[0](x0, F.ACT_RELU))
-        hms, hms_f = self.hms_decoder(x1)
-        mask, dp_f = self.dp_decoder(x1)
+        (hms, hms_f), (mask, dp_f) = F.parallel(lambda: self.hms_decoder(x1), lambda: self.dp_decoder(x1))
         center = self.center_features(x0, ind)                                             # [B,2,1024]  (:790-792)
         emb = [emb0, emb1, x0]
         fl = self.pointnet_plus(cloud[:, 0], emb, choose[:, 0])                            # :805

@@ -89,3 +89,28 @@ def check_packed(got, exp, abs_tol=1e-4, rel_tol=1e-5, skip=()):
         if not d <= lim:
             bad.append((k, d, lim))
     assert not bad, bad
+
+
+def synthetic_model_outputs(B, R, seed):
+    """Model-output-shaped tensors for the loss parity fixture (same generator as oracle/make_goldens.py)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    f = lambda *sh, sc=1.0: torch.from_numpy((g.standard_normal(sh) * sc).astype(np.float32))
+    result = {'verts3d': {h: f(B, 778, 3, sc=0.05) for h in ('left', 'right')},
+              'verts2d': {h: f(B, 778, 2, sc=30.0) + R / 2 for h in ('left', 'right')}}
+    params = {'scale': {h: f(B, sc=0.3) for h in ('left', 'right')}, 'trans2d': {h: f(B, 2, sc=0.3) for h in ('left', 'right')},
+              'root': {h: f(B, 3, sc=3.0) for h in ('left', 'right')}}
+    hand = [{'verts3d': {h: f(B, 252, 3, sc=0.05) for h in ('left', 'right')},
+             'verts2d': {h: f(B, 252, 2, sc=30.0) + R / 2 for h in ('left', 'right')}}]
+    other = {'hms': f(B, 42, R // 4, R // 4, sc=0.3), 'mask': f(B, 2, R, R, sc=0.5),
+             'ret': {'hm': f(B, 2, R // 4, R // 4) - 2.0, 'wh': f(B, 2, R // 4, R // 4), 'params': f(B, 122, R // 4, R // 4)}}
+    return result, params, hand, other
+
+
+def tree_to(obj, device):
+    if torch.is_tensor(obj):
+        return obj.to(device)
+    if isinstance(obj, dict):
+        return {k: tree_to(v, device) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(tree_to(v, device) for v in obj)
+    return obj
