@@ -437,16 +437,27 @@ __global__ void transpose_atb(const float* __restrict__ in, float* __restrict__ 
 // host side
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+#include <cstdlib>
+static int env_int(const char* name, int dflt) {          // tuning overrides for tools/gemm_bench.py sweeps
+    static const char* names[8]; static int vals[8]; static int n = 0;
+    for (int i = 0; i < n; ++i) if (names[i] == name) return vals[i];
+    const char* e = getenv(name);
+    int v = e ? atoi(e) : dflt;
+    if (n < 8) { names[n] = name; vals[n] = v; ++n; }
+    return v;
+}
+
 static int launch_igemm(IGemm& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
     const bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
     // tile choice: wide tiles when there are enough of them to fill 256 CUs, else smaller ones
     long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
-    if (g.N > 64 && t128 >= 192) {
+    // (measured: below ~600 128x128 tiles the 64x64 kernel's 4x block count wins, e.g. ResNet layer2-4)
+    if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600)) {
         int nb = (int)t128;
         if (fast) hipLaunchKernelGGL((igemm_nt<128, 128, 2, 2, true>), dim3(nb), dim3(256), 0, s, g);
         else hipLaunchKernelGGL((igemm_nt<128, 128, 2, 2, false>), dim3(nb), dim3(256), 0, s, g);
-    } else if (g.N <= 64 && (long)cdiv(g.M, 128) >= 192) {
+    } else if (g.N <= 64 && (long)cdiv(g.M, 128) >= env_int("PDF_IG_T128", 600)) {
         int nb = cdiv(g.M, 128) * cdiv(g.N, 64);
         if (fast) hipLaunchKernelGGL((igemm_nt<128, 64, 4, 1, true>), dim3(nb), dim3(256), 0, s, g);
         else hipLaunchKernelGGL((igemm_nt<128, 64, 4, 1, false>), dim3(nb), dim3(256), 0, s, g);
@@ -546,8 +557,11 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     const bool small = (g.NI <= 64 || NJ <= 64);
     const int BI = small ? 64 : 128, BJ = small ? 64 : 128;
     long tiles = (long)cdiv(g.NI, BI) * cdiv(NJ, BJ);
-    int splits = (int)((1024 + tiles - 1) / tiles);
-    int max_by_rows = cdiv(g.M, 128);          // >= 128 rows (8 K-steps) per split: small-M gradients still fill the chip
+    // split policy (measured, tools/gemm_bench.py): big gradient matrices want ~1024 blocks; few-tile / huge-M
+    // (HBM-bound) ones ~512 longer-running blocks; small M may go down to 128 rows per split to fill the chip
+    const int target = env_int("PDF_WG_TARGET", tiles >= 8 ? 1024 : 512);
+    int splits = (int)((target + tiles - 1) / tiles);
+    int max_by_rows = cdiv(g.M, env_int("PDF_WG_MINROWS", g.M >= 16384 ? 512 : 128));
     if (splits > max_by_rows) splits = max_by_rows;
     long per = (long)g.NI * g.ldw;
     if ((long)splits * per > ws_floats) splits = (int)(ws_floats / per);
