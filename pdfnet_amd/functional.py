@@ -87,6 +87,52 @@ def _wgrad_ws(M, NI, NJ, dev):
     return _ws(n, dev), n
 
 
+ASYNC_WGRAD = _os.environ.get("PDFNET_ASYNC_WGRAD", "1") != "0"
+_wg_streams = {}
+_wg_used = set()
+
+
+class wgrad_stream:
+    """Context for weight-gradient kernels that accumulate straight into the trainer's flat gradient buffer: nothing
+    in the backward chain consumes them, so they run on a side HIP stream and overlap the data-gradient chain (whose
+    small layers fill only part of the 256 CUs).  `join_wgrad()` is called once after backward."""
+
+    def __init__(self, enabled, *tensors):
+        self.enabled = enabled and ASYNC_WGRAD and USE_SIDE_STREAMS
+        self.tensors = tensors
+
+    def __enter__(self):
+        if not self.enabled:
+            return self
+        cur = torch.cuda.current_stream()
+        dev = torch.cuda.current_device()
+        key = (dev, cur.cuda_stream)
+        if key not in _wg_streams:
+            _wg_streams[key] = torch.cuda.Stream()
+        side = _wg_streams[key]
+        side.wait_stream(cur)
+        for t in self.tensors:                      # produced / owned by the main stream, read on the side stream
+            if t is not None:
+                t.record_stream(side)
+        _wg_used.add(key)
+        self._ctx = torch.cuda.stream(side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self._ctx.__exit__(*exc)
+        return False
+
+
+def join_wgrad():
+    """Make the current stream wait for every outstanding side-stream weight-gradient kernel."""
+    cur = torch.cuda.current_stream()
+    for key in list(_wg_used):
+        cur.wait_stream(_wg_streams[key])
+    _wg_used.clear()
+
+
 def _main_grad(param, like):
     """The trainer's flat gradient view of `param` if gradients may be accumulated into it directly
     (FlatAdam tags its parameters): skips autograd's separate `grad += dw` pass and the dw allocation."""
@@ -159,9 +205,10 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[1]:
             mg = _main_grad(w_par, w)
             dw = torch.empty_like(w) if mg is None else None
-            ws, n = _wgrad_ws(N * OH * OW, Cout, KH * KW * Cin, x.device)
-            L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                    stride, pad, OH, OW, Cout, int(mg is not None), stream())
+            with wgrad_stream(mg is not None, x, g):
+                ws, n = _wgrad_ws(N * OH * OW, Cout, KH * KW * Cin, x.device)
+                L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+                                        stride, pad, OH, OW, Cout, int(mg is not None), stream())
         if has_b and ctx.needs_input_grad[2]:
             mg = _main_grad(b_par, b_par)
             if mg is None:
@@ -217,9 +264,10 @@ class _Deconv2d(Function):
         if ctx.needs_input_grad[1]:
             mg = _main_grad(w_par, w)
             dw = torch.empty_like(w) if mg is None else None
-            ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
-            L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                      stride, pad, OH, OW, Cout, int(mg is not None), stream())
+            with wgrad_stream(mg is not None, x, g):
+                ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
+                L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+                                          stride, pad, OH, OW, Cout, int(mg is not None), stream())
         if has_b and ctx.needs_input_grad[2]:
             mg = _main_grad(b_par, b_par)
             if mg is None:
@@ -272,8 +320,9 @@ class _Linear(Function):
         if ctx.needs_input_grad[1]:
             mg = _main_grad(w_par, w)
             dw = torch.empty_like(w) if mg is None else None
-            ws, n = _wgrad_ws(M, Nn, K, x.device)
-            L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, M, Nn, K, K, Nn, int(mg is not None), stream())
+            with wgrad_stream(mg is not None, x, g):
+                ws, n = _wgrad_ws(M, Nn, K, x.device)
+                L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, M, Nn, K, K, Nn, int(mg is not None), stream())
         if has_b and ctx.needs_input_grad[2]:
             mg = _main_grad(b_par, b_par)
             if mg is None:

@@ -112,6 +112,7 @@ class Trainer:
         loss, stats, _, _ = self.model_with_loss(batch, 'train', epoch)
         loss = loss.mean()                                     # base_trainer.py:144
         loss.backward()
+        F.join_wgrad()                                         # side-stream weight-gradient kernels -> flat_g complete
         F.step_counter(loss.device).add_(1)                    # fresh dropout masks next step (also under replay)
         return loss.detach(), stats
 
