@@ -27,6 +27,41 @@ def _record(obj, stream_):
             _record(o, stream_)
 
 
+class fork:
+    """Start `fn` on a side HIP stream now; `.join()` makes the current stream wait for it and returns its result.
+    Lets independent sub-networks (sibling decoders, heads) overlap the main chain instead of queueing behind it."""
+    _busy = {}
+
+    def __init__(self, fn):
+        self.stream = None
+        if not USE_SIDE_STREAMS:
+            self.out = fn()
+            return
+        cur = torch.cuda.current_stream()
+        dev = torch.cuda.current_device()
+        pool = _side.setdefault(('fork', dev), [])
+        busy = fork._busy.setdefault(dev, set())
+        free = [i for i in range(len(pool)) if i not in busy]
+        if not free:
+            pool.append(torch.cuda.Stream())
+            free = [len(pool) - 1]
+        self.idx, self.dev = free[0], dev
+        busy.add(self.idx)
+        self.stream = pool[self.idx]
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.out = fn()
+
+    def join(self):
+        if self.stream is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.stream)
+            _record(self.out, cur)
+            fork._busy[self.dev].discard(self.idx)
+            self.stream = None
+        return self.out
+
+
 def parallel(*fns):
     """Run independent branches (left/right hand sub-networks, sibling decoders) on separate HIP streams.
     Their kernels are launch-bound and fill a fraction of the 256 CUs each; forked streams let them overlap, and
@@ -214,7 +249,8 @@ class _Conv2d(Function):
             if mg is None:
                 db = _colsum(g, Cout, N * OH * OW, Cout)
             else:
-                _colsum_into(g, Cout, N * OH * OW, Cout, mg)
+                with wgrad_stream(True, g):
+                    _colsum_into(g, Cout, N * OH * OW, Cout, mg)
         return dx, dw, db, None, None, None
 
 
@@ -273,7 +309,8 @@ class _Deconv2d(Function):
             if mg is None:
                 db = _colsum(g, Cout, N * OH * OW, Cout)
             else:
-                _colsum_into(g, Cout, N * OH * OW, Cout, mg)
+                with wgrad_stream(True, g):
+                    _colsum_into(g, Cout, N * OH * OW, Cout, mg)
         return dx, dw, db, None, None
 
 
@@ -328,7 +365,8 @@ class _Linear(Function):
             if mg is None:
                 db = _colsum(g, Nn, M, Nn)
             else:
-                _colsum_into(g, Nn, M, Nn, mg)
+                with wgrad_stream(True, g):
+                    _colsum_into(g, Nn, M, Nn, mg)
         return dx, dw, db, None
 
 

@@ -234,21 +234,38 @@ class ResNetSimple(nn.Module):
         x3 = r.layer2(x4)
         x2 = r.layer3(x3)
         x1 = r.layer4(x2)
+        # the two up-sampling decoders only need x1: start them on side streams, they overlap the pyramid/feat convs
+        f_hms = F.fork(lambda: self.hms_decoder(x1))
+        f_dp = F.fork(lambda: self.dp_decoder(x1))
         pyr = torch.cat([self.p2_l2(self.p2(x4)), self.p3_l2(self.p3(x3)),
                          self.p4_l2(self.p4(x2)), self.p5_l2(self.p5(x1))], 1)            # NHWC channel concat
         x0 = self.feat_bn(self.feat(pyr), relu=True)                                      # :740-744
         ret = {}
-        for head in self.opt.heads:                                                        # :749-772
-            if 'hm' in ret and ind is None:
-                ind = nms_top1_centers(ret['hm'])
-            fc = getattr(self, head)
-            ret[head] = fc[2](fc[0](x0, F.ACT_RELU))
-        (hms, hms_f), (mask, dp_f) = F.parallel(lambda: self.hms_decoder(x1), lambda: self.dp_decoder(x1))
-        center = self.center_features(x0, ind)                                             # [B,2,1024]  (:790-792)
+        hm_fc = self.hm
+        ret['hm'] = hm_fc[2](hm_fc[0](x0, F.ACT_RELU))                                     # 'hm' is first in opt.heads (:291)
+        if ind is None:                                                                    # :750-758
+            ind = nms_top1_centers(ret['hm'])
+
+        def other_heads():                                                                 # wh / params: no loss term,
+            out = {}                                                                       # nothing downstream waits on them
+            for head in self.opt.heads:
+                if head != 'hm':
+                    fc = getattr(self, head)
+                    out[head] = fc[2](fc[0](x0, F.ACT_RELU))
+            return out
+        f_heads = F.fork(other_heads)
+        f_center = F.fork(lambda: self.center_features(x0, ind))                           # [B,2,1024]  (:790-792)
         emb = [emb0, emb1, x0]
         fl = self.pointnet_plus(cloud[:, 0], emb, choose[:, 0])                            # :805
-        fr = self.pointnet_plus(cloud[:, 1], emb, choose[:, 1])                            # :806
+        fr = self.pointnet_plus(cloud[:, 1], emb, choose[:, 1])                            # :806 (same module: left BN update first)
+        center = f_center.join()
         fuse = self.sft(torch.cat((fl, fr), 1), center)                                    # [B,2,1024]  (:807-809)
+        for head in self.opt.heads:                                                        # keep the reference's key order
+            if head != 'hm':
+                ret[head] = None
+        ret.update(f_heads.join())
+        hms, hms_f = f_hms.join()
+        mask, dp_f = f_dp.join()
         return hms, mask, ret, [fuse, x2, x3, x4], hms_f, dp_f, ind
 
 
