@@ -93,6 +93,16 @@ class GemmProfiler:
         return per
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the GEMM family from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/pmc_traffic.py); PMC counters cannot be read from inside this process, so this is the last profiled value."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return round(json.load(open(p))["gemm_family"]["bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(R, threads):
     """The CPU oracle on a bounded sample of the same workload: B=2, one timed train step
     (forward + surrogate loss + backward + torch Adam) after one warm-up."""
@@ -196,7 +206,7 @@ def main():
         secs = sum(v[2] for v in per.values())
         out["roofline"] = {
             "bound": "mfma", "achieved": round(flops / secs / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(flops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
             "kernel": "igemm_nt / wgemm_tn (fp32 MFMA implicit GEMM family, csrc/gemm.hip)",
             "launches_per_step": calls, "algorithmic_gflop_per_step": round(flops / 1e9, 1),
             "gemm_ms_per_step": round(secs * 1e3, 2),
