@@ -92,6 +92,9 @@ int pdf_scatter_rows_add(const float* dout, int ldo, int C, long HW, const long*
  * mode 0: buf = windows of feat (zero outside); 1: feat += buf (backward); 2: buf = inside-image ? src : 0. */
 int pdf_window_op(float* feat, int ldf, int C, int H, int W, const long* ind, long ind_bstride,
                   int B, int M, int r, float* buf, const float* src, int mode, void* stream);
+/* centre decode of the test path: _nms(5x5) + _topk(K=1) per (sample, channel) map (intaghand_encoder.py:349-367,750-758;
+ * lib/trains/simplified.py:378-384).  hm [BC][H][W] plain, ind int64 [BC], score [BC] or NULL. */
+int pdf_nms_top1(const float* hm, int BC, int H, int W, long* ind, float* score, void* stream);
 /* nn.MaxPool2d((1,K)) / ((S2,1)) of netR_1/2/3 (intaghand_encoder.py:62,82,100): x [R][K][ldx] -> y [R][ldy], arg [R][C] */
 int pdf_maxk_fwd(const float* x, int ldx, int C, long R, int K, float* y, int ldy, int* arg, void* stream);
 int pdf_maxk_bwd(const float* dy, int ldy, const int* arg, int C, long R, int K, float* dx, int ldx, void* stream);
@@ -158,6 +161,13 @@ int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld, int B, 
 int pdf_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* o, const float* dout, int ldo,
                  const float* stat, int B, int V, int H, int dh, float pdrop, unsigned long long seed, const unsigned long long* step,
                  float* dq, float* dk, float* dv, int lddq, float* dvec, void* stream);
+
+/* ---- depth front end (csrc/frontend.hip) ------------------------------------------------------ */
+/* depth2pcl (intaghand_encoder.py:369-491 + get_points_coordinate lib/utils/utils.py:251-262) batched on the GPU:
+ * depth [B][H][W] metres, mask [B][2][H][W] (right, left), K [B][3][3], valid [B][2] ->
+ * choose int64 [B][2][1024] (left, right), cloud [B][2][1024][3], count int32 [B][2] (window candidates) or NULL. */
+int pdf_depth2pcl(const float* depth, const float* mask, const float* K, const float* valid, int B, int H, int W,
+                  unsigned long long seed, long* choose, float* cloud, int* count, void* stream);
 
 /* ---- MANO (csrc/mano.hip) --------------------------------------------------------------------- */
 /* ManoLayer.forward, use_pca=False (lib/models/networks/manolayer.py:257-334): axis-angle root [B][3], pose [B][45],

@@ -368,6 +368,39 @@ def loss_golden():
     save("loss_ctdet_B3_R256", **out)
 
 
+
+def synthetic_depth_scene(R, seed):
+    """Depth map with two blobs (one small: < 1024 window pixels -> wrap-pad path; one large: > 1024 -> random subset),
+    background and out-of-range noise; masks as probabilities."""
+    g = rng(seed)
+    depth = g.uniform(0.1, 3.0, (R, R)).astype(np.float32)                  # includes < 0.2 and > 2.5 noise
+    mask = g.uniform(0.0, 0.45, (2, R, R)).astype(np.float32)
+    yy, xx = np.mgrid[0:R, 0:R]
+    left = (yy - 60) ** 2 + (xx - 70) ** 2 < 14 ** 2                            # ~600 px
+    right = (yy - 150) ** 2 + (xx - 160) ** 2 < 45 ** 2                         # ~6300 px
+    depth[left] = (0.45 + 0.03 * g.standard_normal(left.sum())).astype(np.float32)
+    depth[right] = (0.60 + 0.05 * g.standard_normal(right.sum())).astype(np.float32)
+    mask[1][left] = 0.9                                                         # channel 1 = left
+    mask[0][right] = 0.8                                                        # channel 0 = right
+    K = np.array([[R * 1.1, 0, R / 2 + 3], [0, R * 1.05, R / 2 - 2], [0, 0, 1]], np.float32)
+    return depth, mask, K
+
+
+def depth2pcl_golden():
+    """Reference depth2pcl (intaghand_encoder.py:369-491) under np.random.seed(0) on a synthetic scene."""
+    E = rh.ref_module("lib.models.networks.intaghand_encoder")
+    R = 256
+    depth, mask, K = synthetic_depth_scene(R, 51)
+    out = {"depth": depth, "mask": mask, "K": K}
+    for name, valid in (("both", [1, 1]), ("left_only", [1, 0])):
+        np.random.seed(0)
+        ch, cl = E.depth2pcl(torch.from_numpy(depth)[None, None], torch.from_numpy(mask)[None], torch.from_numpy(K),
+                             np.array([valid]))
+        out["choose_" + name] = ch.astype(np.int32)
+        out["cloud_" + name] = cl.astype(np.float32)
+    save("op_depth2pcl", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["ops", "e2e"]
@@ -376,9 +409,12 @@ if __name__ == "__main__":
         op_gather_sft_l2norm()
         op_decoder_blocks()
         op_mano()
+        depth2pcl_golden()
     if "e2e" in which:
         e2e()
     if "e2e64" in which or "e2e" in which:
         e2e_fp64_oracle()
+    if "d2p" in which:
+        depth2pcl_golden()
     if "loss" in which or "e2e" in which:
         loss_golden()

@@ -310,3 +310,48 @@ PDF_API int pdf_window_op(float* feat, int ldf, int C, int H, int W, const long*
     PDF_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Centre decode (test path): 5x5 max-pool NMS on the centre heat map + top-1 per (sample, channel).
+// Replaces _nms + _topk (reference intaghand_encoder.py:349-367,750-758; lib/trains/simplified.py:378-384).
+//   keep = (maxpool5x5(hm) == hm);  score = hm * keep;  ind = argmax(score)  (lowest index on ties, like a stable top-1)
+// One block per (b, c) map; hm is [B][C][H][W] (plain NCHW, tiny) .
+__global__ __launch_bounds__(256) void nms_top1_kernel(const float* __restrict__ hm, int H, int W, long* __restrict__ ind, float* __restrict__ score) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const float* m = hm + (long)blockIdx.x * H * W;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int p = threadIdx.x; p < H * W; p += 256) {
+        const int y = p / W, x = p - y * W;
+        const float v = m[p];
+        float mx = v;
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                mx = fmaxf(mx, m[yy * W + xx]);
+            }
+        }
+        const float sc = (mx == v) ? v : v * 0.f;          // heat * keep (keeps the sign of zero / NaN behaviour of the product)
+        if (sc > best || (sc == best && p < bi)) { best = sc; bi = p; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float o = sv[threadIdx.x + s]; const int oi = si[threadIdx.x + s];
+            if (o > sv[threadIdx.x] || (o == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = o; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { ind[blockIdx.x] = si[0]; if (score) score[blockIdx.x] = sv[0]; }
+}
+
+PDF_API int pdf_nms_top1(const float* hm, int BC, int H, int W, long* ind, float* score, hipStream_t s) {
+    if (BC <= 0) return 0;
+    hipLaunchKernelGGL(nms_top1_kernel, dim3(BC), dim3(256), 0, s, hm, H, W, ind, score);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}

@@ -840,6 +840,31 @@ def attention(q, k, v, heads, pdrop=0.0, training=False):
 
 
 # ----------------------------------------------------------------------------------------------
+def depth2pcl(depth, mask, K, valid, seed=None):
+    """Depth map -> per-hand clouds on the GPU (reference depth2pcl, intaghand_encoder.py:369-491, batched).
+    depth [B,1,R,R], mask [B,2,R,R] (right, left), K [B,3,3], valid [B,2] -> choose i64 [B,2,1024], cloud [B,2,1024,3], count."""
+    hip.require_gpu(depth, mask)
+    B, _, H, W = depth.shape
+    d, m = depth.detach().contiguous(), mask.detach().contiguous()
+    choose = torch.empty((B, 2, 1024), dtype=torch.int64, device=d.device)
+    cloud = torch.empty((B, 2, 1024, 3), device=d.device)
+    count = torch.empty((B, 2), dtype=torch.int32, device=d.device)
+    _L().pdf_depth2pcl(ptr(d), ptr(m), ptr(K.detach().float().contiguous()), ptr(valid.detach().float().contiguous()), B, H, W,
+                       next_seed() if seed is None else int(seed), ptr(choose), ptr(cloud), ptr(count), stream())
+    return choose, cloud, count
+
+
+def nms_top1(hm):
+    """hm [B,C,H,W] -> (ind int64 [B,C], score [B,C]): 5x5 NMS + top-1 per map (no gradient)."""
+    hip.require_gpu(hm)
+    h = hm.detach().contiguous()                    # plain NCHW copy of a tiny map
+    B, C, H, W = h.shape
+    ind = torch.empty((B, C), dtype=torch.int64, device=h.device)
+    score = torch.empty((B, C), device=h.device)
+    _L().pdf_nms_top1(ptr(h), B * C, H, W, ptr(ind), ptr(score), stream())
+    return ind, score
+
+
 def mano_lbs(consts, root_aa, pose_aa, shape, trans=None, side='left', center_idx=None):
     """ManoLayer.forward (manolayer.py:257-334, use_pca=False). Forward only (the training loss uses
     the joint regressor, not LBS -- SURVEY.md 0.5)."""

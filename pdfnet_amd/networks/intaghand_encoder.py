@@ -164,14 +164,9 @@ def _fc_head(dout):
 
 
 def nms_top1_centers(hm):
-    """Centre pick of the test path (intaghand_encoder.py:349-367,750-758): 5x5 max-pool NMS on the raw
-    logits, top-1 per channel.  Decode is SURVEY 8(f) row 3 ("next"); until it has its own kernel this
-    runs on aten ops (eval/demo only, never in the train step)."""
-    h = hm.detach().contiguous()
-    keep = (torch.nn.functional.max_pool2d(h, 5, 1, 2) == h).float()
-    h = h * keep
-    B = h.shape[0]
-    return torch.cat([torch.topk(h[:, c].reshape(B, -1), 1)[1] for c in (0, 1)], dim=1)
+    """Centre pick of the test path (intaghand_encoder.py:349-367,750-758): 5x5 max-pool NMS on the raw logits,
+    top-1 per channel -- one HIP kernel (pdf_nms_top1)."""
+    return F.nms_top1(hm)[0]
 
 
 class ResNetSimple(nn.Module):
@@ -221,11 +216,7 @@ class ResNetSimple(nn.Module):
         u1 = F.conv2d(u0, up1.weight, None, 1, 0)                                          # [B*2,1024,1,1]
         return u1.reshape(B, 2, 1024)
 
-    def forward(self, img, ind, choose, cloud):
-        if choose is None or cloud is None:
-            raise NotImplementedError(
-                "pdfnet_amd: clouds must be supplied (the reference's CPU depth2pcl branch, "
-                "intaghand_encoder.py:779-784, is SURVEY 8(f) row 2 and not built yet)")
+    def forward(self, img, ind, choose, cloud, depth=None, K_new=None, valid=None):
         r = self.resnet
         img = F.cl(img)
         emb0 = self.e_conv1(img, F.ACT_RELU)                                              # :711
@@ -256,6 +247,16 @@ class ResNetSimple(nn.Module):
         f_heads = F.fork(other_heads)
         f_center = F.fork(lambda: self.center_features(x0, ind))                           # [B,2,1024]  (:790-792)
         emb = [emb0, emb1, x0]
+        if choose is None or cloud is None:
+            # test/demo path (:779-784): clouds from the depth map and the PREDICTED hand masks -- on the GPU, any batch
+            # size (the reference does this on the CPU with numpy, batch 1).  The reference triggers it with a host-side
+            # `choose.sum() == 0`; here it is requested explicitly by passing choose=None (no device->host sync).
+            if depth is None or K_new is None:
+                raise ValueError("pdfnet_amd: choose/cloud are None, so depth and K_new are required to build the clouds")
+            mask_pred, _ = f_dp.join()
+            if valid is None:
+                valid = torch.ones((img.shape[0], 2), device=img.device)
+            choose, cloud, _ = F.depth2pcl(depth, mask_pred, K_new, valid)
         fl = self.pointnet_plus(cloud[:, 0], emb, choose[:, 0])                            # :805
         fr = self.pointnet_plus(cloud[:, 1], emb, choose[:, 1])                            # :806 (same module: left BN update first)
         center = f_center.join()

@@ -19,7 +19,7 @@ class HandNET_GCN(nn.Module):
         self.run_mid_model = run_mid_model
 
     def forward(self, img, choose, cloud, depth, ind, K_new, valid):
-        hms, mask, ret, img_fmaps, hms_fmaps, dp_fmaps, ind = self.encoder(img, ind, choose, cloud)
+        hms, mask, ret, img_fmaps, hms_fmaps, dp_fmaps, ind = self.encoder(img, ind, choose, cloud, depth, K_new, valid)
         if self.run_mid_model:
             gl, gr, _ = self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)
         else:

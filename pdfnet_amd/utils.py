@@ -1,0 +1,62 @@
+"""Counterparts of the reference's checkpoint helpers (lib/utils/utils.py:37-119) and of the dataset's MANO ground-truth
+generation (lib/datasets/interhand.py:555-587) -- SURVEY.md 8(f) row 4."""
+import torch
+
+from . import functional as F
+
+
+def load_model(model, model_path, optimizer=None, resume=False, lr=None, lr_step=None, verbose=True):
+    """lib/utils/utils.py:37-98: accepts {'state_dict':...} or a bare state_dict, strips the DDP `module.` prefix, keeps
+    the model's own tensor where shapes disagree, loads with strict=False; optimizer state only when resume=True."""
+    ckpt = torch.load(model_path, map_location='cpu')
+    sd_in = ckpt['state_dict'] if isinstance(ckpt, dict) and 'state_dict' in ckpt else ckpt
+    sd = {}
+    for k, v in sd_in.items():
+        sd[k[7:] if k.startswith('module') and not k.startswith('module_list') else k] = v
+    own = model.state_dict()
+    for k in list(sd):
+        if k in own:
+            if tuple(sd[k].shape) != tuple(own[k].shape):
+                if verbose:
+                    print('Skip loading parameter {}, required shape{}, loaded shape{}.'.format(k, tuple(own[k].shape), tuple(sd[k].shape)))
+                sd[k] = own[k]
+        elif verbose:
+            print('Drop parameter {}.'.format(k))
+    model.load_state_dict(sd, strict=False)
+    start_epoch = 0
+    if optimizer is not None and resume:
+        if 'optimizer' in ckpt:
+            optimizer.load_state_dict(ckpt['optimizer'])
+            start_epoch = ckpt['epoch']
+            start_lr = lr
+            for step in (lr_step or []):
+                if start_epoch >= step:
+                    start_lr *= 0.1
+            optimizer.lr = start_lr
+        elif verbose:
+            print('No optimizer parameters in checkpoint.')
+    return (model, optimizer, start_epoch) if optimizer is not None else model
+
+
+def save_model(path, epoch, model, optimizer=None):
+    """lib/utils/utils.py:101-119: {'epoch', 'state_dict'[, 'optimizer']} with plain contiguous (OIHW) tensors so the
+    file loads into the reference model as well."""
+    m = model.module if hasattr(model, 'module') else model
+    data = {'epoch': epoch, 'state_dict': {k: v.detach().cpu().contiguous() for k, v in m.state_dict().items()}}
+    if optimizer is not None:
+        data['optimizer'] = optimizer.state_dict()
+    torch.save(data, path)
+
+
+def mano_gt_from_coeff(mano_consts, mano_coeff, K):
+    """H2O ground truth from `mano_coeff` [B,124] (per hand 62 floats: valid, trans 1:4, rot 4:7, pose 7:52, shape 52:62;
+    left then right) as lib/datasets/interhand.py:555-587 does per sample on the CPU -- here batched on the GPU with the
+    LBS kernel.  mano_consts: {'left': consts, 'right': consts}; K [B,3,3].  Returns per hand verts3d/joints3d/verts2d/joints2d."""
+    out = {}
+    for hi, hand in enumerate(('left', 'right')):
+        p = mano_coeff[:, 62 * hi:62 * (hi + 1)]
+        v, j = F.mano_lbs(mano_consts[hand], p[:, 4:7].contiguous(), p[:, 7:52].contiguous(), p[:, 52:62].contiguous(),
+                          trans=p[:, 1:4].contiguous(), side=hand)
+        proj = lambda x: (x @ K.transpose(1, 2))[..., :2] / (x @ K.transpose(1, 2))[..., 2:]
+        out[hand] = {'verts3d': v, 'joints3d': j, 'verts2d': proj(v), 'joints2d': proj(j)}
+    return out

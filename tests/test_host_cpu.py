@@ -59,3 +59,32 @@ def test_product_does_not_import_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) or "/root/reference" in src:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_checkpoint_roundtrip_with_reference_conventions(tmp_path):
+    """save_model / load_model counterparts (reference lib/utils/utils.py:37-119): `module.` prefix stripped, shape
+    mismatches keep the model's tensor, saved tensors are plain contiguous OIHW so the reference can read them."""
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.utils import load_model, save_model
+    torch.manual_seed(1)
+    a = load_model_intag(make_opt(256))
+    p = str(tmp_path / "model_5.pth")
+    save_model(p, 5, a)
+    ck = torch.load(p)
+    assert ck['epoch'] == 5 and len(ck['state_dict']) == 1287
+    assert all(v.is_contiguous() for v in ck['state_dict'].values())
+    # a DDP-style checkpoint with one wrong-shaped tensor
+    ck2 = {'state_dict': {('module.' + k): v for k, v in ck['state_dict'].items()}}
+    ck2['state_dict']['module.encoder.hm.2.bias'] = torch.zeros(7)
+    p2 = str(tmp_path / "ddp.pth")
+    torch.save(ck2, p2)
+    torch.manual_seed(2)
+    b = load_model_intag(make_opt(256))
+    keep = b.state_dict()['encoder.hm.2.bias'].clone()
+    load_model(b, p2, verbose=False)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if k == 'encoder.hm.2.bias':
+            assert torch.equal(sb[k], keep)
+        else:
+            assert torch.equal(sa[k], sb[k]), k

@@ -124,3 +124,24 @@ def test_sparse_center_features_equal_dense_formulation(setup):
     for a, b, what in zip(outs[0], outs[1], ("out", "dx0", "dw0", "dw1")):
         err = (a - b).abs().max().item()
         assert err <= 2e-5 * max(1.0, a.abs().max().item()), (what, err, a.abs().max().item())
+
+
+def test_depth_front_end_path_equals_explicit_clouds(setup):
+    """choose=None: the encoder builds the clouds on the GPU from depth + predicted masks (reference test/demo path,
+    intaghand_encoder.py:779-784) for a whole batch; feeding those clouds back explicitly gives identical outputs."""
+    from pdfnet_amd import functional as F
+    m, sd, b = setup
+    m.load_state_dict(sd)
+    m.eval()
+    B = b['input'].shape[0]
+    depth = torch.full((B, 1, 256, 256), 0.5, device='cuda') + 0.01 * torch.randn(B, 1, 256, 256, device='cuda')
+    with torch.no_grad():
+        F.manual_seed(7)
+        r1 = m(b['input'], None, None, depth, None, b['K_new'], b['valid'])
+        # rebuild the same clouds (same seed stream) from the same predicted mask and feed them explicitly
+        F.manual_seed(7)
+        choose, cloud, cnt = F.depth2pcl(depth, r1[3]['mask'], b['K_new'], b['valid'])
+        r2 = m(b['input'], choose, cloud, depth, r1[3]['ind'], b['K_new'], b['valid'])
+    assert torch.isfinite(r1[0]['verts3d']['left']).all()
+    for h in ('left', 'right'):
+        assert torch.equal(r1[0]['verts3d'][h], r2[0]['verts3d'][h])

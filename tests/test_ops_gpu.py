@@ -399,3 +399,73 @@ def test_adam(F):
         hip.lib().pdf_adam_step(hip.ptr(pd), hip.ptr(dev(g * step)), hip.ptr(m), hip.ptr(v), 10000, 1e-4, 0.9, 0.999, 1e-8,
                                 hip.ptr(corr), 1.0, hip.stream())
     close(pd, pr, 1e-7, what="adam")
+
+
+def test_nms_top1_decode(F):
+    from oracle import pdfnet_cpu as O
+    gd = gold("op_nms_topk")
+    ind, score = F.nms_top1(dev(T(gd["hm"])))
+    assert np.array_equal(ind.cpu().numpy(), gd["ind"])                       # reference _nms + _topk, bit-exact
+    for seed, (B, H, W) in enumerate([(4, 64, 64), (2, 96, 96), (3, 7, 5)]):
+        hm = rnd(B, 2, H, W, seed=seed + 20)
+        ind, score = F.nms_top1(dev(hm))
+        assert torch.equal(ind.cpu(), O.nms_topk_center(hm))
+        assert torch.equal(score.cpu(), hm.reshape(B, 2, -1).gather(2, ind.cpu().unsqueeze(-1)).squeeze(-1))
+
+
+def test_mano_gt_from_coeff(F):
+    from oracle import pdfnet_cpu as O
+    from oracle import synth
+    from pdfnet_amd.utils import mano_gt_from_coeff
+    g = torch.Generator().manual_seed(3)
+    coeff = torch.randn(5, 124, generator=g) * 0.3
+    K = torch.tensor([[[256.0, 0, 128], [0, 256, 128], [0, 0, 1]]]).repeat(5, 1, 1)
+    consts = {h: synth.synthetic_mano_consts(h) for h in ("left", "right")}
+    out = mano_gt_from_coeff({h: {k: dev(v.contiguous()) for k, v in c.items()} for h, c in consts.items()}, dev(coeff), dev(K))
+    for hi, hand in enumerate(("left", "right")):
+        p = coeff[:, 62 * hi:62 * (hi + 1)]
+        v, j = O.mano_lbs(consts[hand], p[:, 4:7], p[:, 7:52], p[:, 52:62], trans=p[:, 1:4], side=hand)
+        close(out[hand]['verts3d'], v, 5e-6, what="gt verts")
+        close(out[hand]['joints3d'], j, 5e-6, what="gt joints")
+        pj = j @ K.transpose(1, 2)
+        close(out[hand]['joints2d'], pj[..., :2] / pj[..., 2:], 1e-3, rtol=1e-5, what="gt joints2d")
+
+
+def test_depth2pcl_front_end(F):
+    """Device depth->cloud front end vs the (reference-pinned) oracle: same candidate sets, the wrap-pad multiset is
+    exact, the >1024 case draws a uniformly random 1024-subset, clouds are the back-projected pixels."""
+    from oracle import pdfnet_cpu as O
+    g = gold("op_depth2pcl")
+    depth, mask, K = g["depth"], g["mask"], g["K"]
+    B = 3
+    dd = dev(T(depth))[None, None].repeat(B, 1, 1, 1)
+    mm = dev(T(mask))[None].repeat(B, 1, 1, 1)
+    KK = dev(T(K))[None].repeat(B, 1, 1)
+    valid = dev(torch.tensor([[1.0, 1.0], [1.0, 0.0], [1.0, 1.0]]))
+    choose, cloud, count = F.depth2pcl(dd, mm, KK, valid, seed=123)
+    choose2, _, _ = F.depth2pcl(dd, mm, KK, valid, seed=124)
+    ptsL, candL = O.depth_candidates(depth, mask[1], K)
+    ptsR, candR = O.depth_candidates(depth, mask[0], K)
+    ch = choose.cpu().numpy()
+    assert count.cpu().numpy()[0].tolist() == [len(candL), len(candR)]
+    # left: n <= 1024 -> np.pad(..., 'wrap') multiset, random order
+    want = np.sort(np.pad(candL, (0, 1024 - len(candL)), 'wrap'))
+    for b in range(B):
+        assert np.array_equal(np.sort(ch[b, 0]), want)
+    assert not np.array_equal(ch[0, 0], np.sort(ch[0, 0]))                       # shuffled
+    # right: n > 1024 -> 1024 distinct candidates
+    for b in (0, 2):
+        sel = ch[b, 1]
+        assert len(np.unique(sel)) == 1024 and np.isin(sel, candR).all()
+    rank = np.searchsorted(candR, ch[0, 1])
+    assert abs(rank.mean() / len(candR) - 0.5) < 0.05                            # uniform over the candidates
+    assert not np.array_equal(np.sort(ch[0, 1]), np.sort(choose2.cpu().numpy()[0, 1]))   # seed changes the subset
+    assert not np.array_equal(ch[0, 1], ch[2, 1])                                # per-(sample, hand) streams differ
+    # invalid hand: zero indices and a zero cloud
+    assert (ch[1, 1] == 0).all() and (cloud[1, 1] == 0).all()
+    # clouds = back-projected pixels
+    close(cloud[0, 0], T(ptsL.T[ch[0, 0]]), 1e-6, rtol=1e-5, what="left cloud")
+    close(cloud[0, 1], T(ptsR.T[ch[0, 1]]), 1e-6, rtol=1e-5, what="right cloud")
+    # degenerate: nothing inside the mask -> all-zero indices
+    c0, cl0, n0 = F.depth2pcl(dd, mm * 0, KK, valid, seed=1)
+    assert (c0 == 0).all() and (n0 == 0).all()

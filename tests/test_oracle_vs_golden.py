@@ -144,3 +144,17 @@ def test_e2e_train_and_grads(model_and_batch):
     for k, v in g.items():
         if k.startswith("stat::"):
             assert np.allclose(new[k[6:]].numpy(), v, atol=1e-5)
+
+
+def test_depth2pcl_front_end():
+    """oracle depth2pcl == the reference's (intaghand_encoder.py:369-491) under the same numpy seed, bit for bit."""
+    g = gold("op_depth2pcl")
+    for name, valid in (("both", [1, 1]), ("left_only", [1, 0])):
+        np.random.seed(0)
+        ch, cl = O.depth2pcl(g["depth"], g["mask"], g["K"], np.array(valid))
+        assert np.array_equal(ch, g["choose_" + name])
+        assert np.array_equal(cl, g["cloud_" + name])
+    # the fixture exercises both selection paths
+    _, cl_ = O.depth_candidates(g["depth"], g["mask"][1], g["K"])
+    _, cr_ = O.depth_candidates(g["depth"], g["mask"][0], g["K"])
+    assert 10 <= len(cl_) <= 1024 < len(cr_)
