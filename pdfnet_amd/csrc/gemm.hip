@@ -417,6 +417,18 @@ __global__ void reduce_slabs(const float* __restrict__ slab, float* __restrict__
     }
 }
 
+// many splits over a small matrix: 64 elements x 4 split-lanes per block, fixed summation tree (deterministic)
+__global__ __launch_bounds__(256) void reduce_slabs_2d(const float* __restrict__ slab, float* __restrict__ out, long n, int splits, int accumulate) {
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long i = blockIdx.x * 64L + tx;
+    float s = 0.f;
+    if (i < n) for (int z = ty; z < splits; z += 4) s += slab[(long)z * n + i];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n) out[i] = (accumulate ? out[i] : 0.f) + ((sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
+}
+
 // in [A][T][B] -> out [B][T][A]   (weight repacks: OHWI <-> IHWO, Linear W <-> W^T)
 __global__ void transpose_atb(const float* __restrict__ in, float* __restrict__ out, int A, int T, int B) {
     __shared__ float tile[32][33];
@@ -447,9 +459,51 @@ static int env_int(const char* name, int dflt) {          // tuning overrides fo
     return v;
 }
 
+// C[m][n] = act(sum_k A[m][k] B[n][k] + bias[n]) for K <= 48, plain rows in / out: HBM-bound streaming (the backward-data
+// of the 2- / 42-channel output convs: dy has 2 or 42 channels, dx 128-256).  B^T lives in LDS; one thread per (m, 4 n).
+#define SMALLK_MAX 48
+__global__ __launch_bounds__(256) void small_k_gemm(const IGemm g) {
+    __shared__ float bt[SMALLK_MAX][260];                    // [k][n] for this block's <= 256 columns
+    const int n0 = blockIdx.y * 256;
+    const int nn = min(256, g.N - n0);
+    for (int i = threadIdx.x; i < nn * g.K; i += 256) {
+        const int n = i / g.K, k = i - n * g.K;
+        bt[k][n] = g.B[(long)(n0 + n) * g.ldb + k];
+    }
+    __syncthreads();
+    const int nq = (nn + 3) / 4;
+    const long total = (long)g.M * nq;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / nq;
+        const int n4 = (int)(i - m * nq) * 4;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float* ar = g.A + m * g.lda;
+        for (int k = 0; k < g.K; ++k) {
+            const float a = ar[k];
+            a0 += a * bt[k][n4]; a1 += a * bt[k][n4 + 1]; a2 += a * bt[k][n4 + 2]; a3 += a * bt[k][n4 + 3];
+        }
+        float v[4] = {a0, a1, a2, a3};
+        float* o = g.C + m * g.ldc + n0 + n4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n4 + e < nn) {
+                float x = v[e] + (g.bias ? g.bias[n0 + n4 + e] : 0.f);
+                if (g.act == 1) x = fmaxf(x, 0.f); else if (g.act == 2) x = x > 0.f ? x : 0.1f * x;
+                o[e] = x;
+            }
+        }
+    }
+}
+
 static int launch_igemm(IGemm& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
     const bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
+    if (!fast && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 && (long)g.M * g.N >= (1L << 20)) {
+        dim3 grid(grid_for((long)g.M * ((min(g.N, 256) + 3) / 4)), cdiv(g.N, 256));
+        hipLaunchKernelGGL(small_k_gemm, grid, dim3(256), 0, s, g);
+        PDF_LAUNCH_CHECK();
+        return 0;
+    }
     // tile choice: wide tiles when there are enough of them to fill 256 CUs, else smaller ones
     long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
     // (measured: below ~600 128x128 tiles the 64x64 kernel's 4x block count wins, e.g. ResNet layer2-4)
@@ -581,7 +635,10 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     }
     PDF_LAUNCH_CHECK();
     if (splits > 1) {
-        hipLaunchKernelGGL(reduce_slabs, dim3(grid_for(per)), dim3(256), 0, s, ws, out, per, splits, accumulate);
+        if (splits >= 16 && per <= (1L << 20))
+            hipLaunchKernelGGL(reduce_slabs_2d, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, ws, out, per, splits, accumulate);
+        else
+            hipLaunchKernelGGL(reduce_slabs, dim3(grid_for(per)), dim3(256), 0, s, ws, out, per, splits, accumulate);
         PDF_LAUNCH_CHECK();
     }
     return 0;

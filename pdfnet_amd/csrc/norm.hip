@@ -500,6 +500,7 @@ PDF_API int pdf_l2norm_fwd(const float* x, int ldx, int C, long R, const float* 
 }
 
 // dx_j = w_j g_j / n - x_j * (sum_c w_c g_c x_c) / (n^2 * (n - eps));  dw_c += sum_r g_c x_c / n
+#define L2_MAXV 8     // channels per lane: C <= 512
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx, int C, long R,
                                                          const float* __restrict__ w, float eps, const float* __restrict__ norm,
                                                          float* __restrict__ dx, int lddx, float* __restrict__ dw) {
@@ -509,19 +510,33 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
     const int lane = threadIdx.x & 63;
     const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
     const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    float acc[L2_MAXV], wv[L2_MAXV];
+#pragma unroll
+    for (int i = 0; i < L2_MAXV; ++i) { acc[i] = 0.f; int c = lane + 64 * i; wv[i] = c < C ? w[c] : 0.f; }
     for (long r = w0; r < R; r += nw) {
         const float n = norm[r];
+        float g[L2_MAXV], xv[L2_MAXV];
         float dot = 0.f;
-        for (int c = lane; c < C; c += 64) dot += w[c] * dy[r * lddy + c] * x[r * ldx + c];
+#pragma unroll
+        for (int i = 0; i < L2_MAXV; ++i) {
+            int c = lane + 64 * i;
+            g[i] = c < C ? dy[r * lddy + c] : 0.f;
+            xv[i] = c < C ? x[r * ldx + c] : 0.f;
+            dot += wv[i] * g[i] * xv[i];
+        }
         dot = wave_sum(dot);
         const float nn = n - eps;
         const float k = nn > 0.f ? dot / (n * n * nn) : 0.f;
-        for (int c = lane; c < C; c += 64) {
-            float g = dy[r * lddy + c], xv = x[r * ldx + c];
-            dx[r * lddx + c] = w[c] * g / n - xv * k;
-            atomicAdd(&sw[c], g * xv / n);
+        const float in = 1.f / n;
+#pragma unroll
+        for (int i = 0; i < L2_MAXV; ++i) {
+            int c = lane + 64 * i;
+            if (c < C) dx[r * lddx + c] = wv[i] * g[i] * in - xv[i] * k;
+            acc[i] += g[i] * xv[i] * in;                     // dw partial stays in registers across this wave's rows
         }
     }
+#pragma unroll
+    for (int i = 0; i < L2_MAXV; ++i) { int c = lane + 64 * i; if (c < C) atomicAdd(&sw[c], acc[i]); }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&dw[i], sw[i]);
 }
@@ -529,7 +544,8 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 PDF_API int pdf_l2norm_bwd(const float* dy, int lddy, const float* x, int ldx, int C, long R, const float* w, float eps,
                            const float* norm, float* dx, int lddx, float* dw, hipStream_t s) {
     if (R <= 0) return 0;
-    int grid = grid_for(R * 64, 256, 512);
+    if (C > 64 * L2_MAXV) return PDF_E_BADARG;
+    int grid = grid_for(R * 64, 256, 1024);
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid), dim3(256), C * sizeof(float), s, dy, lddy, x, ldx, C, R, w, eps, norm, dx, lddx, dw);
     PDF_LAUNCH_CHECK();
     return 0;

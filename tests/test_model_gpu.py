@@ -145,3 +145,30 @@ def test_depth_front_end_path_equals_explicit_clouds(setup):
     assert torch.isfinite(r1[0]['verts3d']['left']).all()
     for h in ('left', 'right'):
         assert torch.equal(r1[0]['verts3d'][h], r2[0]['verts3d'][h])
+
+
+def test_native_resolution_384_batch1_matches_oracle():
+    """The reference's native resolution (scripts/train.sh: 384) and the B=1 edge case, eval mode, vs the pinned oracle."""
+    from oracle import pdfnet_cpu as O
+    from oracle import synth
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    opt = make_opt(384)
+    torch.manual_seed(3)
+    m = load_model_intag(opt)
+    sd = synth.det_state_dict(m.state_dict(), salt=1)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    o = O.load_model_cpu(opt)
+    o.load_state_dict(sd)
+    o.eval()
+    b = synth.synthetic_batch(1, 384, seed=11, variant='mixed')
+    bc, bg = synth.to_torch(b), synth.to_torch(b, 'cuda')
+    with torch.no_grad():
+        ro = o(bc['input'], bc['choose'], bc['cloud'], bc['depth'], bc['ind'], bc['K_new'], bc['valid'])
+        rg = m(bg['input'], bg['choose'], bg['cloud'], bg['depth'], bg['ind'], bg['K_new'], bg['valid'])
+        rg2 = m(bg['input'], bg['choose'], bg['cloud'], bg['depth'], None, bg['K_new'], bg['valid'])
+        ro2 = o(bc['input'], bc['choose'], bc['cloud'], bc['depth'], None, bc['K_new'], bc['valid'])
+    exp = {k: v.numpy() for k, v in pack_outputs(ro, bc['ind']).items()}
+    check_packed(pack_outputs(rg, bg['ind']), exp, abs_tol=1e-4, rel_tol=1e-5)
+    assert rg[3]['hms'].shape == (1, 42, 96, 96) and rg[3]['mask'].shape == (1, 2, 384, 384)
+    assert torch.equal(rg2[3]['ind'].cpu(), ro2[3]['ind'])                      # predicted centres bit-exact
