@@ -236,6 +236,7 @@ struct WGemm {
     int H, W, QH, QW, sy, sx;
     int plain_q;
     int rows_per_split;
+    int tap_major;                            // tile order: channel-block major, taps inner (same XCD re-reads the same pixels)
     int beta;                                 // single-split launches write dW directly: dW = beta*dW + acc
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
@@ -254,7 +255,21 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     const int NJ = g.T * g.Cq;
     const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
     int ti, tj;
-    xcd_tile(blockIdx.x, nti * ntj, ntj, ti, tj);
+    if (g.tap_major) {
+        // Each XCD gets a contiguous run of the tile list ordered (channel block, tap, i-tile): the j-tiles that gather the
+        // SAME channels of the image through different taps (9 shifted views of the same pixels for a 3x3 conv) run on one
+        // XCD, so the image is fetched into that L2 once instead of once per tap-owning XCD.
+        const int nblk = nti * ntj, q = nblk >> 3, r = nblk & 7, x = blockIdx.x & 7;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+        const int nb = g.Cq / BJ;                         // channel blocks per tap (Cq % BJ == 0 guaranteed by the host)
+        const int per_cb = g.T * nti;
+        const int cb = lin / per_cb, rem = lin - cb * per_cb;
+        const int tap = rem / nti;
+        ti = rem - tap * nti;
+        tj = tap * nb + cb;
+    } else {
+        xcd_tile(blockIdx.x, nti * ntj, ntj, ti, tj);
+    }
     const int i0 = ti * BI, j0 = tj * BJ;
     const int ms = blockIdx.y * g.rows_per_split;
     const int me = min(g.M, ms + g.rows_per_split);
@@ -388,6 +403,165 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
         __syncthreads();
         cur ^= 1;
     }
+
+    float* out = g.slab + (long)blockIdx.y * g.NI * g.ldw;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (col >= NJ) continue;
+        const int t = col / g.Cq;
+        const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.NI) {
+                    float* o = out + (long)row * g.ldw + wcol;
+                    *o = g.beta ? *o + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// wgemm_tn_dma: the 128x128 weight-gradient tile with LDS-DMA staging (global_load_lds, 16 B per lane).
+// The register-staged wgemm_tn is bound by L2->CU latency: every K-step reads fresh rows (no L1 reuse) and only one
+// tile is in flight per block.  Here the operand tiles go global -> LDS directly through a 3-stage ring, issued TWO
+// K-steps ahead with counted waits (s_waitcnt vmcnt(4)) and one raw s_barrier per step (guide: T3+T4).  The [k][128]
+// tile image is lane-linear (a wave's 64 x 16 B = two consecutive 128-float rows), exactly what LDS-DMA writes; rows past
+// the split's end and padded / out-of-image taps read a 16-byte zero word instead (the source address is per lane).
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+#define GLDS16(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                                          (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <int ST>
+__global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
+    constexpr int BI = 128, BJ = 128, BK = 16, WN = 2, TM = 2, TN = 2;
+    __shared__ __attribute__((aligned(16))) float smem[ST * 2 * BK * 128];     // [stage][P|Q][k][128]  (48 KB, ONE array)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int NJ = g.T * g.Cq;
+    const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
+    int ti, tj;
+    if (g.tap_major) {
+        const int nblk = nti * ntj, q = nblk >> 3, r = nblk & 7, x = blockIdx.x & 7;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+        const int nb = g.Cq / BJ, per_cb = g.T * nti;
+        const int cb = lin / per_cb, rem = lin - cb * per_cb;
+        const int tap = rem / nti;
+        ti = rem - tap * nti;
+        tj = tap * nb + cb;
+    } else {
+        xcd_tile(blockIdx.x, nti * ntj, ntj, ti, tj);
+    }
+    const int i0 = ti * BI, j0 = tj * BJ;
+    const int ms = blockIdx.y * g.rows_per_split;
+    const int me = min(g.M, ms + g.rows_per_split);
+    const int nt = (me - ms + BK - 1) / BK;
+
+    const int pr = tid >> 5, pc = (tid & 31) * 4;           // this thread's row (0..7, +8 on the 2nd pass) and 4-float column
+    const bool pcol_ok = i0 + pc < g.NI;
+    const int jcol = j0 + pc;
+    const bool qcol_ok = jcol < NJ;
+    const int qtap = qcol_ok ? jcol / g.Cq : 0;
+    const int qch = jcol - qtap * g.Cq;
+    const int tdy = g.dy[qtap], tdx = g.dx[qtap];
+    int q_ni[2], q_y[2], q_x[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = ms + pr + i * 8, hw = g.QH * g.QW;
+        q_ni[i] = m / hw;
+        const int rem = m - q_ni[i] * hw;
+        q_y[i] = rem / g.QW;
+        q_x[i] = rem - q_y[i] * g.QW;
+    }
+    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 2 * 128;      // wave-uniform LDS row base (floats)
+
+    auto issue = [&](int t, int st) {                       // tile t (rows ms + 16t ...) -> ring stage st
+        float* sp = smem + (st * 2 + 0) * BK * 128 + wbase;
+        float* sq = smem + (st * 2 + 1) * BK * 128 + wbase;
+        const int mb = ms + t * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mb + pr + i * 8;
+            const bool rowok = m < me;
+            const float* srcp = (rowok && pcol_ok) ? g.P + (long)m * g.ldp + i0 + pc : g_zero16;
+            const float* srcq;
+            if (g.plain_q) srcq = (rowok && qcol_ok) ? g.Q + (long)m * g.ldq + qch : g_zero16;
+            else {
+                const int iy = q_y[i] * g.sy + tdy, ix = q_x[i] * g.sx + tdx;
+                const bool ok = rowok && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                srcq = ok ? g.Q + ((long)q_ni[i] * g.H * g.W + (long)iy * g.W + ix) * g.ldq + qch : g_zero16;
+            }
+            GLDS16(srcp, sp + i * 8 * 128);
+            GLDS16(srcq, sq + i * 8 * 128);
+        }
+        if (g.QW * 2 >= BK) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                q_x[i] += BK;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const bool wrap = q_x[i] >= g.QW;
+                    q_x[i] -= wrap ? g.QW : 0;
+                    q_y[i] += wrap ? 1 : 0;
+                    const bool wy = q_y[i] >= g.QH;
+                    q_y[i] = wy ? 0 : q_y[i];
+                    q_ni[i] += wy ? 1 : 0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = mb + BK + pr + i * 8, hw = g.QH * g.QW;
+                q_ni[i] = m / hw;
+                const int rem = m - q_ni[i] * hw;
+                q_y[i] = rem / g.QW;
+                q_x[i] = rem - q_y[i] * g.QW;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int aoff = (lane >> 5) * 128 + wm * TM * 32 + (lane & 31);
+    const int boff = (lane >> 5) * 128 + wn * TN * 32 + (lane & 31);
+#pragma unroll
+    for (int p = 0; p < ST - 1; ++p) issue(p, p);
+    int st = 0, stn = ST - 1;
+    for (int t = 0; t < nt; ++t) {
+        // this wave's 4 DMAs of tile t have landed (the ST-2 younger tiles may still fly) ...
+        if (ST == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // ... and everybody's; everybody also finished reading tile t-1
+        issue(t + ST - 1, stn);                             // refill the stage tile t-1 used (rows past the end read zeros)
+        const float* ps = smem + (st * 2 + 0) * BK * 128;
+        const float* qs = smem + (st * 2 + 1) * BK * 128;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ps[aoff + kk * 2 * 128 + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = qs[boff + kk * 2 * 128 + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        st = st == ST - 1 ? 0 : st + 1;
+        stn = stn == ST - 1 ? 0 : stn + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
 
     float* out = g.slab + (long)blockIdx.y * g.NI * g.ldw;
 #pragma unroll
@@ -623,6 +797,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     int rps = cdiv(cdiv(g.M, splits), 16) * 16;
     splits = cdiv(g.M, rps);
     g.rows_per_split = rps;
+    g.tap_major = (!g.plain_q && g.T > 1 && g.Cq % BJ == 0 && env_int("PDF_WG_TAPMAJOR", 1)) ? 1 : 0;
     g.slab = splits == 1 ? out : ws;          // one split: no slab round trip, no reduce launch
     g.beta = splits == 1 ? accumulate : 0;
     dim3 grid((unsigned)tiles, (unsigned)splits);
@@ -630,7 +805,10 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);
     } else {
-        if (fast) hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, true>), grid, dim3(256), 0, s, g);
+        const int dma = env_int("PDF_WG_DMA", 3);
+        if (fast && dma == 4) hipLaunchKernelGGL(wgemm_tn_dma<4>, grid, dim3(256), 0, s, g);
+        else if (fast && dma == 3) hipLaunchKernelGGL(wgemm_tn_dma<3>, grid, dim3(256), 0, s, g);
+        else if (fast) hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, false>), grid, dim3(256), 0, s, g);
     }
     PDF_LAUNCH_CHECK();
