@@ -159,14 +159,44 @@ __global__ void up2_fwd_kernel(const float* __restrict__ x, int N, int H, int W,
         y[i] = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
     }
 }
+// float4 form: one thread per (output pixel, channel quad); grid.y = output row, so the only division is by C/4
+__global__ __launch_bounds__(256) void up2_fwd_v4_kernel(const float* __restrict__ x, int H, int W, int C4, float* __restrict__ y) {
+    const int OH = 2 * H, OW = 2 * W;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= OW * C4) return;
+    const int ox = j / C4, c4 = j - ox * C4;
+    const int n = blockIdx.y / OH, oy = blockIdx.y - n * OH;
+    int y0, y1, x0, x1; float wy, wx;
+    up2_coords(oy, H, OH, y0, y1, wy);
+    up2_coords(ox, W, OW, x0, x1, wx);
+    const float4* b = reinterpret_cast<const float4*>(x) + (long)n * H * W * C4 + c4;
+    const float4 v00 = b[((long)y0 * W + x0) * C4], v01 = b[((long)y0 * W + x1) * C4];
+    const float4 v10 = b[((long)y1 * W + x0) * C4], v11 = b[((long)y1 * W + x1) * C4];
+    const float hy = 1.f - wy, hx = 1.f - wx;
+    float4 o;
+    o.x = hy * (hx * v00.x + wx * v01.x) + wy * (hx * v10.x + wx * v11.x);
+    o.y = hy * (hx * v00.y + wx * v01.y) + wy * (hx * v10.y + wx * v11.y);
+    o.z = hy * (hx * v00.z + wx * v01.z) + wy * (hx * v10.z + wx * v11.z);
+    o.w = hy * (hx * v00.w + wx * v01.w) + wy * (hx * v10.w + wx * v11.w);
+    reinterpret_cast<float4*>(y)[((long)blockIdx.y * OW + ox) * C4 + c4] = o;
+}
+static bool up2_v4_ok(const void* a, const void* b, int N, int H, int W, int C) {
+    return C % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && (long)N * 2 * H < 65536 &&
+           (long)2 * W * (C / 4) < (1L << 30);
+}
 PDF_API int pdf_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, hipStream_t s) {
     long total = (long)N * 4 * H * W * C;
     if (total <= 0) return 0;
+    if (up2_v4_ok(x, y, N, H, W, C)) {
+        hipLaunchKernelGGL(up2_fwd_v4_kernel, dim3(cdiv(2 * W * (C / 4), 256), N * 2 * H), dim3(256), 0, s, x, H, W, C / 4, y);
+        PDF_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(up2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, N, H, W, C, y, total);
     PDF_LAUNCH_CHECK();
     return 0;
 }
-// dx zero-filled by caller
+// scatter form (any C / alignment): dx is zeroed by the entry point
 __global__ void up2_bwd_kernel(const float* __restrict__ dy, int N, int H, int W, int C, float* __restrict__ dx, long total) {
     const int OH = 2 * H, OW = 2 * W;
     GRID_STRIDE(i, total) {
@@ -184,9 +214,48 @@ __global__ void up2_bwd_kernel(const float* __restrict__ dy, int N, int H, int W
         atomicAdd(&b[((long)y1 * W + x1) * C], g * wy * wx);
     }
 }
+// Gather form of the backward (deterministic, no atomics, dx need not be zeroed): one thread per (input pixel, channel
+// quad) sums the <= 5x5 output pixels whose bilinear footprint touches it, with the weights up2_coords gives the forward.
+__device__ __forceinline__ int up2_touching(int i, int in_sz, int out_sz, int (&o_of)[6], float (&w_of)[6]) {
+    int cnt = 0;
+    const int lo = max(0, 2 * i - 2), hi = min(out_sz - 1, 2 * i + 4);
+    for (int o = lo; o <= hi; ++o) {
+        int i0, i1; float w1;
+        up2_coords(o, in_sz, out_sz, i0, i1, w1);
+        float w = 0.f;
+        if (i0 == i) w += 1.f - w1;
+        if (i1 == i) w += w1;
+        if (w != 0.f && cnt < 6) { o_of[cnt] = o; w_of[cnt] = w; ++cnt; }
+    }
+    return cnt;
+}
+__global__ __launch_bounds__(256) void up2_bwd_v4_kernel(const float* __restrict__ dy, int H, int W, int C4, float* __restrict__ dx) {
+    const int OH = 2 * H, OW = 2 * W;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= W * C4) return;
+    const int ix = j / C4, c4 = j - ix * C4;
+    const int n = blockIdx.y / H, iy = blockIdx.y - n * H;
+    int oys[6], oxs[6]; float wys[6], wxs[6];
+    const int ny = up2_touching(iy, H, OH, oys, wys), nx = up2_touching(ix, W, OW, oxs, wxs);
+    const float4* g = reinterpret_cast<const float4*>(dy) + (long)n * OH * OW * C4 + c4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+            const float4 v = g[((long)oys[a] * OW + oxs[b]) * C4];
+            const float w = wys[a] * wxs[b];
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+    reinterpret_cast<float4*>(dx)[((long)blockIdx.y * W + ix) * C4 + c4] = acc;
+}
 PDF_API int pdf_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, hipStream_t s) {
     long total = (long)N * 4 * H * W * C;
     if (total <= 0) return 0;
+    if (up2_v4_ok(dy, dx, N, H, W, C)) {
+        hipLaunchKernelGGL(up2_bwd_v4_kernel, dim3(cdiv(W * (C / 4), 256), N * H), dim3(256), 0, s, dy, H, W, C / 4, dx);
+        PDF_LAUNCH_CHECK();
+        return 0;
+    }
+    { hipError_t e = hipMemsetAsync(dx, 0, (size_t)N * H * W * C * sizeof(float), s); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, N, H, W, C, dx, total);
     PDF_LAUNCH_CHECK();
     return 0;

@@ -34,15 +34,18 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 }
 
 
-// sum the per-chunk partials part[chunk][C][2] for channel c: 64 channels x 4 chunk-lanes per block
+// sum the per-chunk partials part[chunk][C][2] for channel c: 64 channels x 16 chunk-lanes per block
 // (a serial 512-iteration loop per channel was latency-bound: ~50 us for a kernel that moves a few KB)
 #define FIN_TX 64
-#define FIN_TY 4
+#define FIN_TY 16
 __device__ __forceinline__ void reduce_chunks(const float* __restrict__ part, int chunks, int C, int c, int ty,
                                               double (&s1)[FIN_TY][FIN_TX], double (&s2)[FIN_TY][FIN_TX], double& a, double& b) {
     a = 0.0; b = 0.0;
-    if (c < C)
-        for (int k = ty; k < chunks; k += FIN_TY) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    if (c < C) {
+        const float2* p2 = reinterpret_cast<const float2*>(part) + c;
+#pragma unroll 4
+        for (int k = ty; k < chunks; k += FIN_TY) { const float2 v = p2[(long)k * C]; a += v.x; b += v.y; }
+    }
     const int tx = threadIdx.x;
     s1[ty][tx] = a; s2[ty][tx] = b;
     __syncthreads();
@@ -50,7 +53,7 @@ __device__ __forceinline__ void reduce_chunks(const float* __restrict__ part, in
     for (int j = 0; j < FIN_TY; ++j) { a += s1[j][tx]; b += s2[j][tx]; }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int chunks, const float* __restrict__ x, int C, long R,
+__global__ __launch_bounds__(FIN_TX * FIN_TY) void bn_finalize_kernel(const float* __restrict__ part, int chunks, const float* __restrict__ x, int C, long R,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
                                    float* __restrict__ save_mean, float* __restrict__ save_rstd,
@@ -192,11 +195,85 @@ __global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __r
     v4_block_reduce(a, a, sa, sb, part, C, c0, false);
 }
 
+// float4 streaming passes on the same (16 channel-quads x 16 row-lanes) block shape: per-channel coefficients live in
+// registers, no index division, 4 independent 16-byte loads per operand in flight per thread.
+__global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ res, int ldr,
+                                                              float* __restrict__ y, int ldy, int C, long R, long rows_per_chunk, int relu) {
+    const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
+    const int c0 = blockIdx.x * BN_CT + tx * 4;
+    if (c0 >= C) return;
+    const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c0), sh = *reinterpret_cast<const float4*>(shift + c0);
+#pragma unroll 4
+    for (long r = r0 + ty; r < r1; r += V4_TY) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+        float4 v = make_float4(xv.x * sc.x + sh.x, xv.y * sc.y + sh.y, xv.z * sc.z + sh.z, xv.w * sc.w + sh.w);
+        if (res != nullptr) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + r * ldr + c0);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(y + r * ldy + c0) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int relu,
+                                                              const float* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ coef, int C, long R,
+                                                              long rows_per_chunk, float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddr) {
+    const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
+    const int c0 = blockIdx.x * BN_CT + tx * 4;
+    if (c0 >= C) return;
+    const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    const float4 m = *reinterpret_cast<const float4*>(mean + c0), rs = *reinterpret_cast<const float4*>(rstd + c0);
+    const float4 ka = *reinterpret_cast<const float4*>(coef + c0), k1 = *reinterpret_cast<const float4*>(coef + C + c0),
+                 k2 = *reinterpret_cast<const float4*>(coef + 2 * C + c0);
+#pragma unroll 4
+    for (long r = r0 + ty; r < r1; r += V4_TY) {
+        float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c0);
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+        if (relu) {
+            const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c0);
+            if (!(yv.x > 0.f)) g.x = 0.f;
+            if (!(yv.y > 0.f)) g.y = 0.f;
+            if (!(yv.z > 0.f)) g.z = 0.f;
+            if (!(yv.w > 0.f)) g.w = 0.f;
+        }
+        if (dres != nullptr) *reinterpret_cast<float4*>(dres + r * lddr + c0) = g;
+        float4 o;
+        o.x = ka.x * (g.x - k1.x - (xv.x - m.x) * rs.x * k2.x);
+        o.y = ka.y * (g.y - k1.y - (xv.y - m.y) * rs.y * k2.y);
+        o.z = ka.z * (g.z - k1.z - (xv.z - m.z) * rs.z * k2.z);
+        o.w = ka.w * (g.w - k1.w - (xv.w - m.w) * rs.w * k2.w);
+        *reinterpret_cast<float4*>(dx + r * lddx + c0) = o;
+    }
+}
+
+// row chunks for the streaming passes: ~4096 blocks, >= 64 rows each
+static long apply_rows_per_chunk(int C, long R) {
+    long want = 4096 / ((C + BN_CT - 1) / BN_CT);
+    if (want < 1) want = 1;
+    long rpc = (R + want - 1) / want;
+    if (rpc < 64) rpc = 64;
+    return (rpc + V4_TY - 1) / V4_TY * V4_TY;
+}
+
 static bool v4_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
     if (C % 4) return false;
     for (int l : lds) if (l % 4) return false;
     for (const void* p : ptrs) if (p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
     return true;
+}
+
+static void launch_affine_apply(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldr,
+                                float* y, int ldy, int C, long R, int relu, hipStream_t s) {
+    if (v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift})) {
+        const long rpc = apply_rows_per_chunk(C, R);
+        hipLaunchKernelGGL(affine_apply_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)((R + rpc - 1) / rpc)), dim3(256), 0, s,
+                           x, ldx, scale, shift, res, ldr, y, ldy, C, R, rpc, relu);
+    } else
+        hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
 }
 
 // Training forward.  ws: >= pdf_bn_workspace_floats(C, R) floats.  scale/shift [C] are outputs the
@@ -230,7 +307,7 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, x, C, R, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
+    launch_affine_apply(x, ldx, scale, shift, res, ldr, y, ldy, C, R, relu, s);
     PDF_LAUNCH_CHECK();
     return 0;
 }
@@ -241,7 +318,7 @@ PDF_API int pdf_bn_eval_fwd(const float* x, int ldx, int C, long R, const float*
     if (R <= 0 || C <= 0) return 0;
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, C, gamma, beta, running_mean, running_var, eps, scale, shift);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
+    launch_affine_apply(x, ldx, scale, shift, res, ldr, y, ldy, C, R, relu, s);
     PDF_LAUNCH_CHECK();
     return 0;
 }
@@ -273,7 +350,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, long R, const float* __restrict__ gamma,
+__global__ __launch_bounds__(FIN_TX * FIN_TY) void bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C, long R, const float* __restrict__ gamma,
                                        const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                        float* __restrict__ coef /*[3][C]: a, c1, c2*/) {
     __shared__ double s1[FIN_TY][FIN_TX], s2[FIN_TY][FIN_TX];
@@ -323,14 +400,19 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
     PDF_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, R, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef, C, R * C,
-                       dx, lddx, dres, lddr);
+    if (v4_ok(C, {lddy, ldx, lddx, relu ? ldy : 0, dres ? lddr : 0}, {dy, x, dx, dres, relu ? y : nullptr, save_mean, save_rstd, coef})) {
+        const long arpc = apply_rows_per_chunk(C, R);
+        hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)((R + arpc - 1) / arpc)), dim3(256), 0, s, dy, lddy, y, ldy, relu,
+                           x, ldx, save_mean, save_rstd, coef, C, R, arpc, dx, lddx, dres, lddr);
+    } else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef, C, R * C,
+                           dx, lddx, dres, lddr);
     PDF_LAUNCH_CHECK();
     return 0;
 }
 
 // column sums: out[c] (+)= sum_r g[r][c]   (conv / linear bias gradients), optional relu mask by y
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ out, int accumulate) {
+__global__ __launch_bounds__(FIN_TX * FIN_TY) void colsum_finalize_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ out, int accumulate) {
     __shared__ double s1[FIN_TY][FIN_TX], s2[FIN_TY][FIN_TX];
     const int c = blockIdx.x * FIN_TX + threadIdx.x;
     double a, b;

@@ -493,7 +493,7 @@ class _Up2(Function):
     @staticmethod
     def backward(ctx, dy):
         N, C, H, W = ctx.shape
-        dx = _zeros_cl((N, C, H, W), dy.device)
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device, memory_format=CL)
         _L().pdf_upsample2x_bwd(ptr(cl(dy)), N, H, W, C, ptr(dx), stream())
         return dx
 
