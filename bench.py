@@ -73,7 +73,7 @@ class GemmProfiler:
                 e0.record()
                 r = _fn(*a)
                 e1.record()
-                self.records.append((_n, self.flops(_n, a), e0, e1))
+                self.records.append((_n, self.flops(_n, a), e0, e1, tuple(v for v in a if isinstance(v, int) and abs(v) < (1 << 31))))
                 return r
             setattr(self.lib, n, wrapped)
         return self
@@ -85,12 +85,23 @@ class GemmProfiler:
     def summary(self):
         torch.cuda.synchronize()
         per = {}
-        for n, fl, e0, e1 in self.records:
+        for n, fl, e0, e1, _ in self.records:
             d = per.setdefault(n, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += fl
             d[2] += e0.elapsed_time(e1) * 1e-3
         return per
+
+    def by_shape(self):
+        """(entry point, integer arguments) -> [calls, flops, seconds], largest time first."""
+        torch.cuda.synchronize()
+        sh = {}
+        for n, fl, e0, e1, ints in self.records:
+            d = sh.setdefault((n, ints), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += fl
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        return sorted(sh.items(), key=lambda kv: -kv[1][2])
 
 
 def pmc_traffic():
@@ -140,6 +151,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='(default) kept for compatibility')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--gemm-shapes', default=None, help='write the per-shape table of the instrumented step to this file')
     args = ap.parse_args()
 
     from pdfnet_amd import functional as F
@@ -201,6 +213,10 @@ def main():
         with GemmProfiler() as prof:
             trainer.train_step(batch)
         per = prof.summary()
+        if args.gemm_shapes:
+            with open(args.gemm_shapes, 'w') as f:
+                for (n, ints), (c, fl, sec) in prof.by_shape():
+                    f.write("%-26s %-60s calls %3d  %8.3f ms  %6.1f TF\n" % (n, ' '.join(map(str, ints)), c, sec * 1e3, fl / max(sec, 1e-9) / 1e12))
         calls = sum(v[0] for v in per.values())
         flops = sum(v[1] for v in per.values())
         secs = sum(v[2] for v in per.values())

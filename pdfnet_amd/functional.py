@@ -191,6 +191,34 @@ def _colsum(g, C, R, ldg):
     return out
 
 
+ASYNC_WGRAD_MIN_FLOP = float(_os.environ.get("PDFNET_ASYNC_WGRAD_MIN_GFLOP", "0")) * 1e9
+
+
+def _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, C, R, flops):
+    """Weight and bias gradients of a conv / transposed conv / linear layer.  Gradients that go straight into the
+    trainer's flat buffer are issued together on the side stream (one stream switch for both).  A size threshold for the
+    switch was measured (PDFNET_ASYNC_WGRAD_MIN_GFLOP = 0 / 0.5 / 4 -> 316 / 311 / 298 img/s): even the smallest layers
+    gain from leaving the dependent main-stream chain, so the default is 0.  Returns (dw, db) for autograd (None when
+    accumulated directly)."""
+    need_w = ctx.needs_input_grad[1]
+    need_b = has_b and ctx.needs_input_grad[2]
+    mg_w = _main_grad(w_par, w) if need_w else None
+    mg_b = _main_grad(b_par, b_par) if need_b else None
+    dw = db = None
+    if mg_w is not None or mg_b is not None:
+        with wgrad_stream(flops >= ASYNC_WGRAD_MIN_FLOP, x, g):
+            if mg_w is not None:
+                launch_w(mg_w, 1)
+            if mg_b is not None:
+                _colsum_into(g, C, R, C, mg_b)
+    if need_w and mg_w is None:
+        dw = torch.empty_like(w)
+        launch_w(dw, 0)
+    if need_b and mg_b is None:
+        db = _colsum(g, C, R, C)
+    return dw, db
+
+
 def _act_bwd(dy, y, act):
     R, C = _rows(y)
     g = torch.empty_like(y)
@@ -237,20 +265,13 @@ class _Conv2d(Function):
                 dx = torch.empty_like(x)
             L.pdf_conv2d_bwd_data(ptr(g), ptr(wT), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
         w_par, b_par = ctx.params
-        if ctx.needs_input_grad[1]:
-            mg = _main_grad(w_par, w)
-            dw = torch.empty_like(w) if mg is None else None
-            with wgrad_stream(mg is not None, x, g):
-                ws, n = _wgrad_ws(N * OH * OW, Cout, KH * KW * Cin, x.device)
-                L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                        stride, pad, OH, OW, Cout, int(mg is not None), stream())
-        if has_b and ctx.needs_input_grad[2]:
-            mg = _main_grad(b_par, b_par)
-            if mg is None:
-                db = _colsum(g, Cout, N * OH * OW, Cout)
-            else:
-                with wgrad_stream(True, g):
-                    _colsum_into(g, Cout, N * OH * OW, Cout, mg)
+        R = N * OH * OW
+
+        def launch_w(out, acc):
+            ws, n = _wgrad_ws(R, Cout, KH * KW * Cin, x.device)
+            L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+                                    stride, pad, OH, OW, Cout, acc, stream())
+        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin)
         return dx, dw, db, None, None, None
 
 
@@ -297,20 +318,12 @@ class _Deconv2d(Function):
             dx = torch.empty_like(x)
             L.pdf_deconv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
         w_par, b_par = ctx.params
-        if ctx.needs_input_grad[1]:
-            mg = _main_grad(w_par, w)
-            dw = torch.empty_like(w) if mg is None else None
-            with wgrad_stream(mg is not None, x, g):
-                ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
-                L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                          stride, pad, OH, OW, Cout, int(mg is not None), stream())
-        if has_b and ctx.needs_input_grad[2]:
-            mg = _main_grad(b_par, b_par)
-            if mg is None:
-                db = _colsum(g, Cout, N * OH * OW, Cout)
-            else:
-                with wgrad_stream(True, g):
-                    _colsum_into(g, Cout, N * OH * OW, Cout, mg)
+
+        def launch_w(out, acc):
+            ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
+            L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+                                      stride, pad, OH, OW, Cout, acc, stream())
+        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, N * OH * OW, 2.0 * N * H * W * Cin * KH * KW * Cout)
         return dx, dw, db, None, None
 
 
@@ -354,19 +367,11 @@ class _Linear(Function):
             dx = torch.empty_like(x)
             L.pdf_linear_fwd(ptr(g), ptr(wT), None, ptr(dx), M, K, Nn, Nn, Nn, K, 0, stream())
         w_par, b_par = ctx.params
-        if ctx.needs_input_grad[1]:
-            mg = _main_grad(w_par, w)
-            dw = torch.empty_like(w) if mg is None else None
-            with wgrad_stream(mg is not None, x, g):
-                ws, n = _wgrad_ws(M, Nn, K, x.device)
-                L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(dw if mg is None else mg), ptr(ws), n, M, Nn, K, K, Nn, int(mg is not None), stream())
-        if has_b and ctx.needs_input_grad[2]:
-            mg = _main_grad(b_par, b_par)
-            if mg is None:
-                db = _colsum(g, Nn, M, Nn)
-            else:
-                with wgrad_stream(True, g):
-                    _colsum_into(g, Nn, M, Nn, mg)
+
+        def launch_w(out, acc):
+            ws, n = _wgrad_ws(M, Nn, K, x.device)
+            L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
+        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K)
         return dx, dw, db, None
 
 

@@ -2,10 +2,12 @@
 `load_model_intag(opt)` with the reference's forward signature, return structure and state_dict keys, so
 it drops into `ModleWithLoss` (lib/trains/base_trainer.py:24-78) / demo.py:202 unchanged.
 """
+import torch
 import torch.nn as nn
 
 from .intaghand_decoder import load_decoder
 from .intaghand_encoder import load_encoder
+from .layers import BatchNorm
 
 
 class HandNET_GCN(nn.Module):
@@ -19,12 +21,18 @@ class HandNET_GCN(nn.Module):
         self.run_mid_model = run_mid_model
 
     def forward(self, img, choose, cloud, depth, ind, K_new, valid):
-        hms, mask, ret, img_fmaps, hms_fmaps, dp_fmaps, ind = self.encoder(img, ind, choose, cloud, depth, K_new, valid)
-        if self.run_mid_model:
-            gl, gr, _ = self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)
-        else:
-            gl, gr = img_fmaps[0][:, 0], img_fmaps[0][:, 1]
+        st = self.encoder.trunk(img, ind, choose, cloud, depth, K_new, valid)
+        img_fmaps, ind = st['img_fmaps'], st['ind']
+        # The dense branches are issued BEFORE the launch-bound mesh decoder.  Issuing them after it (so that their heavy
+        # convolutions overlap the decoder's small kernels in forward and backward) was measured: 267-272 vs 314 img/s in
+        # one session -- the big kernels starve the critical decoder -> PointNet++ -> trunk backward chain.
+        hms, mask, ret, hms_fmaps, dp_fmaps = self.encoder.dense_branches(st)
+        gl, gr = img_fmaps[0][:, 0], img_fmaps[0][:, 1]                 # what mid_model hands on (intaghand_encoder.py:881)
         result, paramsDict, handDictList, otherInfo = self.decoder(gl, gr)
+        if self.run_mid_model:
+            with torch.no_grad():
+                self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)          # live state: its BN running statistics only
+        BatchNorm.flush_counters()
         otherInfo['hms'] = hms
         otherInfo['mask'] = mask
         otherInfo['ret'] = ret

@@ -92,10 +92,29 @@ class BatchNorm(nn.Module):
         self.register_buffer('running_mean', torch.zeros(c))
         self.register_buffer('running_var', torch.ones(c))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self._pending = 0
+
+    # `num_batches_tracked += 1` is one launch per layer call (84 per step); the increments are counted on the host and
+    # applied by one multi-tensor add (flush_counters: end of HandNET_GCN.forward, and before any state_dict read).
+    _dirty = []
+
+    @staticmethod
+    def flush_counters():
+        mods, BatchNorm._dirty = BatchNorm._dirty, []
+        if mods:
+            torch._foreach_add_([m.num_batches_tracked for m in mods], [m._pending for m in mods])
+            for m in mods:
+                m._pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        BatchNorm.flush_counters()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def forward(self, x, relu=False, res=None):
         if self.training:
-            self.num_batches_tracked += 1
+            if self._pending == 0:
+                BatchNorm._dirty.append(self)
+            self._pending += 1
         return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var,
                             self.training, self.momentum, self.eps, relu, res)
 

@@ -114,17 +114,13 @@ class CtdetLoss(nn.Module):
         l2 = TF.mse_loss
         nrm = lambda x: x / S * 2 - 1
 
-        mask_loss = TF.smooth_l1_loss(otherInfo['mask'], batch['mask'])                    # :368
-        hms_loss = l2(otherInfo['hms'], batch['hms'])                                      # :374
-        center_hm = sigmoid_clamped(otherInfo['ret']['hm'])                                # :376
         test = mode in ('val', 'test')
         if test:
             from ..networks.intaghand_encoder import nms_top1_centers
-            ind = nms_top1_centers(center_hm)
+            ind = nms_top1_centers(sigmoid_clamped(otherInfo['ret']['hm']))                # :376-389
         else:
             ind = batch['ind']
         ind_l, ind_r = ind[:, :1], ind[:, 1:]
-        hm_loss = focal_loss(center_hm, batch['hm'])                                       # :391
 
         vgt = {'left': batch['verts_left_gt'], 'right': batch['verts_right_gt']}
         jgt = {'left': batch['joints_left_gt'], 'right': batch['joints_right_gt']}
@@ -143,7 +139,11 @@ class CtdetLoss(nn.Module):
         jgt_off = {h: F.regress_joints(reg[h], vgt_off[h]) for h in ('left', 'right')}
         joints_loss = sum(l1(jpred_off[h], jgt_off[h]) * hv[h] for h in ('left', 'right'))                  # :435-436
         norm_loss = sum(normal_loss(vpred_off[h], vgt_off[h], face[h]) for h in ('left', 'right'))          # :452
-        edge_loss = sum(edge_length_loss(vpred_off[h], vgt_off[h], face[h]) for h in ('left', 'right'))     # :453
+        alpha = 0 if epoch < 20 else 1                                                                      # :610
+        with torch.set_grad_enabled(torch.is_grad_enabled() and alpha != 0):
+            # weighted by alpha below: while alpha == 0 the term is reported but contributes an exactly-zero gradient,
+            # so its backward graph is not built
+            edge_loss = sum(edge_length_loss(vpred_off[h], vgt_off[h], face[h]) for h in ('left', 'right'))  # :453
 
         # GCN-level supervision: GT in GCN order, 1008 -> 252 by two pair-averagings (:461-482).
         # NB the reference feeds the LEFT GT to both hands and weights both terms by valid[:,0] (:463,481-482).
@@ -171,7 +171,10 @@ class CtdetLoss(nn.Module):
         abs_verts_loss = sum(l1(vpred[h], vgt[h]) * hv[h] for h in ('left', 'right')) * 1000
         bone = sum(bone_direction_loss(lms_proj[h], lmsgt[h], self.bone_a, self.bone_c) * hv[h] for h in ('left', 'right'))           # :517-525
 
-        alpha = 0 if epoch < 20 else 1                                                                      # :610
+        # dense-map terms (created last: their backward is issued first, ahead of the launch-bound mesh terms)
+        mask_loss = TF.smooth_l1_loss(otherInfo['mask'], batch['mask'])                    # :368
+        hms_loss = l2(otherInfo['hms'], batch['hms'])                                      # :374
+        hm_loss = focal_loss(sigmoid_clamped(otherInfo['ret']['hm']), batch['hm'])         # :376, :391
         w = getattr(o, 'reproj_weight', 1.0)
         loss = getattr(o, 'center_weight', 200.0) * hm_loss + w * root_loss
         loss = loss + w * (verts_loss * 500 + abs_verts_loss * 0.1 + verts2d_loss * 50 + norm_loss * 10 +
