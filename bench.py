@@ -40,8 +40,12 @@ def make_opt(R):
 class GemmProfiler:
     """Wraps the GEMM-family C-ABI entry points with start/stop events on the current stream and counts the
     algorithmic FLOPs (2*M*N*K of the contraction each call performs) from the call's own arguments."""
-    NAMES = ('pdf_linear_fwd', 'pdf_linear_bwd_weight', 'pdf_conv2d_fwd', 'pdf_conv2d_bwd_data', 'pdf_conv2d_bwd_weight',
+    NAMES = ('pdf_linear_fwd', 'pdf_linear_bwd_data', 'pdf_linear_bwd_weight', 'pdf_linear_fwd_pair', 'pdf_linear_bwd_data_pair',
+             'pdf_linear_bwd_weight_pair', 'pdf_conv2d_fwd', 'pdf_conv2d_bwd_data', 'pdf_conv2d_bwd_weight',
              'pdf_deconv2d_fwd', 'pdf_deconv2d_bwd_data', 'pdf_deconv2d_bwd_weight')
+    # position of (M, N, K) in the argument list and the number of GEMMs per call, include/pdfnet_hip.h
+    LINEAR = {'pdf_linear_fwd': (4, 1), 'pdf_linear_bwd_data': (3, 1), 'pdf_linear_bwd_weight': (5, 1),
+              'pdf_linear_fwd_pair': (6, 2), 'pdf_linear_bwd_data_pair': (4, 2), 'pdf_linear_bwd_weight_pair': (6, 2)}
 
     def __init__(self):
         from pdfnet_amd import hip
@@ -51,10 +55,9 @@ class GemmProfiler:
 
     @staticmethod
     def flops(name, a):
-        if name == 'pdf_linear_fwd':
-            return 2.0 * a[4] * a[5] * a[6]
-        if name == 'pdf_linear_bwd_weight':
-            return 2.0 * a[5] * a[6] * a[7]
+        if name in GemmProfiler.LINEAR:
+            off, n = GemmProfiler.LINEAR[name]
+            return 2.0 * n * a[off] * a[off + 1] * a[off + 2]
         # conv family: (..., N, H, W, Cin, ld, Cout, KH, KW, stride, pad, OH, OW, ...)
         off = {'pdf_conv2d_fwd': 4, 'pdf_conv2d_bwd_data': 3, 'pdf_conv2d_bwd_weight': 5,
                'pdf_deconv2d_fwd': 4, 'pdf_deconv2d_bwd_data': 3, 'pdf_deconv2d_bwd_weight': 5}[name]

@@ -36,14 +36,26 @@ int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
 int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
                           int M, int N, int K, int ldx, int lddy, int accumulate, void* stream);
 long pdf_wgrad_workspace_floats(int M, int NI, int NJ);
+/* dx[M][K] = dy[M][N] w[N][K] (autograd of nn.Linear wrt its input); w is read in its forward storage */
+int pdf_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx, void* stream);
+/* Paired forms: two same-shaped layers with their own parameters in one launch -- the left / right hand branches of the
+ * mesh decoder (model_attn/DualGraph.py:83-84 graph_left/graph_right, inter_attn.py:66-67 L_/R_self_attn_layer, ffL/ffR).
+ * Rows [0, M) of x / y / dy / dx belong to (w0, b0), rows [M, 2M) to (w1, b1).
+ * pdf_linear_bwd_weight_pair: ws >= 2 * pdf_wgrad_workspace_floats(M, N, K). */
+int pdf_linear_fwd_pair(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
+                        int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream);
+int pdf_linear_bwd_data_pair(const float* dy, const float* w0, const float* w1, float* dx, int M, int N, int K,
+                             int lddy, int ldw, int lddx, void* stream);
+int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* dw0, float* dw1, float* ws, long ws_floats,
+                               int M, int N, int K, int ldx, int lddy, int accumulate, void* stream);
 
 /* nn.Conv2d forward on NHWC: lib/models/networks/resnet.py:202-218 (trunk), intaghand_encoder.py:602 (p2),
  * :617 (feat), :621 (e_conv1), :627-628 (center_feat_up0/1), :675-693 (heads), :270-316 (decoders). */
 int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                    int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                    int stride, int pad, int OH, int OW, int ldy, int act, void* stream);
-/* dx from dy; wT = [Cin][KH][KW][Cout] (pdf_transpose_atb(w, Cout, KH*KW, Cin)); caller zero-fills dx when stride > kernel */
-int pdf_conv2d_bwd_data(const float* dy, const float* wT, float* dx,
+/* dx from dy and the forward weight w = [Cout][KH][KW][Cin] (no transposed copy); caller zero-fills dx when stride > kernel */
+int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
                         int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
                         int stride, int pad, int OH, int OW, int lddy, void* stream);
 int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
@@ -51,9 +63,8 @@ int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws,
                           int stride, int pad, int OH, int OW, int lddy, int accumulate, void* stream);
 
 /* nn.ConvTranspose2d (pyramid laterals p3/p4/p5, intaghand_encoder.py:603-605,721-729).
- * fwd weight repack wP: kernel==stride: [KH*KW*Cout][Cin] = pdf_transpose_atb(w, Cin, 1, KH*KW*Cout);
- *                       otherwise:      [Cout][KH][KW][Cin] = pdf_transpose_atb(w, Cin, KH*KW, Cout). */
-int pdf_deconv2d_fwd(const float* x, const float* wP, const float* bias, float* y,
+ * w = the weight in its natural [Cin][KH][KW][Cout] (channels_last) storage in all three entry points. */
+int pdf_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                      int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                      int stride, int pad, int OH, int OW, int ldy, void* stream);
 int pdf_deconv2d_bwd_data(const float* dy, const float* w, float* dx,
@@ -118,11 +129,27 @@ int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy, int rel
                      float* ws, void* stream);
 /* out[c] (+)= sum_r g[r][c] (bias gradients); ws >= pdf_bn_workspace_floats(C,R) */
 int pdf_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, void* stream);
+/* paired: rows [0, R) -> out0, rows [R, 2R) -> out1; ws >= 2 * pdf_bn_workspace_floats(C,R) */
+int pdf_colsum_pair(const float* g, int ldg, int C, long R, float* out0, float* out1, int accumulate, float* ws, void* stream);
 /* nn.LayerNorm(eps=1e-6): gcn.py:92-97, self_attn.py:58, inter_attn.py:66-67, intaghand_decoder.py:139-142 */
 int pdf_layernorm_fwd(const float* x, int ldx, int F, long R, const float* gamma, const float* beta, float eps,
                       float* y, int ldy, float* mean, float* rstd, void* stream);
 int pdf_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, int F, long R, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, void* stream);
+/* Fused / paired LayerNorm of the mesh decoder blocks (gcn.py:100-110, self_attn.py:24-33,78-84):
+ *   z = x + dropout_p(add)   (add == NULL: z = x, nothing written to z)
+ *   y = act(LayerNorm(z) * gamma_g + beta_g),  act 0 none / 1 relu,  g = 0 for rows < R_split else 1 (R_split >= R: one set).
+ * Backward: dz = LN-backward(dy * act'(y)) + dz_in (dz_in may be NULL) is the gradient of x; dadd = dropout mask applied to dz
+ * (NULL when there was no add); dgamma / dbeta of both sets are ACCUMULATED (atomics; zero-fill or pre-load them). */
+int pdf_layernorm_fused_fwd(const float* x, int ldx, const float* add, int ldadd, float p, unsigned long long seed,
+                            const unsigned long long* step, int F, long R, long R_split,
+                            const float* gamma0, const float* beta0, const float* gamma1, const float* beta1, float eps, int act,
+                            float* z, int ldz, float* y, int ldy, float* mean, float* rstd, void* stream);
+int pdf_layernorm_fused_bwd(const float* dy, int lddy, const float* y, int ldy, int act, const float* z, int ldz, int F, long R, long R_split,
+                            const float* gamma0, const float* gamma1, const float* mean, const float* rstd,
+                            const float* dz_in, int lddzin, float* dz, int lddz, float* dadd, int lddadd,
+                            float p, unsigned long long seed, const unsigned long long* step,
+                            float* dgamma0, float* dbeta0, float* dgamma1, float* dbeta1, void* stream);
 /* L2Norm.forward (intaghand_encoder.py:318-334) */
 int pdf_l2norm_fwd(const float* x, int ldx, int C, long R, const float* w, float eps, float* y, int ldy, float* norm, void* stream);
 int pdf_l2norm_bwd(const float* dy, int lddy, const float* x, int ldx, int C, long R, const float* w, float eps,
@@ -139,6 +166,9 @@ int pdf_sft_bwd(const float* g, int ldg, const float* fea, int ldf, const float*
 /* nn.Dropout(p) with a stateless (seed, index) mask: the same call is its own backward (gcn.py:96, self_attn.py:51-52).
  * step: optional DEVICE counter mixed into the seed so a replayed hipGraph draws a fresh mask every step. */
 int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long seed, const unsigned long long* step, void* stream);
+/* y = res + dropout(x) (residual tails, self_attn.py:31-33,80-84); backward: d res = dy, dx = pdf_dropout(dy, same seed) */
+int pdf_dropout_add(const float* x, const float* res, float* y, long n, float p, unsigned long long seed,
+                    const unsigned long long* step, void* stream);
 /* resnet.maxpool (resnet.py:206) */
 int pdf_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* arg, void* stream);
 int pdf_maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, void* stream);
@@ -155,11 +185,18 @@ int pdf_cheby2_fwd(const float* x, int ldx, int B, int V, int F, const int* col,
                    float* out, int ldo, void* stream);
 int pdf_cheby2_bwd(const float* d, int ldd, int B, int V, int F, const int* colT, const float* valT, int Wd,
                    float* dx, int lddx, void* stream);
-/* multi-head softmax attention (self_attn.py:63-76, inter_attn.py:82-105); stat [B][H][V][2], dvec [B][H][V] */
-int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld, int B, int V, int H, int dh,
+/* paired: samples [0, B) use Laplacian 0, samples [B, 2B) Laplacian 1 (left / right hand graphs, same ELL width) */
+int pdf_cheby2_fwd_pair(const float* x, int ldx, int B, int V, int F, const int* col0, const float* val0,
+                        const int* col1, const float* val1, int Wd, float* out, int ldo, void* stream);
+int pdf_cheby2_bwd_pair(const float* d, int ldd, int B, int V, int F, const int* colT0, const float* valT0,
+                        const int* colT1, const float* valT1, int Wd, float* dx, int lddx, void* stream);
+/* multi-head softmax attention (self_attn.py:63-76, inter_attn.py:82-105); stat [B][H][V][2], dvec [B][H][V].
+ * Queries of sample b attend to keys / values of sample (b + kv_shift) % B: with both hands stacked along the batch axis,
+ * kv_shift = B/2 is the cross-hand attention, 0 the self attention. */
+int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld, int B, int V, int H, int dh, int kv_shift,
                  float pdrop, unsigned long long seed, const unsigned long long* step, float* out, int ldo, float* stat, void* stream);
 int pdf_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* o, const float* dout, int ldo,
-                 const float* stat, int B, int V, int H, int dh, float pdrop, unsigned long long seed, const unsigned long long* step,
+                 const float* stat, int B, int V, int H, int dh, int kv_shift, float pdrop, unsigned long long seed, const unsigned long long* step,
                  float* dq, float* dk, float* dv, int lddq, float* dvec, void* stream);
 
 /* ---- depth front end (csrc/frontend.hip) ------------------------------------------------------ */

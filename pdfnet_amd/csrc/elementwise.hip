@@ -83,6 +83,21 @@ PDF_API int pdf_dropout(const float* x, float* y, long n, float p, unsigned long
     PDF_LAUNCH_CHECK();
     return 0;
 }
+// y = res + dropout(x): the residual tail of MLP_res_block / SelfAttn (self_attn.py:31-33, 80-84).  Backward: d res = dy,
+// dx = pdf_dropout(dy) with the same seed.
+__global__ void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y, long n, float p,
+                                   unsigned long long seed, const unsigned long long* __restrict__ step) {
+    const float sc = 1.f / (1.f - p);
+    if (step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;
+    GRID_STRIDE(i, n) y[i] = res[i] + ((p <= 0.f || pdf_uniform(seed, (unsigned long long)i) >= p) ? x[i] * sc : 0.f);
+}
+PDF_API int pdf_dropout_add(const float* x, const float* res, float* y, long n, float p, unsigned long long seed,
+                            const unsigned long long* step, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, res, y, n, p, seed, step);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // MaxPool2d(3, stride 2, pad 1) on NHWC (resnet.maxpool, intaghand_encoder.py:716)

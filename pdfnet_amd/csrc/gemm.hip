@@ -24,6 +24,11 @@ struct IGemm {
     int OH, OW, osy, osx, ooy, oox, ldc;
     int ps_cout, ps_kw;
     int act;                                  // 0 none, 1 relu, 2 leaky-relu(0.1)
+    // B layout: 0 = [N][K] rows (element (n, tap, ci) at n*ldb + wt[tap]*Cin + ci);  1 = [K][N] rows (element at
+    // ci*ldb + wt[tap]*btap + n): the backward-data / transposed-conv contractions read the weight in its forward storage
+    int b_kn, btap;
+    // group 1 of a paired launch (blockIdx.y == 1): same shapes, own weight/bias, A and C advanced by gsA / gsC floats
+    const float* B1; const float* bias1; long gsA, gsC;
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
 
@@ -36,7 +41,7 @@ __device__ __forceinline__ void xcd_tile(int bid, int nblk, int ntn, int& tm, in
     tm = lin / ntn;
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST>
+template <int BM, int BN, int WM, int WN, bool FAST, bool KN>
 __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
     constexpr int BK = 16, LD = BK + 1;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -46,6 +51,9 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    const float* __restrict__ Ap = g.A; const float* __restrict__ Bp = g.B; const float* __restrict__ biasp = g.bias;
+    float* __restrict__ Cp = g.C;
+    if (blockIdx.y) { Ap += g.gsA; Cp += g.gsC; Bp = g.B1; biasp = g.bias1; }
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     int tmi, tni;
     xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
@@ -67,12 +75,22 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
             abase[i] = (long)ni * g.H * g.W * g.lda;
         }
     }
-    long bbase[RB]; bool bval[RB];
+    // B staging.  [N][K] storage: thread -> (row n = lrow + 64 i, 4 consecutive k).  [K][N] storage (FAST): thread ->
+    // (k row kb[i], 4 consecutive n) -- the float4 runs along n and is scattered into the same Bs[n][k] image.
+    long bbase[RB]; bool bval[RB]; int kb[RB];
+    const int nq4 = (tid % (BN / 4)) * 4;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        int n = n0 + lrow + i * 64;
-        bval[i] = n < g.N;
-        bbase[i] = (long)n * g.ldb;
+        if (FAST && KN) {
+            kb[i] = (tid + i * 256) / (BN / 4);
+            bval[i] = n0 + nq4 < g.N;
+            bbase[i] = (long)kb[i] * g.ldb + n0 + nq4;
+        } else {
+            int n = n0 + lrow + i * 64;
+            kb[i] = 0;
+            bval[i] = n < g.N;
+            bbase[i] = KN ? (long)n : (long)n * g.ldb;
+        }
     }
 
     f32x16 acc[TM][TN];
@@ -88,34 +106,34 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
     float4 ra[RA], rb[RB];
     // tap state of the NEXT tile to load (tiles are loaded strictly in order): no per-tile division and the
     // tap table (scalar loads that share lgkmcnt with the LDS traffic) is read only when the tap changes
-    int nt_tap = 0, nt_ci = 0, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * g.Cin;
+    int nt_tap = 0, nt_ci = 0, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * (KN ? g.btap : g.Cin);
     auto gload = [&](int kt) {
         if (FAST) {
             const int ci0 = nt_ci + kq;
-            const int wofs = wbase + ci0;
+            const long wofs = KN ? (long)nt_ci * g.ldb + wbase : (long)(wbase + ci0);
             nt_ci += BK;
             const bool tap_done = nt_ci >= g.Cin;
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (g.plain_in) {
-                    if (aval[i]) v = *reinterpret_cast<const float4*>(g.A + abase[i] + kt * BK + kq);
+                    if (aval[i]) v = *reinterpret_cast<const float4*>(Ap + abase[i] + kt * BK + kq);
                 } else {
                     int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
                     if (aval[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                        v = *reinterpret_cast<const float4*>(g.A + abase[i] + ((long)iy * g.W + ix) * g.lda + ci0);
+                        v = *reinterpret_cast<const float4*>(Ap + abase[i] + ((long)iy * g.W + ix) * g.lda + ci0);
                 }
                 ra[i] = v;
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (bval[i]) v = *reinterpret_cast<const float4*>(g.B + bbase[i] + wofs);
+                if (bval[i]) v = *reinterpret_cast<const float4*>(Bp + bbase[i] + wofs);
                 rb[i] = v;
             }
             if (tap_done && nt_tap + 1 < g.T) {
                 ++nt_tap; nt_ci = 0;
-                ddy = g.dy[nt_tap]; ddx = g.dx[nt_tap]; wbase = g.wt[nt_tap] * g.Cin;
+                ddy = g.dy[nt_tap]; ddx = g.dx[nt_tap]; wbase = g.wt[nt_tap] * (KN ? g.btap : g.Cin);
             }
         } else {
             float tmpa[RA][4], tmpb[RB][4];
@@ -126,22 +144,22 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
                 int t = kin ? k / g.Cin : 0;
                 int ci = k - t * g.Cin;
                 const int gdy = g.dy[t], gdx = g.dx[t];
-                int wofs = g.wt[t] * g.Cin + ci;
+                const long wofs = KN ? (long)ci * g.ldb + g.wt[t] * g.btap : (long)(g.wt[t] * g.Cin + ci);
 #pragma unroll
                 for (int i = 0; i < RA; ++i) {
                     float v = 0.f;
                     if (kin && aval[i]) {
-                        if (g.plain_in) v = g.A[abase[i] + k];
+                        if (g.plain_in) v = Ap[abase[i] + k];
                         else {
                             int iy = iy0[i] + gdy, ix = ix0[i] + gdx;
                             if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                                v = g.A[abase[i] + ((long)iy * g.W + ix) * g.lda + ci];
+                                v = Ap[abase[i] + ((long)iy * g.W + ix) * g.lda + ci];
                         }
                     }
                     tmpa[i][j] = v;
                 }
 #pragma unroll
-                for (int i = 0; i < RB; ++i) tmpb[i][j] = (kin && bval[i]) ? g.B[bbase[i] + wofs] : 0.f;
+                for (int i = 0; i < RB; ++i) tmpb[i][j] = (kin && bval[i]) ? Bp[bbase[i] + wofs] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < RA; ++i) ra[i] = make_float4(tmpa[i][0], tmpa[i][1], tmpa[i][2], tmpa[i][3]);
@@ -157,8 +175,13 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            float* p = &Bs[buf][(lrow + i * 64) * LD + kq];
-            p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w;
+            if (FAST && KN) {
+                float* p = &Bs[buf][nq4 * LD + kb[i]];
+                p[0] = rb[i].x; p[LD] = rb[i].y; p[2 * LD] = rb[i].z; p[3 * LD] = rb[i].w;
+            } else {
+                float* p = &Bs[buf][(lrow + i * 64) * LD + kq];
+                p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w;
+            }
         }
     };
 
@@ -202,7 +225,7 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
             padd_y = tap / g.ps_kw;
             padd_x = tap - padd_y * g.ps_kw;
         }
-        const float bv = (g.bias != nullptr && cok) ? g.bias[co] : 0.f;
+        const float bv = (biasp != nullptr && cok) ? biasp[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
                         int oy = qy * g.osy + g.ooy + padd_y, ox = qx * g.osx + g.oox + padd_x;
                         o = (((long)ni * g.OH + oy) * g.OW + ox) * g.ldc + co;
                     }
-                    g.C[o] = v;
+                    Cp[o] = v;
                 }
             }
         }
@@ -238,6 +261,8 @@ struct WGemm {
     int rows_per_split;
     int tap_major;                            // tile order: channel-block major, taps inner (same XCD re-reads the same pixels)
     int beta;                                 // single-split launches write dW directly: dW = beta*dW + acc
+    // group 1 of a paired launch (blockIdx.z == 1): P, Q advanced by gsP / gsQ floats, own slab (or output when one split)
+    long gsP, gsQ; float* slab1;
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
 
@@ -251,6 +276,8 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     __shared__ __attribute__((aligned(16))) float Qs[2][BK * BJ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab;
+    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; }
     const int wm = wave / WN, wn = wave % WN;
     const int NJ = g.T * g.Cq;
     const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
@@ -312,7 +339,7 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
             int m = mb + pr + i * (256 / TPR_P);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < me) {
-                const float* p = g.P + (long)m * g.ldp + i0 + pc;
+                const float* p = Pp + (long)m * g.ldp + i0 + pc;
                 if (FAST) { if (i0 + pc < g.NI) v = *reinterpret_cast<const float4*>(p); }
                 else {
                     if (i0 + pc + 0 < g.NI) v.x = p[0];
@@ -329,7 +356,7 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < me) {
                 if (g.plain_q) {
-                    const float* p = g.Q + (long)m * g.ldq;
+                    const float* p = Qp + (long)m * g.ldq;
                     if (FAST) { if (qok[0]) v = *reinterpret_cast<const float4*>(p + qch[0]); }
                     else {
                         if (qok[0]) v.x = p[qch[0]];
@@ -339,7 +366,7 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
                     }
                 } else {
                     const int qy = q_y[i], qx = q_x[i];
-                    const float* img = g.Q + (long)q_ni[i] * g.H * g.W * g.ldq;
+                    const float* img = Qp + (long)q_ni[i] * g.H * g.W * g.ldq;
                     if (FAST) {
                         int iy = qy * g.sy + g.dy[qt[0]], ix = qx * g.sx + g.dx[qt[0]];
                         if (qok[0] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
@@ -404,7 +431,7 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
         cur ^= 1;
     }
 
-    float* out = g.slab + (long)blockIdx.y * g.NI * g.ldw;
+    float* out = slabp + (long)blockIdx.y * g.NI * g.ldw;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -442,6 +469,8 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     constexpr int BI = 128, BJ = 128, BK = 16, WN = 2, TM = 2, TN = 2;
     __shared__ __attribute__((aligned(16))) float smem[ST * 2 * BK * 128];     // [stage][P|Q][k][128]  (48 KB, ONE array)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab;
+    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; }
     const int wm = wave / WN, wn = wave % WN;
     const int NJ = g.T * g.Cq;
     const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
@@ -488,13 +517,13 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
         for (int i = 0; i < 2; ++i) {
             const int m = mb + pr + i * 8;
             const bool rowok = m < me;
-            const float* srcp = (rowok && pcol_ok) ? g.P + (long)m * g.ldp + i0 + pc : g_zero16;
+            const float* srcp = (rowok && pcol_ok) ? Pp + (long)m * g.ldp + i0 + pc : g_zero16;
             const float* srcq;
-            if (g.plain_q) srcq = (rowok && qcol_ok) ? g.Q + (long)m * g.ldq + qch : g_zero16;
+            if (g.plain_q) srcq = (rowok && qcol_ok) ? Qp + (long)m * g.ldq + qch : g_zero16;
             else {
                 const int iy = q_y[i] * g.sy + tdy, ix = q_x[i] * g.sx + tdx;
                 const bool ok = rowok && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-                srcq = ok ? g.Q + ((long)q_ni[i] * g.H * g.W + (long)iy * g.W + ix) * g.ldq + qch : g_zero16;
+                srcq = ok ? Qp + ((long)q_ni[i] * g.H * g.W + (long)iy * g.W + ix) * g.ldq + qch : g_zero16;
             }
             GLDS16(srcp, sp + i * 8 * 128);
             GLDS16(srcq, sq + i * 8 * 128);
@@ -563,7 +592,7 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
 
-    float* out = g.slab + (long)blockIdx.y * g.NI * g.ldw;
+    float* out = slabp + (long)blockIdx.y * g.NI * g.ldw;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -583,7 +612,9 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     }
 }
 
-__global__ void reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, long n, int splits, int accumulate) {
+// (both reducers: blockIdx.y == 1 is group 1 of a paired launch -- slab advanced by splits*n, own output)
+__global__ void reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, float* __restrict__ out1, long n, int splits, int accumulate) {
+    if (blockIdx.y) { slab += (long)splits * n; out = out1; }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float s = accumulate ? out[i] : 0.f;
         for (int z = 0; z < splits; ++z) s += slab[(long)z * n + i];
@@ -592,8 +623,9 @@ __global__ void reduce_slabs(const float* __restrict__ slab, float* __restrict__
 }
 
 // many splits over a small matrix: 64 elements x 4 split-lanes per block, fixed summation tree (deterministic)
-__global__ __launch_bounds__(256) void reduce_slabs_2d(const float* __restrict__ slab, float* __restrict__ out, long n, int splits, int accumulate) {
+__global__ __launch_bounds__(256) void reduce_slabs_2d(const float* __restrict__ slab, float* __restrict__ out, float* __restrict__ out1, long n, int splits, int accumulate) {
     __shared__ float sm[4][64];
+    if (blockIdx.y) { slab += (long)splits * n; out = out1; }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const long i = blockIdx.x * 64L + tx;
     float s = 0.f;
@@ -669,31 +701,36 @@ __global__ __launch_bounds__(256) void small_k_gemm(const IGemm g) {
     }
 }
 
-static int launch_igemm(IGemm& g, hipStream_t s) {
+template <int BM, int BN, int WM, int WN>
+static void launch_igemm_tile(const IGemm& g, bool fast, dim3 grid, hipStream_t s) {
+    if (fast && g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, s, g);
+    else if (fast) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, s, g);
+    else if (g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, s, g);
+}
+
+// groups == 2: paired launch (see IGemm::B1), blockIdx.y selects the group
+static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
-    const bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
-    if (!fast && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 && (long)g.M * g.N >= (1L << 20)) {
+    bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
+    if (g.b_kn) fast = fast && (g.N % 4 == 0) && (g.btap % 4 == 0);
+    if (groups > 1) fast = fast && aligned16(g.B1) && (g.gsA % 4 == 0);
+    if (!fast && groups == 1 && !g.b_kn && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
+        (long)g.M * g.N >= (1L << 20)) {
         dim3 grid(grid_for((long)g.M * ((min(g.N, 256) + 3) / 4)), cdiv(g.N, 256));
         hipLaunchKernelGGL(small_k_gemm, grid, dim3(256), 0, s, g);
         PDF_LAUNCH_CHECK();
         return 0;
     }
     // tile choice: wide tiles when there are enough of them to fill 256 CUs, else smaller ones
-    long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+    long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;
     // (measured: below ~600 128x128 tiles the 64x64 kernel's 4x block count wins, e.g. ResNet layer2-4)
-    if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600)) {
-        int nb = (int)t128;
-        if (fast) hipLaunchKernelGGL((igemm_nt<128, 128, 2, 2, true>), dim3(nb), dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((igemm_nt<128, 128, 2, 2, false>), dim3(nb), dim3(256), 0, s, g);
-    } else if (g.N <= 64 && (long)cdiv(g.M, 128) >= env_int("PDF_IG_T128", 600)) {
-        int nb = cdiv(g.M, 128) * cdiv(g.N, 64);
-        if (fast) hipLaunchKernelGGL((igemm_nt<128, 64, 4, 1, true>), dim3(nb), dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((igemm_nt<128, 64, 4, 1, false>), dim3(nb), dim3(256), 0, s, g);
-    } else {
-        int nb = cdiv(g.M, 64) * cdiv(g.N, 64);
-        if (fast) hipLaunchKernelGGL((igemm_nt<64, 64, 2, 2, true>), dim3(nb), dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((igemm_nt<64, 64, 2, 2, false>), dim3(nb), dim3(256), 0, s, g);
-    }
+    if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600))
+        launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
+    else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int("PDF_IG_T128", 600))
+        launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s);
+    else
+        launch_igemm_tile<64, 64, 2, 2>(g, fast, dim3(cdiv(g.M, 64) * cdiv(g.N, 64), groups), s);
     PDF_LAUNCH_CHECK();
     return 0;
 }
@@ -709,14 +746,41 @@ static void conv_taps(IGemm& g, int KH, int KW, int pad, int dil) {
 
 // Linear / 1x1: y[M][N] = act(x[M][K] w[N][K]^T + b).  Reference: nn.Linear / 1x1 nn.Conv2d call sites
 // (e.g. model_attn/gcn.py:66, intaghand_encoder.py:48-103 netR_*, :205-219 SFT convs).
-PDF_API int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
-                           int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) {
+static IGemm linear_desc(const float* x, const float* w, const float* bias, float* y,
+                         int M, int N, int K, int ldx, int ldw, int ldy, int act) {
     IGemm g = {};
     g.A = x; g.B = w; g.C = y; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.Cin = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldy;
     g.T = 1; g.plain_in = 1; g.plain_out = 1; g.act = act;
     g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
+    return g;
+}
+PDF_API int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
+                           int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) {
+    IGemm g = linear_desc(x, w, bias, y, M, N, K, ldx, ldw, ldy, act);
     return launch_igemm(g, s);
+}
+// Two same-shaped layers with their own parameters in ONE launch (the left / right hand branches of the mesh decoder,
+// DualGraph.py:83-84, inter_attn.py:66-67): rows [0, M) of x / y belong to (w0, b0), rows [M, 2M) to (w1, b1).
+PDF_API int pdf_linear_fwd_pair(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
+                                int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) {
+    IGemm g = linear_desc(x, w0, b0, y, M, N, K, ldx, ldw, ldy, act);
+    g.B1 = w1; g.bias1 = b1; g.gsA = (long)M * ldx; g.gsC = (long)M * ldy;
+    return launch_igemm(g, s, 2);
+}
+// dx[M][K] = dy[M][N] w[N][K]: the weight is read in its forward [N][K] storage (no transposed copy)
+PDF_API int pdf_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx,
+                                hipStream_t s) {
+    IGemm g = linear_desc(dy, w, nullptr, dx, M, K, N, lddy, ldw, lddx, 0);
+    g.b_kn = 1; g.btap = 0;
+    return launch_igemm(g, s);
+}
+PDF_API int pdf_linear_bwd_data_pair(const float* dy, const float* w0, const float* w1, float* dx, int M, int N, int K,
+                                     int lddy, int ldw, int lddx, hipStream_t s) {
+    IGemm g = linear_desc(dy, w0, nullptr, dx, M, K, N, lddy, ldw, lddx, 0);
+    g.b_kn = 1; g.btap = 0;
+    g.B1 = w1; g.bias1 = nullptr; g.gsA = (long)M * lddy; g.gsC = (long)M * lddx;
+    return launch_igemm(g, s, 2);
 }
 
 // Conv2d forward on NHWC.  w is [Cout][KH][KW][Cin] (the channels_last storage of an OIHW weight).
@@ -735,18 +799,18 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
     return launch_igemm(g, s);
 }
 
-// Conv2d backward-data: dx[N,H,W,Cin] from dy[N,OH,OW,Cout] and wT = [Cin][KH][KW][Cout]
-// (pdf_transpose_atb of the forward weight).  One launch per input-parity class so a stride-s conv
+// Conv2d backward-data: dx[N,H,W,Cin] from dy[N,OH,OW,Cout] and the FORWARD weight w = [Cout][KH][KW][Cin], read as
+// the [K = (tap, co)][N = ci] operand it is.  One launch per input-parity class so a stride-s conv
 // never multiplies zeros.  dx must be zero-filled by the caller when stride > kernel (1x1 s2).
-PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* wT, float* dx,
+PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
                                 int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
                                 int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {
             IGemm g = {};
-            g.A = dy; g.B = wT; g.C = dx; g.bias = nullptr;
-            g.N = Cin; g.Cin = Cout; g.lda = lddy; g.ldb = KH * KW * Cout; g.ldc = lddx;
+            g.A = dy; g.B = w; g.C = dx; g.bias = nullptr;
+            g.N = Cin; g.Cin = Cout; g.lda = lddy; g.ldb = KH * KW * Cin; g.b_kn = 1; g.btap = Cin; g.ldc = lddx;
             g.H = OH; g.W = OW;
             g.QH = (H - py + stride - 1) / stride; g.QW = (W - px + stride - 1) / stride;
             if (g.QH <= 0 || g.QW <= 0) continue;
@@ -777,30 +841,33 @@ PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* wT, float* dx,
     return 0;
 }
 
-static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int accumulate, hipStream_t s) {
+// out1 != nullptr: paired launch (see WGemm::gsP); ws then holds both groups' slabs
+static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int accumulate, hipStream_t s, float* out1 = nullptr) {
     const int NJ = g.T * g.Cq;
     if (g.M <= 0 || g.NI <= 0 || NJ <= 0) return 0;
+    const int groups = out1 ? 2 : 1;
     const bool fast = (g.NI % 4 == 0) && (g.Cq % 4 == 0) && (g.ldp % 4 == 0) && (g.ldq % 4 == 0) &&
-                      aligned16(g.P) && aligned16(g.Q);
+                      aligned16(g.P) && aligned16(g.Q) && (g.gsP % 4 == 0) && (g.gsQ % 4 == 0);
     const bool small = (g.NI <= 64 || NJ <= 64);
     const int BI = small ? 64 : 128, BJ = small ? 64 : 128;
     long tiles = (long)cdiv(g.NI, BI) * cdiv(NJ, BJ);
     // split policy (measured, tools/gemm_bench.py): big gradient matrices want ~1024 blocks; few-tile / huge-M
     // (HBM-bound) ones ~512 longer-running blocks; small M may go down to 128 rows per split to fill the chip
     const int target = env_int("PDF_WG_TARGET", tiles >= 8 ? 1024 : 512);
-    int splits = (int)((target + tiles - 1) / tiles);
+    int splits = (int)((target + tiles * groups - 1) / (tiles * groups));
     int max_by_rows = cdiv(g.M, env_int("PDF_WG_MINROWS", g.M >= 16384 ? 512 : 128));
     if (splits > max_by_rows) splits = max_by_rows;
     long per = (long)g.NI * g.ldw;
-    if ((long)splits * per > ws_floats) splits = (int)(ws_floats / per);
+    if ((long)splits * per * groups > ws_floats) splits = (int)(ws_floats / (per * groups));
     if (splits < 1) splits = 1;
     int rps = cdiv(cdiv(g.M, splits), 16) * 16;
     splits = cdiv(g.M, rps);
     g.rows_per_split = rps;
     g.tap_major = (!g.plain_q && g.T > 1 && g.Cq % BJ == 0 && env_int("PDF_WG_TAPMAJOR", 1)) ? 1 : 0;
     g.slab = splits == 1 ? out : ws;          // one split: no slab round trip, no reduce launch
+    g.slab1 = splits == 1 ? out1 : ws + (long)splits * per;
     g.beta = splits == 1 ? accumulate : 0;
-    dim3 grid((unsigned)tiles, (unsigned)splits);
+    dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     if (small) {
         if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);
@@ -814,9 +881,9 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     PDF_LAUNCH_CHECK();
     if (splits > 1) {
         if (splits >= 16 && per <= (1L << 20))
-            hipLaunchKernelGGL(reduce_slabs_2d, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, ws, out, per, splits, accumulate);
+            hipLaunchKernelGGL(reduce_slabs_2d, dim3((unsigned)((per + 63) / 64), groups), dim3(256), 0, s, ws, out, out1, per, splits, accumulate);
         else
-            hipLaunchKernelGGL(reduce_slabs, dim3(grid_for(per)), dim3(256), 0, s, ws, out, per, splits, accumulate);
+            hipLaunchKernelGGL(reduce_slabs, dim3(grid_for(per), groups), dim3(256), 0, s, ws, out, out1, per, splits, accumulate);
         PDF_LAUNCH_CHECK();
     }
     return 0;
@@ -844,6 +911,17 @@ PDF_API int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, fl
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s);
 }
 
+// paired form of the above: rows [0, M) -> dw0, rows [M, 2M) -> dw1; ws >= 2 * pdf_wgrad_workspace_floats(M, N, K)
+PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* dw0, float* dw1, float* ws, long ws_floats,
+                                       int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) {
+    WGemm g = {};
+    g.P = dy; g.Q = x; g.M = M; g.NI = N; g.Cq = K; g.T = 1; g.ldp = lddy; g.ldq = ldx; g.ldw = K;
+    g.plain_q = 1; g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
+    g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
+    g.gsP = (long)M * lddy; g.gsQ = (long)M * ldx;
+    return launch_wgemm(g, dw0, ws, ws_floats, accumulate, s, dw1);
+}
+
 // dW[Cout][KH][KW][Cin] (+)= sum over output pixels dy[m][co] * x[pos(m,tap)][ci]
 PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
                                   int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
@@ -863,20 +941,19 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
 }
 
 // ConvTranspose2d forward on NHWC: y[n, iy*s - pad + ky, ix*s - pad + kx, co] += x[n,iy,ix,ci] w[ci][co][ky][kx].
-// wP = [Cout][KH][KW][Cin] repack of the weight (pdf_transpose_atb of its [Cin][KH][KW][Cout] storage).
+// w = the weight in its natural [Cin][KH][KW][Cout] storage, read as the [K = (tap, ci)][N = co] operand it is.
 // kernel == stride (p4/p5, intaghand_encoder.py:604-605): ONE plain GEMM + pixel-shuffle epilogue;
 // otherwise (p3: k4 s2 p1, :603) one launch per output-parity class.
-PDF_API int pdf_deconv2d_fwd(const float* x, const float* wP, const float* bias, float* y,
+PDF_API int pdf_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                              int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                              int stride, int pad, int OH, int OW, int ldy, hipStream_t s) {
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (KH == stride && KW == stride && pad == 0) {
         IGemm g = {};
-        g.A = x; g.B = wP; g.C = y; g.bias = bias;
+        g.A = x; g.B = w; g.C = y; g.bias = bias;
         g.M = N * H * W; g.N = KH * KW * Cout; g.K = Cin; g.Cin = Cin; g.lda = ldx; g.ldc = ldy;
-        // B rows: n = (tap, co) -> wP[co][tap][ci]: not a uniform row stride, so B is addressed as
-        // [tap*Cout + co] rows of a [KH*KW][Cout][Cin] repack -- caller passes that layout (see host).
-        g.ldb = Cin;
+        // columns n = (tap, co): w[ci][tap][co] is exactly a [K = ci][N] matrix
+        g.ldb = KH * KW * Cout; g.b_kn = 1; g.btap = 0;
         g.T = 1; g.plain_in = 1; g.plain_out = 0; g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
         g.H = H; g.W = W; g.QH = H; g.QW = W; g.sy = 1; g.sx = 1;
         g.OH = OH; g.OW = OW; g.osy = stride; g.osx = stride; g.ooy = 0; g.oox = 0;
@@ -886,8 +963,8 @@ PDF_API int pdf_deconv2d_fwd(const float* x, const float* wP, const float* bias,
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {
             IGemm g = {};
-            g.A = x; g.B = wP; g.C = y; g.bias = bias;
-            g.N = Cout; g.Cin = Cin; g.lda = ldx; g.ldb = KH * KW * Cin; g.ldc = ldy;
+            g.A = x; g.B = w; g.C = y; g.bias = bias;
+            g.N = Cout; g.Cin = Cin; g.lda = ldx; g.ldb = KH * KW * Cout; g.b_kn = 1; g.btap = Cout; g.ldc = ldy;
             g.H = H; g.W = W;
             g.QH = (OH - py + stride - 1) / stride; g.QW = (OW - px + stride - 1) / stride;
             if (g.QH <= 0 || g.QW <= 0) continue;

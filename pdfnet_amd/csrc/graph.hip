@@ -8,11 +8,15 @@
 
 // out[b][v][2f] = x[b][v][f];  out[b][v][2f+1] = sum_w val[v][w] * x[b][col[v][w]][f]
 // (feature order fin*K + k, k fastest: gcn.py:61-63)
-__global__ void cheby2_fwd_kernel(const float* __restrict__ x, int ldx, int V, int F, const int* __restrict__ col, const float* __restrict__ val, int Wd,
+// samples b >= Bsplit use the second Laplacian (col1/val1): left and right hand graphs in one launch (DualGraph.py:83-84)
+__global__ void cheby2_fwd_kernel(const float* __restrict__ x, int ldx, int V, int F, const int* __restrict__ col0, const float* __restrict__ val0,
+                                  const int* __restrict__ col1, const float* __restrict__ val1, long Bsplit, int Wd,
                                   float* __restrict__ out, int ldo, long total) {
     GRID_STRIDE(i, total) {
         int f = (int)(i % F); long p = i / F;
         int v = (int)(p % V); long b = p / V;
+        const int* __restrict__ col = b < Bsplit ? col0 : col1;
+        const float* __restrict__ val = b < Bsplit ? val0 : val1;
         const float* xb = x + b * V * ldx;
         float acc = 0.f;
         for (int w = 0; w < Wd; ++w) acc += val[v * Wd + w] * xb[(long)col[v * Wd + w] * ldx + f];
@@ -25,16 +29,28 @@ PDF_API int pdf_cheby2_fwd(const float* x, int ldx, int B, int V, int F, const i
                            float* out, int ldo, hipStream_t s) {
     long total = (long)B * V * F;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(cheby2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, ldx, V, F, col, val, Wd, out, ldo, total);
+    hipLaunchKernelGGL(cheby2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, ldx, V, F, col, val, col, val, (long)B, Wd, out, ldo, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// paired: samples [0, B) with (col0, val0), samples [B, 2B) with (col1, val1)
+PDF_API int pdf_cheby2_fwd_pair(const float* x, int ldx, int B, int V, int F, const int* col0, const float* val0,
+                                const int* col1, const float* val1, int Wd, float* out, int ldo, hipStream_t s) {
+    long total = (long)2 * B * V * F;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(cheby2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, ldx, V, F, col0, val0, col1, val1, (long)B, Wd, out, ldo, total);
     PDF_LAUNCH_CHECK();
     return 0;
 }
 // dx[b][v][f] = d[b][v][2f] + sum_w valT[v][w] * d[b][colT[v][w]][2f+1]     (colT/valT = ELL of L^T)
-__global__ void cheby2_bwd_kernel(const float* __restrict__ d, int ldd, int V, int F, const int* __restrict__ colT, const float* __restrict__ valT, int Wd,
+__global__ void cheby2_bwd_kernel(const float* __restrict__ d, int ldd, int V, int F, const int* __restrict__ colT0, const float* __restrict__ valT0,
+                                  const int* __restrict__ colT1, const float* __restrict__ valT1, long Bsplit, int Wd,
                                   float* __restrict__ dx, int lddx, long total) {
     GRID_STRIDE(i, total) {
         int f = (int)(i % F); long p = i / F;
         int v = (int)(p % V); long b = p / V;
+        const int* __restrict__ colT = b < Bsplit ? colT0 : colT1;
+        const float* __restrict__ valT = b < Bsplit ? valT0 : valT1;
         const float* db = d + b * V * ldd;
         float acc = db[(long)v * ldd + 2 * f];
         for (int w = 0; w < Wd; ++w) acc += valT[v * Wd + w] * db[(long)colT[v * Wd + w] * ldd + 2 * f + 1];
@@ -45,7 +61,15 @@ PDF_API int pdf_cheby2_bwd(const float* d, int ldd, int B, int V, int F, const i
                            float* dx, int lddx, hipStream_t s) {
     long total = (long)B * V * F;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(cheby2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, d, ldd, V, F, colT, valT, Wd, dx, lddx, total);
+    hipLaunchKernelGGL(cheby2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, d, ldd, V, F, colT, valT, colT, valT, (long)B, Wd, dx, lddx, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+PDF_API int pdf_cheby2_bwd_pair(const float* d, int ldd, int B, int V, int F, const int* colT0, const float* valT0,
+                                const int* colT1, const float* valT1, int Wd, float* dx, int lddx, hipStream_t s) {
+    long total = (long)2 * B * V * F;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(cheby2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, d, ldd, V, F, colT0, valT0, colT1, valT1, (long)B, Wd, dx, lddx, total);
     PDF_LAUNCH_CHECK();
     return 0;
 }
@@ -54,9 +78,11 @@ PDF_API int pdf_cheby2_bwd(const float* d, int ldd, int B, int V, int F, const i
 // softmax(q k^T / sqrt(dh)) v per (sample, head); heads are contiguous dh-slices of the feature axis
 // (self_attn.py:63-76, inter_attn.py:82-105).  One block per (b, h); one query row per thread.
 // Dropout on the attention matrix (dropout1) uses the stateless mask of common.h.
+// kv_shift: queries of sample b attend to keys / values of sample (b + kv_shift) % B -- with the two hands stacked along
+// the batch axis, kv_shift = B/2 is the cross-hand attention of inter_attn.py:82-105 in one launch.
 template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
-                                                       int V, int H, float inv_norm, float pdrop, unsigned long long seed, const unsigned long long* __restrict__ step,
+                                                       int V, int H, int kv_shift, float inv_norm, float pdrop, unsigned long long seed, const unsigned long long* __restrict__ step,
                                                        float* __restrict__ out, int ldo, float* __restrict__ stat /*[B][H][V][2] = max, sumexp*/) {
     if (step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;
     extern __shared__ float sm[];
@@ -64,10 +90,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     float* sv = sm + V * DH;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const long base = (long)b * V * ld + h * DH;
+    const long kbase = (long)((b + kv_shift) % (int)(gridDim.x / H)) * V * ld + h * DH;
     for (int i = threadIdx.x; i < V * DH; i += 256) {
         int r = i / DH, d = i - r * DH;
-        sk[i] = k[base + (long)r * ld + d];
-        sv[i] = v[base + (long)r * ld + d];
+        sk[i] = k[kbase + (long)r * ld + d];
+        sv[i] = v[kbase + (long)r * ld + d];
     }
     __syncthreads();
     const float keep_scale = 1.f / (1.f - pdrop);
@@ -102,13 +129,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
 }
 
-PDF_API int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld, int B, int V, int H, int dh,
+PDF_API int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld, int B, int V, int H, int dh, int kv_shift,
                          float pdrop, unsigned long long seed, const unsigned long long* step, float* out, int ldo, float* stat, hipStream_t s) {
     size_t smem = (size_t)2 * V * dh * sizeof(float);
     if (smem > 64 * 1024) return PDF_E_BADARG;
     float inv_norm = 1.f / sqrtf((float)dh);
     dim3 grid(B * H);
-#define ATT_CASE(D) case D: hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, V, H, inv_norm, pdrop, seed, step, out, ldo, stat); break;
+#define ATT_CASE(D) case D: hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, V, H, kv_shift, inv_norm, pdrop, seed, step, out, ldo, stat); break;
     switch (dh) { ATT_CASE(4) ATT_CASE(16) ATT_CASE(32) ATT_CASE(64) default: return PDF_E_BADARG; }
 #undef ATT_CASE
     PDF_LAUNCH_CHECK();
@@ -120,7 +147,7 @@ PDF_API int pdf_attn_fwd(const float* q, const float* k, const float* v, int ld,
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
                                                          const float* __restrict__ o, const float* __restrict__ dout, int ldo,
-                                                         const float* __restrict__ stat, int V, int H, float inv_norm, float pdrop, unsigned long long seed, const unsigned long long* __restrict__ step,
+                                                         const float* __restrict__ stat, int V, int H, int kv_shift, float inv_norm, float pdrop, unsigned long long seed, const unsigned long long* __restrict__ step,
                                                          float* __restrict__ dq, int lddq, float* __restrict__ dvec /*[B][H][V] D_i*/) {
     if (step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;
     extern __shared__ float sm[];
@@ -128,10 +155,11 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
     float* sv = sm + V * DH;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const long base = (long)b * V * ld + h * DH;
+    const long kbase = (long)((b + kv_shift) % (int)(gridDim.x / H)) * V * ld + h * DH;
     for (int i = threadIdx.x; i < V * DH; i += 256) {
         int r = i / DH, d = i - r * DH;
-        sk[i] = k[base + (long)r * ld + d];
-        sv[i] = v[base + (long)r * ld + d];
+        sk[i] = k[kbase + (long)r * ld + d];
+        sv[i] = v[kbase + (long)r * ld + d];
     }
     __syncthreads();
     const float keep_scale = 1.f / (1.f - pdrop);
@@ -168,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
                                                           const float* __restrict__ dout, int ldo, const float* __restrict__ stat,
-                                                          const float* __restrict__ dvec, int V, int H, float inv_norm, float pdrop, unsigned long long seed, const unsigned long long* __restrict__ step,
+                                                          const float* __restrict__ dvec, int V, int H, int kv_shift, float inv_norm, float pdrop, unsigned long long seed, const unsigned long long* __restrict__ step,
                                                           float* __restrict__ dk, float* __restrict__ dv, int lddk) {
     if (step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;
     extern __shared__ float sm[];
@@ -176,6 +204,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
     float* sg = sm + V * DH;     // dO
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const long base = (long)b * V * ld + h * DH;
+    const int bkv = (b + kv_shift) % (int)(gridDim.x / H);
+    const long kbase = (long)bkv * V * ld + h * DH;
     for (int i = threadIdx.x; i < V * DH; i += 256) {
         int r = i / DH, d = i - r * DH;
         sq[i] = q[base + (long)r * ld + d];
@@ -187,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
     for (int j = threadIdx.x; j < V; j += 256) {
         float kr[DH], vr[DH], ak[DH], av[DH];
 #pragma unroll
-        for (int d = 0; d < DH; ++d) { kr[d] = k[base + (long)j * ld + d]; vr[d] = v[base + (long)j * ld + d]; ak[d] = 0.f; av[d] = 0.f; }
+        for (int d = 0; d < DH; ++d) { kr[d] = k[kbase + (long)j * ld + d]; vr[d] = v[kbase + (long)j * ld + d]; ak[d] = 0.f; av[d] = 0.f; }
         for (int i = 0; i < V; ++i) {
             float sdot = 0.f, gv = 0.f;
 #pragma unroll
@@ -205,22 +235,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
         }
 #pragma unroll
         for (int d = 0; d < DH; ++d) {
-            dk[(long)b * V * lddk + (long)j * lddk + h * DH + d] = ak[d];
-            dv[(long)b * V * lddk + (long)j * lddk + h * DH + d] = av[d];
+            dk[(long)bkv * V * lddk + (long)j * lddk + h * DH + d] = ak[d];
+            dv[(long)bkv * V * lddk + (long)j * lddk + h * DH + d] = av[d];
         }
     }
 }
 
 PDF_API int pdf_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* o, const float* dout, int ldo,
-                         const float* stat, int B, int V, int H, int dh, float pdrop, unsigned long long seed, const unsigned long long* step,
+                         const float* stat, int B, int V, int H, int dh, int kv_shift, float pdrop, unsigned long long seed, const unsigned long long* step,
                          float* dq, float* dk, float* dv, int lddq, float* dvec, hipStream_t s) {
     size_t smem = (size_t)2 * V * dh * sizeof(float);
     if (smem > 64 * 1024) return PDF_E_BADARG;
     float inv_norm = 1.f / sqrtf((float)dh);
     dim3 grid(B * H);
 #define ATT_CASE(D) case D: \
-        hipLaunchKernelGGL(attn_bwd_q_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, o, dout, ldo, stat, V, H, inv_norm, pdrop, seed, step, dq, lddq, dvec); \
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, dout, ldo, stat, dvec, V, H, inv_norm, pdrop, seed, step, dk, dv, lddq); break;
+        hipLaunchKernelGGL(attn_bwd_q_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, o, dout, ldo, stat, V, H, kv_shift, inv_norm, pdrop, seed, step, dq, lddq, dvec); \
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<D>, grid, dim3(256), smem, s, q, k, v, ld, dout, ldo, stat, dvec, V, H, kv_shift, inv_norm, pdrop, seed, step, dk, dv, lddq); break;
     switch (dh) { ATT_CASE(4) ATT_CASE(16) ATT_CASE(32) ATT_CASE(64) default: return PDF_E_BADARG; }
 #undef ATT_CASE
     PDF_LAUNCH_CHECK();

@@ -178,9 +178,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
     v4_block_reduce(a, b, sa, sb, part, C, c0, true);
 }
 
+// (colsum kernels: blockIdx.z == 1 is group 1 of a paired call -- rows [R, 2R), partials after group 0's)
 __global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __restrict__ g, int ldg, int C, long R, long rows_per_chunk,
                                                                 float* __restrict__ part) {
     __shared__ float4 sa[V4_TY][V4_TX], sb[V4_TY][V4_TX];
+    if (blockIdx.z) { g += R * ldg; part += (long)gridDim.y * C * 2; }
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
     const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
@@ -412,8 +414,10 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
 }
 
 // column sums: out[c] (+)= sum_r g[r][c]   (conv / linear bias gradients), optional relu mask by y
-__global__ __launch_bounds__(FIN_TX * FIN_TY) void colsum_finalize_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ out, int accumulate) {
+__global__ __launch_bounds__(FIN_TX * FIN_TY) void colsum_finalize_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ out,
+                                                                          float* __restrict__ out1, int accumulate) {
     __shared__ double s1[FIN_TY][FIN_TX], s2[FIN_TY][FIN_TX];
+    if (blockIdx.y) { part += (long)chunks * C * 2; out = out1; }
     const int c = blockIdx.x * FIN_TX + threadIdx.x;
     double a, b;
     reduce_chunks(part, chunks, C, c, threadIdx.y, s1, s2, a, b);
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(FIN_TX * FIN_TY) void colsum_finalize_kernel(const 
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, int ldg, int C, long R, long rows_per_chunk, float* __restrict__ part) {
     __shared__ float s1[4][BN_CT];
+    if (blockIdx.z) { g += R * ldg; part += (long)gridDim.y * C * 2; }
     const int tx = threadIdx.x & (BN_CT - 1), ty = threadIdx.x / BN_CT;
     const int c = blockIdx.x * BN_CT + tx;
     const long r0 = blockIdx.y * rows_per_chunk;
@@ -437,38 +442,68 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
-PDF_API int pdf_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s) {
+static int colsum_launch(const float* g, int ldg, int C, long R, float* out, float* out1, int accumulate, float* ws, hipStream_t s) {
     if (R <= 0 || C <= 0) return 0;
+    const unsigned groups = out1 ? 2 : 1;
     long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
-    if (v4_ok(C, {ldg}, {g}))
-        hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, g, ldg, C, R, rpc, ws);
+    if (v4_ok(C, {ldg, (int)((R * ldg) % 4)}, {g}))
+        hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks, groups), dim3(256), 0, s, g, ldg, C, R, rpc, ws);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, g, ldg, C, R, rpc, ws);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks, groups), dim3(256), 0, s, g, ldg, C, R, rpc, ws);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, FIN_TX), groups), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, out, out1, accumulate);
     PDF_LAUNCH_CHECK();
     return 0;
+}
+PDF_API int pdf_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s) {
+    return colsum_launch(g, ldg, C, R, out, nullptr, accumulate, ws, s);
+}
+// paired bias gradients: rows [0, R) -> out0, rows [R, 2R) -> out1; ws >= 2 * pdf_bn_workspace_floats(C, R)
+PDF_API int pdf_colsum_pair(const float* g, int ldg, int C, long R, float* out0, float* out1, int accumulate, float* ws, hipStream_t s) {
+    return colsum_launch(g, ldg, C, R, out0, out1, accumulate, ws, s);
 }
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last axis (F <= 1024), one wave per row (nn.LayerNorm(eps=1e-6) in model_attn/*).
 #define LN_MAXV 16
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, int F, long R, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
+// One kernel family serves the plain op and the decoder's fused forms (gcn.py:100-110, self_attn.py:24-33,78-84):
+//   z = x + dropout(add)      (optional; z is written out because it is also the residual the next block adds)
+//   y = act( LayerNorm(z) * gamma_g + beta_g ),  g = 0 for rows < R_split, 1 otherwise (left / right hand parameters)
+// blockIdx.y = group, so a block's dgamma / dbeta partial sums belong to one parameter set.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ add, int ldadd,
+                                                            float p, unsigned long long seed, const unsigned long long* __restrict__ step,
+                                                            int F, long R, long R_split, const float* __restrict__ gamma0, const float* __restrict__ beta0,
+                                                            const float* __restrict__ gamma1, const float* __restrict__ beta1, float eps, int act,
+                                                            float* __restrict__ z, int ldz, float* __restrict__ y, int ldy,
                                                             float* __restrict__ mean, float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63;
+    const long rb = blockIdx.y ? R_split : 0, re = blockIdx.y ? R : min(R, R_split);
+    const float* __restrict__ gamma = blockIdx.y ? gamma1 : gamma0;
+    const float* __restrict__ beta = blockIdx.y ? beta1 : beta0;
     const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
     const long nw = ((long)gridDim.x * blockDim.x) >> 6;
-    for (long r = w0; r < R; r += nw) {
+    const float sc = 1.f / (1.f - p);
+    if (add != nullptr && p > 0.f && step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;
+    for (long r = rb + w0; r < re; r += nw) {
         float v[LN_MAXV];
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             int c = lane + 64 * i;
-            v[i] = c < F ? x[r * ldx + c] : 0.f;
-            sum += v[i];
+            float t = 0.f;
+            if (c < F) {
+                t = x[r * ldx + c];
+                if (add != nullptr) {
+                    float a = add[r * ldadd + c];
+                    if (p > 0.f) a = pdf_uniform(seed, (unsigned long long)(r * F + c)) >= p ? a * sc : 0.f;
+                    t += a;
+                    z[r * ldz + c] = t;
+                }
+            }
+            v[i] = t;
+            sum += t;
         }
         const float mu = wave_sum(sum) / (float)F;
         float sq = 0.f;
@@ -482,36 +517,68 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             int c = lane + 64 * i;
-            if (c < F) y[r * ldy + c] = (v[i] - mu) * rs * gamma[c] + beta[c];
+            if (c < F) {
+                float o = (v[i] - mu) * rs * gamma[c] + beta[c];
+                if (act == 1) o = fmaxf(o, 0.f);
+                y[r * ldy + c] = o;
+            }
         }
         if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
     }
 }
 
-PDF_API int pdf_layernorm_fwd(const float* x, int ldx, int F, long R, const float* gamma, const float* beta, float eps,
-                              float* y, int ldy, float* mean, float* rstd, hipStream_t s) {
-    if (F > 64 * LN_MAXV) return PDF_E_BADARG;
+static int ln_fwd_launch(const float* x, int ldx, const float* add, int ldadd, float p, unsigned long long seed, const unsigned long long* step,
+                         int F, long R, long R_split, const float* g0, const float* b0, const float* g1, const float* b1, float eps, int act,
+                         float* z, int ldz, float* y, int ldy, float* mean, float* rstd, hipStream_t s) {
+    if (F > 64 * LN_MAXV || (add != nullptr && z == nullptr)) return PDF_E_BADARG;
     if (R <= 0) return 0;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(R * 64)), dim3(256), 0, s, x, ldx, F, R, gamma, beta, eps, y, ldy, mean, rstd);
+    const unsigned groups = R_split < R ? 2 : 1;
+    const long rows = groups == 2 ? max(R_split, R - R_split) : R;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(rows * 64), groups), dim3(256), 0, s, x, ldx, add, ldadd, p, seed, step, F, R, R_split,
+                       g0, b0, g1, b1, eps, act, z, ldz, y, ldy, mean, rstd);
     PDF_LAUNCH_CHECK();
     return 0;
 }
+PDF_API int pdf_layernorm_fwd(const float* x, int ldx, int F, long R, const float* gamma, const float* beta, float eps,
+                              float* y, int ldy, float* mean, float* rstd, hipStream_t s) {
+    return ln_fwd_launch(x, ldx, nullptr, 0, 0.f, 0, nullptr, F, R, R, gamma, beta, gamma, beta, eps, 0, nullptr, 0, y, ldy, mean, rstd, s);
+}
+// fused / paired form, see the kernel comment.  add == NULL: plain LayerNorm input (z unused).  R_split >= R: one parameter set.
+PDF_API int pdf_layernorm_fused_fwd(const float* x, int ldx, const float* add, int ldadd, float p, unsigned long long seed,
+                                    const unsigned long long* step, int F, long R, long R_split,
+                                    const float* gamma0, const float* beta0, const float* gamma1, const float* beta1, float eps, int act,
+                                    float* z, int ldz, float* y, int ldy, float* mean, float* rstd, hipStream_t s) {
+    return ln_fwd_launch(x, ldx, add, ldadd, p, seed, step, F, R, R_split, gamma0, beta0, gamma1, beta1, eps, act, z, ldz, y, ldy, mean, rstd, s);
+}
 
-// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma; dgamma += sum dy*xhat; dbeta += sum dy
+// dz = rstd * (g - mean(g) - xhat * mean(g*xhat)) [+ dz_in], g = dy * act'(y) * gamma; dgamma += sum dy' * xhat; dbeta += sum dy'
+// dadd = dropout-mask(dz) (the gradient of the dropped operand); dz itself is the gradient of x (the residual operand).
 // (dgamma/dbeta accumulated with one atomic per channel per block; caller zero-fills or accumulates)
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx, int F, long R,
-                                                            const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ dx, int lddx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int act,
+                                                            const float* __restrict__ zin, int ldz, int F, long R, long R_split,
+                                                            const float* __restrict__ gamma0, const float* __restrict__ gamma1,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ dz_in, int lddzin, float* __restrict__ dz, int lddz,
+                                                            float* __restrict__ dadd, int lddadd, float p, unsigned long long seed,
+                                                            const unsigned long long* __restrict__ step,
+                                                            float* __restrict__ dgamma0, float* __restrict__ dbeta0,
+                                                            float* __restrict__ dgamma1, float* __restrict__ dbeta1) {
     __shared__ float sg[64 * LN_MAXV], sb[64 * LN_MAXV];
     for (int i = threadIdx.x; i < F; i += 256) { sg[i] = 0.f; sb[i] = 0.f; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    const long rb = blockIdx.y ? R_split : 0, re = blockIdx.y ? R : min(R, R_split);
+    const float* __restrict__ gamma = blockIdx.y ? gamma1 : gamma0;
+    float* __restrict__ dgamma = blockIdx.y ? dgamma1 : dgamma0;
+    float* __restrict__ dbeta = blockIdx.y ? dbeta1 : dbeta0;
     const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
     const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    const float sc = 1.f / (1.f - p);
+    if (dadd != nullptr && p > 0.f && step != nullptr) seed += step[0] * 0x9E3779B97F4A7C15ull;
     float ag[LN_MAXV], ab[LN_MAXV];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
-    for (long r = w0; r < R; r += nw) {
+    for (long r = rb + w0; r < re; r += nw) {
         const float mu = mean[r], rs = rstd[r];
         float g[LN_MAXV], xh[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
@@ -521,7 +588,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             float d = 0.f, h = 0.f;
             if (c < F) {
                 d = dy[r * lddy + c];
-                h = (x[r * ldx + c] - mu) * rs;
+                if (act == 1 && !(y[r * ldy + c] > 0.f)) d = 0.f;
+                h = (zin[r * ldz + c] - mu) * rs;
                 ag[i] += d * h; ab[i] += d;
                 d *= gamma[c];
             }
@@ -533,7 +601,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             int c = lane + 64 * i;
-            if (c < F) dx[r * lddx + c] = rs * (g[i] - s1 - xh[i] * s2);
+            if (c < F) {
+                float o = rs * (g[i] - s1 - xh[i] * s2);
+                if (dz_in != nullptr) o += dz_in[r * lddzin + c];
+                dz[r * lddz + c] = o;
+                if (dadd != nullptr) {
+                    if (p > 0.f) o = pdf_uniform(seed, (unsigned long long)(r * F + c)) >= p ? o * sc : 0.f;
+                    dadd[r * lddadd + c] = o;
+                }
+            }
         }
     }
 #pragma unroll
@@ -548,14 +624,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-PDF_API int pdf_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, int F, long R, const float* gamma,
-                              const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, hipStream_t s) {
-    if (F > 64 * LN_MAXV) return PDF_E_BADARG;
+static int ln_bwd_launch(const float* dy, int lddy, const float* y, int ldy, int act, const float* z, int ldz, int F, long R, long R_split,
+                         const float* g0, const float* g1, const float* mean, const float* rstd, const float* dz_in, int lddzin,
+                         float* dz, int lddz, float* dadd, int lddadd, float p, unsigned long long seed, const unsigned long long* step,
+                         float* dg0, float* db0, float* dg1, float* db1, hipStream_t s) {
+    if (F > 64 * LN_MAXV || (act == 1 && y == nullptr)) return PDF_E_BADARG;
     if (R <= 0) return 0;
-    int grid = grid_for(R * 64, 256, 512);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, s, dy, lddy, x, ldx, F, R, gamma, mean, rstd, dx, lddx, dgamma, dbeta);
+    const unsigned groups = R_split < R ? 2 : 1;
+    const long rows = groups == 2 ? max(R_split, R - R_split) : R;
+    int grid = grid_for(rows * 64, 256, 512);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid, groups), dim3(256), 0, s, dy, lddy, y, ldy, act, z, ldz, F, R, R_split, g0, g1, mean, rstd,
+                       dz_in, lddzin, dz, lddz, dadd, lddadd, p, seed, step, dg0, db0, dg1, db1);
     PDF_LAUNCH_CHECK();
     return 0;
+}
+PDF_API int pdf_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, int F, long R, const float* gamma,
+                              const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, hipStream_t s) {
+    return ln_bwd_launch(dy, lddy, nullptr, 0, 0, x, ldx, F, R, R, gamma, gamma, mean, rstd, nullptr, 0, dx, lddx, nullptr, 0, 0.f, 0, nullptr,
+                         dgamma, dbeta, dgamma, dbeta, s);
+}
+PDF_API int pdf_layernorm_fused_bwd(const float* dy, int lddy, const float* y, int ldy, int act, const float* z, int ldz, int F, long R, long R_split,
+                                    const float* gamma0, const float* gamma1, const float* mean, const float* rstd,
+                                    const float* dz_in, int lddzin, float* dz, int lddz, float* dadd, int lddadd,
+                                    float p, unsigned long long seed, const unsigned long long* step,
+                                    float* dgamma0, float* dbeta0, float* dgamma1, float* dbeta1, hipStream_t s) {
+    return ln_bwd_launch(dy, lddy, y, ldy, act, z, ldz, F, R, R_split, gamma0, gamma1, mean, rstd, dz_in, lddzin, dz, lddz, dadd, lddadd, p, seed, step,
+                         dgamma0, dbeta0, dgamma1, dbeta1, s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -257,13 +257,11 @@ class _Conv2d(Function):
         dx = dw = db = None
         L = _L()
         if ctx.needs_input_grad[0]:
-            wT = torch.empty(Cin * KH * KW * Cout, dtype=torch.float32, device=x.device)
-            L.pdf_transpose_atb(ptr(w), ptr(wT), Cout, KH * KW, Cin, stream())
             if stride > KH:
                 dx = torch.zeros_like(x)
             else:
                 dx = torch.empty_like(x)
-            L.pdf_conv2d_bwd_data(ptr(g), ptr(wT), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+            L.pdf_conv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
         w_par, b_par = ctx.params
         R = N * OH * OW
 
@@ -292,13 +290,8 @@ class _Deconv2d(Function):
         OH = (H - 1) * stride - 2 * pad + KH
         OW = (W - 1) * stride - 2 * pad + KW
         L = _L()
-        wP = torch.empty(w.numel(), dtype=torch.float32, device=x.device)
-        if KH == stride and KW == stride and pad == 0:
-            L.pdf_transpose_atb(ptr(w), ptr(wP), Cin, 1, KH * KW * Cout, stream())
-        else:
-            L.pdf_transpose_atb(ptr(w), ptr(wP), Cin, KH * KW, Cout, stream())
         y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
-        L.pdf_deconv2d_fwd(ptr(x), ptr(wP), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+        L.pdf_deconv2d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, b is not None)
         ctx.params = (w_in, b)
@@ -362,10 +355,8 @@ class _Linear(Function):
         L = _L()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wT = torch.empty(K * Nn, dtype=torch.float32, device=x.device)
-            L.pdf_transpose_atb(ptr(w), ptr(wT), Nn, 1, K, stream())
             dx = torch.empty_like(x)
-            L.pdf_linear_fwd(ptr(g), ptr(wT), None, ptr(dx), M, K, Nn, Nn, Nn, K, 0, stream())
+            L.pdf_linear_bwd_data(ptr(g), ptr(w), ptr(dx), M, Nn, K, Nn, K, K, stream())
         w_par, b_par = ctx.params
 
         def launch_w(out, acc):
@@ -377,6 +368,77 @@ class _Linear(Function):
 
 def linear(x, w, b=None, act=ACT_NONE):
     return _Linear.apply(x, w, b, act)
+
+
+class _LinearPair(Function):
+    """Two same-shaped Linear layers in one launch: x [2, ..., K]; half 0 goes through (w0, b0), half 1 through (w1, b1).
+    The mesh decoder's left / right hand branches (DualGraph.py:83-84, inter_attn.py:66-67)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, act):
+        hip.require_gpu(x, w0, w1)
+        if x.shape[0] != 2 or w0.shape != w1.shape or (b0 is None) != (b1 is None):
+            raise ValueError("pdfnet_amd: linear_pair wants x [2, ..., K] and two equal-shaped layers")
+        w0_in, w1_in = w0, w1
+        x, w0, w1 = x.contiguous(), w0.contiguous(), w1.contiguous()
+        K = x.shape[-1]
+        M = x.numel() // K // 2
+        Nn = w0.shape[0]
+        y = torch.empty(x.shape[:-1] + (Nn,), dtype=torch.float32, device=x.device)
+        _L().pdf_linear_fwd_pair(ptr(x), ptr(w0), ptr(w1), ptr(b0), ptr(b1), ptr(y), M, Nn, K, K, K, Nn, act, stream())
+        ctx.save_for_backward(x, w0, w1, y if act else None)
+        ctx.cfg = (act, b0 is not None)
+        ctx.params = (w0_in, b0, w1_in, b1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w0, w1, y = ctx.saved_tensors
+        act, has_b = ctx.cfg
+        K = x.shape[-1]
+        M = x.numel() // K // 2
+        Nn = w0.shape[0]
+        g = dy.contiguous()
+        if act:
+            g = _act_bwd(g, y, act)
+        L = _L()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.pdf_linear_bwd_data_pair(ptr(g), ptr(w0), ptr(w1), ptr(dx), M, Nn, K, Nn, K, K, stream())
+        w0_par, b0_par, w1_par, b1_par = ctx.params
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        need_b = has_b and (ctx.needs_input_grad[2] or ctx.needs_input_grad[4])
+        mg_w0, mg_w1 = (_main_grad(w0_par, w0), _main_grad(w1_par, w1)) if need_w else (None, None)
+        mg_b0, mg_b1 = (_main_grad(b0_par, b0_par), _main_grad(b1_par, b1_par)) if need_b else (None, None)
+        direct_w = mg_w0 is not None and mg_w1 is not None
+        direct_b = mg_b0 is not None and mg_b1 is not None
+
+        def launch_w(o0, o1, acc):
+            n = 2 * L.pdf_wgrad_workspace_floats(M, Nn, K)
+            L.pdf_linear_bwd_weight_pair(ptr(x), ptr(g), ptr(o0), ptr(o1), ptr(_ws(n, x.device)), n, M, Nn, K, K, Nn, acc, stream())
+
+        def launch_b(o0, o1, acc):
+            ws = _ws(2 * L.pdf_bn_workspace_floats(Nn, M), x.device)
+            L.pdf_colsum_pair(ptr(g), Nn, Nn, M, ptr(o0), ptr(o1), acc, ptr(ws), stream())
+        dw0 = dw1 = db0 = db1 = None
+        if (need_w and direct_w) or (need_b and direct_b):
+            with wgrad_stream(True, x, g):
+                if need_w and direct_w:
+                    launch_w(mg_w0, mg_w1, 1)
+                if need_b and direct_b:
+                    launch_b(mg_b0, mg_b1, 1)
+        if need_w and not direct_w:
+            dw0, dw1 = torch.empty_like(w0), torch.empty_like(w1)
+            launch_w(dw0, dw1, 0)
+        if need_b and not direct_b:
+            db0, db1 = torch.empty(Nn, device=x.device), torch.empty(Nn, device=x.device)
+            launch_b(db0, db1, 0)
+        return dx, dw0, db0, dw1, db1, None
+
+
+def linear_pair(x, w0, b0, w1, b1, act=ACT_NONE):
+    return _LinearPair.apply(x, w0, b0, w1, b1, act)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -538,7 +600,7 @@ class _LayerNorm(Function):
     def forward(ctx, x, gamma, beta, eps):
         hip.require_gpu(x)
         x = x.contiguous()
-        R, Fd = _rows(x)
+        R, Fd = x.numel() // x.shape[-1], x.shape[-1]
         y = torch.empty_like(x)
         mean = torch.empty(R, device=x.device)
         rstd = torch.empty(R, device=x.device)
@@ -550,7 +612,7 @@ class _LayerNorm(Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
-        R, Fd = _rows(x)
+        R, Fd = x.numel() // x.shape[-1], x.shape[-1]
         dx = torch.empty_like(x)
         g_par, b_par = ctx.params
         mg_g, mg_b = _main_grad(g_par, g_par), _main_grad(b_par, b_par)
@@ -567,9 +629,76 @@ def layer_norm(x, gamma, beta, eps=1e-6):
     return _LayerNorm.apply(x, gamma, beta, eps)
 
 
+class _LayerNormFused(Function):
+    """z = x + dropout_p(add) (optional);  y = act(LayerNorm(z) * gamma_g + beta_g), g = first / second half of the rows when a
+    second parameter set is given (x stacked [2, ...]).  Returns y, or (z, y) when `add` is given (z is the residual stream
+    the caller keeps using)."""
+
+    @staticmethod
+    def forward(ctx, x, add, g0, b0, g1, b1, eps, act, p, seed):
+        hip.require_gpu(x)
+        x = x.contiguous()
+        R, Fd = x.numel() // x.shape[-1], x.shape[-1]
+        pair = g1 is not None
+        if pair and (x.shape[0] != 2):
+            raise ValueError("pdfnet_amd: paired layer_norm wants x stacked [2, ...]")
+        split = R // 2 if pair else R
+        y = torch.empty_like(x)
+        mean = torch.empty(R, device=x.device)
+        rstd = torch.empty(R, device=x.device)
+        z = None
+        if add is not None:
+            add = add.contiguous()
+            z = torch.empty_like(x)
+        _L().pdf_layernorm_fused_fwd(ptr(x), Fd, ptr(add), Fd, p, seed, ptr(step_counter(x.device)), Fd, R, split,
+                                     ptr(g0), ptr(b0), ptr(g1 if pair else g0), ptr(b1 if pair else b0), eps, act,
+                                     ptr(z), Fd, ptr(y), Fd, ptr(mean), ptr(rstd), stream())
+        ctx.save_for_backward(x if z is None else z, g0, g1, mean, rstd, y if act else None)
+        ctx.cfg = (act, p, seed, add is not None, pair)
+        ctx.params = (g0, b0, g1, b1)
+        ctx.set_materialize_grads(False)
+        if z is None:
+            return y
+        return z, y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        zin, g0, g1, mean, rstd, y = ctx.saved_tensors
+        act, p, seed, has_add, pair = ctx.cfg
+        dz_in, dy = grads if has_add else (None, grads[0])
+        R, Fd = zin.numel() // zin.shape[-1], zin.shape[-1]
+        split = R // 2 if pair else R
+        if dy is None:                                       # only the residual stream was used downstream
+            if dz_in is None:
+                return (None,) * 10
+            dadd = _Dropout.apply(dz_in, p, seed, True) if p > 0 else dz_in
+            return dz_in, dadd, None, None, None, None, None, None, None, None
+        pars = ctx.params
+        mgs = [_main_grad(t, t) if t is not None else None for t in pars]
+        need = [t is not None for t in pars]
+        direct = all(m is not None for m, n in zip(mgs, need) if n)
+        outs = [m if direct else (torch.zeros_like(t) if t is not None else None) for m, t in zip(mgs, pars)]
+        dz = torch.empty_like(zin)
+        dadd = torch.empty_like(zin) if has_add else None
+        d0, e0 = outs[0], outs[1]
+        d1, e1 = (outs[2], outs[3]) if pair else (d0, e0)
+        _L().pdf_layernorm_fused_bwd(ptr(dy.contiguous()), Fd, ptr(y), Fd, act, ptr(zin), Fd, Fd, R, split, ptr(g0), ptr(g1 if pair else g0),
+                                     ptr(mean), ptr(rstd), ptr(dz_in.contiguous() if dz_in is not None else None), Fd, ptr(dz), Fd,
+                                     ptr(dadd), Fd, p, seed, ptr(step_counter(zin.device)), ptr(d0), ptr(e0), ptr(d1), ptr(e1), stream())
+        if direct:
+            outs = [None] * 4
+        return dz, dadd, outs[0], outs[1], outs[2], outs[3], None, None, None, None
+
+
+def layer_norm_fused(x, gamma, beta, eps=1e-6, act=ACT_NONE, add=None, p=0.0, training=False, gamma1=None, beta1=None):
+    """See _LayerNormFused.  `add` is the operand that goes through dropout(p) before the sum."""
+    p = float(p) if (training and add is not None) else 0.0
+    return _LayerNormFused.apply(x, add, gamma, beta, gamma1, beta1, eps, act, p, next_seed() if p > 0 else 0)
+
+
 class _Dropout(Function):
     @staticmethod
-    def forward(ctx, x, p, seed):
+    def forward(ctx, x, p, seed, _unused=None):
         x = x.contiguous()
         y = torch.empty_like(x)
         _L().pdf_dropout(ptr(x), ptr(y), x.numel(), p, seed, ptr(step_counter(x.device)), stream())
@@ -582,7 +711,35 @@ class _Dropout(Function):
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
         _L().pdf_dropout(ptr(dy), ptr(dx), dy.numel(), p, seed, ptr(step_counter(dy.device)), stream())
-        return dx, None, None
+        return dx, None, None, None
+
+
+class _DropoutAdd(Function):
+    """res + dropout(x)."""
+
+    @staticmethod
+    def forward(ctx, x, res, p, seed):
+        x, res = x.contiguous(), res.contiguous()
+        y = torch.empty_like(x)
+        _L().pdf_dropout_add(ptr(x), ptr(res), ptr(y), x.numel(), p, seed, ptr(step_counter(x.device)), stream())
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        dx = dy
+        if p > 0 and ctx.needs_input_grad[0]:
+            dy = dy.contiguous()
+            dx = torch.empty_like(dy)
+            _L().pdf_dropout(ptr(dy), ptr(dx), dy.numel(), p, seed, ptr(step_counter(dy.device)), stream())
+        return dx, dy, None, None
+
+
+def dropout_add(x, res, p, training):
+    """res + dropout(x, p)."""
+    p = float(p) if training else 0.0
+    return _DropoutAdd.apply(x, res, p, next_seed() if p > 0 else 0)
 
 
 _seed_state = [0x5DEECE66D]
@@ -811,37 +968,71 @@ def cheby2(x, ell):
     return _Cheby2.apply(x, *ell)
 
 
+class _Cheby2Pair(Function):
+    """x [2,B,V,F] -> [2,B,V,2F]; half 0 with Laplacian ell0, half 1 with ell1 (same ELL width)."""
+
+    @staticmethod
+    def forward(ctx, x, col0, val0, colT0, valT0, col1, val1, colT1, valT1):
+        hip.require_gpu(x)
+        x = x.contiguous()
+        _, B, V, Fd = x.shape
+        if col0.shape != col1.shape or colT0.shape != colT1.shape:
+            raise ValueError("pdfnet_amd: cheby2_pair wants both Laplacians padded to the same ELL width")
+        out = torch.empty((2, B, V, 2 * Fd), device=x.device)
+        _L().pdf_cheby2_fwd_pair(ptr(x), Fd, B, V, Fd, ptr(col0), ptr(val0), ptr(col1), ptr(val1), col0.shape[1], ptr(out), 2 * Fd, stream())
+        ctx.save_for_backward(colT0, valT0, colT1, valT1)
+        ctx.cfg = (B, V, Fd)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        colT0, valT0, colT1, valT1 = ctx.saved_tensors
+        B, V, Fd = ctx.cfg
+        dx = torch.empty((2, B, V, Fd), device=d.device)
+        _L().pdf_cheby2_bwd_pair(ptr(d.contiguous()), 2 * Fd, B, V, Fd, ptr(colT0), ptr(valT0), ptr(colT1), ptr(valT1), colT0.shape[1],
+                                 ptr(dx), Fd, stream())
+        return (dx,) + (None,) * 8
+
+
+def cheby2_pair(x, ell0, ell1):
+    return _Cheby2Pair.apply(x, *ell0, *ell1)
+
+
 class _Attention(Function):
     """softmax(q k^T / sqrt(dh)) v, heads = contiguous dh slices of the last axis; q,k,v [B,V,F]."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, pdrop, seed):
+    def forward(ctx, q, k, v, heads, pdrop, seed, kv_shift):
         hip.require_gpu(q, k, v)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, V, Fd = q.shape
         dh = Fd // heads
         out = torch.empty_like(q)
         stat = torch.empty((B, heads, V, 2), device=q.device)
-        _L().pdf_attn_fwd(ptr(q), ptr(k), ptr(v), Fd, B, V, heads, dh, pdrop, seed, ptr(step_counter(q.device)), ptr(out), Fd, ptr(stat), stream())
+        _L().pdf_attn_fwd(ptr(q), ptr(k), ptr(v), Fd, B, V, heads, dh, kv_shift, pdrop, seed, ptr(step_counter(q.device)), ptr(out), Fd, ptr(stat), stream())
         ctx.save_for_backward(q, k, v, out, stat)
-        ctx.cfg = (heads, pdrop, seed)
+        ctx.cfg = (heads, pdrop, seed, kv_shift)
         return out
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, out, stat = ctx.saved_tensors
-        heads, pdrop, seed = ctx.cfg
+        heads, pdrop, seed, kv_shift = ctx.cfg
         B, V, Fd = q.shape
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         dvec = torch.empty((B, heads, V), device=q.device)
         _L().pdf_attn_bwd(ptr(q), ptr(k), ptr(v), Fd, ptr(out), ptr(do.contiguous()), Fd, ptr(stat), B, V, heads, Fd // heads,
-                          pdrop, seed, ptr(step_counter(q.device)), ptr(dq), ptr(dk), ptr(dv), Fd, ptr(dvec), stream())
-        return dq, dk, dv, None, None, None
+                          kv_shift, pdrop, seed, ptr(step_counter(q.device)), ptr(dq), ptr(dk), ptr(dv), Fd, ptr(dvec), stream())
+        return dq, dk, dv, None, None, None, None
 
 
-def attention(q, k, v, heads, pdrop=0.0, training=False):
+def attention(q, k, v, heads, pdrop=0.0, training=False, kv_shift=0):
+    """kv_shift: queries of sample b attend to keys / values of sample (b + kv_shift) % B (q, k, v flattened to [B, V, F])."""
     p = float(pdrop) if training else 0.0
-    return _Attention.apply(q, k, v, heads, p, next_seed() if p > 0 else 0)
+    shp = q.shape
+    if q.dim() > 3:
+        q, k, v = (t.reshape(-1, shp[-2], shp[-1]) for t in (q, k, v))
+    return _Attention.apply(q, k, v, heads, p, next_seed() if p > 0 else 0, int(kv_shift)).reshape(shp)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -49,6 +49,14 @@ def load_graph_constants():
         out['ell_' + hand] = ells
         out['perm_' + hand] = torch.from_numpy(z['graph_perm_' + hand])
         out['perm_rev_' + hand] = torch.from_numpy(z['graph_perm_reverse_' + hand][:778])
+    for i in range(3):                                                  # paired launches want one ELL width per level
+        l, r = out['ell_left'][i], out['ell_right'][i]
+        padded = [[], []]
+        for a, b in zip(l, r):
+            w = max(a.shape[1], b.shape[1])
+            for k, t in enumerate((a, b)):
+                padded[k].append(torch.nn.functional.pad(t, (0, w - t.shape[1])))
+        out['ell_left'][i], out['ell_right'][i] = tuple(padded[0]), tuple(padded[1])
     return out
 
 
@@ -89,12 +97,28 @@ class GCN_ResBlock(nn.Module):
         self.norm3 = LayerNorm(cout)
         self.p = drop
 
-    def forward(self, x):
-        ell = (self.ell_col, self.ell_val, self.ell_colT, self.ell_valT)
-        y = self.fc1(F.cheby2(x, ell))
-        y = self.fc2(F.cheby2(F.relu(self.norm2(y)), ell))
-        y = F.dropout(y, self.p, self.training)
-        return self.norm3(y + self.shortcut(x))
+    @property
+    def ell(self):
+        return (self.ell_col, self.ell_val, self.ell_colT, self.ell_valT)
+
+
+def _lin2(l, r, x, act=F.ACT_NONE):
+    return F.linear_pair(x, l.weight, l.bias, r.weight, r.bias, act)
+
+
+def _ln2(l, r, x, act=F.ACT_NONE, add=None, p=0.0, training=False):
+    return F.layer_norm_fused(x, l.weight, l.bias, l.eps, act, add, p, training, r.weight, r.bias)
+
+
+def gcn_block_pair(bl, br, x, relu_out):
+    """Both hands' GCN_ResBlock (gcn.py:99-110) on x [2,B,V,C]: 7 launches --
+    cheby, fc1 | LN2+ReLU | cheby, fc2 | shortcut | dropout + add + LN3 [+ the ReLU GraphLayer puts between blocks]."""
+    y = _lin2(bl.fc1, br.fc1, F.cheby2_pair(x, bl.ell, br.ell))
+    h = _ln2(bl.norm2, br.norm2, y, F.ACT_RELU)
+    y = _lin2(bl.fc2, br.fc2, F.cheby2_pair(h, bl.ell, br.ell))
+    s = _lin2(bl.shortcut, br.shortcut, x)
+    _, out = _ln2(bl.norm3, br.norm3, s, F.ACT_RELU if relu_out else F.ACT_NONE, add=y, p=bl.p, training=bl.training)
+    return out
 
 
 class GraphLayer(nn.Module):
@@ -102,14 +126,6 @@ class GraphLayer(nn.Module):
         super().__init__()
         self.GCN_blocks = nn.ModuleList([GCN_ResBlock(cin if i == 0 else cout, cout, ell, drop) for i in range(n)])
         xavier_(self)
-
-    def forward(self, x):
-        last = len(self.GCN_blocks) - 1
-        for i, blk in enumerate(self.GCN_blocks):
-            x = blk(x)
-            if i != last:
-                x = F.relu(x)
-        return x
 
 
 class MLP_res_block(nn.Module):
@@ -121,9 +137,13 @@ class MLP_res_block(nn.Module):
         self.fc1, self.fc2 = Linear(d, hid), Linear(hid, d)
         self.p = drop
 
-    def forward(self, x):
-        h = F.dropout(self.fc1(self.layer_norm(x), F.ACT_RELU), self.p, self.training)
-        return x + F.dropout(self.fc2(h), self.p, self.training)
+
+def attn_tail_pair(fl, fr, x, o, p, training):
+    """x + dropout(o), then both hands' MLP_res_block (self_attn.py:24-33) on the sum: the residual sum and the block's
+    LayerNorm are one kernel, its closing dropout + residual another."""
+    z, hn = _ln2(fl.layer_norm, fr.layer_norm, x, add=o, p=p, training=training)
+    h = F.dropout(_lin2(fl.fc1, fr.fc1, hn, F.ACT_RELU), fl.p, training)
+    return F.dropout_add(_lin2(fl.fc2, fr.fc2, h), z, fl.p, training)
 
 
 class SelfAttn(nn.Module):
@@ -137,10 +157,14 @@ class SelfAttn(nn.Module):
         self.fc = Linear(d, d)
         self.ff = MLP_res_block(d, d, drop)
 
-    def forward(self, x):
-        h = self.layer_norm(x)
-        a = F.attention(self.w_qs(h), self.w_ks(h), self.w_vs(h), self.n_heads, self.p, self.training)
-        return self.ff(x + F.dropout(self.fc(a), self.p, self.training))
+
+def self_attn_pair(al, ar, x):
+    """L_self_attn_layer / R_self_attn_layer (inter_attn.py:108-109) on x [2,B,V,d]; attention itself has no parameters,
+    so it runs once over the 2B stacked samples."""
+    h = _ln2(al.layer_norm, ar.layer_norm, x)
+    a = F.attention(_lin2(al.w_qs, ar.w_qs, h), _lin2(al.w_ks, ar.w_ks, h), _lin2(al.w_vs, ar.w_vs, h),
+                    al.n_heads, al.p, al.training)
+    return attn_tail_pair(al.ff, ar.ff, x, _lin2(al.fc, ar.fc, a), al.p, al.training)
 
 
 class inter_attn(nn.Module):
@@ -156,18 +180,14 @@ class inter_attn(nn.Module):
         self.ffL, self.ffR = MLP_res_block(d, d, drop), MLP_res_block(d, d, drop)
         xavier_(self)
 
-    def forward(self, Lf0, Rf0):
-        Lf, Rf = F.parallel(lambda: self.L_self_attn_layer(Lf0), lambda: self.R_self_attn_layer(Rf0))
-        l2, r2 = self.layer_norm1(Lf), self.layer_norm2(Rf)
-        B = l2.shape[0]
-        both = torch.cat((l2, r2), 0)                                   # shared projections: one GEMM for both hands
-        q, k, v = self.w_qs(both), self.w_ks(both), self.w_vs(both)
-        r2l = F.attention(q[:B], k[B:], v[B:], self.n_heads, self.p, self.training)
-        l2r = F.attention(q[B:], k[:B], v[:B], self.n_heads, self.p, self.training)
-        o = self.fc(torch.cat((r2l, l2r), 0))
-        Lf = self.ffL(Lf + F.dropout(o[:B], self.p, self.training))
-        Rf = self.ffR(Rf + F.dropout(o[B:], self.p, self.training))
-        return Lf, Rf
+    def forward(self, x):
+        """x [2,B,V,d] = (left, right) features."""
+        x = self_attn_pair(self.L_self_attn_layer, self.R_self_attn_layer, x)
+        n = _ln2(self.layer_norm1, self.layer_norm2, x)
+        q, k, v = self.w_qs(n), self.w_ks(n), self.w_vs(n)              # shared projections: one GEMM for both hands
+        # left queries attend to right keys / values and vice versa (:82-105): the other hand is B samples away
+        c = F.attention(q, k, v, self.n_heads, self.p, self.training, kv_shift=x.shape[1])
+        return attn_tail_pair(self.ffL, self.ffR, x, self.fc(c), self.p, self.training)
 
 
 class img_ex(nn.Module):
@@ -190,7 +210,8 @@ class img_ex(nn.Module):
 
 
 class DualGraphLayer(nn.Module):
-    """DualGraph.py:21-96."""
+    """DualGraph.py:21-96.  Both hands travel as one stacked tensor [2,B,V,C]; every layer that has per-hand parameters
+    runs as a paired launch (F.linear_pair / layer_norm_fused / cheby2_pair)."""
 
     def __init__(self, V, cin, cout, ellL, ellR, n, img_size, img_c, grid_c, heads, drop):
         super().__init__()
@@ -201,10 +222,12 @@ class DualGraphLayer(nn.Module):
         self.img_ex_right = img_ex(img_size, img_c, 6, grid_c, cout, heads, drop)
         self.attn = inter_attn(cout, heads, drop)
 
-    def forward(self, Lf, Rf):
-        pe = self.position_embeddings.weight.unsqueeze(0)
-        Lg, Rg = F.parallel(lambda: self.graph_left(Lf + pe), lambda: self.graph_right(Rf + pe))
-        return self.attn(Lg, Rg)
+    def forward(self, x):
+        x = x + self.position_embeddings.weight
+        blocks = list(zip(self.graph_left.GCN_blocks, self.graph_right.GCN_blocks))
+        for i, (bl, br) in enumerate(blocks):
+            x = gcn_block_pair(bl, br, x, relu_out=i != len(blocks) - 1)
+        return self.attn(x)
 
 
 class DualGraph(nn.Module):
@@ -212,13 +235,13 @@ class DualGraph(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList(layers)
 
-    def forward(self, Lf, Rf):
+    def forward(self, x):
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
-            Lf, Rf = layer(Lf, Rf)
+            x = layer(x)
             if i != last:                                   # nearest x2 on the vertex axis (DualGraph.py:11-18)
-                Lf, Rf = Lf.repeat_interleave(2, dim=1), Rf.repeat_interleave(2, dim=1)
-        return Lf, Rf
+                x = x.repeat_interleave(2, dim=2)
+        return x
 
 
 def projection_batch(scale, trans2d, pts, img_size):
@@ -254,34 +277,45 @@ class decoder(nn.Module):
         self.root_head = Linear(cout[-1], 3)
         for m in (self.gf_layer_left, self.gf_layer_right, self.coord_head, self.avg_head, self.params_head, self.root_head):
             xavier_(m)
+        self._pe_key, self._pe = None, None
 
     def get_converter(self):
         return self.converter
 
-    def hand_pe(self, bs, hand):
-        """:170-178: dense_coor*2-1 in GCN order (1008 nodes), average-pooled by 16 -> [bs,63,3]."""
-        pe = self.converter[hand].vert_to_GCN((self.dense_coor * 2 - 1).unsqueeze(0))
-        return pe.view(1, 63, 16, 3).mean(2).expand(bs, -1, -1)
+    def hand_pe(self):
+        """:170-178: dense_coor*2-1 in GCN order (1008 nodes), average-pooled by 16 -> [2,1,63,3] (left, right)."""
+        key = (self.dense_coor._version, self.dense_coor.device)
+        if self._pe_key != key:
+            with torch.no_grad():
+                c = (self.dense_coor * 2 - 1).unsqueeze(0)
+                self._pe = torch.stack([self.converter[h].vert_to_GCN(c).view(1, 63, 16, 3).mean(2) for h in ('left', 'right')])
+            self._pe_key = key
+        return self._pe
 
     def forward(self, gl, gr):
         bs = gl.shape[0]
-        feats = []
-        for hand, gf, layer in (('left', gl, self.gf_layer_left), ('right', gr, self.gf_layer_right)):
-            f = layer[1](layer[0](gf))
-            feats.append(torch.cat([f.unsqueeze(1).expand(-1, 63, -1), self.hand_pe(bs, hand)], -1))
-        Lf, Rf = self.dual_gcn(feats[0], feats[1])
-        scale, trans2d, root, v3, v2 = {}, {}, {}, {}, {}
-        result = {'verts3d': {}, 'verts2d': {}}
-        for hand, f in (('left', Lf), ('right', Rf)):
-            t = self.avg_head(f.transpose(1, 2))[..., 0]                                 # [B,64]      (:205)
-            p = self.params_head(t)
-            scale[hand], trans2d[hand], root[hand] = p[:, 0], p[:, 1:], self.root_head(t)
-            v3[hand] = self.coord_head(f)                                                # [B,252,3]
-            v2[hand] = projection_batch(scale[hand], trans2d[hand], v3[hand], IMG_SIZE)
-            result['verts3d'][hand] = self.unsample_layer(v3[hand].transpose(1, 2)).transpose(1, 2)
-            result['verts2d'][hand] = projection_batch(scale[hand], trans2d[hand], result['verts3d'][hand], IMG_SIZE)
+        g = torch.stack((gl, gr))                                                         # [2,B,1024]
+        f = _ln2(self.gf_layer_left[1], self.gf_layer_right[1], _lin2(self.gf_layer_left[0], self.gf_layer_right[0], g))
+        x = torch.cat([f.unsqueeze(2).expand(-1, -1, 63, -1), self.hand_pe().expand(-1, bs, -1, -1)], -1)
+        x = self.dual_gcn(x)                                                              # [2,B,252,C]
+        # the heads are shared by both hands (:203-227): one launch each over the stacked features
+        t = self.avg_head(x.transpose(2, 3))[..., 0]                                      # [2,B,C]      (:205)
+        p = self.params_head(t)
+        rt = self.root_head(t)
+        c3 = self.coord_head(x)                                                           # [2,B,252,3]
+        up3 = self.unsample_layer(c3.transpose(2, 3)).transpose(2, 3)                     # [2,B,778,3]
+        sc, tr = p[..., 0], p[..., 1:]
+        c2 = projection_batch(sc.reshape(-1), tr.reshape(-1, 2), c3.reshape(2 * bs, -1, 3), IMG_SIZE).view(2, bs, -1, 2)
+        up2 = projection_batch(sc.reshape(-1), tr.reshape(-1, 2), up3.reshape(2 * bs, -1, 3), IMG_SIZE).view(2, bs, -1, 2)
+        hands = ('left', 'right')
+        scale = {h: sc[i] for i, h in enumerate(hands)}
+        trans2d = {h: tr[i] for i, h in enumerate(hands)}
+        root = {h: rt[i] for i, h in enumerate(hands)}
+        v3 = {h: c3[i] for i, h in enumerate(hands)}
+        v2 = {h: c2[i] for i, h in enumerate(hands)}
+        result = {'verts3d': {h: up3[i] for i, h in enumerate(hands)}, 'verts2d': {h: up2[i] for i, h in enumerate(hands)}}
         other = {'verts3d_MANO_list': {'left': [], 'right': []}, 'verts2d_MANO_list': {'left': [], 'right': []}}
-        for hand in ('left', 'right'):                                                    # :230-240
+        for hand in hands:                                                                # :230-240
             for key, src in (('verts3d_MANO_list', v3), ('verts2d_MANO_list', v2)):
                 other[key][hand].append(self.converter[hand].GCN_to_vert(src[hand].repeat_interleave(4, dim=1)))
         return (result, {'scale': scale, 'trans2d': trans2d, 'root': root},

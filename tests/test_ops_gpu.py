@@ -469,3 +469,106 @@ def test_depth2pcl_front_end(F):
     # degenerate: nothing inside the mask -> all-zero indices
     c0, cl0, n0 = F.depth2pcl(dd, mm * 0, KK, valid, seed=1)
     assert (c0 == 0).all() and (n0 == 0).all()
+
+
+def test_paired_decoder_ops(F):
+    """The paired / fused launches of the mesh decoder against their one-branch-at-a-time compositions (torch CPU)."""
+    from oracle import pdfnet_cpu as O
+    B, V, K, N = 3, 63, 128, 64
+    # linear_pair (+ReLU) = two Linear layers
+    x = rnd(2, B, V, K, seed=1)
+    ws = [rnd(N, K, seed=2 + i, scale=K ** -0.5) for i in range(2)]
+    bs = [rnd(N, seed=4 + i) for i in range(2)]
+    gy = rnd(2, B, V, N, seed=6)
+    xr = x.clone().requires_grad_()
+    wr = [w.clone().requires_grad_() for w in ws]
+    br = [b.clone().requires_grad_() for b in bs]
+    ref = torch.stack([TF.relu(TF.linear(xr[i], wr[i], br[i])) for i in range(2)])
+    ref.backward(gy)
+    xd = dev(x).requires_grad_()
+    wd = [dev(w).requires_grad_() for w in ws]
+    bd = [dev(b).requires_grad_() for b in bs]
+    out = F.linear_pair(xd, wd[0], bd[0], wd[1], bd[1], F.ACT_RELU)
+    out.backward(dev(gy))
+    close(out, ref, 3e-5, what="linear_pair")
+    close(xd.grad, xr.grad, 1e-4, what="linear_pair dx")
+    for i in range(2):
+        close(wd[i].grad, wr[i].grad, 1e-4, rtol=2e-5, what="linear_pair dw%d" % i)
+        close(bd[i].grad, br[i].grad, 1e-4, rtol=2e-5, what="linear_pair db%d" % i)
+
+    # layer_norm_fused: paired parameters, ReLU, residual add (no dropout), extra gradient on the residual stream
+    Fd = 96
+    x, a = rnd(2, B, V, Fd, seed=7), rnd(2, B, V, Fd, seed=8)
+    gs = [rnd(Fd, seed=9 + i) for i in range(2)]
+    be = [rnd(Fd, seed=11 + i) for i in range(2)]
+    gz, gy = rnd(2, B, V, Fd, seed=13), rnd(2, B, V, Fd, seed=14)
+    xr, ar = x.clone().requires_grad_(), a.clone().requires_grad_()
+    gr = [t.clone().requires_grad_() for t in gs]
+    er = [t.clone().requires_grad_() for t in be]
+    zr = xr + ar
+    yr = torch.stack([TF.relu(TF.layer_norm(zr[i], (Fd,), gr[i], er[i], 1e-6)) for i in range(2)])
+    ((zr * gz).sum() + (yr * gy).sum()).backward()
+    xd, ad = dev(x).requires_grad_(), dev(a).requires_grad_()
+    gd = [dev(t).requires_grad_() for t in gs]
+    ed = [dev(t).requires_grad_() for t in be]
+    zd, yd = F.layer_norm_fused(xd, gd[0], ed[0], 1e-6, F.ACT_RELU, add=ad, p=0.5, training=False, gamma1=gd[1], beta1=ed[1])
+    ((zd * dev(gz)).sum() + (yd * dev(gy)).sum()).backward()
+    close(zd, zr, 1e-6, what="ln_fused z")
+    close(yd, yr, 2e-5, what="ln_fused y")
+    close(xd.grad, xr.grad, 5e-5, what="ln_fused dx")
+    close(ad.grad, ar.grad, 5e-5, what="ln_fused dadd")
+    for i in range(2):
+        close(gd[i].grad, gr[i].grad, 2e-4, rtol=2e-5, what="ln_fused dgamma%d" % i)
+        close(ed[i].grad, er[i].grad, 2e-4, rtol=2e-5, what="ln_fused dbeta%d" % i)
+    # single parameter set, no add, no act == plain layer_norm
+    y1 = F.layer_norm_fused(dev(x), gd[0], ed[0])
+    close(y1, TF.layer_norm(x, (Fd,), gs[0], be[0], 1e-6), 2e-5, what="ln_fused plain")
+    # dropout inside the fused op: the dropped operand's gradient carries the forward mask, the residual's does not
+    xd, ad = dev(torch.zeros(2, B, V, Fd)).requires_grad_(), dev(torch.ones(2, B, V, Fd)).requires_grad_()
+    zd, yd = F.layer_norm_fused(xd, gd[0], ed[0], add=ad, p=0.25, training=True, gamma1=gd[1], beta1=ed[1])
+    keep = zd > 0
+    assert abs(keep.float().mean().item() - 0.75) < 0.02 and abs(zd.max().item() - 1 / 0.75) < 1e-6
+    zd.sum().backward()
+    assert torch.equal(ad.grad > 0, keep) and torch.equal(xd.grad, torch.ones_like(xd))
+    # dropout_add
+    xd, rd = dev(torch.ones(1 << 16)).requires_grad_(), dev(torch.zeros(1 << 16)).requires_grad_()
+    yd = F.dropout_add(xd, rd, 0.1, True)
+    yd.sum().backward()
+    assert torch.equal(xd.grad > 0, yd > 0) and torch.equal(rd.grad, torch.ones_like(rd))
+    close(F.dropout_add(xd, rd + 2, 0.1, False), torch.full((1 << 16,), 3.0), 0, what="dropout_add eval")
+
+    # cheby2_pair = left and right Laplacians
+    g = O.load_graph_constants()
+    DL, DR = g['L_left'][0], g['L_right'][0]
+    ells = []
+    for D in (DL, DR):
+        col, val = _ell(D)
+        colT, valT = _ell(D.t().contiguous())
+        ells.append([col, val, colT, valT])
+    for k in range(4):                                                   # common ELL width
+        w = max(ells[0][k].shape[1], ells[1][k].shape[1])
+        for e in ells:
+            e[k] = TF.pad(e[k], (0, w - e[k].shape[1]))
+    x = rnd(2, B, 63, 32, seed=15)
+    gy = rnd(2, B, 63, 64, seed=16)
+    xr = x.clone().requires_grad_()
+    ref = torch.stack([torch.stack((xr[i], torch.einsum('vw,bwf->bvf', D, xr[i])), -1).flatten(2) for i, D in enumerate((DL, DR))])
+    ref.backward(gy)
+    xd = dev(x).requires_grad_()
+    out = F.cheby2_pair(xd, tuple(dev(t) for t in ells[0]), tuple(dev(t) for t in ells[1]))
+    out.backward(dev(gy))
+    close(out, ref, 1e-5, what="cheby2_pair")
+    close(xd.grad, xr.grad, 1e-5, what="cheby2_pair bwd")
+
+    # attention with kv_shift = B: each hand's queries against the other hand's keys / values
+    q, k, v = rnd(2, B, V, 64, seed=17), rnd(2, B, V, 64, seed=18), rnd(2, B, V, 64, seed=19)
+    gy = rnd(2, B, V, 64, seed=20)
+    qr, kr, vr = (t.clone().requires_grad_() for t in (q, k, v))
+    ref = torch.stack((O.mha(qr[0], kr[1], vr[1], 4, lambda a: a), O.mha(qr[1], kr[0], vr[0], 4, lambda a: a)))
+    ref.backward(gy)
+    qd, kd, vd = (dev(t).requires_grad_() for t in (q, k, v))
+    out = F.attention(qd, kd, vd, 4, kv_shift=B)
+    out.backward(dev(gy))
+    close(out, ref, 2e-5, what="attn kv_shift")
+    for u, w_ in ((qd, qr), (kd, kr), (vd, vr)):
+        close(u.grad, w_.grad, 5e-5, rtol=2e-5, what="attn kv_shift bwd")

@@ -51,13 +51,11 @@ def main():
         dy = torch.randn_like(y)
         dx = torch.zeros_like(x)
         dw = torch.empty_like(w)
-        wT = torch.empty(w.numel(), device=dev)
-        L.pdf_transpose_atb(ptr(w), ptr(wT), Cout, k * k, Cin, stream())
         n = L.pdf_wgrad_workspace_floats(B * OH * OH, Cout, k * k * Cin)
         ws = torch.empty(max(n, 1), device=dev)
         fl = 2.0 * B * OH * OH * Cout * Cin * k * k
         t_f = timeit(lambda: L.pdf_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream()))
-        t_d = timeit(lambda: L.pdf_conv2d_bwd_data(ptr(dy), ptr(wT), ptr(dx), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, stream()))
+        t_d = timeit(lambda: L.pdf_conv2d_bwd_data(ptr(dy), ptr(w), ptr(dx), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, stream()))
         t_w = timeit(lambda: L.pdf_conv2d_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), n, B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream()))
         print("%-16s M=%7d N=%5d K=%5d  %7.1f GF | fwd %6.3f ms %6.1f TF | bwd_data %6.3f ms %6.1f TF | bwd_w %6.3f ms %6.1f TF" %
               (name, B * OH * OH, Cout, Cin * k * k, fl / 1e9, t_f * 1e3, fl / t_f / 1e12, t_d * 1e3, fl / t_d / 1e12, t_w * 1e3, fl / t_w / 1e12), flush=True)
@@ -70,14 +68,12 @@ def main():
         dy = torch.randn(M, N, device=dev)
         dx = torch.empty(M, K, device=dev)
         dw = torch.empty(N, K, device=dev)
-        wT = torch.empty(K * N, device=dev)
-        L.pdf_transpose_atb(ptr(w), ptr(wT), N, 1, K, stream())
         n = L.pdf_wgrad_workspace_floats(M, N, K)
         ws = torch.empty(max(n, 1), device=dev)
         fl = 2.0 * M * N * K
         by = 4.0 * (M * K + M * N)
         t_f = timeit(lambda: L.pdf_linear_fwd(ptr(x), ptr(w), None, ptr(y), M, N, K, K, K, N, 1, stream()))
-        t_d = timeit(lambda: L.pdf_linear_fwd(ptr(dy), ptr(wT), None, ptr(dx), M, K, N, N, N, K, 0, stream()))
+        t_d = timeit(lambda: L.pdf_linear_bwd_data(ptr(dy), ptr(w), ptr(dx), M, N, K, N, K, K, stream()))
         t_w = timeit(lambda: L.pdf_linear_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), n, M, N, K, K, N, 0, stream()))
         print("%-16s M=%7d N=%5d K=%5d  %7.1f GF | fwd %6.3f ms %6.1f TF %5.2f TB/s | bwd_data %6.3f ms %6.1f TF | bwd_w %6.3f ms %6.1f TF" %
               (name, M, N, K, fl / 1e9, t_f * 1e3, fl / t_f / 1e12, by / t_f / 1e12, t_d * 1e3, fl / t_d / 1e12, t_w * 1e3, fl / t_w / 1e12), flush=True)
