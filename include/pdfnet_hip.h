@@ -199,6 +199,18 @@ int pdf_attn_bwd(const float* q, const float* k, const float* v, int ld, const f
                  const float* stat, int B, int V, int H, int dh, int kv_shift, float pdrop, unsigned long long seed, const unsigned long long* step,
                  float* dq, float* dk, float* dv, int lddq, float* dvec, void* stream);
 
+/* ---- mesh loss terms (csrc/loss.hip) ---------------------------------------------------------- */
+/* out[r] = mean_i f(pred[r][i] - tgt[r][i]); mode 0: |.| (the `l1` of lib/trains/simplified.py:427-436,481,506-511),
+ * mode 1: (.)^2 (F.mse_loss, :425,482,499).  bwd: dpred[r][i] = gout[r]/n * f'(.) */
+int pdf_rowloss_fwd(const float* pred, const float* tgt, long rows, long n, int mode, float* out, void* stream);
+int pdf_rowloss_bwd(const float* pred, const float* tgt, const float* gout, long rows, long n, int mode, float* dpred, void* stream);
+/* normal_loss + edge_length_loss (lib/trains/simplified.py:66-115) for G vertex sets (hands) x B samples: pred, gt [G][B][V][3],
+ * faces [G][Fc][3] int64.  fwd: part[(g*B+b)*2 + {0,1}] = per-sample sums of the normal / edge terms over the faces.
+ * bwd: dpred of sum_g (wn[g]*normal_sum + we[g]*edge_sum); we may be NULL (no edge term).  V <= 1024. */
+int pdf_face_loss_fwd(const float* pred, const float* gt, const long long* faces, int G, int B, int V, int Fc, float* part, void* stream);
+int pdf_face_loss_bwd(const float* pred, const float* gt, const long long* faces, int G, int B, int V, int Fc,
+                      const float* wn, const float* we, float* dpred, void* stream);
+
 /* ---- depth front end (csrc/frontend.hip) ------------------------------------------------------ */
 /* depth2pcl (intaghand_encoder.py:369-491 + get_points_coordinate lib/utils/utils.py:251-262) batched on the GPU:
  * depth [B][H][W] metres, mask [B][2][H][W] (right, left), K [B][3][3], valid [B][2] ->

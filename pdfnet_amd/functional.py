@@ -1105,3 +1105,102 @@ class _RegressJoints(Function):
 
 def regress_joints(reg, verts):
     return _RegressJoints.apply(reg, verts)
+
+
+class _RegressJointsPair(Function):
+    """verts [2,B,V,3] -> joints [2,B,J,3]: half 0 with reg0, half 1 with reg1 (left / right full regressors)."""
+
+    @staticmethod
+    def forward(ctx, reg0, reg1, verts):
+        verts = verts.contiguous()
+        _, B, Vn, _ = verts.shape
+        J = reg0.shape[0]
+        out = torch.empty((2, B, J, 3), device=verts.device)
+        for i, reg in enumerate((reg0, reg1)):
+            _L().pdf_bmm_strided(ptr(reg), ptr(verts[i]), ptr(out[i]), B, J, 3, Vn, 1,
+                                 0, 0, Vn, 1, Vn * 3, 0, 3, 1, J * 3, 3, 1, 0, stream())
+        ctx.save_for_backward(reg0, reg1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        regs = ctx.saved_tensors
+        g = g.contiguous()
+        _, B, J, _ = g.shape
+        Vn = regs[0].shape[1]
+        dv = torch.empty((2, B, Vn, 3), device=g.device)
+        for i, reg in enumerate(regs):
+            _L().pdf_bmm_strided(ptr(reg), ptr(g[i]), ptr(dv[i]), B, Vn, 3, J, 1,
+                                 0, 0, 1, Vn, J * 3, 0, 3, 1, Vn * 3, 3, 1, 0, stream())
+        return None, None, dv
+
+
+def regress_joints_pair(reg0, reg1, verts):
+    return _RegressJointsPair.apply(reg0, reg1, verts)
+
+
+class _RowLoss(Function):
+    """out[rows...] = mean over the trailing dims of |pred - tgt| (mode 0) or (pred - tgt)^2 (mode 1); gradient to pred only."""
+
+    @staticmethod
+    def forward(ctx, pred, tgt, row_dims, mode):
+        hip.require_gpu(pred, tgt)
+        pred, tgt = pred.contiguous(), tgt.contiguous()
+        if pred.shape != tgt.shape:
+            raise ValueError("pdfnet_amd: rowloss wants equal shapes, got %s vs %s" % (tuple(pred.shape), tuple(tgt.shape)))
+        rows = 1
+        for d in pred.shape[:row_dims]:
+            rows *= d
+        n = pred.numel() // max(rows, 1)
+        out = torch.empty(pred.shape[:row_dims], dtype=torch.float32, device=pred.device)
+        _L().pdf_rowloss_fwd(ptr(pred), ptr(tgt), rows, n, mode, ptr(out), stream())
+        ctx.save_for_backward(pred, tgt)
+        ctx.cfg = (rows, n, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgt = ctx.saved_tensors
+        rows, n, mode = ctx.cfg
+        dp = torch.empty_like(pred)
+        _L().pdf_rowloss_bwd(ptr(pred), ptr(tgt), ptr(g.contiguous()), rows, n, mode, ptr(dp), stream())
+        return dp, None, None, None
+
+
+def rowloss(pred, tgt, row_dims, mode):
+    """mode 'l1' | 'l2'."""
+    return _RowLoss.apply(pred, tgt.detach(), row_dims, 0 if mode == 'l1' else 1)
+
+
+class _FaceLoss(Function):
+    """(normal_loss[G], edge_length_loss[G]) of lib/trains/simplified.py:66-115 for pred / gt [G,B,V,3] and faces [G,F,3] int64."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, faces, edge_grad):
+        hip.require_gpu(pred, gt, faces)
+        pred, gt, faces = pred.contiguous(), gt.contiguous(), faces.contiguous()
+        G, B, V, _ = pred.shape
+        Fc = faces.shape[1]
+        part = torch.empty((G, B, 2), dtype=torch.float32, device=pred.device)
+        _L().pdf_face_loss_fwd(ptr(pred), ptr(gt), ptr(faces), G, B, V, Fc, ptr(part), stream())
+        ctx.save_for_backward(pred, gt, faces)
+        ctx.edge_grad = edge_grad
+        ctx.set_materialize_grads(False)
+        m = part.sum(1) / float(B * 3 * Fc)
+        return m[:, 0], m[:, 1]
+
+    @staticmethod
+    def backward(ctx, gn, ge):
+        pred, gt, faces = ctx.saved_tensors
+        G, B, V, _ = pred.shape
+        Fc = faces.shape[1]
+        k = 1.0 / float(B * 3 * Fc)
+        wn = (gn * k).contiguous() if gn is not None else torch.zeros(G, device=pred.device)
+        we = (ge * k).contiguous() if (ge is not None and ctx.edge_grad) else None
+        dp = torch.empty_like(pred)
+        _L().pdf_face_loss_bwd(ptr(pred), ptr(gt), ptr(faces), G, B, V, Fc, ptr(wn), ptr(we), ptr(dp), stream())
+        return dp, None, None, None
+
+
+def face_loss(pred, gt, faces, edge_grad=True):
+    return _FaceLoss.apply(pred, gt.detach(), faces, edge_grad)

@@ -303,7 +303,7 @@ class decoder(nn.Module):
         p = self.params_head(t)
         rt = self.root_head(t)
         c3 = self.coord_head(x)                                                           # [2,B,252,3]
-        up3 = self.unsample_layer(c3.transpose(2, 3)).transpose(2, 3)                     # [2,B,778,3]
+        up3 = self.unsample_layer(c3.transpose(2, 3)).transpose(2, 3).contiguous()        # [2,B,778,3]
         sc, tr = p[..., 0], p[..., 1:]
         c2 = projection_batch(sc.reshape(-1), tr.reshape(-1, 2), c3.reshape(2 * bs, -1, 3), IMG_SIZE).view(2, bs, -1, 2)
         up2 = projection_batch(sc.reshape(-1), tr.reshape(-1, 2), up3.reshape(2 * bs, -1, 3), IMG_SIZE).view(2, bs, -1, 2)

@@ -37,54 +37,42 @@ def bone_direction_loss(j2d, gt2d, a, c):
     """lib/models/losses.py:26-94 `get_bone_loss` with unit confidences -> [B]; a, c = bone end-point indices."""
 
     def unit(j):
-        v = j[:, c] - j[:, a]                                            # [B,20,2]
+        v = j.index_select(1, c) - j.index_select(1, a)                  # [B,20,2]
         return v / torch.sqrt((v ** 2).sum(-1, keepdim=True) + 1e-4)
     return ((unit(j2d) - unit(gt2d)) ** 2).sum(-1).mean(dim=1)
 
 
-def _unit(v):
-    return TF.normalize(v, p=2, dim=2)
-
-
-def normal_loss(pred, gt, face):
-    """simplified.py:66-91."""
-    f0, f1, f2 = face[:, 0], face[:, 1], face[:, 2]
-    v1o, v2o, v3o = _unit(pred[:, f1] - pred[:, f0]), _unit(pred[:, f2] - pred[:, f0]), _unit(pred[:, f2] - pred[:, f1])
-    n = _unit(torch.cross(_unit(gt[:, f1] - gt[:, f0]), _unit(gt[:, f2] - gt[:, f0]), dim=2))
-    cos = [torch.abs((v * n).sum(2, keepdim=True)) for v in (v1o, v2o, v3o)]
-    return torch.cat(cos, 1).mean()
-
-
-def edge_length_loss(pred, gt, face):
-    """simplified.py:94-115."""
-    f0, f1, f2 = face[:, 0], face[:, 1], face[:, 2]
-
-    def d(x, i, j):
-        return torch.sqrt(((x[:, i] - x[:, j]) ** 2).sum(2, keepdim=True))
-    diffs = [torch.abs(d(pred, i, j) - d(gt, i, j)) for i, j in ((f0, f1), (f0, f2), (f1, f2))]
-    return torch.cat(diffs, 1).mean()
-
-
 def perspective(pts, K):
     """Mano_render.py:203-209 `get_Landmarks_new`."""
-    p = pts.bmm(K.reshape(-1, 3, 3).transpose(2, 1))
+    p = pts @ K.reshape(-1, 3, 3).transpose(2, 1)                        # pts [..., B, n, 3]
     return p[..., :2] / (p[..., 2:] + 1e-7)
 
 
 def uv_root_3d(index, root_xy, root_z, K, input_res, down_ratio=4):
     """Mano_render.py:211-223 `get_uv_root_3d`."""
-    g = input_res // down_ratio
-    cx = ((index % g) * down_ratio).squeeze(-1)
-    cy = ((index // g) * down_ratio).squeeze(-1)
-    x = root_z * (root_xy[:, 0] + cx - K[:, 0, 2]) / (K[:, 0, 0] + 1e-7)
-    y = root_z * (root_xy[:, 1] + cy - K[:, 1, 2]) / (K[:, 1, 1] + 1e-7)
-    return torch.stack((x, y, root_z), 1).unsqueeze(1)
+    g = input_res // down_ratio                                         # index [..., B], root_xy [..., B, 2], root_z [..., B]
+    cx = (index % g) * down_ratio
+    cy = (index // g) * down_ratio
+    x = root_z * (root_xy[..., 0] + cx - K[:, 0, 2]) / (K[:, 0, 0] + 1e-7)
+    y = root_z * (root_xy[..., 1] + cy - K[:, 1, 2]) / (K[:, 1, 1] + 1e-7)
+    return torch.stack((x, y, root_z), -1).unsqueeze(-2)
 
 
-def _pool2(x):
-    """simplified.py:117-122 `mesh_downsample` (average pairs along the vertex axis)."""
-    B, N, Fd = x.shape
-    return x.view(B, N // 2, 2, Fd).mean(2)
+def _pool4(x):
+    """simplified.py:117-122 `mesh_downsample` applied twice (pair averages of pair averages along the vertex axis)."""
+    *lead, N, Fd = x.shape
+    return x.reshape(*lead, N // 2, 2, Fd).mean(-2).reshape(*lead, N // 4, 2, Fd).mean(-2)
+
+
+def _pair(d):
+    """{'left': t, 'right': t} -> [2, ...]; no copy when the two are the halves of one stacked tensor (our decoder's outputs)."""
+    l, r = d['left'], d['right']
+    b = l._base
+    if (b is not None and b is r._base and b.dim() == l.dim() + 1 and b.shape[0] == 2 and b.shape[1:] == l.shape and b.is_contiguous()
+            and l.is_contiguous() and r.is_contiguous() and l.data_ptr() == b.data_ptr()
+            and r.data_ptr() == b.data_ptr() + l.numel() * l.element_size()):
+        return b
+    return torch.stack((l, r))
 
 
 def projection_batch(scale, trans2d, pts, img_size):
@@ -102,88 +90,111 @@ class CtdetLoss(nn.Module):
         self.opt = opt
         for k, v in consts.items():
             self.register_buffer(k, v.clone(), persistent=False)
+        self.register_buffer('faces_pair', torch.stack((consts['faces_left'], consts['faces_right'])).long(), persistent=False)
         self.register_buffer('bone_a', torch.tensor([b[0] for b in _BONES]), persistent=False)
         self.register_buffer('bone_c', torch.tensor([b[1] for b in _BONES]), persistent=False)
 
     def forward(self, result, paramsDict, handDictList, otherInfo, batch, mode, epoch):
-        o = self.opt
-        S = float(o.size_train[0])
-        valid = batch['valid']
-        B = valid.shape[0]
-        l1 = lambda a, b: TF.l1_loss(a, b, reduction='none').reshape(B, -1).mean(dim=1)
-        l2 = TF.mse_loss
-        nrm = lambda x: x / S * 2 - 1
-
         test = mode in ('val', 'test')
         if test:
             from ..networks.intaghand_encoder import nms_top1_centers
             ind = nms_top1_centers(sigmoid_clamped(otherInfo['ret']['hm']))                # :376-389
         else:
             ind = batch['ind']
-        ind_l, ind_r = ind[:, :1], ind[:, 1:]
+        t = self.mesh_terms(result, paramsDict, handDictList, otherInfo['converter_left'], otherInfo['converter_right'],
+                            batch, ind, test, epoch)
+        if test:
+            return t
+        # dense-map terms (created last: their backward is issued first, ahead of the launch-bound mesh terms)
+        t.update(self.dense_terms(otherInfo, batch))
+        return self.total(t, epoch)
 
-        vgt = {'left': batch['verts_left_gt'], 'right': batch['verts_right_gt']}
-        jgt = {'left': batch['joints_left_gt'], 'right': batch['joints_right_gt']}
-        v2gt = {'left': batch['verts2d_left_gt'], 'right': batch['verts2d_right_gt']}
-        lmsgt = {'left': batch['lms_left_gt'], 'right': batch['lms_right_gt']}
-        root_gt = {h: jgt[h][:, 9:10] for h in jgt}
-        vgt_off = {h: vgt[h] - root_gt[h] for h in vgt}
-        vpred_off = result['verts3d']
-        reg = {'left': self.full_regressor_left, 'right': self.full_regressor_right}
-        face = {'left': self.faces_left, 'right': self.faces_right}
-        hv = {'left': valid[:, 0], 'right': valid[:, 1]}
+    def dense_terms(self, otherInfo, batch):
+        """The terms on the encoder's dense maps: hand masks (:368), joint heat-maps (:374), centre heat-map (:376,391)."""
+        return {'mask_loss': TF.smooth_l1_loss(otherInfo['mask'], batch['mask']),
+                'hms_loss': TF.mse_loss(otherInfo['hms'], batch['hms']),
+                'hm_loss': focal_loss(sigmoid_clamped(otherInfo['ret']['hm']), batch['hm'])}
 
-        verts2d_loss = sum(l2(nrm(result['verts2d'][h]), nrm(v2gt[h])) for h in ('left', 'right'))          # :425-426
-        verts_loss = sum(l1(vpred_off[h], vgt_off[h]) * hv[h] for h in ('left', 'right'))                   # :427-428
-        jpred_off = {h: F.regress_joints(reg[h], vpred_off[h]) for h in ('left', 'right')}                  # :431-432
-        jgt_off = {h: F.regress_joints(reg[h], vgt_off[h]) for h in ('left', 'right')}
-        joints_loss = sum(l1(jpred_off[h], jgt_off[h]) * hv[h] for h in ('left', 'right'))                  # :435-436
-        norm_loss = sum(normal_loss(vpred_off[h], vgt_off[h], face[h]) for h in ('left', 'right'))          # :452
+    def dense_part(self, t):
+        """What dense_terms contribute to the total ([B]); total == dense_part + mesh_part up to summation order."""
+        o = self.opt
+        return getattr(o, 'center_weight', 200.0) * t['hm_loss'] + getattr(o, 'reproj_weight', 1.0) * (t['mask_loss'] * 2000 + t['hms_loss'] * 2000)
+
+    def mesh_part(self, t, epoch):
+        o = self.opt
+        alpha = 0 if epoch < 20 else 1
+        w = getattr(o, 'reproj_weight', 1.0)
+        return (w * (t['root_loss'] + t['verts_loss'] * 500 + t['abs_verts_loss'] * 0.1 + t['verts2d_loss'] * 50 + t['norm_loss'] * 10 +
+                     t['edge_loss'] * 2000 * alpha + t['gcn_loss'] * 100 + t['gcn_2d_loss'] * 50 + t['abs_joints_loss'] * 0.1 +
+                     t['joints2d_loss'] * 1000 * alpha + t['joints_loss'] * 500) + getattr(o, 'bone_dir_weight', 200.0) * t['bone_direc_loss'])
+
+    def total(self, t, epoch):
+        """The reference's weighted sum in the reference's order (:610-640) -> (loss [B], stats, None, None)."""
+        o = self.opt
         alpha = 0 if epoch < 20 else 1                                                                      # :610
-        with torch.set_grad_enabled(torch.is_grad_enabled() and alpha != 0):
-            # weighted by alpha below: while alpha == 0 the term is reported but contributes an exactly-zero gradient,
-            # so its backward graph is not built
-            edge_loss = sum(edge_length_loss(vpred_off[h], vgt_off[h], face[h]) for h in ('left', 'right'))  # :453
+        w = getattr(o, 'reproj_weight', 1.0)
+        loss = getattr(o, 'center_weight', 200.0) * t['hm_loss'] + w * t['root_loss']
+        loss = loss + w * (t['verts_loss'] * 500 + t['abs_verts_loss'] * 0.1 + t['verts2d_loss'] * 50 + t['norm_loss'] * 10 +
+                           t['edge_loss'] * 2000 * alpha + t['gcn_loss'] * 100 + t['gcn_2d_loss'] * 50)
+        loss = loss + w * (t['mask_loss'] * 2000 + t['abs_joints_loss'] * 0.1 + t['hms_loss'] * 2000 +
+                           t['joints2d_loss'] * 1000 * alpha + t['joints_loss'] * 500)
+        loss = loss + getattr(o, 'bone_dir_weight', 200.0) * t['bone_direc_loss']
+        order = ('hm_loss', 'root_loss', 'verts_loss', 'abs_verts_loss', 'verts2d_loss', 'norm_loss', 'edge_loss', 'gcn_loss',
+                 'gcn_2d_loss', 'mask_loss', 'abs_joints_loss', 'hms_loss', 'joints2d_loss', 'joints_loss', 'bone_direc_loss')
+        stats = {k: t[k] for k in order}
+        stats['loss'] = loss
+        return loss, stats, None, None
+
+    def mesh_terms(self, result, paramsDict, handDictList, cl, cr, batch, ind, test, epoch):
+        """Every term on the mesh decoder's outputs (:425-525).  cl / cr: the decoder's GCN <-> MANO vertex-order converters.
+        Returns the dict of terms, or the evaluation tuple (:652-653) when `test`.
+
+        Both hands are processed as one stacked [2, B, ...] tensor (row 0 left, row 1 right); each L1 / MSE term is one
+        `F.rowloss` launch, normal + edge-length terms one `F.face_loss` launch.  nrm(x) = x/S*2 - 1 (:421) only rescales the
+        MSE terms: mse(nrm(a), nrm(b)) = (2/S)^2 mse(a, b)."""
+        o = self.opt
+        S = float(o.size_train[0])
+        k2 = (2.0 / S) ** 2
+        valid = batch['valid']
+        B = valid.shape[0]
+        hv = valid.t()                                                                                      # [2,B]
+        gt = lambda k: torch.stack((batch[k % 'left'], batch[k % 'right']))
+        vgt, jgt, v2gt, lmsgt = gt('verts_%s_gt'), gt('joints_%s_gt'), gt('verts2d_%s_gt'), gt('lms_%s_gt')
+        root_gt = jgt[:, :, 9:10]
+        vgt_off = vgt - root_gt
+        vp, v2p = _pair(result['verts3d']), _pair(result['verts2d'])
+        regs = (self.full_regressor_left, self.full_regressor_right)
+
+        verts2d_loss = F.rowloss(v2p, v2gt, 1, 'l2').sum() * k2                                             # :425-426
+        verts_loss = (F.rowloss(vp, vgt_off, 2, 'l1') * hv).sum(0)                                          # :427-428
+        jp_off = F.regress_joints_pair(*regs, vp)                                                           # :431-432
+        jg_off = F.regress_joints_pair(*regs, vgt_off)
+        joints_loss = (F.rowloss(jp_off, jg_off, 2, 'l1') * hv).sum(0)                                      # :435-436
+        alpha = 0 if epoch < 20 else 1                                                                      # :610
+        # edge term: weighted by alpha in `total`; while alpha == 0 it is reported but its (exactly zero) gradient is skipped
+        nl, el = F.face_loss(vp, vgt_off, self.faces_pair, edge_grad=alpha != 0)                            # :452-453
+        norm_loss, edge_loss = nl.sum(), el.sum()
 
         # GCN-level supervision: GT in GCN order, 1008 -> 252 by two pair-averagings (:461-482).
         # NB the reference feeds the LEFT GT to both hands and weights both terms by valid[:,0] (:463,481-482).
-        cl, cr = otherInfo['converter_left'], otherInfo['converter_right']
-        g3 = {'left': _pool2(_pool2(cl.vert_to_GCN(vgt_off['left']))), 'right': _pool2(_pool2(cr.vert_to_GCN(vgt_off['left'])))}
-        g2 = {'left': _pool2(_pool2(cl.vert_to_GCN(v2gt['left']))), 'right': _pool2(_pool2(cr.vert_to_GCN(v2gt['right'])))}
+        g3 = _pool4(torch.stack((cl.vert_to_GCN(vgt_off[0]), cr.vert_to_GCN(vgt_off[0]))))
+        g2 = _pool4(torch.stack((cl.vert_to_GCN(v2gt[0]), cr.vert_to_GCN(v2gt[1]))))
         hd = handDictList[0]
-        gcn_loss = sum(l1(hd['verts3d'][h], g3[h]) * valid[:, 0] for h in ('left', 'right'))
-        gcn_2d_loss = sum(l2(nrm(hd['verts2d'][h]), nrm(g2[h])) for h in ('left', 'right'))
+        gcn_loss = (F.rowloss(_pair(hd['verts3d']), g3, 2, 'l1') * valid[:, 0]).sum(0)
+        gcn_2d_loss = F.rowloss(_pair(hd['verts2d']), g2, 1, 'l2').sum() * k2
 
-        root_pred, jpred, vpred, lms_proj = {}, {}, {}, {}
-        for h, idx in (('left', ind_l), ('right', ind_r)):                                                  # :489-506
-            r = paramsDict['root'][h]
-            root_pred[h] = uv_root_3d(idx, r[:, 1:] / 100, 0.4 + r[:, 0] / 100, batch['K_new'], int(S), getattr(o, 'down_ratio', 4))
-            jpred[h] = jpred_off[h] + (root_pred[h] if test else root_gt[h])
-            lms_proj[h] = perspective(jpred[h], batch['K_new'])
-            vpred[h] = vpred_off[h] + root_pred[h]
+        r = _pair(paramsDict['root'])                                                                       # :489-506
+        root_pred = uv_root_3d(ind.t(), r[..., 1:] / 100, 0.4 + r[..., 0] / 100, batch['K_new'], int(S), getattr(o, 'down_ratio', 4))
+        jp = jp_off + (root_pred if test else root_gt)
+        lms = perspective(jp, batch['K_new'])
+        vpred = vp + root_pred
         if test:                                                                                            # :652-653
-            cat = lambda d, n: torch.cat((d['left'], d['right']), dim=1).reshape(B, -1, n, d['left'].shape[-1])
-            return (cat(vpred, 778), cat(jpred, 21), cat(vgt, 778), cat(jgt, 21), cat(lms_proj, 21),
-                    cat(vpred_off, 778), cat(jpred_off, 21), cat(vgt_off, 778), cat(jgt_off, 21))
-        joints2d_loss = sum(l2(nrm(lms_proj[h]), nrm(lmsgt[h])) * hv[h] for h in ('left', 'right'))         # :499-500
-        root_loss = sum(l1(root_pred[h], root_gt[h]) * hv[h] * 1000 for h in ('left', 'right'))             # :506-507
-        abs_joints_loss = sum(l1(jpred[h], jgt[h]) * hv[h] for h in ('left', 'right')) * 1000
-        abs_verts_loss = sum(l1(vpred[h], vgt[h]) * hv[h] for h in ('left', 'right')) * 1000
-        bone = sum(bone_direction_loss(lms_proj[h], lmsgt[h], self.bone_a, self.bone_c) * hv[h] for h in ('left', 'right'))           # :517-525
-
-        # dense-map terms (created last: their backward is issued first, ahead of the launch-bound mesh terms)
-        mask_loss = TF.smooth_l1_loss(otherInfo['mask'], batch['mask'])                    # :368
-        hms_loss = l2(otherInfo['hms'], batch['hms'])                                      # :374
-        hm_loss = focal_loss(sigmoid_clamped(otherInfo['ret']['hm']), batch['hm'])         # :376, :391
-        w = getattr(o, 'reproj_weight', 1.0)
-        loss = getattr(o, 'center_weight', 200.0) * hm_loss + w * root_loss
-        loss = loss + w * (verts_loss * 500 + abs_verts_loss * 0.1 + verts2d_loss * 50 + norm_loss * 10 +
-                           edge_loss * 2000 * alpha + gcn_loss * 100 + gcn_2d_loss * 50)
-        loss = loss + w * (mask_loss * 2000 + abs_joints_loss * 0.1 + hms_loss * 2000 +
-                           joints2d_loss * 1000 * alpha + joints_loss * 500)
-        loss = loss + getattr(o, 'bone_dir_weight', 200.0) * bone
-        stats = {'hm_loss': hm_loss, 'root_loss': root_loss, 'verts_loss': verts_loss, 'abs_verts_loss': abs_verts_loss,
-                 'verts2d_loss': verts2d_loss, 'norm_loss': norm_loss, 'edge_loss': edge_loss, 'gcn_loss': gcn_loss,
-                 'gcn_2d_loss': gcn_2d_loss, 'mask_loss': mask_loss, 'abs_joints_loss': abs_joints_loss, 'hms_loss': hms_loss,
-                 'joints2d_loss': joints2d_loss, 'joints_loss': joints_loss, 'bone_direc_loss': bone, 'loss': loss}
-        return loss, stats, None, None
+            return tuple(t.transpose(0, 1).contiguous() for t in (vpred, jp, vgt, jgt, lms, vp, jp_off, vgt_off, jg_off))
+        joints2d_loss = (F.rowloss(lms, lmsgt, 1, 'l2').unsqueeze(1) * k2 * hv).sum(0)                      # :499-500
+        root_loss = (F.rowloss(root_pred, root_gt, 2, 'l1') * hv * 1000).sum(0)                             # :506-507
+        abs_joints_loss = (F.rowloss(jp, jgt, 2, 'l1') * hv).sum(0) * 1000
+        abs_verts_loss = (F.rowloss(vpred, vgt, 2, 'l1') * hv).sum(0) * 1000
+        bone = (bone_direction_loss(lms.reshape(2 * B, -1, 2), lmsgt.reshape(2 * B, -1, 2), self.bone_a, self.bone_c).view(2, B) * hv).sum(0)  # :517-525
+        return {'root_loss': root_loss, 'verts_loss': verts_loss, 'abs_verts_loss': abs_verts_loss, 'verts2d_loss': verts2d_loss,
+                'norm_loss': norm_loss, 'edge_loss': edge_loss, 'gcn_loss': gcn_loss, 'gcn_2d_loss': gcn_2d_loss,
+                'abs_joints_loss': abs_joints_loss, 'joints2d_loss': joints2d_loss, 'joints_loss': joints_loss, 'bone_direc_loss': bone}

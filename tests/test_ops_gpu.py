@@ -572,3 +572,52 @@ def test_paired_decoder_ops(F):
     close(out, ref, 2e-5, what="attn kv_shift")
     for u, w_ in ((qd, qr), (kd, kr), (vd, vr)):
         close(u.grad, w_.grad, 5e-5, rtol=2e-5, what="attn kv_shift bwd")
+
+
+def test_mesh_loss_kernels(F):
+    """rowloss / face_loss against the torch composition of lib/trains/simplified.py:66-115 and F.l1_loss / F.mse_loss."""
+    G, B, V = 2, 3, 778
+    pred, gt = rnd(G, B, V, 3, seed=1, scale=0.05), rnd(G, B, V, 3, seed=2, scale=0.05)
+    gen = torch.Generator().manual_seed(3)
+    faces = torch.stack([torch.stack([torch.randperm(V, generator=gen)[:3] for _ in range(1538)]) for _ in range(G)])
+    unit = lambda v: TF.normalize(v, p=2, dim=2)
+
+    def ref_terms(p, q, fc):
+        f0, f1, f2 = fc[:, 0], fc[:, 1], fc[:, 2]
+        n = unit(torch.cross(unit(q[:, f1] - q[:, f0]), unit(q[:, f2] - q[:, f0]), dim=2))
+        cos = [torch.abs((unit(v) * n).sum(2, keepdim=True)) for v in (p[:, f1] - p[:, f0], p[:, f2] - p[:, f0], p[:, f2] - p[:, f1])]
+        d = lambda x, i, j: torch.sqrt(((x[:, i] - x[:, j]) ** 2).sum(2, keepdim=True))
+        ed = [torch.abs(d(p, i, j) - d(q, i, j)) for i, j in ((f0, f1), (f0, f2), (f1, f2))]
+        return torch.cat(cos, 1).mean(), torch.cat(ed, 1).mean()
+    pr = pred.clone().requires_grad_()
+    refs = [ref_terms(pr[g], gt[g], faces[g]) for g in range(G)]
+    wn, we = torch.tensor([1.5, -0.7]), torch.tensor([0.3, 2.0])
+    sum(wn[g] * refs[g][0] + we[g] * refs[g][1] for g in range(G)).backward()
+    pd = dev(pred).requires_grad_()
+    nl, el = F.face_loss(pd, dev(gt), dev(faces))
+    (nl * dev(wn) + el * dev(we)).sum().backward()
+    close(nl, torch.stack([r[0] for r in refs]), 1e-6, rtol=2e-5, what="normal loss")
+    close(el, torch.stack([r[1] for r in refs]), 1e-7, rtol=2e-5, what="edge loss")
+    close(pd.grad, pr.grad, 1e-7, rtol=2e-4, what="face loss grad")
+    # without the edge gradient (alpha == 0 in the trainer): only the normal term reaches pred
+    pr.grad = None
+    refs = [ref_terms(pr[g], gt[g], faces[g]) for g in range(G)]
+    sum(wn[g] * refs[g][0] for g in range(G)).backward()
+    pd.grad = None
+    nl, el = F.face_loss(pd, dev(gt), dev(faces), edge_grad=False)
+    (nl * dev(wn) + el * 0.0).sum().backward()
+    close(pd.grad, pr.grad, 1e-7, rtol=2e-4, what="face loss grad (normal only)")
+
+    for mode, rd in (('l1', 2), ('l2', 1), ('l1', 1)):
+        a, b = rnd(2, 5, 21, 3, seed=4), rnd(2, 5, 21, 3, seed=5)
+        b[0, 0, 0, 0] = a[0, 0, 0, 0]                                   # an exact tie: sign(0) = 0 like torch
+        ar = a.clone().requires_grad_()
+        e = (ar - b).abs() if mode == 'l1' else (ar - b) ** 2
+        ref = e.reshape(*a.shape[:rd], -1).mean(-1)
+        w = rnd(*a.shape[:rd], seed=6)
+        (ref * w).sum().backward()
+        ad = dev(a).requires_grad_()
+        out = F.rowloss(ad, dev(b), rd, mode)
+        (out * dev(w)).sum().backward()
+        close(out, ref, 1e-6, what="rowloss " + mode)
+        close(ad.grad, ar.grad, 1e-7, rtol=1e-5, what="rowloss grad " + mode)
