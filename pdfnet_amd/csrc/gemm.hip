@@ -32,6 +32,9 @@ struct IGemm {
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
 
+// the word masked lanes read instead of branching around their load
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ void xcd_tile(int bid, int nblk, int ntn, int& tm, int& tn) {
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous chunk of the
     // tile list so the n-tiles that re-read one A panel hit the same L2 (guide T1, bijective form)
@@ -114,22 +117,22 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
             nt_ci += BK;
             const bool tap_done = nt_ci >= g.Cin;
 #pragma unroll
+            // branch-free: a masked element reads a 16-byte zero word through a SELECTED ADDRESS.  (`if (ok) v = load`
+            // compiles to exec-mask branches with an s_waitcnt vmcnt(0) per load, which serialises the tile's loads.)
             for (int i = 0; i < RA; ++i) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g.plain_in) {
-                    if (aval[i]) v = *reinterpret_cast<const float4*>(Ap + abase[i] + kt * BK + kq);
-                } else {
-                    int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
-                    if (aval[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                        v = *reinterpret_cast<const float4*>(Ap + abase[i] + ((long)iy * g.W + ix) * g.lda + ci0);
+                const float* src;
+                if (g.plain_in) src = aval[i] ? Ap + abase[i] + kt * BK + kq : g_zero16;
+                else {
+                    const int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
+                    const bool ok = aval[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                    src = ok ? Ap + abase[i] + ((long)iy * g.W + ix) * g.lda + ci0 : g_zero16;
                 }
-                ra[i] = v;
+                ra[i] = *reinterpret_cast<const float4*>(src);
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (bval[i]) v = *reinterpret_cast<const float4*>(Bp + bbase[i] + wofs);
-                rb[i] = v;
+                const float* src = bval[i] ? Bp + bbase[i] + wofs : g_zero16;
+                rb[i] = *reinterpret_cast<const float4*>(src);
             }
             if (tap_done && nt_tap + 1 < g.T) {
                 ++nt_tap; nt_ci = 0;
@@ -459,7 +462,6 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
 // K-steps ahead with counted waits (s_waitcnt vmcnt(4)) and one raw s_barrier per step (guide: T3+T4).  The [k][128]
 // tile image is lane-linear (a wave's 64 x 16 B = two consecutive 128-float rows), exactly what LDS-DMA writes; rows past
 // the split's end and padded / out-of-image taps read a 16-byte zero word instead (the source address is per lane).
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 #define GLDS16(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                                           (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
@@ -725,7 +727,9 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     // tile choice: wide tiles when there are enough of them to fill 256 CUs, else smaller ones
     long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;
     // (measured: below ~600 128x128 tiles the 64x64 kernel's 4x block count wins, e.g. ResNet layer2-4)
-    if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600))
+    if (g.N > 64 && fast && (long)cdiv(g.M, 256) * cdiv(g.N, 128) * groups >= env_int("PDF_IG_T256", 1 << 30))
+        launch_igemm_tile<256, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 256) * cdiv(g.N, 128), groups), s);
+    else if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600))
         launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
     else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int("PDF_IG_T128", 600))
         launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s);

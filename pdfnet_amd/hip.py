@@ -12,7 +12,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpdfnet_hip.so")
+LIB_PATH = os.environ.get("PDFNET_HIP_LIB") or os.path.join(_HERE, "libpdfnet_hip.so")   # override: A/B of two builds in one session
 HEADER_PATH = os.path.join(_HERE, "..", "include", "pdfnet_hip.h")
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
