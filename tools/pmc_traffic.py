@@ -13,7 +13,7 @@ import sys
 
 
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -46,6 +46,12 @@ def main():
     res["gemm_family"] = {"hbm_GB_per_step": tot_b / steps / 1e9, "bytes_per_launch": tot_b / max(tot_l, 1)}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["gemm_family"]), json.dumps(res["families"]))
+    # the heaviest single dispatches (reads), for tile-order / reuse work
+    f = (glob.glob(fdir + "/*counter_collection.csv") + glob.glob(fdir + "/*/*counter_collection.csv"))[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE"]
+    rows.sort(key=lambda r: -float(r["Counter_Value"]))
+    for r in rows[:16]:
+        print("%-64s grid %-8s %8.1f MB read" % (r["Kernel_Name"][:64], r.get("Grid_Size", "?"), float(r["Counter_Value"]) * 2 * 1024 / 1e6))
 
 
 if __name__ == "__main__":
