@@ -73,8 +73,6 @@ int pdf_deconv2d_bwd_data(const float* dy, const float* w, float* dx,
 int pdf_deconv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
                             int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                             int stride, int pad, int OH, int OW, int lddy, int accumulate, void* stream);
-/* in [A][T][B] -> out [B][T][A] */
-int pdf_transpose_atb(const float* in, float* out, int A, int T, int B, void* stream);
 /* C[b][m][n] (+)= sum_{r<RB} sum_k A[b,r][m][k] B[b,r][k][n], element strides (0 = broadcast).
  * Small matmuls: avg_head / unsample_layer (intaghand_decoder.py:205,224), full_regressor (Mano_model.py:309-323). */
 int pdf_bmm_strided(const float* A, const float* B, float* C, int batch, int M, int N, int K, int RB,

@@ -637,22 +637,6 @@ __global__ __launch_bounds__(256) void reduce_slabs_2d(const float* __restrict__
     if (ty == 0 && i < n) out[i] = (accumulate ? out[i] : 0.f) + ((sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
 }
 
-// in [A][T][B] -> out [B][T][A]   (weight repacks: OHWI <-> IHWO, Linear W <-> W^T)
-__global__ void transpose_atb(const float* __restrict__ in, float* __restrict__ out, int A, int T, int B) {
-    __shared__ float tile[32][33];
-    const int t = blockIdx.z;
-    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
-    for (int r = threadIdx.y; r < 32; r += 8) {
-        int a = a0 + r, b = b0 + threadIdx.x;
-        tile[r][threadIdx.x] = (a < A && b < B) ? in[((long)a * T + t) * B + b] : 0.f;
-    }
-    __syncthreads();
-    for (int r = threadIdx.y; r < 32; r += 8) {
-        int b = b0 + r, a = a0 + threadIdx.x;
-        if (a < A && b < B) out[((long)b * T + t) * A + a] = tile[threadIdx.x][r];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // host side
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -727,9 +711,8 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     // tile choice: wide tiles when there are enough of them to fill 256 CUs, else smaller ones
     long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;
     // (measured: below ~600 128x128 tiles the 64x64 kernel's 4x block count wins, e.g. ResNet layer2-4)
-    if (g.N > 64 && fast && (long)cdiv(g.M, 256) * cdiv(g.N, 128) * groups >= env_int("PDF_IG_T256", 1 << 30))
-        launch_igemm_tile<256, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 256) * cdiv(g.N, 128), groups), s);
-    else if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600))
+    // (a 256x128 tile -- 128 accumulator registers, one wave per SIMD -- was measured: 104 vs 123 TFLOP/s on the largest conv)
+    if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600))
         launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
     else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int("PDF_IG_T128", 600))
         launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s);
@@ -1026,12 +1009,4 @@ PDF_API int pdf_deconv2d_bwd_weight(const float* x, const float* dy, float* dw, 
             g.dy[t] = (short)(ky - pad); g.dx[t] = (short)(kx - pad); g.wt[t] = (short)t;
         }
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s);
-}
-
-PDF_API int pdf_transpose_atb(const float* in, float* out, int A, int T, int B, hipStream_t s) {
-    if (A <= 0 || T <= 0 || B <= 0) return 0;
-    dim3 grid(cdiv(B, 32), cdiv(A, 32), T);
-    hipLaunchKernelGGL(transpose_atb, grid, dim3(32, 8), 0, s, in, out, A, T, B);
-    PDF_LAUNCH_CHECK();
-    return 0;
 }
