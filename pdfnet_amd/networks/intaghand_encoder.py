@@ -90,6 +90,8 @@ def _sa_mlp(cin, dims):
     return mods + [Slot()]          # index 9 = the reference's MaxPool2d slot
 
 
+
+
 class PointNet_Plus(nn.Module):
     """intaghand_encoder.py:32-159.  One call per hand (BN batch statistics are per hand, :805-806)."""
 
@@ -111,18 +113,30 @@ class PointNet_Plus(nn.Module):
         return x
 
     def forward(self, cloud, emb, choose):
+        return self.stage_b(*self.stage_a(cloud, emb[0], emb[1], choose), emb[2], choose)
+
+    def stage_a(self, cloud, emb0, emb1, choose):
+        """Set-abstraction levels 1 and 2 (:120-145).  They read only the two shallow embeddings (e_conv1 and the stem), so
+        the encoder starts them on a side stream next to the ResNet trunk: HBM-bound point kernels under MFMA-bound convs."""
         o = self.opt
         R, S1, S2, K = o.default_resolution, o.sample_num_level1, o.sample_num_level2, o.knn_K
         B = cloud.shape[0]
-        pts = self.sft0(cloud, F.gather_rows(emb[0], choose))                              # [B,1024,3]   (:120-122)
+        pts = self.sft0(cloud, F.gather_rows(emb0, choose))                                # [B,1024,3]   (:120-122)
         g1, _ = F.knn_ball_group(pts, 3, S1, K, o.ball_radius, _pad16(3))                  # [B,S1,K,16]  (:123)
         x = F.max_over_k(self._mlp(self.netR_1, g1).view(B * S1, K, 128))                  # [B*S1,128]   (:132)
-        e1 = F.gather_rows(emb[1], choose[:, :S1], R, 1)                                   # [B,S1,64]    (:125-127)
+        e1 = F.gather_rows(emb1, choose[:, :S1], R, 1)                                     # [B,S1,64]    (:125-127)
         x = torch.cat((pts[:, :S1], x.view(B, S1, 128)), 2)                                # [B,S1,131]   (:134)
         x = self.sft1(x, e1)                                                               #              (:137)
         g2, _ = F.knn_ball_group(x, 131, S2, K, o.ball_radius2, _pad16(131))               # [B,S2,K,144] (:139)
         y = F.max_over_k(self._mlp(self.netR_2, g2).view(B * S2, K, 256))                  # [B*S2,256]
-        e2 = F.gather_rows(emb[2], choose[:, :S2], R, 2)                                   # [B,S2,256]   (:126,128)
+        return x, y
+
+    def stage_b(self, x, y, emb2, choose):
+        """Level 3 (:146-152): needs the fused pyramid feature map x0."""
+        o = self.opt
+        R, S2 = o.default_resolution, o.sample_num_level2
+        B = x.shape[0]
+        e2 = F.gather_rows(emb2, choose[:, :S2], R, 2)                                     # [B,S2,256]   (:126,128)
         y = torch.cat((x[:, :S2, :3], y.view(B, S2, 256)), 2)                              # [B,S2,259]
         y = self.sft2(y, e2)                                                               #              (:147)
         y = torch.nn.functional.pad(y, (0, _pad16(259) - 259))
@@ -229,14 +243,20 @@ class ResNetSimple(nn.Module):
         img = F.cl(img)
         emb0 = self.e_conv1(img, F.ACT_RELU)                                              # :711
         emb1 = r.bn1(r.conv1(img), relu=True)                                             # :712-715
+        have_clouds = choose is not None and cloud is not None
+        f_pn = None
+        if have_clouds:                                                                    # measured: 374 vs 348 img/s
+            pn = self.pointnet_plus                                                        # left first: BN update order (:805-806)
+            f_pn = F.fork(lambda: (pn.stage_a(cloud[:, 0], emb0, emb1, choose[:, 0]), pn.stage_a(cloud[:, 1], emb0, emb1, choose[:, 1])))
         x4 = r.layer1(F.maxpool3s2(emb1))
         x3 = r.layer2(x4)
         x2 = r.layer3(x3)
         x1 = r.layer4(x2)
+        st = {'x1': x1, 'ret': {}}
         pyr = torch.cat([self.p2_l2(self.p2(x4)), self.p3_l2(self.p3(x3)),
                          self.p4_l2(self.p4(x2)), self.p5_l2(self.p5(x1))], 1)            # NHWC channel concat
         x0 = self.feat_bn(self.feat(pyr), relu=True)                                      # :740-744
-        st = {'x0': x0, 'x1': x1, 'ret': {}}
+        st['x0'] = x0
         hm_fc = self.hm
         st['ret']['hm'] = hm_fc[2](hm_fc[0](x0, F.ACT_RELU))                               # 'hm' is first in opt.heads (:291)
         if ind is None:                                                                    # :750-758
@@ -253,8 +273,13 @@ class ResNetSimple(nn.Module):
             if valid is None:
                 valid = torch.ones((img.shape[0], 2), device=img.device)
             choose, cloud, _ = F.depth2pcl(depth, st['dp'][0], K_new, valid)
-        fl = self.pointnet_plus(cloud[:, 0], emb, choose[:, 0])                            # :805
-        fr = self.pointnet_plus(cloud[:, 1], emb, choose[:, 1])                            # :806 (same module: left BN update first)
+        if f_pn is not None:
+            al, ar = f_pn.join()
+            fl = self.pointnet_plus.stage_b(*al, x0, choose[:, 0])
+            fr = self.pointnet_plus.stage_b(*ar, x0, choose[:, 1])
+        else:
+            fl = self.pointnet_plus(cloud[:, 0], emb, choose[:, 0])                        # :805
+            fr = self.pointnet_plus(cloud[:, 1], emb, choose[:, 1])                        # :806 (same module: left BN update first)
         center = f_center.join()
         fuse = self.sft(torch.cat((fl, fr), 1), center)                                    # [B,2,1024]  (:807-809)
         st['img_fmaps'] = [fuse, x2, x3, x4]
@@ -263,7 +288,9 @@ class ResNetSimple(nn.Module):
 
     def dense_branches(self, st):
         """The two up-sampling decoders (need only x1) and the wh / params heads (need only x0; no loss term): heavy
-        convolutions with few launches, each on its own side stream."""
+        convolutions with few launches, each on its own side stream, joined right away.  (Starting them as early as their
+        inputs exist, next to the pyramid / feat convolutions, was measured: 346 vs 366 img/s -- MFMA-bound work gains
+        nothing from running beside MFMA-bound work; only the HBM-bound PointNet++ levels are started early.)"""
         x0, x1 = st['x0'], st['x1']
         f_hms = F.fork(lambda: self.hms_decoder(x1))
         f_dp = F.fork(lambda: self.dp_decoder(x1)) if 'dp' not in st else None
