@@ -120,9 +120,11 @@ int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float* gamma,
 int pdf_bn_eval_fwd(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
                     const float* running_mean, const float* running_var, float eps,
                     const float* res, int ldr, int relu, float* y, int ldy, float* scale, float* shift, void* stream);
-/* ws >= pdf_bn_workspace_floats(C,R) + 3*C */
+/* ws >= pdf_bn_workspace_floats(C,R) + 3*C.  relu: 0 none; 1 ReLU, mask read from the saved output y; 2 ReLU with no
+ * residual: mask recomputed from x with the forward's scale / shift (y may be NULL, dres must be NULL) */
 int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy, int relu, const float* x, int ldx,
-                     const float* save_mean, const float* save_rstd, const float* gamma, int C, long R,
+                     const float* save_mean, const float* save_rstd, const float* gamma,
+                     const float* scale, const float* shift, int C, long R,
                      float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
                      float* ws, void* stream);
 /* out[c] (+)= sum_r g[r][c] (bias gradients); ws >= pdf_bn_workspace_floats(C,R) */

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / C;
         const int c = (int)(i - r * C);
-        float v = x[r * ldx + c] * scale[c] + shift[c];
+        float v = fmaf(x[r * ldx + c], scale[c], shift[c]);
         if (res != nullptr) v += res[r * ldr + c];
         if (relu) v = fmaxf(v, 0.f);
         y[r * ldy + c] = v;
@@ -148,9 +148,12 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
     v4_block_reduce(a, b, sa, sb, part, C, c0, true);
 }
 
+// relu == 2: no residual went into the ReLU, so its mask is recomputed from x as fmaf(x, scale, shift) > 0 -- the exact
+// expression of the forward -- and y is not read at all
 __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int relu,
                                                                 const float* __restrict__ x, int ldx, const float* __restrict__ mean,
-                                                                const float* __restrict__ rstd, int C, long R, long rows_per_chunk,
+                                                                const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int C, long R, long rows_per_chunk,
                                                                 float* __restrict__ part) {
     __shared__ float4 sa[V4_TY][V4_TX], sb[V4_TY][V4_TX];
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
@@ -159,12 +162,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (c0 < C) {
         const float4 m = *reinterpret_cast<const float4*>(mean + c0), rs = *reinterpret_cast<const float4*>(rstd + c0);
+        float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+        if (relu == 2) { sc = *reinterpret_cast<const float4*>(scale + c0); sh = *reinterpret_cast<const float4*>(shift + c0); }
 #pragma unroll 4
         for (long r = r0 + ty; r < r1; r += V4_TY) {
             float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c0);
             const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c0);
             if (relu) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c0);
+                const float4 yv = relu == 2 ? make_float4(fmaf(xv.x, sc.x, sh.x), fmaf(xv.y, sc.y, sh.y), fmaf(xv.z, sc.z, sh.z), fmaf(xv.w, sc.w, sh.w))
+                                            : *reinterpret_cast<const float4*>(y + r * ldy + c0);
                 if (!(yv.x > 0.f)) g.x = 0.f;
                 if (!(yv.y > 0.f)) g.y = 0.f;
                 if (!(yv.z > 0.f)) g.z = 0.f;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __res
 #pragma unroll 4
     for (long r = r0 + ty; r < r1; r += V4_TY) {
         const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c0);
-        float4 v = make_float4(xv.x * sc.x + sh.x, xv.y * sc.y + sh.y, xv.z * sc.z + sh.z, xv.w * sc.w + sh.w);
+        float4 v = make_float4(fmaf(xv.x, sc.x, sh.x), fmaf(xv.y, sc.y, sh.y), fmaf(xv.z, sc.z, sh.z), fmaf(xv.w, sc.w, sh.w));
         if (res != nullptr) {
             const float4 rv = *reinterpret_cast<const float4*>(res + r * ldr + c0);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
@@ -222,7 +228,8 @@ __global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int relu,
                                                               const float* __restrict__ x, int ldx, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, const float* __restrict__ coef, int C, long R,
+                                                              const float* __restrict__ rstd, const float* __restrict__ coef,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, int C, long R,
                                                               long rows_per_chunk, float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddr) {
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
@@ -231,12 +238,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
     const float4 m = *reinterpret_cast<const float4*>(mean + c0), rs = *reinterpret_cast<const float4*>(rstd + c0);
     const float4 ka = *reinterpret_cast<const float4*>(coef + c0), k1 = *reinterpret_cast<const float4*>(coef + C + c0),
                  k2 = *reinterpret_cast<const float4*>(coef + 2 * C + c0);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+    if (relu == 2) { sc = *reinterpret_cast<const float4*>(scale + c0); sh = *reinterpret_cast<const float4*>(shift + c0); }
 #pragma unroll 4
     for (long r = r0 + ty; r < r1; r += V4_TY) {
         float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c0);
         const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c0);
         if (relu) {
-            const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c0);
+            const float4 yv = relu == 2 ? make_float4(fmaf(xv.x, sc.x, sh.x), fmaf(xv.y, sc.y, sh.y), fmaf(xv.z, sc.z, sh.z), fmaf(xv.w, sc.w, sh.w))
+                                        : *reinterpret_cast<const float4*>(y + r * ldy + c0);
             if (!(yv.x > 0.f)) g.x = 0.f;
             if (!(yv.y > 0.f)) g.y = 0.f;
             if (!(yv.z > 0.f)) g.z = 0.f;
@@ -328,7 +338,8 @@ PDF_API int pdf_bn_eval_fwd(const float* x, int ldx, int C, long R, const float*
 // backward partials: sum(g), sum(g * xhat) with g = dy * (y > 0 if relu)
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int relu,
                                                              const float* __restrict__ x, int ldx, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, int C, long R, long rows_per_chunk,
+                                                             const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int C, long R, long rows_per_chunk,
                                                              float* __restrict__ part) {
     __shared__ float s1[4][BN_CT], s2[4][BN_CT];
     const int tx = threadIdx.x & (BN_CT - 1), ty = threadIdx.x / BN_CT;
@@ -340,7 +351,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const float m = mean[c], rs = rstd[c];
         for (long r = r0 + ty; r < r1; r += 4) {
             float g = dy[r * lddy + c];
-            if (relu && !(y[r * ldy + c] > 0.f)) g = 0.f;
+            if (relu && !((relu == 2 ? fmaf(x[r * ldx + c], scale[c], shift[c]) : y[r * ldy + c]) > 0.f)) g = 0.f;
             a += g; b += g * (x[r * ldx + c] - m) * rs;
         }
     }
@@ -370,13 +381,14 @@ __global__ __launch_bounds__(FIN_TX * FIN_TY) void bn_bwd_finalize_kernel(const 
 // dx = a * (g - c1 - xhat * c2);  dres = g (optional)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int relu,
                                                            const float* __restrict__ x, int ldx, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ coef, int C, long total,
+                                                           const float* __restrict__ rstd, const float* __restrict__ coef,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int C, long total,
                                                            float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddr) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / C;
         const int c = (int)(i - r * C);
         float g = dy[r * lddy + c];
-        if (relu && !(y[r * ldy + c] > 0.f)) g = 0.f;
+        if (relu && !((relu == 2 ? fmaf(x[r * ldx + c], scale[c], shift[c]) : y[r * ldy + c]) > 0.f)) g = 0.f;
         if (dres != nullptr) dres[r * lddr + c] = g;
         const float xh = (x[r * ldx + c] - mean[c]) * rstd[c];
         dx[r * lddx + c] = coef[c] * (g - coef[C + c] - xh * coef[2 * C + c]);
@@ -384,31 +396,37 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ws: pdf_bn_workspace_floats(C,R) + 3*C floats
+// relu: 0 none; 1 ReLU, mask from the saved output y; 2 ReLU without residual, mask recomputed from x with the forward's
+// scale / shift (y may be NULL: two fewer full-tensor reads)
 PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy, int relu, const float* x, int ldx,
-                             const float* save_mean, const float* save_rstd, const float* gamma, int C, long R,
+                             const float* save_mean, const float* save_rstd, const float* gamma,
+                             const float* scale, const float* shift, int C, long R,
                              float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
                              float* ws, hipStream_t s) {
     if (R <= 0 || C <= 0) return 0;
+    if ((relu == 1 && y == nullptr) || (relu == 2 && (scale == nullptr || shift == nullptr || dres != nullptr))) return PDF_E_BADARG;
     long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
     float* coef = ws + pdf_bn_workspace_floats(C, R);
-    if (v4_ok(C, {lddy, ldx, relu ? ldy : 0}, {dy, x, relu ? y : nullptr, save_mean, save_rstd}))
+    const bool vec = v4_ok(C, {lddy, ldx, lddx, relu == 1 ? ldy : 0, dres ? lddr : 0},
+                           {dy, x, dx, dres, relu == 1 ? y : nullptr, save_mean, save_rstd, coef, relu == 2 ? scale : nullptr, relu == 2 ? shift : nullptr});
+    if (vec)
         hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
-                           save_mean, save_rstd, C, R, rpc, ws);
+                           save_mean, save_rstd, scale, shift, C, R, rpc, ws);
     else
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
-                           save_mean, save_rstd, C, R, rpc, ws);
+                           save_mean, save_rstd, scale, shift, C, R, rpc, ws);
     PDF_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, R, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
     PDF_LAUNCH_CHECK();
-    if (v4_ok(C, {lddy, ldx, lddx, relu ? ldy : 0, dres ? lddr : 0}, {dy, x, dx, dres, relu ? y : nullptr, save_mean, save_rstd, coef})) {
+    if (vec) {
         const long arpc = apply_rows_per_chunk(C, R);
         hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)((R + arpc - 1) / arpc)), dim3(256), 0, s, dy, lddy, y, ldy, relu,
-                           x, ldx, save_mean, save_rstd, coef, C, R, arpc, dx, lddx, dres, lddr);
+                           x, ldx, save_mean, save_rstd, coef, scale, shift, C, R, arpc, dx, lddx, dres, lddr);
     } else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef, C, R * C,
-                           dx, lddx, dres, lddr);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef,
+                           scale, shift, C, R * C, dx, lddx, dres, lddr);
     PDF_LAUNCH_CHECK();
     return 0;
 }

@@ -462,19 +462,25 @@ class _BatchNorm(Function):
             ws = _ws(L.pdf_bn_workspace_floats(C, R), dev)
             L.pdf_bn_train_fwd(ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
                                ptr(res), C, int(relu), ptr(y), C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
-            ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
+            # ReLU without a residual: the backward recomputes the mask from x with (scale, shift); y is not kept for it
+            recompute = relu and res is None
+            ctx.save_for_backward(x, gamma, mean, rstd, (scale if recompute else (y if relu else None)), (shift if recompute else None))
         else:
             L.pdf_bn_eval_fwd(ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps,
                               ptr(res), C, int(relu), ptr(y), C, ptr(scale), ptr(shift), stream())
-            ctx.save_for_backward(x, gamma, None, None, y if relu else None)
+            ctx.save_for_backward(x, gamma, None, None, y if relu else None, None)
         ctx.cfg = (training, relu, res is not None, eps)
         ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean, rstd, y = ctx.saved_tensors
+        x, gamma, mean, rstd, y, shift = ctx.saved_tensors
         training, relu, has_res, eps = ctx.cfg
+        scale = None
+        mode = int(relu)
+        if relu and not has_res:
+            scale, y, mode = y, None, 2
         if not training:
             raise RuntimeError("pdfnet_amd: BatchNorm backward in eval mode is not implemented")
         R, C = _rows(x)
@@ -488,7 +494,7 @@ class _BatchNorm(Function):
         dbeta = mg_b if direct else torch.empty(C, device=x.device)
         L = _L()
         ws = _ws(L.pdf_bn_workspace_floats(C, R) + 3 * C, x.device)
-        L.pdf_bn_train_bwd(ptr(g), C, ptr(y), C, int(relu), ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), C, R,
+        L.pdf_bn_train_bwd(ptr(g), C, ptr(y), C, mode, ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R,
                            ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream())
         if direct:
             dgamma = dbeta = None

@@ -46,7 +46,7 @@ def main():
         t_f = timeit(lambda: F.batch_norm(x, g, b, rm, rv, True, 0.1, 1e-5, True, r))
         t_b = timeit(lambda: torch.autograd.grad(y, [x] + ([r] if res else []), gy, retain_graph=True))
         report(name + " fwd", n * (3 + (1 if res else 0)), t_f)               # stats read, apply read (+res), write
-        report(name + " bwd", n * (7 + (1 if res else 0)), t_b)               # (dy,x,y) twice, dx (+dres) write
+        report(name + " bwd", n * (8 if res else 5), t_b)                     # residual: (dy,x,y) twice + dx + dres; else (dy,x) twice + dx
     for name, C, H in (("l2norm 256@64", 256, 64),):
         if flt not in name:
             continue
