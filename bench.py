@@ -44,8 +44,8 @@ class GemmProfiler:
              'pdf_linear_bwd_weight_pair', 'pdf_conv2d_fwd', 'pdf_conv2d_bwd_data', 'pdf_conv2d_bwd_weight',
              'pdf_deconv2d_fwd', 'pdf_deconv2d_bwd_data', 'pdf_deconv2d_bwd_weight')
     # position of (M, N, K) in the argument list and the number of GEMMs per call, include/pdfnet_hip.h
-    LINEAR = {'pdf_linear_fwd': (4, 1), 'pdf_linear_bwd_data': (3, 1), 'pdf_linear_bwd_weight': (5, 1),
-              'pdf_linear_fwd_pair': (6, 2), 'pdf_linear_bwd_data_pair': (4, 2), 'pdf_linear_bwd_weight_pair': (6, 2)}
+    LINEAR = {'pdf_linear_fwd': (4, 1), 'pdf_linear_bwd_data': (3, 1), 'pdf_linear_bwd_weight': (6, 1),
+              'pdf_linear_fwd_pair': (6, 2), 'pdf_linear_bwd_data_pair': (4, 2), 'pdf_linear_bwd_weight_pair': (8, 2)}
 
     def __init__(self):
         from pdfnet_amd import hip
@@ -59,7 +59,7 @@ class GemmProfiler:
             off, n = GemmProfiler.LINEAR[name]
             return 2.0 * n * a[off] * a[off + 1] * a[off + 2]
         # conv family: (..., N, H, W, Cin, ld, Cout, KH, KW, stride, pad, OH, OW, ...)
-        off = {'pdf_conv2d_fwd': 4, 'pdf_conv2d_bwd_data': 3, 'pdf_conv2d_bwd_weight': 5,
+        off = {'pdf_conv2d_fwd': 4, 'pdf_conv2d_bwd_data': 3, 'pdf_conv2d_bwd_weight': 6,
                'pdf_deconv2d_fwd': 4, 'pdf_deconv2d_bwd_data': 3, 'pdf_deconv2d_bwd_weight': 5}[name]
         N, H, W, Cin, _, Cout, KH, KW, stride, pad, OH, OW = a[off:off + 12]
         if name.startswith('pdf_conv2d'):

@@ -32,8 +32,9 @@ extern "C" {
  * model_attn/gcn.py:66 (cl(x)), self_attn.py:66-68,79, intaghand_encoder.py:48-103 (netR_*), :213-218 (SFT convs). */
 int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
                    int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream);
-/* dW[N][K] (+)= dy[M][N]^T x[M][K]; ws >= pdf_wgrad_workspace_floats(M,N,K) floats. (autograd of the above) */
-int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+/* dW[N][K] (+)= dy[M][N]^T x[M][K]; ws >= pdf_wgrad_workspace_floats(M,N,K) floats. (autograd of the above)
+ * db != NULL: also db[N] (+)= column sums of dy (the bias gradient rides along in the same launches). */
+int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                           int M, int N, int K, int ldx, int lddy, int accumulate, void* stream);
 long pdf_wgrad_workspace_floats(int M, int NI, int NJ);
 /* dx[M][K] = dy[M][N] w[N][K] (autograd of nn.Linear wrt its input); w is read in its forward storage */
@@ -46,8 +47,8 @@ int pdf_linear_fwd_pair(const float* x, const float* w0, const float* w1, const 
                         int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream);
 int pdf_linear_bwd_data_pair(const float* dy, const float* w0, const float* w1, float* dx, int M, int N, int K,
                              int lddy, int ldw, int lddx, void* stream);
-int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* dw0, float* dw1, float* ws, long ws_floats,
-                               int M, int N, int K, int ldx, int lddy, int accumulate, void* stream);
+int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* dw0, float* dw1, float* db0, float* db1,
+                               float* ws, long ws_floats, int M, int N, int K, int ldx, int lddy, int accumulate, void* stream);
 
 /* nn.Conv2d forward on NHWC: lib/models/networks/resnet.py:202-218 (trunk), intaghand_encoder.py:602 (p2),
  * :617 (feat), :621 (e_conv1), :627-628 (center_feat_up0/1), :675-693 (heads), :270-316 (decoders). */
@@ -58,7 +59,7 @@ int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
 int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
                         int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
                         int stride, int pad, int OH, int OW, int lddy, void* stream);
-int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                           int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                           int stride, int pad, int OH, int OW, int lddy, int accumulate, void* stream);
 

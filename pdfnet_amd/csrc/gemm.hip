@@ -266,6 +266,9 @@ struct WGemm {
     int beta;                                 // single-split launches write dW directly: dW = beta*dW + acc
     // group 1 of a paired launch (blockIdx.z == 1): P, Q advanced by gsP / gsQ floats, own slab (or output when one split)
     long gsP, gsQ; float* slab1;
+    // optional bias gradient (column sums of P) riding along: per-split partials [split][NI] (or the output itself when one
+    // split), accumulated by the j-tile-0 blocks from the P tiles they stage anyway
+    float* bslab; float* bslab1;
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
 
@@ -279,8 +282,8 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     __shared__ __attribute__((aligned(16))) float Qs[2][BK * BJ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab;
-    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; }
+    const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab; float* bslabp = g.bslab;
+    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; bslabp = g.bslab1; }
     const int wm = wave / WN, wn = wave % WN;
     const int NJ = g.T * g.Cq;
     const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
@@ -301,6 +304,8 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
         xcd_tile(blockIdx.x, nti * ntj, ntj, ti, tj);
     }
     const int i0 = ti * BI, j0 = tj * BJ;
+    const bool do_bias = bslabp != nullptr && tj == 0 && tid < BI;
+    float bsum = 0.f;
     const int ms = blockIdx.y * g.rows_per_split;
     const int me = min(g.M, ms + g.rows_per_split);
 
@@ -416,6 +421,10 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
         if (more) gload(mb + BK);
         const float* ps = Ps[cur];
         const float* qs = Qs[cur];
+        if (do_bias) {
+#pragma unroll
+            for (int kb = 0; kb < BK; ++kb) bsum += ps[kb * BI + tid];
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], b[TN];
@@ -434,6 +443,10 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
         cur ^= 1;
     }
 
+    if (do_bias && i0 + tid < g.NI) {
+        float* bo = bslabp + (long)blockIdx.y * g.NI + i0 + tid;
+        *bo = g.beta ? *bo + bsum : bsum;
+    }
     float* out = slabp + (long)blockIdx.y * g.NI * g.ldw;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -471,8 +484,8 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     constexpr int BI = 128, BJ = 128, BK = 16, WN = 2, TM = 2, TN = 2;
     __shared__ __attribute__((aligned(16))) float smem[ST * 2 * BK * 128];     // [stage][P|Q][k][128]  (48 KB, ONE array)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab;
-    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; }
+    const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab; float* bslabp = g.bslab;
+    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; bslabp = g.bslab1; }
     const int wm = wave / WN, wn = wave % WN;
     const int NJ = g.T * g.Cq;
     const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
@@ -489,6 +502,8 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
         xcd_tile(blockIdx.x, nti * ntj, ntj, ti, tj);
     }
     const int i0 = ti * BI, j0 = tj * BJ;
+    const bool do_bias = bslabp != nullptr && tj == 0 && tid < BI;
+    float bsum = 0.f;
     const int ms = blockIdx.y * g.rows_per_split;
     const int me = min(g.M, ms + g.rows_per_split);
     const int nt = (me - ms + BK - 1) / BK;
@@ -576,6 +591,10 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
         issue(t + ST - 1, stn);                             // refill the stage tile t-1 used (rows past the end read zeros)
         const float* ps = smem + (st * 2 + 0) * BK * 128;
         const float* qs = smem + (st * 2 + 1) * BK * 128;
+        if (do_bias) {
+#pragma unroll
+            for (int kb = 0; kb < BK; ++kb) bsum += ps[kb * 128 + tid];
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], b[TN];
@@ -594,6 +613,10 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
 
+    if (do_bias && i0 + tid < g.NI) {
+        float* bo = bslabp + (long)blockIdx.y * g.NI + i0 + tid;
+        *bo = g.beta ? *bo + bsum : bsum;
+    }
     float* out = slabp + (long)blockIdx.y * g.NI * g.ldw;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -614,27 +637,42 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     }
 }
 
-// (both reducers: blockIdx.y == 1 is group 1 of a paired launch -- slab advanced by splits*n, own output)
-__global__ void reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, float* __restrict__ out1, long n, int splits, int accumulate) {
-    if (blockIdx.y) { slab += (long)splits * n; out = out1; }
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float s = accumulate ? out[i] : 0.f;
-        for (int z = 0; z < splits; ++z) s += slab[(long)z * n + i];
+// Slab reducers.  blockIdx.y == 1 is group 1 of a paired launch (slabs after group 0's, own outputs).  A launch may carry a
+// second, short segment -- the bias-gradient partials [splits][nb] behind the weight slabs -- handled by the trailing blocks.
+struct Reduce {
+    const float* slab; float* out; float* out1; long n;          // weight gradient: [groups][splits][n] -> out / out1
+    const float* bslab; float* bout; float* bout1; int nb;        // bias gradient:   [groups][splits][nb] -> bout / bout1 (nb = 0: none)
+    int splits, accumulate;
+};
+__global__ void reduce_slabs(const Reduce r, int main_blocks) {
+    const bool bias = (int)blockIdx.x >= main_blocks;
+    const float* slab = bias ? r.bslab : r.slab;
+    float* out = bias ? (blockIdx.y ? r.bout1 : r.bout) : (blockIdx.y ? r.out1 : r.out);
+    const long n = bias ? r.nb : r.n;
+    if (blockIdx.y) slab += (long)r.splits * n;
+    const long b0 = bias ? blockIdx.x - main_blocks : blockIdx.x, nblk = bias ? gridDim.x - main_blocks : main_blocks;
+    for (long i = b0 * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) {
+        float s = r.accumulate ? out[i] : 0.f;
+        for (int z = 0; z < r.splits; ++z) s += slab[(long)z * n + i];
         out[i] = s;
     }
 }
 
 // many splits over a small matrix: 64 elements x 4 split-lanes per block, fixed summation tree (deterministic)
-__global__ __launch_bounds__(256) void reduce_slabs_2d(const float* __restrict__ slab, float* __restrict__ out, float* __restrict__ out1, long n, int splits, int accumulate) {
+__global__ __launch_bounds__(256) void reduce_slabs_2d(const Reduce r, int main_blocks) {
     __shared__ float sm[4][64];
-    if (blockIdx.y) { slab += (long)splits * n; out = out1; }
+    const bool bias = (int)blockIdx.x >= main_blocks;
+    const float* slab = bias ? r.bslab : r.slab;
+    float* out = bias ? (blockIdx.y ? r.bout1 : r.bout) : (blockIdx.y ? r.out1 : r.out);
+    const long n = bias ? r.nb : r.n;
+    if (blockIdx.y) slab += (long)r.splits * n;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const long i = blockIdx.x * 64L + tx;
+    const long i = (bias ? blockIdx.x - main_blocks : blockIdx.x) * 64L + tx;
     float s = 0.f;
-    if (i < n) for (int z = ty; z < splits; z += 4) s += slab[(long)z * n + i];
+    if (i < n) for (int z = ty; z < r.splits; z += 4) s += slab[(long)z * n + i];
     sm[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && i < n) out[i] = (accumulate ? out[i] : 0.f) + ((sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
+    if (ty == 0 && i < n) out[i] = (r.accumulate ? out[i] : 0.f) + ((sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -829,7 +867,9 @@ PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
 }
 
 // out1 != nullptr: paired launch (see WGemm::gsP); ws then holds both groups' slabs
-static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int accumulate, hipStream_t s, float* out1 = nullptr) {
+// db / db1 != nullptr: also the bias gradient (column sums of P), see WGemm::bslab
+static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int accumulate, hipStream_t s, float* out1 = nullptr,
+                        float* db = nullptr, float* db1 = nullptr) {
     const int NJ = g.T * g.Cq;
     if (g.M <= 0 || g.NI <= 0 || NJ <= 0) return 0;
     const int groups = out1 ? 2 : 1;
@@ -847,7 +887,8 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     int max_by_rows = cdiv(g.M, env_int("PDF_WG_MINROWS", g.M >= 16384 ? 512 : 128));
     if (splits > max_by_rows) splits = max_by_rows;
     long per = (long)g.NI * g.ldw;
-    if ((long)splits * per * groups > ws_floats) splits = (int)(ws_floats / (per * groups));
+    const long perb = db ? g.NI : 0;
+    if ((long)splits * (per + perb) * groups > ws_floats) splits = (int)(ws_floats / ((per + perb) * groups));
     if (splits < 1) splits = 1;
     int rps = cdiv(cdiv(g.M, splits), 16) * 16;
     splits = cdiv(g.M, rps);
@@ -855,6 +896,9 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     g.tap_major = (!g.plain_q && g.T > 1 && g.Cq % BJ == 0 && env_int("PDF_WG_TAPMAJOR", 1)) ? 1 : 0;
     g.slab = splits == 1 ? out : ws;          // one split: no slab round trip, no reduce launch
     g.slab1 = splits == 1 ? out1 : ws + (long)splits * per;
+    float* bws = ws + (long)splits * per * groups;              // bias partials behind the weight slabs
+    g.bslab = db ? (splits == 1 ? db : bws) : nullptr;
+    g.bslab1 = db ? (splits == 1 ? db1 : bws + (long)splits * perb) : nullptr;
     g.beta = splits == 1 ? accumulate : 0;
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     if (small) {
@@ -869,10 +913,14 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     }
     PDF_LAUNCH_CHECK();
     if (splits > 1) {
-        if (splits >= 16 && per <= (1L << 20))
-            hipLaunchKernelGGL(reduce_slabs_2d, dim3((unsigned)((per + 63) / 64), groups), dim3(256), 0, s, ws, out, out1, per, splits, accumulate);
-        else
-            hipLaunchKernelGGL(reduce_slabs, dim3(grid_for(per), groups), dim3(256), 0, s, ws, out, out1, per, splits, accumulate);
+        Reduce r = {ws, out, out1, per, bws, db, db1, (int)perb, splits, accumulate};
+        if (splits >= 16 && per <= (1L << 20)) {
+            const int mb = (int)((per + 63) / 64);
+            hipLaunchKernelGGL(reduce_slabs_2d, dim3(mb + (int)((perb + 63) / 64), groups), dim3(256), 0, s, r, mb);
+        } else {
+            const int mb = grid_for(per);
+            hipLaunchKernelGGL(reduce_slabs, dim3(mb + (perb ? cdiv(perb, 256) : 0), groups), dim3(256), 0, s, r, mb);
+        }
         PDF_LAUNCH_CHECK();
     }
     return 0;
@@ -887,32 +935,32 @@ PDF_API long pdf_wgrad_workspace_floats(int M, int NI, int NJ) {
     int max_by_rows = cdiv(M, 128);
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
-    return (long)splits * NI * NJ;
+    return (long)splits * ((long)NI * NJ + NI);           // weight slabs + bias partials
 }
 
 // dW[N][K] (+)= dy[M][N]^T x[M][K]   (Linear / 1x1 weight gradient)
-PDF_API int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+PDF_API int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) {
     WGemm g = {};
     g.P = dy; g.Q = x; g.M = M; g.NI = N; g.Cq = K; g.T = 1; g.ldp = lddy; g.ldq = ldx; g.ldw = K;
     g.plain_q = 1; g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
     g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
-    return launch_wgemm(g, dw, ws, ws_floats, accumulate, s);
+    return launch_wgemm(g, dw, ws, ws_floats, accumulate, s, nullptr, db);
 }
 
 // paired form of the above: rows [0, M) -> dw0, rows [M, 2M) -> dw1; ws >= 2 * pdf_wgrad_workspace_floats(M, N, K)
-PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* dw0, float* dw1, float* ws, long ws_floats,
-                                       int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) {
+PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* dw0, float* dw1, float* db0, float* db1,
+                                       float* ws, long ws_floats, int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) {
     WGemm g = {};
     g.P = dy; g.Q = x; g.M = M; g.NI = N; g.Cq = K; g.T = 1; g.ldp = lddy; g.ldq = ldx; g.ldw = K;
     g.plain_q = 1; g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
     g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
     g.gsP = (long)M * lddy; g.gsQ = (long)M * ldx;
-    return launch_wgemm(g, dw0, ws, ws_floats, accumulate, s, dw1);
+    return launch_wgemm(g, dw0, ws, ws_floats, accumulate, s, dw1, db0, db1);
 }
 
 // dW[Cout][KH][KW][Cin] (+)= sum over output pixels dy[m][co] * x[pos(m,tap)][ci]
-PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                                   int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
@@ -926,7 +974,7 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
             int t = ky * KW + kx;
             g.dy[t] = (short)(ky - pad); g.dx[t] = (short)(kx - pad); g.wt[t] = (short)t;
         }
-    return launch_wgemm(g, dw, ws, ws_floats, accumulate, s);
+    return launch_wgemm(g, dw, ws, ws_floats, accumulate, s, nullptr, db);
 }
 
 // ConvTranspose2d forward on NHWC: y[n, iy*s - pad + ky, ix*s - pad + kx, co] += x[n,iy,ix,ci] w[ci][co][ky][kx].

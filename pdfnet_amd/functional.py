@@ -194,27 +194,32 @@ def _colsum(g, C, R, ldg):
 ASYNC_WGRAD_MIN_FLOP = float(_os.environ.get("PDFNET_ASYNC_WGRAD_MIN_GFLOP", "0")) * 1e9
 
 
-def _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, C, R, flops):
+def _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, C, R, flops, fused_bias=False):
     """Weight and bias gradients of a conv / transposed conv / linear layer.  Gradients that go straight into the
     trainer's flat buffer are issued together on the side stream (one stream switch for both).  A size threshold for the
     switch was measured (PDFNET_ASYNC_WGRAD_MIN_GFLOP = 0 / 0.5 / 4 -> 316 / 311 / 298 img/s): even the smallest layers
-    gain from leaving the dependent main-stream chain, so the default is 0.  Returns (dw, db) for autograd (None when
+    gain from leaving the dependent main-stream chain, so the default is 0.
+    `launch_w(out_w, out_b, accumulate)`; with `fused_bias` the weight-gradient launch also produces the bias gradient
+    (out_b may be None), otherwise the bias gradient is a separate column-sum.  Returns (dw, db) for autograd (None when
     accumulated directly)."""
     need_w = ctx.needs_input_grad[1]
     need_b = has_b and ctx.needs_input_grad[2]
     mg_w = _main_grad(w_par, w) if need_w else None
     mg_b = _main_grad(b_par, b_par) if need_b else None
     dw = db = None
+    ride = fused_bias and need_w and need_b and (mg_w is None) == (mg_b is None)      # same accumulate mode for both
     if mg_w is not None or mg_b is not None:
         with wgrad_stream(flops >= ASYNC_WGRAD_MIN_FLOP, x, g):
             if mg_w is not None:
-                launch_w(mg_w, 1)
-            if mg_b is not None:
+                launch_w(mg_w, mg_b if ride else None, 1)
+            if mg_b is not None and not ride:
                 _colsum_into(g, C, R, C, mg_b)
     if need_w and mg_w is None:
         dw = torch.empty_like(w)
-        launch_w(dw, 0)
-    if need_b and mg_b is None:
+        if ride:
+            db = torch.empty(C, dtype=torch.float32, device=x.device)
+        launch_w(dw, db, 0)
+    if need_b and mg_b is None and not ride:
         db = _colsum(g, C, R, C)
     return dw, db
 
@@ -265,11 +270,11 @@ class _Conv2d(Function):
         w_par, b_par = ctx.params
         R = N * OH * OW
 
-        def launch_w(out, acc):
+        def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(R, Cout, KH * KW * Cin, x.device)
-            L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+            L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
                                     stride, pad, OH, OW, Cout, acc, stream())
-        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin)
+        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True)
         return dx, dw, db, None, None, None
 
 
@@ -312,7 +317,7 @@ class _Deconv2d(Function):
             L.pdf_deconv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
         w_par, b_par = ctx.params
 
-        def launch_w(out, acc):
+        def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
             L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
                                       stride, pad, OH, OW, Cout, acc, stream())
@@ -359,10 +364,10 @@ class _Linear(Function):
             L.pdf_linear_bwd_data(ptr(g), ptr(w), ptr(dx), M, Nn, K, Nn, K, K, stream())
         w_par, b_par = ctx.params
 
-        def launch_w(out, acc):
+        def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(M, Nn, K, x.device)
-            L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
-        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K)
+            L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
+        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K, fused_bias=True)
         return dx, dw, db, None
 
 
@@ -414,24 +419,27 @@ class _LinearPair(Function):
         direct_w = mg_w0 is not None and mg_w1 is not None
         direct_b = mg_b0 is not None and mg_b1 is not None
 
-        def launch_w(o0, o1, acc):
+        def launch_w(o0, o1, p0, p1, acc):
             n = 2 * L.pdf_wgrad_workspace_floats(M, Nn, K)
-            L.pdf_linear_bwd_weight_pair(ptr(x), ptr(g), ptr(o0), ptr(o1), ptr(_ws(n, x.device)), n, M, Nn, K, K, Nn, acc, stream())
+            L.pdf_linear_bwd_weight_pair(ptr(x), ptr(g), ptr(o0), ptr(o1), ptr(p0), ptr(p1), ptr(_ws(n, x.device)), n, M, Nn, K, K, Nn, acc, stream())
 
         def launch_b(o0, o1, acc):
             ws = _ws(2 * L.pdf_bn_workspace_floats(Nn, M), x.device)
             L.pdf_colsum_pair(ptr(g), Nn, Nn, M, ptr(o0), ptr(o1), acc, ptr(ws), stream())
         dw0 = dw1 = db0 = db1 = None
+        ride = need_w and need_b and direct_w == direct_b                 # the bias gradients ride along with the weight launch
         if (need_w and direct_w) or (need_b and direct_b):
             with wgrad_stream(True, x, g):
                 if need_w and direct_w:
-                    launch_w(mg_w0, mg_w1, 1)
-                if need_b and direct_b:
+                    launch_w(mg_w0, mg_w1, mg_b0 if ride else None, mg_b1 if ride else None, 1)
+                if need_b and direct_b and not ride:
                     launch_b(mg_b0, mg_b1, 1)
         if need_w and not direct_w:
             dw0, dw1 = torch.empty_like(w0), torch.empty_like(w1)
-            launch_w(dw0, dw1, 0)
-        if need_b and not direct_b:
+            if ride:
+                db0, db1 = torch.empty(Nn, device=x.device), torch.empty(Nn, device=x.device)
+            launch_w(dw0, dw1, db0, db1, 0)
+        if need_b and not direct_b and not ride:
             db0, db1 = torch.empty(Nn, device=x.device), torch.empty(Nn, device=x.device)
             launch_b(db0, db1, 0)
         return dx, dw0, db0, dw1, db1, None

@@ -56,7 +56,7 @@ def main():
         fl = 2.0 * B * OH * OH * Cout * Cin * k * k
         t_f = timeit(lambda: L.pdf_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream()))
         t_d = timeit(lambda: L.pdf_conv2d_bwd_data(ptr(dy), ptr(w), ptr(dx), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, stream()))
-        t_w = timeit(lambda: L.pdf_conv2d_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), n, B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream()))
+        t_w = timeit(lambda: L.pdf_conv2d_bwd_weight(ptr(x), ptr(dy), ptr(dw), None, ptr(ws), n, B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream()))
         print("%-16s M=%7d N=%5d K=%5d  %7.1f GF | fwd %6.3f ms %6.1f TF | bwd_data %6.3f ms %6.1f TF | bwd_w %6.3f ms %6.1f TF" %
               (name, B * OH * OH, Cout, Cin * k * k, fl / 1e9, t_f * 1e3, fl / t_f / 1e12, t_d * 1e3, fl / t_d / 1e12, t_w * 1e3, fl / t_w / 1e12), flush=True)
     for name, M, K, N in LINS:
@@ -74,7 +74,7 @@ def main():
         by = 4.0 * (M * K + M * N)
         t_f = timeit(lambda: L.pdf_linear_fwd(ptr(x), ptr(w), None, ptr(y), M, N, K, K, K, N, 1, stream()))
         t_d = timeit(lambda: L.pdf_linear_bwd_data(ptr(dy), ptr(w), ptr(dx), M, N, K, N, K, K, stream()))
-        t_w = timeit(lambda: L.pdf_linear_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), n, M, N, K, K, N, 0, stream()))
+        t_w = timeit(lambda: L.pdf_linear_bwd_weight(ptr(x), ptr(dy), ptr(dw), None, ptr(ws), n, M, N, K, K, N, 0, stream()))
         print("%-16s M=%7d N=%5d K=%5d  %7.1f GF | fwd %6.3f ms %6.1f TF %5.2f TB/s | bwd_data %6.3f ms %6.1f TF | bwd_w %6.3f ms %6.1f TF" %
               (name, M, N, K, fl / 1e9, t_f * 1e3, fl / t_f / 1e12, by / t_f / 1e12, t_d * 1e3, fl / t_d / 1e12, t_w * 1e3, fl / t_w / 1e12), flush=True)
 
