@@ -200,6 +200,11 @@ int pdf_attn_bwd(const float* q, const float* k, const float* v, int ld, const f
                  const float* stat, int B, int V, int H, int dh, int kv_shift, float pdrop, unsigned long long seed, const unsigned long long* step,
                  float* dq, float* dk, float* dv, int lddq, float* dvec, void* stream);
 
+/* Farthest point sampling, `farthest_point_sampling_fast` (lib/datasets/interhand.py:147-178; `--sample_strategy FPS`,
+ * opts.py:231): xyz [Bc][N][ld] (N <= 16384), start [Bc] (first pick, NULL = 0) -> idx [Bc][S] in pick order (the helper
+ * returns np.unique of it).  Once every remaining distance is <= 1e-8 the picks repeat, like the helper's. */
+int pdf_fps(const float* xyz, int ld, int Bc, int N, int S, const int* start, int* idx, void* stream);
+
 /* ---- mesh loss terms (csrc/loss.hip) ---------------------------------------------------------- */
 /* out[r] = mean_i f(pred[r][i] - tgt[r][i]); mode 0: |.| (the `l1` of lib/trains/simplified.py:427-436,481,506-511),
  * mode 1: (.)^2 (F.mse_loss, :425,482,499).  bwd: dpred[r][i] = gout[r]/n * f'(.) */

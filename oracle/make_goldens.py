@@ -401,6 +401,26 @@ def depth2pcl_golden():
     save("op_depth2pcl", **out)
 
 
+def fps_golden():
+    """The reference's NumPy FPS helper (lib/datasets/interhand.py:147-178) on float32 clouds; the helper draws its first
+    pick from numpy's global RNG, so the state is seeded and the draw reproduced to record `start`."""
+    D = rh.ref_module("lib.datasets.interhand")
+    out = {}
+    cases = (("a", 1024, 512, 61, False), ("b", 777, 128, 62, False), ("dup", 1024, 256, 63, True))
+    for name, n, s, seed, dup in cases:
+        g = rng(seed)
+        pts = np.concatenate([g.uniform(-0.1, 0.1, (n, 2)), g.uniform(0.4, 0.5, (n, 1))], 1).astype(np.float32)
+        if dup:
+            pts[n // 2:] = pts[:n - n // 2]                     # wrap-padded cloud: every point twice
+        np.random.seed(seed)
+        start = np.random.randint(n)
+        np.random.seed(seed)
+        got = D.InterHandDataset.farthest_point_sampling_fast(None, pts, s)
+        out["pts_" + name], out["start_" + name] = pts, np.array([start], np.int32)
+        out["unique_" + name], out["S_" + name] = got.astype(np.int32), np.array([s], np.int32)
+    save("op_fps", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["ops", "e2e"]
@@ -416,5 +436,7 @@ if __name__ == "__main__":
         e2e_fp64_oracle()
     if "d2p" in which:
         depth2pcl_golden()
+    if "fps" in which or "ops" in which:
+        fps_golden()
     if "loss" in which or "e2e" in which:
         loss_golden()

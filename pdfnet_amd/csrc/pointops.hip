@@ -355,3 +355,82 @@ PDF_API int pdf_nms_top1(const float* hm, int BC, int H, int W, long* ind, float
     PDF_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Farthest point sampling (lib/datasets/interhand.py:147-178 `farthest_point_sampling_fast`, the NumPy helper the reference
+// keeps for `--sample_strategy FPS`, opts.py:231): idx[0] = start; idx[i] = argmax of the running minimum squared distance
+// (first index on ties); distances are frozen once they are <= 1e-8 (:171-173).  One 1024-thread block per cloud, the
+// points and their running distances live in registers (<= 16 per thread), one block-wide arg-max per picked point.
+#define FPS_THREADS 1024
+#define FPS_MAXPT 16
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restrict__ xyz, int ld, int N, int S,
+                                                          const int* __restrict__ start, int* __restrict__ idx) {
+    __shared__ float s_val[FPS_THREADS / 64];
+    __shared__ int s_idx[FPS_THREADS / 64];
+    __shared__ float s_pick[3];
+    __shared__ int s_best;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = xyz + (long)blockIdx.x * N * ld;
+    int* out = idx + (long)blockIdx.x * S;
+    float px[FPS_MAXPT], py[FPS_MAXPT], pz[FPS_MAXPT], d[FPS_MAXPT];
+#pragma unroll
+    for (int k = 0; k < FPS_MAXPT; ++k) {
+        const int i = tid + k * FPS_THREADS;
+        const bool ok = i < N;
+        px[k] = ok ? p[(long)i * ld] : 0.f;
+        py[k] = ok ? p[(long)i * ld + 1] : 0.f;
+        pz[k] = ok ? p[(long)i * ld + 2] : 0.f;
+    }
+    int cur = start != nullptr ? start[blockIdx.x] : 0;
+    cur = min(max(cur, 0), N - 1);
+    for (int it = 0; it < S; ++it) {
+        if (tid == 0) {
+            out[it] = cur;
+            s_pick[0] = p[(long)cur * ld]; s_pick[1] = p[(long)cur * ld + 1]; s_pick[2] = p[(long)cur * ld + 2];
+        }
+        __syncthreads();
+        const float cx = s_pick[0], cy = s_pick[1], cz = s_pick[2];
+        float best = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < FPS_MAXPT; ++k) {
+            const int i = tid + k * FPS_THREADS;
+            if (i < N) {
+                const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+                // (dx*dx + dy*dy) + dz*dz without fused multiply-adds: the NumPy helper's float32 arithmetic
+                const float nd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                if (it == 0) d[k] = nd;
+                else if (d[k] > 1e-8f) d[k] = fminf(d[k], nd);
+                if (d[k] > best) { best = d[k]; bi = i; }       // k ascending => i ascending: the first maximum of this thread
+            }
+        }
+        // block arg-max, lowest index among equal values
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+        __syncthreads();
+        if (wave == 0) {
+            float v = lane < FPS_THREADS / 64 ? s_val[lane] : -2.f;
+            int vi = lane < FPS_THREADS / 64 ? s_idx[lane] : 0x7fffffff;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(vi, o, 64);
+                if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+            }
+            if (lane == 0) s_best = vi;
+        }
+        __syncthreads();
+        cur = s_best;
+    }
+}
+PDF_API int pdf_fps(const float* xyz, int ld, int Bc, int N, int S, const int* start, int* idx, hipStream_t s) {
+    if (N <= 0 || S <= 0 || N > FPS_THREADS * FPS_MAXPT || ld < 3) return PDF_E_BADARG;
+    if (Bc <= 0) return 0;
+    hipLaunchKernelGGL(fps_kernel, dim3(Bc), dim3(FPS_THREADS), 0, s, xyz, ld, N, S, start, idx);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}

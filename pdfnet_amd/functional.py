@@ -926,6 +926,18 @@ def knn_ball_group(pts, C, S, K, r2, ldg):
     return _KnnGroup.apply(pts, C, S, K, float(r2), ldg)
 
 
+def fps(xyz, S, start=None):
+    """Farthest point sampling (the reference's `farthest_point_sampling_fast`, lib/datasets/interhand.py:147-178):
+    xyz [Bc,N,>=3] -> int32 [Bc,S] picks in order; start int32 [Bc] (first pick, default 0).  No gradient."""
+    hip.require_gpu(xyz)
+    x = xyz.detach().contiguous()
+    Bc, N, ld = x.shape
+    idx = torch.empty((Bc, S), dtype=torch.int32, device=x.device)
+    st = start.to(torch.int32).contiguous() if start is not None else None
+    _L().pdf_fps(ptr(x), ld, Bc, N, S, ptr(st), ptr(idx), stream())
+    return idx
+
+
 class _MaxK(Function):
     """x [R, K, C] -> max over K -> [R, C]."""
 

@@ -621,3 +621,22 @@ def test_mesh_loss_kernels(F):
         (out * dev(w)).sum().backward()
         close(out, ref, 1e-6, what="rowloss " + mode)
         close(ad.grad, ar.grad, 1e-7, rtol=1e-5, what="rowloss grad " + mode)
+
+
+def test_fps(F):
+    """pdf_fps picks, in order, against the oracle restatement of the reference helper (bit-exact indices)."""
+    from oracle import pdfnet_cpu as O
+    g = gold("op_fps")
+    for name in ("a", "b", "dup"):
+        pts, S, start = g["pts_" + name], int(g["S_" + name][0]), int(g["start_" + name][0])
+        ref = O.fps_order(pts, S, start)
+        got = F.fps(dev(torch.from_numpy(pts))[None], S, dev(torch.tensor([start], dtype=torch.int32)))
+        assert np.array_equal(got[0].cpu().numpy().astype(np.int64), ref), name
+        assert np.array_equal(np.unique(got[0].cpu().numpy()), g["unique_" + name]), name
+    # batched, padded rows, start defaulting to 0, a large cloud
+    gen = torch.Generator().manual_seed(5)
+    big = torch.rand(3, 9000, 4, generator=gen)
+    got = F.fps(dev(big), 64).cpu().numpy()
+    for b in range(3):
+        assert np.array_equal(got[b].astype(np.int64), O.fps_order(big[b, :, :3].numpy(), 64, 0)), b
+

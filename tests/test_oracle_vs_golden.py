@@ -158,3 +158,13 @@ def test_depth2pcl_front_end():
     _, cl_ = O.depth_candidates(g["depth"], g["mask"][1], g["K"])
     _, cr_ = O.depth_candidates(g["depth"], g["mask"][0], g["K"])
     assert 10 <= len(cl_) <= 1024 < len(cr_)
+
+
+def test_fps_matches_reference_helper():
+    """oracle.fps_order (picks in order) against the reference's farthest_point_sampling_fast (np.unique of the picks)."""
+    from oracle import pdfnet_cpu as O
+    g = gold("op_fps")
+    for name in ("a", "b", "dup"):
+        order = O.fps_order(g["pts_" + name], int(g["S_" + name][0]), int(g["start_" + name][0]))
+        assert np.array_equal(np.unique(order), g["unique_" + name]), name
+

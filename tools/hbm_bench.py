@@ -80,6 +80,11 @@ def main():
             pts[..., C:] = 0
             t = timeit(lambda: F.knn_ball_group(pts, C, S, 64, 0.1 if C == 3 else 0.3, Cp))
             report(name, 2 * B * (N * Cp * 4 + S * 64 * 4 + S * 64 * Cp * 4), t)
+    if flt in "fps":
+        x = torch.rand(2 * B, 4096, 3, device=dev)
+        for S in (512, 1024):
+            t = timeit(lambda: F.fps(x, S), iters=5)
+            print("%-34s %8.3f ms  (%d clouds x 4096 points, %.2f us per pick: latency-bound)" % ("fps 4096 -> %d" % S, t * 1e3, 2 * B, t / S * 1e6))
     if flt in "adam":
         n = 100_500_000
         p, g, m, v = (torch.zeros(n, device=dev) for _ in range(4))
