@@ -640,3 +640,25 @@ def test_fps(F):
     for b in range(3):
         assert np.array_equal(got[b].astype(np.int64), O.fps_order(big[b, :, :3].numpy(), 64, 0)), b
 
+
+
+def test_limits_and_empty_inputs(F):
+    """Error behaviour at the documented limits (RuntimeError, not a crash or a silent fallback) and empty inputs."""
+    with pytest.raises(RuntimeError):
+        F.layer_norm(dev(torch.zeros(4, 2048)), dev(torch.ones(2048)), dev(torch.zeros(2048)))      # F <= 1024
+    with pytest.raises(RuntimeError):
+        F.fps(dev(torch.zeros(1, 20000, 3)), 8)                                                      # N <= 16384
+    with pytest.raises(RuntimeError):
+        F.attention(dev(torch.zeros(1, 600, 256)), dev(torch.zeros(1, 600, 256)), dev(torch.zeros(1, 600, 256)), 4)   # K/V of one head in 64 KB
+    with pytest.raises(RuntimeError):
+        F.linear(torch.zeros(4, 8), torch.zeros(8, 8))                                               # CPU tensors: no fallback
+    # zero rows: nothing is launched, shapes are kept, gradients are zeros
+    x = dev(torch.zeros(0, 64)).requires_grad_()
+    w = dev(rnd(32, 64)).requires_grad_()
+    y = F.linear(x, w)
+    assert y.shape == (0, 32)
+    y.sum().backward()
+    assert w.grad.shape == w.shape and float(w.grad.abs().sum()) == 0.0
+    # a batch whose hands are all invalid: every per-sample term is weighted by 0, the loss stays finite
+    got = F.rowloss(dev(rnd(2, 3, 5)), dev(rnd(2, 3, 5, seed=1)), 2, 'l1') * dev(torch.zeros(2, 3))
+    assert torch.isfinite(got).all() and float(got.abs().sum()) == 0.0
