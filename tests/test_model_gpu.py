@@ -77,7 +77,7 @@ def test_train_forward_and_grads_match_reference_golden(setup):
         ref = g["gradhead::" + name]
         if np.abs(head - ref).max() > 0.25 * np.abs(ref).max():
             bad.append((name, "head32", float(np.abs(head - ref).max()), float(np.abs(ref).max())))
-    assert not bad, bad
+    assert not bad, "\n".join("%s %s %.2e" % b for b in bad)
     assert sum(p.grad is None for p in named.values()) == int(g["n_params_without_grad"][0])
     new = m.state_dict()
     for k, v in g.items():
@@ -172,3 +172,72 @@ def test_native_resolution_384_batch1_matches_oracle():
     check_packed(pack_outputs(rg, bg['ind']), exp, abs_tol=1e-4, rel_tol=1e-5)
     assert rg[3]['hms'].shape == (1, 42, 96, 96) and rg[3]['mask'].shape == (1, 2, 384, 384)
     assert torch.equal(rg2[3]['ind'].cpu(), ro2[3]['ind'])                      # predicted centres bit-exact
+
+
+def test_trainer_step_equals_plain_autograd_plus_adam():
+    """The MI355X train loop (flat buffers, gradients written straight into the flat buffer by side-stream kernels, fused
+    Adam) against the textbook loop on the same modules: model -> CtdetLoss -> .backward() into p.grad -> torch.optim.Adam."""
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch, to_device
+    from pdfnet_amd.trains.base_trainer import ModleWithLoss, Trainer
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    R, B = 128, 2
+    dev = torch.device('cuda')
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    batch = to_device(synthetic_train_batch(B, R, seed=3, consts=consts), dev)
+    models = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        m = load_model_intag(opt).to(dev)
+        for mod in m.modules():
+            if hasattr(mod, 'p') and isinstance(getattr(mod, 'p'), float):
+                mod.p = 0.0
+        models.append(m)
+    ma, mb = models
+    crit = CtdetLoss(opt, consts).to(dev)
+
+    # textbook loop
+    mwl = ModleWithLoss(mb, crit).train()
+    adam = torch.optim.Adam(mb.parameters(), lr=1e-4)
+    adam.zero_grad()
+    loss_b, _, _, _ = mwl(batch, 'train', 0)
+    loss_b.mean().backward()
+    from pdfnet_amd import functional as F
+    F.join_wgrad()
+    grads_b = {n: (p.grad.clone() if p.grad is not None else None) for n, p in mb.named_parameters()}
+    before = {n: p.detach().clone() for n, p in mb.named_parameters()}
+    adam.step()
+
+    # MI355X loop
+    tr = Trainer(opt, ma, crit, lr=1e-4)
+    loss_a = tr.train_step(batch, 0)
+    torch.cuda.synchronize()
+    assert abs(float(loss_a) - float(loss_b.mean().detach())) <= 1e-5 * abs(float(loss_b.mean().detach()))
+    pa = dict(ma.named_parameters())
+    checked = 0
+    bad = []
+    for n, pb in mb.named_parameters():
+        gb = grads_b[n]
+        ga = pa[n].grad                                    # view into the flat gradient buffer (not cleared by the step)
+        if gb is None:
+            assert float(ga.abs().max()) == 0.0, n         # never-used parameter: zero gradient, untouched weights
+            assert torch.equal(pa[n].detach(), before[n]), n
+            continue
+        scale = float(gb.abs().max())
+        err = float((ga - gb).abs().max())
+        # biases whose exact gradient is zero (before a BatchNorm; key biases of a softmax; a constant shift of the cloud)
+        # hold rounding noise only: judge them against their layer's weight gradient
+        wn = n[:-4] + 'weight'
+        floor = 1e-4 * float(grads_b[wn].abs().max()) if n.endswith('.bias') and grads_b.get(wn) is not None else 0.0
+        if err > 2e-4 * scale + floor + 1e-7:
+            bad.append((n, tuple(gb.shape), err / (scale + 1e-30)))
+            continue
+        # Adam moves every element by ~lr * sign(g) on the first step; compare where the gradient is well above its noise
+        big = gb.abs() > max(1e-3 * scale, 100 * floor)
+        if big.any():
+            da, db = (pa[n].detach() - before[n])[big], (pb.detach() - before[n])[big]
+            assert float((da - db).abs().max()) <= 2e-6, n
+            checked += 1
+    assert not bad, "\n".join("%s %s %.2e" % b for b in bad)
+    assert checked > 600
