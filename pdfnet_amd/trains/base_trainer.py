@@ -66,6 +66,7 @@ class FlatAdam:
         self.flat_g.zero_()
 
     def step(self, grad_scale=1.0):
+        F.join_wgrad()                                 # side-stream gradient kernels must have landed (no-op when already joined)
         self.step_t += 1
         torch.sub(1.0, torch.pow(self._b, self.step_t), out=self.corr)        # [1-b1^t, 1-b2^t]
         hip.lib().pdf_adam_step(hip.ptr(self.flat_p), hip.ptr(self.flat_g), hip.ptr(self.flat_m), hip.ptr(self.flat_v),
