@@ -77,7 +77,7 @@ def test_train_forward_and_grads_match_reference_golden(setup):
         ref = g["gradhead::" + name]
         if np.abs(head - ref).max() > 0.25 * np.abs(ref).max():
             bad.append((name, "head32", float(np.abs(head - ref).max()), float(np.abs(ref).max())))
-    assert not bad, "\n".join("%s %s %.2e" % b for b in bad)
+    assert not bad, bad
     assert sum(p.grad is None for p in named.values()) == int(g["n_params_without_grad"][0])
     new = m.state_dict()
     for k, v in g.items():
