@@ -187,6 +187,7 @@ class ResNetSimple(nn.Module):
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
+        self.on_trunk_output_grad = None        # set by the trainer: overlaps the gradient all-reduce with the trunk's backward
         self.resnet = ResNet50()
         self.p2 = Conv2d(256, 256, 3, 1, 1)
         self.p3 = ConvTranspose2d(512, 256, 4, 2, 1)
@@ -252,6 +253,10 @@ class ResNetSimple(nn.Module):
         x3 = r.layer2(x4)
         x2 = r.layer3(x3)
         x1 = r.layer4(x2)
+        if self.on_trunk_output_grad is not None and x1.requires_grad:
+            # fires in the backward once d loss / d x1 is complete, i.e. when every branch above the trunk has run its backward
+            cb = self.on_trunk_output_grad
+            x1.register_hook(lambda g: cb())
         st = {'x1': x1, 'ret': {}}
         pyr = torch.cat([self.p2_l2(self.p2(x4)), self.p3_l2(self.p3(x3)),
                          self.p4_l2(self.p4(x2)), self.p5_l2(self.p5(x1))], 1)            # NHWC channel concat

@@ -47,6 +47,7 @@ class FlatAdam:
             offs.append(n)
             n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = n
+        self.offsets = offs                            # flat offset of params[i] (the buffers follow the order given)
         self.flat_p = torch.zeros(n, device=dev)
         self.flat_g = torch.zeros(n, device=dev)
         self.flat_m = torch.zeros(n, device=dev)
@@ -83,16 +84,27 @@ class FlatAdam:
         self.lr = sd.get('lr', self.lr)
 
 
-def allreduce_flat_grads(flat_g, chunks=4):
+def allreduce_flat_grads(flat_g, chunks=4, wait=True):
     """Gradient SUM across ranks (the mean's 1/world is folded into the optimizer's grad_scale).  A few large
-    RCCL all-reduces on the contiguous buffer: xGMI rings are per-link bound, so fewer/larger beats many/small."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
+    RCCL all-reduces on the contiguous buffer: xGMI rings are per-link bound, so fewer/larger beats many/small.
+    wait=False returns the outstanding work handles instead of waiting for them."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or flat_g.numel() == 0:
+        return []
     n = flat_g.numel()
     per = (n + chunks - 1) // chunks
     works = [dist.all_reduce(flat_g[i:min(n, i + per)], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, n, per)]
+    if not wait:
+        return works
     for w in works:
         w.wait()
+    return []
+
+
+# Parameters whose gradients are complete only at the very end of the backward: the ResNet trunk and what hangs off the
+# stem (e_conv1, and PointNet++ levels 1-2, whose backward runs last on its side stream).  Everything else -- two thirds
+# of the buffer: pyramid laterals, feat, heads, dense decoders, centre convolutions, SFT, mesh decoder -- is complete when
+# the gradient of the trunk output x1 has been formed (autograd runs later-created nodes first, SURVEY 8e).
+LATE_PREFIXES = ('encoder.resnet.', 'encoder.e_conv1.', 'encoder.pointnet_plus.')
 
 
 class Trainer:
@@ -101,14 +113,34 @@ class Trainer:
     def __init__(self, opt, model, loss, lr=1e-4, use_graph=False):
         self.opt = opt
         self.model_with_loss = ModleWithLoss(model, loss)
-        self.optimizer = FlatAdam(model.parameters(), lr=lr)
+        named = list(model.named_parameters())
+        early = [p for n, p in named if not n.startswith(LATE_PREFIXES)]
+        late = [p for n, p in named if n.startswith(LATE_PREFIXES)]
+        self.optimizer = FlatAdam(early + late, lr=lr)         # flat order: [early | late], see LATE_PREFIXES
+        self.n_early = self.optimizer.offsets[len(early)] if late else self.optimizer.numel
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._early_works = None
+        self.early_probe = None                                # test hook: called with the early gradient slice when it is complete
+        if hasattr(model, 'encoder'):
+            model.encoder.on_trunk_output_grad = self._early_grads_ready
         self.use_graph = use_graph
         self._graph = None
         self._static = None
         self._loss_out = None
 
+    def _early_grads_ready(self):
+        """Runs inside the backward, when d loss / d x1 is complete: start the all-reduce of the early part of the flat
+        gradient buffer while the trunk's backward (~a third of the step) still runs."""
+        if self.use_graph or self._early_works is not None or (self.world == 1 and self.early_probe is None):
+            return
+        F.join_wgrad()                                         # the side-stream kernels issued so far wrote into this part
+        early = self.optimizer.flat_g[:self.n_early]
+        if self.early_probe is not None:
+            self.early_probe(early)
+        self._early_works = allreduce_flat_grads(early, chunks=3, wait=False)
+
     def _fwd_bwd(self, batch, epoch):
+        self._early_works = None
         self.optimizer.zero_grad()
         loss, stats, _, _ = self.model_with_loss(batch, 'train', epoch)
         loss = loss.mean()                                     # base_trainer.py:144
@@ -124,7 +156,12 @@ class Trainer:
             loss = self._graph_step(batch, epoch)
         else:
             loss, _ = self._fwd_bwd(batch, epoch)
-        allreduce_flat_grads(self.optimizer.flat_g)
+        if self._early_works is not None:                      # early part already in flight (or nothing to do at world 1)
+            allreduce_flat_grads(self.optimizer.flat_g[self.n_early:], chunks=2)
+            for w in self._early_works:
+                w.wait()
+        else:
+            allreduce_flat_grads(self.optimizer.flat_g)
         self.optimizer.step(grad_scale=1.0 / self.world)
         return loss
 

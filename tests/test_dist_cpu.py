@@ -1,5 +1,5 @@
-"""CPU (gloo, world_size 2): the N>1 gradient path of the trainer -- a chunked SUM all-reduce over the flat
-gradient buffer followed by 1/world scaling -- gives every rank the mean of the per-rank gradients."""
+"""CPU (gloo, world_size 2): the N>1 gradient path of the trainer -- chunked SUM all-reduces over the early and the late
+slice of the flat gradient buffer followed by 1/world scaling -- gives every rank the mean of the per-rank gradients."""
 import os
 import socket
 
@@ -24,7 +24,14 @@ def _worker(rank, world, port, q):
     n = 100003                                   # not divisible by the chunk count
     g = torch.randn(n)
     mine = g.clone()
-    allreduce_flat_grads(g, chunks=4)
+    # the trainer's overlapped form: the early slice goes out first without waiting (from inside the backward), the late
+    # slice follows after the backward, then both are waited for
+    n_early = 66001
+    early = allreduce_flat_grads(g[:n_early], chunks=3, wait=False)
+    assert len(early) == 3
+    assert allreduce_flat_grads(g[n_early:], chunks=2) == []
+    for w in early:
+        w.wait()
     g *= 1.0 / world                             # FlatAdam's grad_scale
     gathered = [torch.empty(n) for _ in range(world)]
     dist.all_gather(gathered, mine)

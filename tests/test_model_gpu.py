@@ -241,3 +241,34 @@ def test_trainer_step_equals_plain_autograd_plus_adam():
             checked += 1
     assert not bad, "\n".join("%s %s %.2e" % b for b in bad)
     assert checked > 600
+
+
+def test_early_gradient_slice_is_complete_when_the_trunk_backward_starts():
+    """The overlapped all-reduce sends flat_g[:n_early] as soon as d loss / d x1 is complete.  That is only
+    correct if nothing writes into that slice afterwards: snapshot it at the trigger and compare with the end of the step."""
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch, to_device
+    from pdfnet_amd.trains.base_trainer import LATE_PREFIXES, Trainer
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    R, B = 128, 2
+    dev = torch.device('cuda')
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    batch = to_device(synthetic_train_batch(B, R, seed=4, consts=consts), dev)
+    torch.manual_seed(11)
+    m = load_model_intag(opt).to(dev)
+    tr = Trainer(opt, m, CtdetLoss(opt, consts).to(dev), lr=1e-4)
+    snaps = []
+    tr.early_probe = lambda early: snaps.append(early.clone())
+    for _ in range(2):
+        tr.train_step(batch, 0)
+        torch.cuda.synchronize()
+    assert len(snaps) == 2                                   # the trigger fires exactly once per step
+    assert 0 < tr.n_early < tr.optimizer.numel
+    assert torch.equal(snaps[-1], tr.optimizer.flat_g[:tr.n_early])
+    # the split is the documented one: early = everything outside the trunk / stem branches, and it is the larger part
+    names = dict(m.named_parameters())
+    late = sum(p.numel() for n, p in names.items() if n.startswith(LATE_PREFIXES))
+    assert tr.n_early > 0.6 * tr.optimizer.numel and late > 0.2 * tr.optimizer.numel
+    # and the early slice really carries gradients (not an empty trigger)
+    assert float(snaps[-1].abs().sum()) > 0
