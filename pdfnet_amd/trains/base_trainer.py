@@ -84,11 +84,12 @@ class FlatAdam:
         self.lr = sd.get('lr', self.lr)
 
 
-def allreduce_flat_grads(flat_g, chunks=4, wait=True):
+def allreduce_flat_grads(flat_g, chunks=4, wait=True, force=False):
     """Gradient SUM across ranks (the mean's 1/world is folded into the optimizer's grad_scale).  A few large
     RCCL all-reduces on the contiguous buffer: xGMI rings are per-link bound, so fewer/larger beats many/small.
-    wait=False returns the outstanding work handles instead of waiting for them."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or flat_g.numel() == 0:
+    wait=False returns the outstanding work handles instead of waiting for them; force=True issues the collectives on
+    a one-rank group too (tests: exercises the RCCL calls on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force) or flat_g.numel() == 0:
         return []
     n = flat_g.numel()
     per = (n + chunks - 1) // chunks
@@ -120,6 +121,7 @@ class Trainer:
         self.n_early = self.optimizer.offsets[len(early)] if late else self.optimizer.numel
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._early_works = None
+        self.force_collectives = False                         # tests: run the all-reduces on a one-rank group as well
         self.early_probe = None                                # test hook: called with the early gradient slice when it is complete
         if hasattr(model, 'encoder'):
             model.encoder.on_trunk_output_grad = self._early_grads_ready
@@ -131,13 +133,13 @@ class Trainer:
     def _early_grads_ready(self):
         """Runs inside the backward, when d loss / d x1 is complete: start the all-reduce of the early part of the flat
         gradient buffer while the trunk's backward (~a third of the step) still runs."""
-        if self.use_graph or self._early_works is not None or (self.world == 1 and self.early_probe is None):
+        if self.use_graph or self._early_works is not None or (self.world == 1 and self.early_probe is None and not self.force_collectives):
             return
         F.join_wgrad()                                         # the side-stream kernels issued so far wrote into this part
         early = self.optimizer.flat_g[:self.n_early]
         if self.early_probe is not None:
             self.early_probe(early)
-        self._early_works = allreduce_flat_grads(early, chunks=3, wait=False)
+        self._early_works = allreduce_flat_grads(early, chunks=3, wait=False, force=self.force_collectives)
 
     def _fwd_bwd(self, batch, epoch):
         self._early_works = None
@@ -157,11 +159,11 @@ class Trainer:
         else:
             loss, _ = self._fwd_bwd(batch, epoch)
         if self._early_works is not None:                      # early part already in flight (or nothing to do at world 1)
-            allreduce_flat_grads(self.optimizer.flat_g[self.n_early:], chunks=2)
+            allreduce_flat_grads(self.optimizer.flat_g[self.n_early:], chunks=2, force=self.force_collectives)
             for w in self._early_works:
                 w.wait()
         else:
-            allreduce_flat_grads(self.optimizer.flat_g)
+            allreduce_flat_grads(self.optimizer.flat_g, force=self.force_collectives)
         self.optimizer.step(grad_scale=1.0 / self.world)
         return loss
 

@@ -272,3 +272,84 @@ def test_early_gradient_slice_is_complete_when_the_trunk_backward_starts():
     assert tr.n_early > 0.6 * tr.optimizer.numel and late > 0.2 * tr.optimizer.numel
     # and the early slice really carries gradients (not an empty trigger)
     assert float(snaps[-1].abs().sum()) > 0
+
+
+def test_wrappable_by_ddp_like_the_reference(setup):
+    """lib/trains/base_trainer.py:94-95 wraps the model in DistributedDataParallel(find_unused_parameters=True) over NCCL
+    (= RCCL).  A one-rank process group is enough to check that the module goes through DDP's reducer unchanged."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    m, sd, b = setup
+    m.load_state_dict(sd)
+    m.train()
+    m.zero_grad(set_to_none=True)
+    surrogate_loss(_run(m, b, b['ind'])).backward()
+    ref = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        created = True
+    try:
+        m.load_state_dict(sd)
+        m.zero_grad(set_to_none=True)
+        ddp = DDP(m, device_ids=[torch.cuda.current_device()], find_unused_parameters=True)
+        surrogate_loss(ddp(b['input'], b['choose'], b['cloud'], b['depth'], b['ind'], b['K_new'], b['valid'])).backward()
+        torch.cuda.synchronize()
+        got = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+        assert set(got) == set(ref)
+        for n in ref:
+            scale = float(ref[n].abs().max())
+            wn = n[:-4] + 'weight'                      # biases with an exactly-zero gradient hold rounding noise only
+            floor = 1e-3 * float(ref[wn].abs().max()) if n.endswith('.bias') and wn in ref else 0.0
+            assert float((got[n] - ref[n]).abs().max()) <= 1e-3 * scale + floor + 1e-6, n
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_trainer_collectives_on_a_one_rank_rccl_group():
+    """The trainer's gradient reduction -- early slice from inside the backward (autograd hook), late slice after it, both
+    asynchronous -- issued for real on a one-rank NCCL (RCCL) group: the step must give what it gives without collectives."""
+    import os
+    import torch.distributed as dist
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch, to_device
+    from pdfnet_amd.trains.base_trainer import Trainer
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    R, B = 128, 2
+    dev = torch.device('cuda')
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    batch = to_device(synthetic_train_batch(B, R, seed=4, consts=consts), dev)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29534')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        created = True
+    try:
+        out = []
+        for force in (False, True):
+            torch.manual_seed(11)
+            m = load_model_intag(opt).to(dev)
+            for mod in m.modules():
+                if hasattr(mod, 'p') and isinstance(getattr(mod, 'p'), float):
+                    mod.p = 0.0
+            tr = Trainer(opt, m, CtdetLoss(opt, consts).to(dev), lr=1e-4)
+            tr.force_collectives = force
+            losses = [float(tr.train_step(batch, 0))]
+            torch.cuda.synchronize()
+            g1 = tr.optimizer.flat_g.clone()                  # first-step gradients: later steps diverge chaotically (Adam)
+            losses.append(float(tr.train_step(batch, 0)))     # the trigger re-arms every step
+            torch.cuda.synchronize()
+            assert (tr._early_works is not None and len(tr._early_works) == 3) == force
+            out.append((losses, g1))
+        assert abs(out[0][0][0] - out[1][0][0]) <= 1e-5 * abs(out[0][0][0])
+        ga, gb = out[0][1], out[1][1]
+        assert float((ga - gb).abs().max()) <= 2e-3 * float(ga.abs().max())
+    finally:
+        if created:
+            dist.destroy_process_group()
