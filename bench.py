@@ -107,6 +107,14 @@ class GemmProfiler:
         return sorted(sh.items(), key=lambda kv: -kv[1][2])
 
 
+def _flush_c_stdout():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def pmc_traffic():
     """HBM bytes per launch of the GEMM family from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
     tools/pmc_traffic.py); PMC counters cannot be read from inside this process, so this is the last profiled value."""
@@ -163,6 +171,10 @@ def main():
     from pdfnet_amd.trains.base_trainer import Trainer, init_distributed
     from pdfnet_amd.trains.simplified import CtdetLoss
 
+    # RCCL writes its NCCL_DEBUG=VERSION banner to the C stdout buffer, which is flushed at exit -- AFTER the JSON line the
+    # driver reads.  Keep rank 0's stdout to that one line: drop the banner (a user's INFO / TRACE setting is left alone) ...
+    if os.environ.get('NCCL_DEBUG', '').upper() == 'VERSION':
+        os.environ['NCCL_DEBUG'] = 'WARN'
     rank, local, world = init_distributed()
     assert world == args.gpus or (world == 1 and args.gpus == 1), "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device('cuda', local)
@@ -240,11 +252,12 @@ def main():
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, max(1, (os.cpu_count() or 2) // 2))
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdout()                                  # ... and whatever native code buffered goes out before the result line
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
