@@ -224,6 +224,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # instrumented eager step: events around every implicit-GEMM entry point on the launch stream
         trainer.use_graph = False
+        trainer.collectives = False        # rank-local step: the other ranks are already past their last collective
         F.USE_SIDE_STREAMS = False         # exclusive per-launch durations (no overlapped branches)
         with GemmProfiler() as prof:
             trainer.train_step(batch)

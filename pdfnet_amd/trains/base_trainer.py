@@ -122,6 +122,7 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._early_works = None
         self.force_collectives = False                         # tests: run the all-reduces on a one-rank group as well
+        self.collectives = True                                # False: a rank-local step (bench.py's instrumented step on rank 0)
         self.early_probe = None                                # test hook: called with the early gradient slice when it is complete
         if hasattr(model, 'encoder'):
             model.encoder.on_trunk_output_grad = self._early_grads_ready
@@ -133,7 +134,8 @@ class Trainer:
     def _early_grads_ready(self):
         """Runs inside the backward, when d loss / d x1 is complete: start the all-reduce of the early part of the flat
         gradient buffer while the trunk's backward (~a third of the step) still runs."""
-        if self.use_graph or self._early_works is not None or (self.world == 1 and self.early_probe is None and not self.force_collectives):
+        if self.use_graph or self._early_works is not None or not self.collectives or \
+                (self.world == 1 and self.early_probe is None and not self.force_collectives):
             return
         F.join_wgrad()                                         # the side-stream kernels issued so far wrote into this part
         early = self.optimizer.flat_g[:self.n_early]
@@ -158,13 +160,15 @@ class Trainer:
             loss = self._graph_step(batch, epoch)
         else:
             loss, _ = self._fwd_bwd(batch, epoch)
-        if self._early_works is not None:                      # early part already in flight (or nothing to do at world 1)
+        if not self.collectives:
+            pass
+        elif self._early_works is not None:                    # early part already in flight (or nothing to do at world 1)
             allreduce_flat_grads(self.optimizer.flat_g[self.n_early:], chunks=2, force=self.force_collectives)
             for w in self._early_works:
                 w.wait()
         else:
             allreduce_flat_grads(self.optimizer.flat_g, force=self.force_collectives)
-        self.optimizer.step(grad_scale=1.0 / self.world)
+        self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0)
         return loss
 
     def _graph_step(self, batch, epoch):
