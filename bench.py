@@ -73,10 +73,14 @@ class GemmProfiler:
 
             def wrapped(*a, _fn=fn, _n=n):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n0 = self.lib.pdf_debug_igemm_launches()
                 e0.record()
                 r = _fn(*a)
                 e1.record()
-                self.records.append((_n, self.flops(_n, a), e0, e1, tuple(v for v in a if isinstance(v, int) and abs(v) < (1 << 31))))
+                weight = 'weight' in _n
+                tile = -1 if weight else self.lib.pdf_debug_last_tile()
+                launches = 1 if weight else self.lib.pdf_debug_igemm_launches() - n0
+                self.records.append((_n, self.flops(_n, a), e0, e1, tuple(v for v in a if isinstance(v, int) and abs(v) < (1 << 31)), tile, launches))
                 return r
             setattr(self.lib, n, wrapped)
         return self
@@ -88,18 +92,29 @@ class GemmProfiler:
     def summary(self):
         torch.cuda.synchronize()
         per = {}
-        for n, fl, e0, e1, _ in self.records:
+        for n, fl, e0, e1, _, _t, _l in self.records:
             d = per.setdefault(n, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += fl
             d[2] += e0.elapsed_time(e1) * 1e-3
         return per
 
+    def by_tile(self):
+        """tile code (pdf_debug_last_tile; -1 = weight-gradient kernels) -> [kernel launches, flops, seconds]."""
+        torch.cuda.synchronize()
+        out = {}
+        for n, fl, e0, e1, _, t, launches in self.records:
+            d = out.setdefault(t, [0, 0.0, 0.0])
+            d[0] += launches
+            d[1] += fl
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        return out
+
     def by_shape(self):
         """(entry point, integer arguments) -> [calls, flops, seconds], largest time first."""
         torch.cuda.synchronize()
         sh = {}
-        for n, fl, e0, e1, ints in self.records:
+        for n, fl, e0, e1, ints, _t, _l in self.records:
             d = sh.setdefault((n, ints), [0, 0.0, 0.0])
             d[0] += 1
             d[1] += fl
@@ -115,12 +130,14 @@ def _flush_c_stdout():
         pass
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the GEMM family from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    tools/pmc_traffic.py); PMC counters cannot be read from inside this process, so this is the last profiled value."""
+def pmc_traffic(kernel=None):
+    """HBM bytes per launch of one kernel (by tile name) or of the whole GEMM family from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 + WRITE_SIZE, see tools/pmc_traffic.py); PMC counters cannot be read from inside this process, so this
+    is the last profiled value."""
     p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
-        return round(json.load(open(p))["gemm_family"]["bytes_per_launch"])
+        d = json.load(open(p))
+        return round(d["kernels"][kernel]["bytes_per_launch"] if kernel else d["gemm_family"]["bytes_per_launch"])
     except Exception:
         return None
 
@@ -236,14 +253,25 @@ def main():
         calls = sum(v[0] for v in per.values())
         flops = sum(v[1] for v in per.values())
         secs = sum(v[2] for v in per.values())
+        tiles = prof.by_tile()
+        tname = {128128: "igemm_nt<128,128>", 128064: "igemm_nt<128,64>", 64064: "igemm_nt<64,64>", 0: "small_k_gemm", -1: "wgemm_tn*"}
+        dom = tiles.get(128128, [0, 0.0, 1e-9])          # the kernel with the most time per step
         out["roofline"] = {
-            "bound": "mfma", "achieved": round(flops / secs / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
-            "kernel": "igemm_nt / wgemm_tn (fp32 MFMA implicit GEMM family, csrc/gemm.hip)",
-            "launches_per_step": calls, "algorithmic_gflop_per_step": round(flops / 1e9, 1),
-            "gemm_ms_per_step": round(secs * 1e3, 2),
-            "per_entry_point": {k: {"calls": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
-                                    "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(per.items())},
+            "bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "kernel": "igemm_nt<128,128,2,2> (csrc/gemm.hip: fp32 MFMA implicit GEMM, forward / backward-data / transposed-conv passes "
+                      "of the large layers; the kernel with the most time per step)",
+            "achieved": round(dom[1] / dom[2] / 1e12, 2), "frac": round(dom[1] / dom[2] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "launches_per_step": dom[0], "ms_per_step": round(dom[2] * 1e3, 2),
+            "algorithmic_gflop_per_launch": round(dom[1] / max(dom[0], 1) / 1e9, 1), "avg_launch_ms": round(dom[2] / max(dom[0], 1) * 1e3, 4),
+            "traffic": pmc_traffic("igemm_nt<128,128>"),
+            "all_gemm_kernels": {
+                "achieved": round(flops / secs / 1e12, 2), "frac": round(flops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "launches_per_step": calls, "algorithmic_gflop_per_step": round(flops / 1e9, 1), "gemm_ms_per_step": round(secs * 1e3, 2),
+                "traffic": pmc_traffic(),
+                "per_tile": {tname.get(k, str(k)): {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
+                                                    "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(tiles.items())},
+                "per_entry_point": {k: {"calls": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
+                                        "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(per.items())}},
             "formulation": "executed contraction = exact sparse centre features (SURVEY 8a6): ~214 GFLOP/img/step; "
                            "reference formulation (dense centre convs) = 358 GFLOP/img/step",
             "step_level": {"gflop_per_img_step_reference_formulation": ALGO_GFLOP_PER_IMG_STEP_DENSE,

@@ -37,6 +37,10 @@ int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
 int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                           int M, int N, int K, int ldx, int lddy, int accumulate, void* stream);
 long pdf_wgrad_workspace_floats(int M, int NI, int NJ);
+/* measurement aids (bench.py): BM*1000+BN of the calling thread's last implicit-GEMM launch (0 = streaming small-K
+ * kernel), and the number of implicit-GEMM kernels it has launched so far (one entry point may launch several) */
+int pdf_debug_last_tile(void);
+int pdf_debug_igemm_launches(void);
 /* dx[M][K] = dy[M][N] w[N][K] (autograd of nn.Linear wrt its input); w is read in its forward storage */
 int pdf_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx, void* stream);
 /* Paired forms: two same-shaped layers with their own parameters in one launch -- the left / right hand branches of the

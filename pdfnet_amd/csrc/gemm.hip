@@ -733,9 +733,15 @@ static void launch_igemm_tile(const IGemm& g, bool fast, dim3 grid, hipStream_t 
     else hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, s, g);
 }
 
+static thread_local int g_last_tile = 0;            // BM * 1000 + BN of this thread's last implicit-GEMM launch (0: streaming small-K kernel)
+static thread_local int g_igemm_launches = 0;       // implicit-GEMM kernel launches of this thread so far
+PDF_API int pdf_debug_last_tile() { return g_last_tile; }
+PDF_API int pdf_debug_igemm_launches() { return g_igemm_launches; }
+
 // groups == 2: paired launch (see IGemm::B1), blockIdx.y selects the group
 static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
+    ++g_igemm_launches;
     bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
     if (g.b_kn) fast = fast && (g.N % 4 == 0) && (g.btap % 4 == 0);
     if (groups > 1) fast = fast && aligned16(g.B1) && (g.gsA % 4 == 0);
@@ -743,6 +749,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
         (long)g.M * g.N >= (1L << 20)) {
         dim3 grid(grid_for((long)g.M * ((min(g.N, 256) + 3) / 4)), cdiv(g.N, 256));
         hipLaunchKernelGGL(small_k_gemm, grid, dim3(256), 0, s, g);
+        g_last_tile = 0;
         PDF_LAUNCH_CHECK();
         return 0;
     }
@@ -751,11 +758,11 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     // (measured: below ~600 128x128 tiles the 64x64 kernel's 4x block count wins, e.g. ResNet layer2-4)
     // (a 256x128 tile -- 128 accumulator registers, one wave per SIMD -- was measured: 104 vs 123 TFLOP/s on the largest conv)
     if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600))
-        launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
+        launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s), g_last_tile = 128128;
     else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int("PDF_IG_T128", 600))
-        launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s);
+        launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s), g_last_tile = 128064;
     else
-        launch_igemm_tile<64, 64, 2, 2>(g, fast, dim3(cdiv(g.M, 64) * cdiv(g.N, 64), groups), s);
+        launch_igemm_tile<64, 64, 2, 2>(g, fast, dim3(cdiv(g.M, 64) * cdiv(g.N, 64), groups), s), g_last_tile = 64064;
     PDF_LAUNCH_CHECK();
     return 0;
 }

@@ -29,6 +29,8 @@ def parse_header(path=HEADER_PATH):
         types = []
         for a in args.split(","):
             a = " ".join(a.split())
+            if a in ("", "void"):
+                continue
             if "*" in a:
                 types.append(ctypes.c_void_p)
             else:
@@ -53,7 +55,7 @@ class _Lib:
 
     def __getattr__(self, name):
         fn = getattr(self.cdll, name)
-        is_status = self.protos[name][0] is ctypes.c_int
+        is_status = self.protos[name][0] is ctypes.c_int and not name.startswith("pdf_debug_")     # int = status code
 
         def call(*args):
             rc = fn(*args)

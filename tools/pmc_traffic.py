@@ -9,17 +9,30 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 
-def load(d, counter):
+def tile_name(k):
+    """'void igemm_nt<128, 128, 2, 2, true, false>(IGemm)' -> 'igemm_nt<128,128>' (tile shape; the B-layout / fast-path flags merged)."""
+    m = re.search(r"(igemm_nt|wgemm_tn_dma|wgemm_tn)<([^>]*)>", k)
+    if not m:
+        return None
+    args = [a.strip() for a in m.group(2).split(",")]
+    return "%s<%s>" % (m.group(1), ",".join(args[:2])) if m.group(1) != "wgemm_tn_dma" else "wgemm_tn_dma<128,128>"
+
+
+def load(d, counter, by_tile=False):
     f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        fam = "igemm_nt" if "igemm_nt" in k else "wgemm_tn" if "wgemm_tn" in k else "reduce_slabs" if "reduce_slabs" in k else None
+        if by_tile:
+            fam = tile_name(k)
+        else:
+            fam = "igemm_nt" if "igemm_nt" in k else "wgemm_tn" if "wgemm_tn" in k else "reduce_slabs" if "reduce_slabs" in k else None
         if fam is None:
             continue
         agg[fam][0] += 1
@@ -44,6 +57,12 @@ def main():
             tot_b += rb + wb
             tot_l += n
     res["gemm_family"] = {"hbm_GB_per_step": tot_b / steps / 1e9, "bytes_per_launch": tot_b / max(tot_l, 1)}
+    fk, wk = load(fdir, "FETCH_SIZE", True), load(wdir, "WRITE_SIZE", True)
+    res["kernels"] = {}
+    for k in sorted(set(fk) | set(wk)):
+        n = fk[k][0] or wk[k][0]
+        b = fk[k][1] * 1024 * 2 + wk[k][1] * 1024
+        res["kernels"][k] = {"launches_per_step": n / steps, "hbm_GB_per_step": b / steps / 1e9, "bytes_per_launch": b / max(n, 1)}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["gemm_family"]), json.dumps(res["families"]))
     # the heaviest single dispatches (reads), for tile-order / reuse work
