@@ -273,9 +273,9 @@ struct WGemm {
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
 
-template <int BI, int BJ, int WM, int WN, bool FAST>
+template <int BI, int BJ, int WM, int WN, bool FAST, int BKT = 16>
 __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
-    constexpr int BK = 16;
+    constexpr int BK = BKT;
     constexpr int TM = BI / WM / 32, TN = BJ / WN / 32;
     constexpr int TPR_P = BI / 4, TPR_Q = BJ / 4;        // threads per LDS row
     constexpr int RP = BK / (256 / TPR_P), RQ = BK / (256 / TPR_Q);
@@ -916,7 +916,8 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     g.beta = splits == 1 ? accumulate : 0;
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     if (small) {
-        if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
+        if (fast && env_int("PDF_WG_BK32", 1)) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
+        else if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);
     } else {
         const int dma = env_int("PDF_WG_DMA", 3);
