@@ -45,10 +45,11 @@ __device__ __forceinline__ void xcd_tile(int bid, int nblk, int ntn, int& tm, in
 }
 
 template <int BM, int BN, int WM, int WN, bool FAST, bool KN, int BKT = 16>
-__global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
+__global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
+    constexpr int NT = WM * WN * 64;                     // threads: one wave per (BM/WM) x (BN/WN) sub-tile
     constexpr int BK = BKT, LD = BK + 1;                 // K-step: 16, or 32 for the small tile (half the barriers per flop)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int TPR = BK / 4, RPP = 256 / TPR;         // threads per staged row (a float4 each), rows per pass of the block
+    constexpr int TPR = BK / 4, RPP = NT / TPR;          // threads per staged row (a float4 each), rows per pass of the block
     constexpr int RA = BM / RPP, RB = BN / RPP;
     __shared__ float As[2][BM * LD];
     __shared__ float Bs[2][BN * LD];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void igemm_nt(const IGemm g) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         if (FAST && KN) {
-            kb[i] = (tid + i * 256) / (BN / 4);
+            kb[i] = (tid + i * NT) / (BN / 4);
             bval[i] = n0 + nq4 < g.N;
             bbase[i] = (long)kb[i] * g.ldb + n0 + nq4;
         } else {
@@ -728,10 +729,11 @@ __global__ __launch_bounds__(256) void small_k_gemm(const IGemm g) {
 
 template <int BM, int BN, int WM, int WN, int BKF = 16>
 static void launch_igemm_tile(const IGemm& g, bool fast, dim3 grid, hipStream_t s) {
-    if (fast && g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, true, BKF>), grid, dim3(256), 0, s, g);
-    else if (fast) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, false, BKF>), grid, dim3(256), 0, s, g);
-    else if (g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, s, g);
+    constexpr int NT = WM * WN * 64;
+    if (fast && g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, true, BKF>), grid, dim3(NT), 0, s, g);
+    else if (fast) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, false, BKF>), grid, dim3(NT), 0, s, g);
+    else if (g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, true>), grid, dim3(NT), 0, s, g);
+    else hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, false>), grid, dim3(NT), 0, s, g);
 }
 
 static thread_local int g_last_tile = 0;            // BM * 1000 + BN of this thread's last implicit-GEMM launch (0: streaming small-K kernel)
@@ -758,6 +760,8 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;
     // (measured: below ~600 128x128 tiles the 64x64 kernel's 4x block count wins, e.g. ResNet layer2-4)
     // (a 256x128 tile -- 128 accumulator registers, one wave per SIMD -- was measured: 104 vs 123 TFLOP/s on the largest conv)
+    // (also measured for this tile: 8 waves per block with K-step 32 -- <128,128,4,2,..,32>, 4 waves/SIMD, half the barriers
+    // per flop: +1 % alone (125.5 vs 124.2 TFLOP/s on the largest conv), -0.3 % inside the step)
     if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600))
         launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s), g_last_tile = 128128;
     else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int("PDF_IG_T128", 600))
