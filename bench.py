@@ -114,8 +114,8 @@ class GemmProfiler:
         """(entry point, integer arguments) -> [calls, flops, seconds], largest time first."""
         torch.cuda.synchronize()
         sh = {}
-        for n, fl, e0, e1, ints, _t, _l in self.records:
-            d = sh.setdefault((n, ints), [0, 0.0, 0.0])
+        for n, fl, e0, e1, ints, t, _l in self.records:
+            d = sh.setdefault((n, ints + (('tile', t),)), [0, 0.0, 0.0])
             d[0] += 1
             d[1] += fl
             d[2] += e0.elapsed_time(e1) * 1e-3
