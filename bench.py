@@ -130,41 +130,171 @@ def _flush_c_stdout():
         pass
 
 
-def pmc_traffic(kernel=None):
-    """HBM bytes per launch of one kernel (by tile name) or of the whole GEMM family from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x2 + WRITE_SIZE, see tools/pmc_traffic.py); PMC counters cannot be read from inside this process, so this
-    is the last profiled value."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_traffic():
+    """-> (HBM bytes per launch of igemm_nt<128,128>, of the whole GEMM family, source tag).  PMC counters cannot be read
+    from inside this process: the figures come from the last committed profile (tools/profile_step.sh -> profiles/*_pmc_traffic.json,
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950).  The profile records the sha256 of csrc/gemm.hip it
+    was taken with; if the kernel source has changed since, the numbers are withheld (null) instead of going stale."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None, "no PMC profile committed"
+    p = files[-1]
     try:
         d = json.load(open(p))
-        return round(d["kernels"][kernel]["bytes_per_launch"] if kernel else d["gemm_family"]["bytes_per_launch"])
-    except Exception:
-        return None
+        cur = hashlib.sha256(open(os.path.join(ROOT, "pdfnet_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
+        if d.get("gemm_hip_sha256") != cur:
+            return None, None, "%s is older than csrc/gemm.hip (withheld)" % os.path.basename(p)
+        return (round(d["kernels"]["igemm_nt<128,128>"]["bytes_per_launch"]), round(d["gemm_family"]["bytes_per_launch"]),
+                "%s (rocprofv3 --pmc, %s)" % (os.path.basename(p), d.get("tag", "")))
+    except Exception as e:                                     # noqa: BLE001
+        return None, None, "unreadable profile: %s" % e
 
 
-def cpu_baseline(R, threads):
-    """The CPU oracle on a bounded sample of the same workload: B=2, one timed train step
-    (forward + surrogate loss + backward + torch Adam) after one warm-up."""
+def oracle_with_loss(R, state_dict=None):
+    """CPU oracle model + CPU oracle CtdetLoss (oracle/pdfnet_cpu.py, oracle/loss_cpu.py: both pinned to the reference)."""
+    import numpy as np
+    from oracle import loss_cpu as LC
     from oracle import pdfnet_cpu as O
-    from oracle import synth
-    from tests.util import surrogate_loss
+    from pdfnet_amd.synthetic import synthetic_loss_constants
+    opt = make_opt(R)
+    o = O.load_model_cpu(opt)
+    if state_dict is not None:
+        o.load_state_dict(state_dict)
+    z = np.load(os.path.join(ROOT, "pdfnet_amd", "data", "gcn_core.npz"))
+    conv = {h: LC.Converter(z['graph_perm_' + h], z['graph_perm_reverse_' + h]) for h in ('left', 'right')}
+    consts = synthetic_loss_constants()
+
+    def run(batch, mode, epoch=0):
+        ind = batch['ind'] if mode == 'train' else None
+        result, params, hand, other = o(batch['input'], batch['choose'], batch['cloud'], batch['depth'], ind, batch['K_new'], batch['valid'])
+        other['converter_left'], other['converter_right'] = conv['left'], conv['right']
+        return LC.ctdet_loss(opt, consts, result, params, hand, other, batch, mode, epoch)
+    return o, run, consts
+
+
+def cpu_baseline(R, threads, B=4, steps=3):
+    """The CPU oracle on a bounded sample of the SAME workload: B=4, the oracle model + the oracle CtdetLoss (same loss as
+    the GPU step), forward + loss + backward + torch Adam; one warm-up step, then the median of `steps` timed steps."""
+    from pdfnet_amd.synthetic import synthetic_train_batch
     torch.set_num_threads(threads)
-    B = 2
-    o = O.load_model_cpu(make_opt(R))
+    o, run, consts = oracle_with_loss(R)
     opt = torch.optim.Adam(o.parameters(), lr=1e-4)
-    b = synth.to_torch(synth.synthetic_batch(B, R, seed=1))
+    b = synthetic_train_batch(B, R, seed=1, consts=consts)
     o.train()
     times = []
-    for _ in range(2):
+    for _ in range(steps + 1):
         t0 = time.time()
         opt.zero_grad()
-        res = o(b['input'], b['choose'], b['cloud'], b['depth'], b['ind'], b['K_new'], b['valid'])
-        surrogate_loss(res).backward()
+        loss, _ = run(b, 'train', 0)
+        loss.mean().backward()
         opt.step()
         times.append(time.time() - t0)
-    return {"value": round(B / times[-1], 4), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "CPU oracle (oracle/pdfnet_cpu.py, PyTorch fp32), B=%d %dx%d RGB-D, 1 train step "
-                      "(fwd + surrogate loss + bwd + Adam) after 1 warm-up, %.1f s" % (B, R, R, times[-1])}
+    med = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(B / med, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "CPU oracle (oracle/pdfnet_cpu.py + oracle/loss_cpu.py, PyTorch fp32): B=%d %dx%d RGB-D, full train step "
+                      "(fwd + CtdetLoss + bwd + Adam), median of %d steps after 1 warm-up (%.1f s each)" % (B, R, R, steps, med)}
+
+
+def mpjpe_report(trainer, consts, R, B_eval, dev):
+    """MPJPE on synthetic ground truth (metric: "...; MPJPE parity vs ref"): the HIP path's test-mode pass over a fresh
+    synthetic batch (lib/trains/base_trainer.py:207-429 counterpart, all ranks), and -- rank 0, bounded to B=2 -- the same
+    weights and samples through the CPU oracle (model + loss pinned to the reference)."""
+    from pdfnet_amd.synthetic import synthetic_train_batch
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    batch = synthetic_train_batch(B_eval, R, seed=1001 + rank, consts=consts)
+    ev = trainer.evaluation([batch], dev)
+    out = {"mpjpe_mm": round(ev['mpjpe_mm'], 3), "mpvpe_mm": round(ev['mpvpe_mm'], 3), "mpjpe_root_relative_mm": round(ev['mpjpe_off_mm'], 3),
+           "lms_px": round(ev['lms_px'], 3), "samples": ev['samples']}
+    return out, batch
+
+
+def mpjpe_parity(trainer, consts, R, dev, batch):
+    """HIP path vs CPU oracle path on the first two samples of `batch`, same (trained) weights: |delta MPJPE| in mm."""
+    from oracle import loss_cpu as LC
+    from pdfnet_amd.trains.base_trainer import evaluation_sums, finish_evaluation
+    sub = {k: v[:2] for k, v in batch.items()}
+    mwl = trainer.model_with_loss
+    mwl.eval()
+    with torch.no_grad():
+        tup = mwl({k: v.to(dev) for k, v in sub.items()}, 'test', None)
+        hip = finish_evaluation(evaluation_sums(tup, {k: v.to(dev) for k, v in sub.items()}).cpu())
+    sd = {k: v.detach().cpu().contiguous() for k, v in trainer.model.state_dict().items()}
+    o, run, _ = oracle_with_loss(R, sd)
+    o.eval()
+    with torch.no_grad():
+        ref = LC.evaluation_metrics(run(sub, 'test'), (sub['lms_left_gt'], sub['lms_right_gt']))
+    ref_mpjpe = (ref['abs_left_joints'] + ref['abs_right_joints']) / 2
+    mwl.train()
+    return {"hip_mm": round(hip['mpjpe_mm'], 4), "cpu_oracle_mm": round(ref_mpjpe, 4), "abs_diff_mm": round(abs(hip['mpjpe_mm'] - ref_mpjpe), 5),
+            "samples": 2, "note": "same weights (after the timed steps) and samples through the HIP path and the CPU oracle path"}
+
+
+def rgb_encoder_bench(args, dev, rank, world):
+    """BASELINE config 2: B=8 256x256 RGB-only ResNet encoder forward + backward (intaghand_encoder.py:711-744: e_conv1,
+    ResNet-50, pyramid laterals + L2Norm, feat + BN + ReLU) with the weight gradients accumulated into the flat buffer --
+    the MFMA conv kernels on their own.  No loss module, no optimizer: a step is forward + backward of sum(x0^2)/N + ..."""
+    from pdfnet_amd import functional as F
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.trains.base_trainer import FlatAdam
+    R, B = args.res, args.batch
+    torch.manual_seed(0)
+    enc = load_model_intag(make_opt(R)).encoder.to(dev)
+    names = ('resnet.', 'p2', 'p3', 'p4', 'p5', 'feat', 'e_conv1')
+    params = [p for n, p in enc.named_parameters() if n.startswith(names) and not n.startswith('resnet.fc')]
+    flat = FlatAdam(params, lr=1e-4)
+    img = torch.randn(B, 3, R, R, device=dev)
+    enc.train()
+
+    def step():
+        flat.zero_grad()
+        x0, emb0, x1 = enc.rgb_encoder(img)
+        (x0.pow(2).mean() + emb0.pow(2).mean() + x1.pow(2).mean()).backward()
+        F.join_wgrad()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    # algorithmic FLOPs of this sub-path, SURVEY 8(d): a1 10.68 + a2 15.57 + a3 19.33 + a7 0.01 GF/img forward, x3 for the step
+    gf_img = 3 * (10.68 + 15.57 + 19.33 + 0.01) * (R / 256.0) ** 2
+    out = {"metric": "RGB-only encoder fwd+bwd images/sec @%dx%d B=%d" % (R, R, B), "value": round(B * args.steps / dt, 2), "unit": "images/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[1]: B=%d RGB-only ResNet-50 encoder + pyramid + feat forward/backward (weight gradients included), "
+                                  "fp32, %dx%d" % (B, R, R), "global_batch": B, "parallelism": "dp1"},
+           "roofline": {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "kernel": "whole sub-path (step level)",
+                        "achieved": round(gf_img * B * args.steps / dt / 1e3, 2), "frac": round(gf_img * B * args.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "algorithmic_gflop_per_img_step": round(gf_img, 2), "traffic": None}}
+    print(json.dumps(out), flush=True)
+
+
+def check_grads(trainer, batch, world, dev):
+    """--check-grads (N > 1): the gradient the trainer's overlapped all-reduce leaves in the flat buffer must equal the
+    sum over ranks of the rank-local gradients, gathered with a plain all_gather.  Two extra steps after the timed region
+    at frozen weights (lr = 0) with dropout off, so both see the same function."""
+    tr = trainer
+    tr.optimizer.lr = 0.0
+    for mod in tr.model.modules():
+        if isinstance(getattr(mod, 'p', None), float):
+            mod.p = 0.0
+    tr.collectives = False
+    tr.train_step(batch)                                 # rank-local gradient
+    torch.cuda.synchronize()
+    local = tr.optimizer.flat_g[:tr.n_live].clone()
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local)
+    want = torch.stack(parts).sum(0)
+    tr.collectives = True
+    tr.train_step(batch)                                 # early slice reduced from inside the backward, late slice after it
+    torch.cuda.synchronize()
+    got = tr.optimizer.flat_g[:tr.n_live]
+    err = float((got - want).abs().max() / (want.abs().max() + 1e-30))
+    return {"max_abs_err_over_max_abs": err, "ok": bool(err < 1e-4), "elements": int(got.numel()), "ranks": world}
 
 
 def main():
@@ -172,15 +302,22 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (BASELINE config 3: 32)')
+    ap.add_argument('--config', default='full', choices=['full', 'rgb-encoder'],
+                    help="full: BASELINE configs[2] (the headline); rgb-encoder: configs[1], B=8 RGB-only ResNet encoder fwd/bwd")
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 32; rgb-encoder: 8)')
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--graph', action='store_true', help='replay forward+loss+backward as one hipGraph (default: eager launches with\n'
                     'side-stream overlap of the weight-gradient kernels, measured faster on MI355X)')
     ap.add_argument('--no-graph', action='store_true', help='(default) kept for compatibility')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-mpjpe', action='store_true')
+    ap.add_argument('--broadcast-buffers', action='store_true', help="DDP's per-iteration BN-buffer broadcast (base_trainer.py:94-95)")
+    ap.add_argument('--check-grads', action='store_true', help='N>1: verify the reduced gradient against an all_gather of the rank-local ones')
     ap.add_argument('--gemm-shapes', default=None, help='write the per-shape table of the instrumented step to this file')
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 8 if args.config == 'rgb-encoder' else 32
 
     from pdfnet_amd import functional as F
     from pdfnet_amd.networks.intaghand_model import load_model_intag
@@ -195,6 +332,9 @@ def main():
     rank, local, world = init_distributed()
     assert world == args.gpus or (world == 1 and args.gpus == 1), "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device('cuda', local)
+    if args.config == 'rgb-encoder':
+        assert world == 1, "--config rgb-encoder is a one-GPU kernel benchmark"
+        return rgb_encoder_bench(args, dev, rank, world)
     R, B = args.res, args.batch
     opt = make_opt(R)
     torch.manual_seed(0)
@@ -204,10 +344,13 @@ def main():
     loss = CtdetLoss(opt, consts).to(dev)
     if args.graph:
         F.ASYNC_WGRAD = False              # hipGraph replay of the forked wgrad stream measured slower than the plain graph
-    trainer = Trainer(opt, model, loss, lr=1e-4, use_graph=args.graph)
-    if world > 1:
-        dist.broadcast(trainer.optimizer.flat_p, 0)            # identical replicas (DDP constructor semantics)
+    trainer = Trainer(opt, model, loss, lr=1e-4, use_graph=args.graph, broadcast_buffers=args.broadcast_buffers)   # world > 1: replicas synced from rank 0
     batch = to_device(synthetic_train_batch(B, R, seed=1 + rank, consts=consts), dev)
+    rccl_ranks = 1
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                  # what the data path's collective sees: every rank answers
+        rccl_ranks = int(ones.item())
 
     def barrier():
         if world > 1:
@@ -236,8 +379,15 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[2]: B=%d/GPU full RGB-D pyramid fusion + PointNet++ + GCN decoder fwd + CtdetLoss + bwd + Adam, "
                                "fp32, %dx%d" % (B, R, R), "global_batch": world * B, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph(fwd+loss+bwd) + fused Adam" if args.graph else "eager, weight-gradient kernels overlapped on a side HIP stream, fused Adam", "final_loss": round(loss_val, 4)},
+                   "launch": "hipGraph(fwd+loss+bwd) + fused Adam" if args.graph else "eager, weight-gradient kernels overlapped on a side HIP stream, fused Adam", "final_loss": round(loss_val, 4),
+                   "rccl_ranks": rccl_ranks, "allreduce_mb_per_step": round(trainer.n_live * 4 / 1e6, 1) if world > 1 else 0.0,
+                   "broadcast_buffers": bool(args.broadcast_buffers)},
     }
+    mp_batch = None
+    if not args.no_mpjpe:
+        out["mpjpe"], mp_batch = mpjpe_report(trainer, consts, R, min(B, 8), dev)      # every rank takes part (all-reduced sums)
+    if world > 1 and args.check_grads:
+        out["check_grads"] = check_grads(trainer, batch, world, dev)
     if rank == 0 and not args.no_roofline:
         # instrumented eager step: events around every implicit-GEMM entry point on the launch stream
         trainer.use_graph = False
@@ -256,6 +406,7 @@ def main():
         tiles = prof.by_tile()
         tname = {128128: "igemm_nt<128,128>", 128064: "igemm_nt<128,64>", 64064: "igemm_nt<64,64>", 0: "small_k_gemm", -1: "wgemm_tn*"}
         dom = tiles.get(128128, [0, 0.0, 1e-9])          # the kernel with the most time per step
+        traffic, traffic_all, traffic_src = pmc_traffic()
         out["roofline"] = {
             "bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "kernel": "igemm_nt<128,128,2,2> (csrc/gemm.hip: fp32 MFMA implicit GEMM, forward / backward-data / transposed-conv passes "
@@ -263,11 +414,11 @@ def main():
             "achieved": round(dom[1] / dom[2] / 1e12, 2), "frac": round(dom[1] / dom[2] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             "launches_per_step": dom[0], "ms_per_step": round(dom[2] * 1e3, 2),
             "algorithmic_gflop_per_launch": round(dom[1] / max(dom[0], 1) / 1e9, 1), "avg_launch_ms": round(dom[2] / max(dom[0], 1) * 1e3, 4),
-            "traffic": pmc_traffic("igemm_nt<128,128>"),
+            "traffic": traffic, "traffic_source": traffic_src,
             "all_gemm_kernels": {
                 "achieved": round(flops / secs / 1e12, 2), "frac": round(flops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "launches_per_step": calls, "algorithmic_gflop_per_step": round(flops / 1e9, 1), "gemm_ms_per_step": round(secs * 1e3, 2),
-                "traffic": pmc_traffic(),
+                "traffic": traffic_all,
                 "per_tile": {tname.get(k, str(k)): {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
                                                     "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(tiles.items())},
                 "per_entry_point": {k: {"calls": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
@@ -277,10 +428,15 @@ def main():
             "step_level": {"gflop_per_img_step_reference_formulation": ALGO_GFLOP_PER_IMG_STEP_DENSE,
                            "tflops_reference_formulation": round(ALGO_GFLOP_PER_IMG_STEP_DENSE * out["value"] / world / 1e3, 2),
                            "gflop_per_img_step_executed": round(flops / 1e9 / B, 1),
-                           "tflops_executed": round(flops / 1e9 / B * out["value"] / world / 1e3, 2)},
+                           "tflops_executed": round(flops / 1e9 / B * out["value"] / world / 1e3, 2),
+                           "frac_of_fp32_mfma_peak": round(flops / 1e9 / B * out["value"] / world / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
         }
+        F.USE_SIDE_STREAMS = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(R, max(1, (os.cpu_count() or 2) // 2))
+        threads = max(1, (os.cpu_count() or 2) // 2)
+        out["cpu_baseline"] = cpu_baseline(R, threads)
+        if mp_batch is not None:
+            out["mpjpe"]["parity_vs_cpu_oracle"] = mpjpe_parity(trainer, consts, R, dev, mp_batch)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -221,6 +221,24 @@ int pdf_face_loss_fwd(const float* pred, const float* gt, const long long* faces
 int pdf_face_loss_bwd(const float* pred, const float* gt, const long long* faces, int G, int B, int V, int Fc,
                       const float* wn, const float* we, float* dpred, void* stream);
 
+/* Dense-map terms of CtdetLoss (lib/trains/simplified.py:368 SmoothL1 on `mask`, :374 MSE on `hms`, :376,391 focal loss
+ * lib/models/losses.py:138-165 on the clamped sigmoid lib/models/utils.py:8-10 of `hm`), all three in one forward (partials +
+ * finalize) and one backward launch.  Predictions NHWC [B][HW][C], targets NCHW [B][C][HW].  ws: pdf_dense_loss_workspace_floats(B).
+ * out[0] = mask mean, out[1] = hms mean, out[2+b] = focal loss of sample b, out[2+B+b] = num_pos[b], out[2+2B] = 1 when the
+ * batch has no positive (losses.py:161); 3 + 2B floats.  bwd: g_mask, g_hms (one float each), g_hm [B] = upstream gradients,
+ * stat = the forward's out; a NULL d* or g_* pointer skips that term. */
+long pdf_dense_loss_workspace_floats(int B);
+int pdf_dense_loss_fwd(const float* mask, const float* mask_gt, int mask_c, int mask_hw,
+                       const float* hms, const float* hms_gt, int hms_c, int hms_hw,
+                       const float* hm, const float* hm_gt, int hm_c, int hm_hw, int B, float* ws, float* out, void* stream);
+int pdf_dense_loss_bwd(const float* mask, const float* mask_gt, float* dmask, int mask_c, int mask_hw,
+                       const float* hms, const float* hms_gt, float* dhms, int hms_c, int hms_hw,
+                       const float* hm, const float* hm_gt, float* dhm, int hm_c, int hm_hw, int B,
+                       const float* g_mask, const float* g_hms, const float* g_hm, const float* stat, void* stream);
+/* Evaluation metric of BaseTrainer.evaluation (lib/trains/base_trainer.py:263-323): out[r] = sum_i ||pred[r][i] - gt[r][i]||_2
+ * over the n points (dim 2 or 3) of row r = (sample, hand). */
+int pdf_point_dist_sum(const float* pred, const float* gt, int rows, int n, int dim, float* out, void* stream);
+
 /* ---- depth front end (csrc/frontend.hip) ------------------------------------------------------ */
 /* depth2pcl (intaghand_encoder.py:369-491 + get_points_coordinate lib/utils/utils.py:251-262) batched on the GPU:
  * depth [B][H][W] metres, mask [B][2][H][W] (right, left), K [B][3][3], valid [B][2] ->

@@ -682,13 +682,24 @@ __global__ __launch_bounds__(256) void reduce_slabs_2d(const Reduce r, int main_
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #include <cstdlib>
-static int env_int(const char* name, int dflt) {          // tuning overrides for tools/gemm_bench.py sweeps
-    static const char* names[8]; static int vals[8]; static int n = 0;
-    for (int i = 0; i < n; ++i) if (names[i] == name) return vals[i];
-    const char* e = getenv(name);
-    int v = e ? atoi(e) : dflt;
-    if (n < 8) { names[n] = name; vals[n] = v; ++n; }
-    return v;
+#include <climits>
+#include <mutex>
+// Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
+// autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
+// several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_SPLITK, ENV_IG_HALO, ENV_COUNT };
+static int env_int(int which, int dflt) {
+    static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_SPLITK", "PDF_IG_HALO"};
+    static int vals[ENV_COUNT];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int i = 0; i < ENV_COUNT; ++i) {
+            const char* e = getenv(names[i]);
+            vals[i] = e ? atoi(e) : INT_MIN;
+        }
+    });
+    return vals[which] == INT_MIN ? dflt : vals[which];
 }
 
 // C[m][n] = act(sum_k A[m][k] B[n][k] + bias[n]) for K <= 48, plain rows in / out: HBM-bound streaming (the backward-data
@@ -762,15 +773,15 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     // (a 256x128 tile -- 128 accumulator registers, one wave per SIMD -- was measured: 104 vs 123 TFLOP/s on the largest conv)
     // (also measured for this tile: 8 waves per block with K-step 32 -- <128,128,4,2,..,32>, 4 waves/SIMD, half the barriers
     // per flop: +1 % alone (125.5 vs 124.2 TFLOP/s on the largest conv), -0.3 % inside the step)
-    if (g.N > 64 && t128 >= env_int("PDF_IG_T128", 600))
+    if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600))
         launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s), g_last_tile = 128128;
-    else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int("PDF_IG_T128", 600))
+    else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int(ENV_IG_T128, 600))
         launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s), g_last_tile = 128064;   // (K-step 32: no gain here)
     else
     {
         const dim3 grid(cdiv(g.M, 64) * cdiv(g.N, 64), groups);
         // K-step 32 for the small tile: its 8 MFMAs per wave and 16-wide step leave the barrier exposed (l4 3x3: 62 -> 72 TFLOP/s)
-        if (fast && g.Cin % 32 == 0 && env_int("PDF_IG_BK32", 1)) launch_igemm_tile<64, 64, 2, 2, 32>(g, fast, grid, s);
+        if (fast && g.Cin % 32 == 0 && env_int(ENV_IG_BK32, 1)) launch_igemm_tile<64, 64, 2, 2, 32>(g, fast, grid, s);
         else launch_igemm_tile<64, 64, 2, 2>(g, fast, grid, s);
         g_last_tile = 64064;
     }
@@ -900,9 +911,9 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     long tiles = (long)cdiv(g.NI, BI) * cdiv(NJ, BJ);
     // split policy (measured, tools/gemm_bench.py): big gradient matrices want ~1024 blocks; few-tile / huge-M
     // (HBM-bound) ones ~512 longer-running blocks; small M may go down to 128 rows per split to fill the chip
-    const int target = env_int("PDF_WG_TARGET", tiles >= 8 ? 1024 : 512);
+    const int target = env_int(ENV_WG_TARGET, tiles >= 8 ? 1024 : 512);
     int splits = (int)((target + tiles * groups - 1) / (tiles * groups));
-    int max_by_rows = cdiv(g.M, env_int("PDF_WG_MINROWS", g.M >= 16384 ? 512 : 128));
+    int max_by_rows = cdiv(g.M, env_int(ENV_WG_MINROWS, g.M >= 16384 ? 512 : 128));
     if (splits > max_by_rows) splits = max_by_rows;
     long per = (long)g.NI * g.ldw;
     const long perb = db ? g.NI : 0;
@@ -911,7 +922,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     int rps = cdiv(cdiv(g.M, splits), 16) * 16;
     splits = cdiv(g.M, rps);
     g.rows_per_split = rps;
-    g.tap_major = (!g.plain_q && g.T > 1 && g.Cq % BJ == 0 && env_int("PDF_WG_TAPMAJOR", 1)) ? 1 : 0;
+    g.tap_major = (!g.plain_q && g.T > 1 && g.Cq % BJ == 0 && env_int(ENV_WG_TAPMAJOR, 1)) ? 1 : 0;
     g.slab = splits == 1 ? out : ws;          // one split: no slab round trip, no reduce launch
     g.slab1 = splits == 1 ? out1 : ws + (long)splits * per;
     float* bws = ws + (long)splits * per * groups;              // bias partials behind the weight slabs
@@ -920,11 +931,11 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     g.beta = splits == 1 ? accumulate : 0;
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     if (small) {
-        if (fast && env_int("PDF_WG_BK32", 1)) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
+        if (fast && env_int(ENV_WG_BK32, 1)) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);
     } else {
-        const int dma = env_int("PDF_WG_DMA", 3);
+        const int dma = env_int(ENV_WG_DMA, 3);
         if (fast && dma == 4) hipLaunchKernelGGL(wgemm_tn_dma<4>, grid, dim3(256), 0, s, g);
         else if (fast && dma == 3) hipLaunchKernelGGL(wgemm_tn_dma<3>, grid, dim3(256), 0, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, true>), grid, dim3(256), 0, s, g);

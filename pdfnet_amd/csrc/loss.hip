@@ -149,3 +149,147 @@ PDF_API int pdf_face_loss_bwd(const float* pred, const float* gt, const long lon
     PDF_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Dense-map terms of CtdetLoss (lib/trains/simplified.py:368,374,376,391): SmoothL1 on the hand masks, MSE on the joint
+// heat-maps and the CornerNet focal loss (lib/models/losses.py:138-165) on the clamped sigmoid (lib/models/utils.py:8-10) of
+// the centre heat-map -- ~40 aten launches forward + backward in the reference, here two launches forward (partials +
+// finalize) and one backward for all three terms.  Predictions are NHWC (the model's layout), targets NCHW (the
+// dataset's): element (n, c, p) of a prediction sits at ((n*HW + p)*C + c), of a target at ((n*C + c)*HW + p).
+struct DenseTerm { const float* pred; const float* tgt; float* dpred; int C, HW; };
+struct DenseLoss { DenseTerm t[3]; int B, nblk; };            // t[0] mask (SmoothL1), t[1] hms (MSE), t[2] hm (focal)
+
+__device__ __forceinline__ float clamp_sigmoid(float x) { return fminf(fmaxf(1.f / (1.f + expf(-x)), 1e-4f), 1.f - 1e-4f); }
+
+// part[((term*B + b)*nblk + blk)*3 + {0,1,2}]: SmoothL1 / MSE: {sum, 0, 0}; focal: {pos_sum, neg_sum, num_pos}
+__global__ __launch_bounds__(256) void dense_loss_partial_kernel(const DenseLoss a, float* __restrict__ part) {
+    __shared__ float sm[4];
+    const int term = blockIdx.z, b = blockIdx.y, blk = blockIdx.x;
+    const DenseTerm t = a.t[term];
+    const long per = (long)t.C * t.HW;
+    const float* pt = t.tgt + b * per;
+    const float* pp = t.pred + b * per;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (long i = blk * 256L + threadIdx.x; i < per; i += a.nblk * 256L) {
+        const int c = (int)(i / t.HW), p = (int)(i - (long)c * t.HW);
+        const float x = pp[(long)p * t.C + c], g = pt[i];
+        if (term == 0) { const float d = fabsf(x - g); s0 += d < 1.f ? 0.5f * d * d : d - 0.5f; }
+        else if (term == 1) { const float d = x - g; s0 += d * d; }
+        else {
+            const float q = clamp_sigmoid(x);
+            if (g == 1.f) { s0 += logf(q) * (1.f - q) * (1.f - q); s2 += 1.f; }
+            else if (g < 1.f) { const float w = (1.f - g) * (1.f - g); s1 += logf(1.f - q) * q * q * w * w; }
+        }
+    }
+    s0 = block_sum_256(s0, sm);
+    s1 = block_sum_256(s1, sm);
+    s2 = block_sum_256(s2, sm);
+    if (threadIdx.x == 0) {
+        float* o = part + (((long)term * a.B + b) * a.nblk + blk) * 3;
+        o[0] = s0; o[1] = s1; o[2] = s2;
+    }
+}
+// out[0] = SmoothL1 mean, out[1] = MSE mean, out[2 + b] = focal loss of sample b, out[2 + B + b] = num_pos[b],
+// out[2 + 2B] = 1 if the batch holds no positive at all (the reference's `if num_pos.sum() == 0` branch, losses.py:161)
+__global__ __launch_bounds__(64) void dense_loss_finalize_kernel(const DenseLoss a, const float* __restrict__ part, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    for (int term = 0; term < 2; ++term) {
+        float s = 0.f;
+        for (int i = lane; i < a.B * a.nblk; i += 64) s += part[((long)term * a.B * a.nblk + i) * 3];
+        s = wave_sum(s);
+        if (lane == 0) out[term] = s / ((float)a.B * a.t[term].C * a.t[term].HW);
+    }
+    float tot = 0.f;
+    for (int b = lane; b < a.B; b += 64)
+        for (int k = 0; k < a.nblk; ++k) tot += part[(((long)2 * a.B + b) * a.nblk + k) * 3 + 2];
+    tot = wave_sum(tot);
+    for (int b = lane; b < a.B; b += 64) {
+        float ps = 0.f, ns = 0.f, np = 0.f;
+        for (int k = 0; k < a.nblk; ++k) {
+            const float* p = part + (((long)2 * a.B + b) * a.nblk + k) * 3;
+            ps += p[0]; ns += p[1]; np += p[2];
+        }
+        out[2 + b] = tot == 0.f ? -ns : -(ps + ns) / (np + 1e-3f);
+        out[2 + a.B + b] = np;
+    }
+    if (lane == 0) out[2 + 2 * a.B] = tot == 0.f ? 1.f : 0.f;
+}
+PDF_API long pdf_dense_loss_workspace_floats(int B) { return 3L * B * 8 * 3; }
+PDF_API int pdf_dense_loss_fwd(const float* mask, const float* mask_gt, int mask_c, int mask_hw,
+                               const float* hms, const float* hms_gt, int hms_c, int hms_hw,
+                               const float* hm, const float* hm_gt, int hm_c, int hm_hw, int B, float* ws, float* out, hipStream_t s) {
+    if (B <= 0) return 0;
+    DenseLoss a = {{{mask, mask_gt, nullptr, mask_c, mask_hw}, {hms, hms_gt, nullptr, hms_c, hms_hw}, {hm, hm_gt, nullptr, hm_c, hm_hw}}, B, 8};
+    hipLaunchKernelGGL(dense_loss_partial_kernel, dim3(a.nblk, B, 3), dim3(256), 0, s, a, ws);
+    hipLaunchKernelGGL(dense_loss_finalize_kernel, dim3(1), dim3(64), 0, s, a, ws, out);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// g0, g1: upstream gradients (one float each) of the two means; g2[b]: of the focal loss of sample b; stat = the forward's `out`
+__global__ __launch_bounds__(256) void dense_loss_bwd_kernel(const DenseLoss a, const float* __restrict__ g0, const float* __restrict__ g1,
+                                                             const float* __restrict__ g2, const float* __restrict__ stat) {
+    const int term = blockIdx.z, b = blockIdx.y;
+    const DenseTerm t = a.t[term];
+    if (t.dpred == nullptr) return;
+    const long per = (long)t.C * t.HW;
+    const float* pt = t.tgt + b * per;
+    const float* pp = t.pred + b * per;
+    float* dp = t.dpred + b * per;
+    float k;
+    if (term < 2) k = (term == 0 ? g0[0] : g1[0]) / ((float)a.B * per);
+    else k = stat[2 + 2 * a.B] != 0.f ? -g2[b] : -g2[b] / (stat[2 + a.B + b] + 1e-3f);
+    const bool no_pos = term == 2 && stat[2 + 2 * a.B] != 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += gridDim.x * 256L) {
+        const int c = (int)(i / t.HW), p = (int)(i - (long)c * t.HW);
+        const long o = (long)p * t.C + c;
+        const float x = pp[o], gt = pt[i];
+        float d;
+        if (term == 0) { const float e = x - gt; d = k * (fabsf(e) < 1.f ? e : (e > 0.f ? 1.f : -1.f)); }
+        else if (term == 1) d = k * 2.f * (x - gt);
+        else {
+            const float sgm = 1.f / (1.f + expf(-x));
+            const float q = fminf(fmaxf(sgm, 1e-4f), 1.f - 1e-4f);
+            const float dq = (sgm >= 1e-4f && sgm <= 1.f - 1e-4f) ? sgm * (1.f - sgm) : 0.f;      // clamp passes gradient inside [min, max]
+            float dl = 0.f;
+            if (gt == 1.f) dl = no_pos ? 0.f : (1.f - q) * (1.f - q) / q - 2.f * (1.f - q) * logf(q);
+            else if (gt < 1.f) { const float w = (1.f - gt) * (1.f - gt); dl = w * w * (2.f * q * logf(1.f - q) - q * q / (1.f - q)); }
+            d = k * dl * dq;
+        }
+        dp[o] = d;
+    }
+}
+PDF_API int pdf_dense_loss_bwd(const float* mask, const float* mask_gt, float* dmask, int mask_c, int mask_hw,
+                               const float* hms, const float* hms_gt, float* dhms, int hms_c, int hms_hw,
+                               const float* hm, const float* hm_gt, float* dhm, int hm_c, int hm_hw, int B,
+                               const float* g_mask, const float* g_hms, const float* g_hm, const float* stat, hipStream_t s) {
+    if (B <= 0) return 0;
+    DenseLoss a = {{{mask, mask_gt, g_mask ? dmask : nullptr, mask_c, mask_hw}, {hms, hms_gt, g_hms ? dhms : nullptr, hms_c, hms_hw},
+                    {hm, hm_gt, g_hm ? dhm : nullptr, hm_c, hm_hw}}, B, 8};
+    hipLaunchKernelGGL(dense_loss_bwd_kernel, dim3(32, B, 3), dim3(256), 0, s, a, g_mask, g_hms, g_hm, stat);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Evaluation metric (lib/trains/base_trainer.py:263-323): out[r] = sum over the n points of row r of ||pred - gt||_2
+// (dim = 3: joints / vertices in metres, dim = 2: landmarks in pixels).  One block per row = (sample, hand).
+__global__ __launch_bounds__(256) void point_dist_sum_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int n, int dim,
+                                                             float* __restrict__ out) {
+    __shared__ float sm[4];
+    const float* p = pred + (long)blockIdx.x * n * dim;
+    const float* q = gt + (long)blockIdx.x * n * dim;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float s = 0.f;
+        for (int k = 0; k < dim; ++k) { const float d = p[i * dim + k] - q[i * dim + k]; s += d * d; }
+        a += sqrtf(s);
+    }
+    a = block_sum_256(a, sm);
+    if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+PDF_API int pdf_point_dist_sum(const float* pred, const float* gt, int rows, int n, int dim, float* out, hipStream_t s) {
+    if (rows <= 0 || n <= 0) return 0;
+    if (dim < 1 || dim > 4) return PDF_E_BADARG;
+    hipLaunchKernelGGL(point_dist_sum_kernel, dim3(rows), dim3(256), 0, s, pred, gt, n, dim, out);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}

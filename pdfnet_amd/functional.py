@@ -130,11 +130,17 @@ _wg_used = set()
 class wgrad_stream:
     """Context for weight-gradient kernels that accumulate straight into the trainer's flat gradient buffer: nothing
     in the backward chain consumes them, so they run on a side HIP stream and overlap the data-gradient chain (whose
-    small layers fill only part of the 256 CUs).  `join_wgrad()` is called once after backward."""
+    small layers fill only part of the 256 CUs).  `join_wgrad()` is called once after backward.
 
-    def __init__(self, enabled, *tensors):
+    There is one side stream per launching stream, so two branches' weight gradients overlap each other too.  A parameter
+    that is used by modules running on DIFFERENT streams (a shared layer called from two forked branches) would get two
+    non-atomic `dW += ...` launches on two side streams at once: `params` names the accumulation targets, and a side
+    stream first waits for the stream that last accumulated into the same parameter."""
+
+    def __init__(self, enabled, *tensors, params=()):
         self.enabled = enabled and ASYNC_WGRAD and USE_SIDE_STREAMS
         self.tensors = tensors
+        self.params = params
 
     def __enter__(self):
         if not self.enabled:
@@ -146,6 +152,12 @@ class wgrad_stream:
             _wg_streams[key] = torch.cuda.Stream()
         side = _wg_streams[key]
         side.wait_stream(cur)
+        for p in self.params:
+            if p is not None:
+                last = getattr(p, '_pdf_wg_last', None)
+                if last is not None and last is not side:
+                    side.wait_stream(last)
+                p._pdf_wg_last = side
         for t in self.tensors:                      # produced / owned by the main stream, read on the side stream
             if t is not None:
                 t.record_stream(side)
@@ -209,7 +221,7 @@ def _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, C, R, flops, fused
     dw = db = None
     ride = fused_bias and need_w and need_b and (mg_w is None) == (mg_b is None)      # same accumulate mode for both
     if mg_w is not None or mg_b is not None:
-        with wgrad_stream(flops >= ASYNC_WGRAD_MIN_FLOP, x, g):
+        with wgrad_stream(flops >= ASYNC_WGRAD_MIN_FLOP, x, g, params=(w_par, b_par)):
             if mg_w is not None:
                 launch_w(mg_w, mg_b if ride else None, 1)
             if mg_b is not None and not ride:
@@ -429,7 +441,7 @@ class _LinearPair(Function):
         dw0 = dw1 = db0 = db1 = None
         ride = need_w and need_b and direct_w == direct_b                 # the bias gradients ride along with the weight launch
         if (need_w and direct_w) or (need_b and direct_b):
-            with wgrad_stream(True, x, g):
+            with wgrad_stream(True, x, g, params=(w0_par, b0_par, w1_par, b1_par)):
                 if need_w and direct_w:
                     launch_w(mg_w0, mg_w1, mg_b0 if ride else None, mg_b1 if ride else None, 1)
                 if need_b and direct_b and not ride:
@@ -1230,3 +1242,57 @@ class _FaceLoss(Function):
 
 def face_loss(pred, gt, faces, edge_grad=True):
     return _FaceLoss.apply(pred, gt.detach(), faces, edge_grad)
+
+
+class _DenseLoss(Function):
+    """The three dense-map terms of CtdetLoss (simplified.py:368,374,376,391) in one forward and one backward launch:
+    (SmoothL1(mask, mask_gt) scalar, MSE(hms, hms_gt) scalar, focal(clamp(sigmoid(hm)), hm_gt) [B])."""
+
+    @staticmethod
+    def forward(ctx, mask, mask_gt, hms, hms_gt, hm, hm_gt):
+        hip.require_gpu(mask, hms, hm)
+        mask, hms, hm = cl(mask), cl(hms), cl(hm)                       # the model's own layout: no copies on the product path
+        mask_gt, hms_gt, hm_gt = (t.detach().float().contiguous() for t in (mask_gt, hms_gt, hm_gt))
+        for a, b in ((mask, mask_gt), (hms, hms_gt), (hm, hm_gt)):
+            if a.shape != b.shape:
+                raise ValueError("pdfnet_amd: dense_loss wants equal shapes, got %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        B = mask.shape[0]
+        L = _L()
+        ws = _ws(L.pdf_dense_loss_workspace_floats(B), mask.device)
+        out = torch.empty(3 + 2 * B, dtype=torch.float32, device=mask.device)
+        dims = lambda t: (t.shape[1], t.shape[2] * t.shape[3])
+        L.pdf_dense_loss_fwd(ptr(mask), ptr(mask_gt), *dims(mask), ptr(hms), ptr(hms_gt), *dims(hms), ptr(hm), ptr(hm_gt), *dims(hm),
+                             B, ptr(ws), ptr(out), stream())
+        ctx.save_for_backward(mask, mask_gt, hms, hms_gt, hm, hm_gt, out)
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2:2 + B]
+
+    @staticmethod
+    def backward(ctx, g_mask, g_hms, g_hm):
+        mask, mask_gt, hms, hms_gt, hm, hm_gt, out = ctx.saved_tensors
+        B = mask.shape[0]
+        g_mask, g_hms, g_hm = (t.contiguous() if t is not None else None for t in (g_mask, g_hms, g_hm))
+        need = ctx.needs_input_grad
+        dmask = torch.empty_like(mask) if need[0] and g_mask is not None else None
+        dhms = torch.empty_like(hms) if need[2] and g_hms is not None else None
+        dhm = torch.empty_like(hm) if need[4] and g_hm is not None else None
+        dims = lambda t: (t.shape[1], t.shape[2] * t.shape[3])
+        _L().pdf_dense_loss_bwd(ptr(mask), ptr(mask_gt), ptr(dmask), *dims(mask), ptr(hms), ptr(hms_gt), ptr(dhms), *dims(hms),
+                                ptr(hm), ptr(hm_gt), ptr(dhm), *dims(hm), B, ptr(g_mask), ptr(g_hms), ptr(g_hm), ptr(out), stream())
+        return dmask, None, dhms, None, dhm, None
+
+
+def dense_loss(mask, mask_gt, hms, hms_gt, hm, hm_gt):
+    return _DenseLoss.apply(mask, mask_gt, hms, hms_gt, hm, hm_gt)
+
+
+def point_dist_sum(pred, gt):
+    """pred, gt [..., n, dim] -> [...] sums over the n points of the Euclidean distance (evaluation metric, no gradient)."""
+    hip.require_gpu(pred, gt)
+    p, q = pred.detach().float().contiguous(), gt.detach().float().contiguous()
+    if p.shape != q.shape:
+        raise ValueError("pdfnet_amd: point_dist_sum wants equal shapes, got %s vs %s" % (tuple(p.shape), tuple(q.shape)))
+    n, dim = p.shape[-2], p.shape[-1]
+    out = torch.empty(p.shape[:-2], dtype=torch.float32, device=p.device)
+    _L().pdf_point_dist_sum(ptr(p), ptr(q), out.numel(), n, dim, ptr(out), stream())
+    return out

@@ -237,6 +237,21 @@ class ResNetSimple(nn.Module):
         hms, mask, ret, hms_f, dp_f = self.dense_branches(st)
         return hms, mask, ret, st['img_fmaps'], hms_f, dp_f, st['ind']
 
+    def rgb_encoder(self, img):
+        """BASELINE config 2: the RGB-only part of the encoder call (intaghand_encoder.py:711-744) -- e_conv1, the ResNet-50
+        trunk, the pyramid laterals + L2Norm, cat -> feat -> feat_bn -> ReLU.
+        Returns (x0 [B,256,R/4,R/4], emb0 [B,3,R,R], x1 [B,2048,R/32,R/32])."""
+        r = self.resnet
+        img = F.cl(img)
+        emb0 = self.e_conv1(img, F.ACT_RELU)                                              # :711
+        emb1 = r.bn1(r.conv1(img), relu=True)                                             # :712-715
+        x4 = r.layer1(F.maxpool3s2(emb1))
+        x3 = r.layer2(x4)
+        x2 = r.layer3(x3)
+        x1 = r.layer4(x2)
+        pyr = torch.cat([self.p2_l2(self.p2(x4)), self.p3_l2(self.p3(x3)), self.p4_l2(self.p4(x2)), self.p5_l2(self.p5(x1))], 1)
+        return self.feat_bn(self.feat(pyr), relu=True), emb0, x1                          # :740-744
+
     def trunk(self, img, ind, choose, cloud, depth=None, K_new=None, valid=None):
         """Everything the mesh decoder waits on: ResNet, pyramid, `feat`, the centre heat-map head, centre features,
         PointNet++ per hand and the SFT fusion.  Returns a state dict for `dense_branches`."""

@@ -10,6 +10,7 @@ MI355X-first differences from the reference loop:
   * the step has no host synchronisation, so forward+loss+backward (and the optimizer) replay as a hipGraph.
 """
 import os
+import re
 
 import torch
 import torch.distributed as dist
@@ -34,13 +35,20 @@ class ModleWithLoss(torch.nn.Module):
 
 
 class FlatAdam:
-    """torch.optim.Adam(params, lr) semantics (main.py:63) on flat buffers with one fused HIP kernel."""
+    """torch.optim.Adam(params, lr) semantics (main.py:63) on flat buffers with one fused HIP kernel.
 
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    `params` fixes the order of the flat buffers; `ckpt_order` (default: the same list) is the order the reference's
+    optimizer sees -- `model.parameters()` -- and is the index space of `state_dict()`, which is written and read in
+    torch.optim.Adam's own format ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}) so that
+    `load_model(..., resume=True)` (lib/utils/utils.py:84-96) works across the two implementations in both directions.
+    `n_live` (flat offset): the range [n_live, numel) holds tensors that never receive a gradient; the Adam launch and the
+    gradient all-reduce stop there (their moments stay zero, so skipping them is exact)."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, ckpt_order=None, n_live_params=None):
         self.params = [p for p in params]
         dev = self.params[0].device
         assert dev.type == 'cuda', "FlatAdam: parameters must be on the GPU (no CPU fallback)"
-        self.lr, self.betas, self.eps = lr, betas, eps
+        self.param_groups = [{'lr': lr, 'betas': tuple(betas), 'eps': eps, 'weight_decay': 0, 'amsgrad': False}]
         ALIGN = 64                                     # every tensor starts on a 256-byte boundary: the GEMM fast
         offs, n = [], 0                                # path needs 16-byte aligned operands (float4 loads)
         for p in self.params:
@@ -48,40 +56,106 @@ class FlatAdam:
             n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = n
         self.offsets = offs                            # flat offset of params[i] (the buffers follow the order given)
+        self.n_live = n if n_live_params is None else (offs[n_live_params] if n_live_params < len(offs) else n)
         self.flat_p = torch.zeros(n, device=dev)
         self.flat_g = torch.zeros(n, device=dev)
         self.flat_m = torch.zeros(n, device=dev)
         self.flat_v = torch.zeros(n, device=dev)
+        self._grad_views = []
         for p, o in zip(self.params, offs):
             k = p.numel()
             view = self.flat_p[o:o + k].as_strided(p.shape, p.stride())      # keeps e.g. channels_last storage
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_g[o:o + k].as_strided(p.shape, p.stride())
+            self._grad_views.append(p.grad)
             p._pdf_main_grad = True                   # HIP backward kernels accumulate straight into this view
+        pos = {id(p): i for i, p in enumerate(self.params)}
+        order = self.params if ckpt_order is None else [p for p in ckpt_order]
+        assert len(order) == len(self.params) and all(id(p) in pos for p in order), "FlatAdam: ckpt_order must be a permutation of params"
+        self.ckpt_index = [pos[id(p)] for p in order]                        # checkpoint index -> position in the flat order
         self.step_t = torch.zeros(1, device=dev)                             # device-side step count (graph-safe)
         self.corr = torch.ones(2, device=dev)
         self._b = torch.tensor(betas, device=dev)
 
+    # the reference edits `param_group['lr']` in place (lib/utils/utils.py:93-94, main.py:129-132)
+    @property
+    def lr(self):
+        return self.param_groups[0]['lr']
+
+    @lr.setter
+    def lr(self, v):
+        if v is not None:
+            self.param_groups[0]['lr'] = float(v)
+
+    @property
+    def betas(self):
+        return self.param_groups[0]['betas']
+
+    @property
+    def eps(self):
+        return self.param_groups[0]['eps']
+
+    def reattach_grads(self):
+        """The HIP backward kernels accumulate into `p.grad` only while it is the view into the flat gradient buffer.
+        `model.zero_grad()` (set_to_none=True), `p.grad = None` or an optimizer-style zero_grad replace it; autograd would
+        then allocate fresh gradients that step() never reads.  Called before every backward: puts the views back."""
+        for p, v in zip(self.params, self._grad_views):
+            if p.grad is not v:
+                p.grad = v
+
     def zero_grad(self):
-        self.flat_g.zero_()
+        self.reattach_grads()
+        self.flat_g[:self.n_live].zero_()
 
     def step(self, grad_scale=1.0):
         F.join_wgrad()                                 # side-stream gradient kernels must have landed (no-op when already joined)
         self.step_t += 1
         torch.sub(1.0, torch.pow(self._b, self.step_t), out=self.corr)        # [1-b1^t, 1-b2^t]
         hip.lib().pdf_adam_step(hip.ptr(self.flat_p), hip.ptr(self.flat_g), hip.ptr(self.flat_m), hip.ptr(self.flat_v),
-                                self.numel, self.lr, self.betas[0], self.betas[1], self.eps, hip.ptr(self.corr),
+                                self.n_live, float(self.lr), self.betas[0], self.betas[1], self.eps, hip.ptr(self.corr),
                                 float(grad_scale), hip.stream())
 
+    def _view(self, flat, i):
+        p, o = self.params[i], self.offsets[i]
+        return flat[o:o + p.numel()].as_strided(p.shape, p.stride())
+
     def state_dict(self):
-        return {'step': self.step_t.clone(), 'exp_avg': self.flat_m.clone(), 'exp_avg_sq': self.flat_v.clone(), 'lr': self.lr}
+        """torch.optim.Adam's layout: per-parameter moments in logical (OIHW-contiguous) form, indexed in `ckpt_order`."""
+        step = self.step_t.detach().cpu().reshape(())
+        state = {}
+        for ci, i in enumerate(self.ckpt_index):
+            state[ci] = {'step': step.clone(), 'exp_avg': self._view(self.flat_m, i).detach().cpu().contiguous(),
+                         'exp_avg_sq': self._view(self.flat_v, i).detach().cpu().contiguous()}
+        g = dict(self.param_groups[0])
+        g.update({'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                  'params': list(range(len(self.ckpt_index)))})
+        return {'state': state, 'param_groups': [g]}
 
     def load_state_dict(self, sd):
-        self.step_t.copy_(sd['step'])
-        self.flat_m.copy_(sd['exp_avg'])
-        self.flat_v.copy_(sd['exp_avg_sq'])
-        self.lr = sd.get('lr', self.lr)
+        if 'state' not in sd or 'param_groups' not in sd:
+            raise ValueError("FlatAdam.load_state_dict: expected torch.optim.Adam's {'state', 'param_groups'} layout")
+        ids = sd['param_groups'][0]['params']
+        if len(ids) != len(self.ckpt_index):
+            raise ValueError("FlatAdam.load_state_dict: checkpoint has %d parameters, the model %d" % (len(ids), len(self.ckpt_index)))
+        self.flat_m.zero_()
+        self.flat_v.zero_()
+        step = 0.0
+        for ci, pid in enumerate(ids):
+            st = sd['state'].get(pid)
+            if st is None:                             # torch keeps no state for a parameter that never had a gradient
+                continue
+            i = self.ckpt_index[ci]
+            if tuple(st['exp_avg'].shape) != tuple(self.params[i].shape):
+                raise ValueError("FlatAdam.load_state_dict: parameter %d has shape %s in the checkpoint, %s in the model"
+                                 % (ci, tuple(st['exp_avg'].shape), tuple(self.params[i].shape)))
+            self._view(self.flat_m, i).copy_(st['exp_avg'])
+            self._view(self.flat_v, i).copy_(st['exp_avg_sq'])
+            step = max(step, float(st['step']))
+        self.step_t.fill_(step)
+        g = sd['param_groups'][0]
+        self.param_groups[0].update({'lr': float(g['lr']), 'betas': tuple(g['betas']), 'eps': g['eps']})
+        self._b.copy_(torch.tensor(self.betas))
 
 
 def allreduce_flat_grads(flat_g, chunks=4, wait=True, force=False):
@@ -107,29 +181,59 @@ def allreduce_flat_grads(flat_g, chunks=4, wait=True, force=False):
 # the gradient of the trunk output x1 has been formed (autograd runs later-created nodes first).
 LATE_PREFIXES = ('encoder.resnet.', 'encoder.e_conv1.', 'encoder.pointnet_plus.')
 
+# Parameters no autograd path of HandNET_GCN.forward reaches, whatever the loss (the reference needs
+# find_unused_parameters=True for them, base_trainer.py:95): constructed-but-unused heads, the mid model (run under
+# no_grad for its BN statistics), the image-feature extractors of the dual GCN and the GCN blocks' overwritten norm1
+# (SURVEY Appendix A.1).  13.6 M elements: laid out BEHIND the live ranges so that zero_grad, the gradient all-reduce and
+# Adam stop before them.  tests/test_host_cpu.py checks the rule against tests/golden/params_without_grad.txt.
+DEAD_PATTERN = re.compile(r'^(mid_model\.|encoder\.(joint_head_l|joint_head_r|mano_head|resnet\.fc|pointnet_plus\.netR_FC)\.|'
+                          r'decoder\.dual_gcn\.layers\.\d+\.(img_ex_(left|right)\.|graph_(left|right)\.GCN_blocks\.\d+\.norm1\.))')
+
+
+def split_parameters(named):
+    """-> (early, late, dead) lists of (name, parameter), each in model order."""
+    early, late, dead = [], [], []
+    for n, p in named:
+        (dead if DEAD_PATTERN.match(n) else late if n.startswith(LATE_PREFIXES) else early).append((n, p))
+    return early, late, dead
+
 
 class Trainer:
     """train(epoch, loader) / train_step(batch) for `HandNET_GCN` + `CtdetLoss`."""
 
-    def __init__(self, opt, model, loss, lr=1e-4, use_graph=False):
+    def __init__(self, opt, model, loss, lr=1e-4, use_graph=False, broadcast_buffers=False):
         self.opt = opt
+        self.model = model
         self.model_with_loss = ModleWithLoss(model, loss)
         named = list(model.named_parameters())
-        early = [p for n, p in named if not n.startswith(LATE_PREFIXES)]
-        late = [p for n, p in named if n.startswith(LATE_PREFIXES)]
-        self.optimizer = FlatAdam(early + late, lr=lr)         # flat order: [early | late], see LATE_PREFIXES
-        self.n_early = self.optimizer.offsets[len(early)] if late else self.optimizer.numel
+        early, late, dead = split_parameters(named)
+        flat = [p for _, p in early + late + dead]             # flat order: [early | late | never used]
+        self.optimizer = FlatAdam(flat, lr=lr, ckpt_order=[p for _, p in named], n_live_params=len(early) + len(late))
+        self.n_early = self.optimizer.offsets[len(early)] if late else self.optimizer.n_live
+        self.n_live = self.optimizer.n_live
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._early_works = None
         self.force_collectives = False                         # tests: run the all-reduces on a one-rank group as well
         self.collectives = True                                # False: a rank-local step (bench.py's instrumented step on rank 0)
         self.early_probe = None                                # test hook: called with the early gradient slice when it is complete
+        # DDP(broadcast_buffers=True) re-sends rank 0's BatchNorm statistics before every forward (base_trainer.py:94-95).
+        # Off by default: statistics then evolve per rank and rank 0's are what a checkpoint holds (DESIGN.md section 6).
+        self.broadcast_buffers = broadcast_buffers
         if hasattr(model, 'encoder'):
             model.encoder.on_trunk_output_grad = self._early_grads_ready
         self.use_graph = use_graph
-        self._graph = None
-        self._static = None
-        self._loss_out = None
+        self._graphs = {}
+        if self.world > 1:
+            self.sync_replicas()
+
+    def sync_replicas(self):
+        """What DistributedDataParallel's constructor does: every rank starts from rank 0's parameters and buffers."""
+        dist.broadcast(self.optimizer.flat_p, 0)
+        for b in self._float_buffers():
+            dist.broadcast(b, 0)
+
+    def _float_buffers(self):
+        return [b for b in self.model.buffers() if b.is_floating_point() and b.numel() > 0]
 
     def _early_grads_ready(self):
         """Runs inside the backward, when d loss / d x1 is complete: start the all-reduce of the early part of the flat
@@ -156,45 +260,116 @@ class Trainer:
     def train_step(self, batch, epoch=0):
         """batch: dict of device tensors. Returns the (device) scalar loss; no host sync."""
         self.model_with_loss.train()
+        if self.broadcast_buffers and self.world > 1 and self.collectives:
+            for b in self._float_buffers():
+                dist.broadcast(b, 0)
         if self.use_graph:
             loss = self._graph_step(batch, epoch)
         else:
             loss, _ = self._fwd_bwd(batch, epoch)
+        live = self.optimizer.flat_g[:self.n_live]             # the never-used tail is not reduced (its gradient is zero on every rank)
         if not self.collectives:
             pass
         elif self._early_works is not None:                    # early part already in flight (or nothing to do at world 1)
-            allreduce_flat_grads(self.optimizer.flat_g[self.n_early:], chunks=2, force=self.force_collectives)
+            allreduce_flat_grads(live[self.n_early:], chunks=2, force=self.force_collectives)
             for w in self._early_works:
                 w.wait()
         else:
-            allreduce_flat_grads(self.optimizer.flat_g, force=self.force_collectives)
+            allreduce_flat_grads(live, force=self.force_collectives)
         self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0)
         return loss
 
     def _graph_step(self, batch, epoch):
-        if self._graph is None:
-            self._static = {k: v.clone() for k, v in batch.items()}
+        """One hipGraph per (loss schedule phase, batch signature): `epoch` only enters the step through
+        alpha = 0 if epoch < 20 else 1 (simplified.py:610), which switches two loss weights and the edge-length gradient,
+        so a graph captured before epoch 20 must not be replayed after it; a last, smaller batch gets its own graph too."""
+        tens = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        key = (epoch >= 20,) + tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tens.items()))
+        entry = self._graphs.get(key)
+        if entry is None:
+            static = {k: v.clone() for k, v in tens.items()}
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):                         # warm-up on a side stream (allocator, lazy init)
                 for _ in range(2):
-                    self._fwd_bwd(self._static, epoch)
+                    self._fwd_bwd(static, epoch)
             torch.cuda.current_stream().wait_stream(s)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self._loss_out, _ = self._fwd_bwd(self._static, epoch)
-        for k, v in batch.items():
-            self._static[k].copy_(v, non_blocking=True)
-        self._graph.replay()
-        return self._loss_out
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss_out, _ = self._fwd_bwd(static, epoch)
+            entry = self._graphs[key] = (graph, static, loss_out)
+        graph, static, loss_out = entry
+        for k, v in tens.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return loss_out
 
     def train(self, epoch, loader, device):
         tot, n = 0.0, 0
         for batch in loader:
-            batch = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
+            # the reference loader also yields non-tensor entries ('meta', base_trainer.py:134-136 skips them)
+            batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
             loss = self.train_step(batch, epoch)
             tot, n = tot + float(loss), n + 1                 # one host sync per iteration, like the reference's logging
         return tot / max(n, 1)
+
+
+    def evaluation(self, loader, device=None):
+        """Counterpart of `BaseTrainer.evaluation` (lib/trains/base_trainer.py:207-429, H2O branch): the test-mode pass
+        (centres from the predicted heat-map, root from the predicted depth) and the mean Euclidean errors per hand --
+        absolute and root-relative joints / vertices in mm, 2-D landmarks in pixels.  The reference evaluates on rank 0
+        with batch size 1 and pulls every error to the host; here any batch size, every rank takes the batches its
+        loader yields, the sums stay on the device (`F.point_dist_sum`) and are all-reduced once at the end.
+        Returns a dict of floats (one host sync)."""
+        mwl = self.model_with_loss
+        was_training = mwl.training
+        mwl.eval()
+        dev = device or self.optimizer.flat_p.device
+        acc = torch.zeros(11, dtype=torch.float64, device=dev)        # 5 metrics x 2 hands + sample count
+        with torch.no_grad():
+            for batch in loader:
+                batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                acc += evaluation_sums(mwl(batch, 'test', None), batch)
+        if self.world > 1:
+            dist.all_reduce(acc)
+        mwl.train(was_training)
+        return finish_evaluation(acc.cpu())
+
+
+EVAL_KEYS = ('abs_joints', 'abs_verts', 'off_joints', 'off_verts', 'lms_px')
+
+
+def evaluation_sums(tup, batch):
+    """test-mode 9-tuple of the loss module (simplified.py:652-653) -> float64 [11]: per metric and hand the sum over the
+    batch of the per-sample mean error, then the sample count."""
+    vp, jp, vg, jg, lms, vpo, jpo, vgo, jgo = tup
+    lms_gt = torch.stack((batch['lms_left_gt'], batch['lms_right_gt']), 1)
+    parts = []
+    for pred, gt in ((jp, jg), (vp, vg), (jpo, jgo), (vpo, vgo), (lms, lms_gt)):
+        parts.append((F.point_dist_sum(pred, gt) / pred.shape[-2]).sum(0))        # [B,2] -> [2]
+    n = torch.full((1,), float(vp.shape[0]), device=vp.device)
+    return torch.cat(parts + [n]).double()
+
+
+def finish_evaluation(acc):
+    """-> {'abs_left_joints' ... 'off_right_verts' in mm, 'lms_px', 'mpjpe_mm' / 'mpvpe_mm' (both hands, absolute),
+    'mpjpe_off_mm' / 'mpvpe_off_mm' (root-relative), 'samples'} -- the figures base_trainer.py:420-429 prints."""
+    n = float(acc[10])
+    out = {'samples': int(n)}
+    if n == 0:
+        return out
+    for i, k in enumerate(EVAL_KEYS):
+        l, r = float(acc[2 * i]) / n, float(acc[2 * i + 1]) / n
+        if k == 'lms_px':
+            out[k] = (l + r) / 2
+        else:
+            kind, what = k.split('_')
+            out['%s_left_%s' % (kind, what)], out['%s_right_%s' % (kind, what)] = l * 1000, r * 1000
+    out['mpjpe_mm'] = (out['abs_left_joints'] + out['abs_right_joints']) / 2
+    out['mpvpe_mm'] = (out['abs_left_verts'] + out['abs_right_verts']) / 2
+    out['mpjpe_off_mm'] = (out['off_left_joints'] + out['off_right_joints']) / 2
+    out['mpvpe_off_mm'] = (out['off_left_verts'] + out['off_right_verts']) / 2
+    return out
 
 
 def init_distributed():
@@ -212,5 +387,5 @@ def init_distributed():
 
 
 def mpjpe_mm(pred, gt):
-    """base_trainer.py:263-285: mean ||pred - gt||_2 * 1000."""
-    return torch.norm(pred - gt, dim=-1).mean() * 1000
+    """base_trainer.py:263-285: mean ||pred - gt||_2 * 1000 over [..., n, 3] points (HIP reduction, one host sync)."""
+    return float((F.point_dist_sum(pred, gt) / pred.shape[-2]).mean()) * 1000

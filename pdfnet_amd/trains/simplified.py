@@ -1,15 +1,16 @@
 """Counterpart of the reference's live loss branch, `CtdetLoss.forward` (lib/trains/simplified.py:364-655),
 for the H2O RGB-D two-hand task (flags of scripts/train.sh: --reproj_loss --bone_loss, dataset H2O).
 
-SURVEY.md 8(f) row 1 ("next"): the loss is ~40 launch-bound element-wise / tiny-matmul ops.  In this round
-it is sync-free device code written with aten element-wise ops plus the HIP joint-regressor kernel, so the
-whole train step is hipGraph-capturable; fusing it into a handful of HIP kernels is the next widening step.
+SURVEY.md 8(f) row 1: the reference's loss is ~40 launch-bound element-wise / tiny-matmul ops per term and hand.  Here
+every term is a HIP kernel of csrc/loss.hip over BOTH hands: `F.rowloss` (all L1 / MSE mesh terms), `F.face_loss` (normal +
+edge-length), `F.dense_loss` (SmoothL1 mask + MSE heat-maps + focal centre loss, one forward and one backward launch),
+`F.regress_joints_pair`; only index bookkeeping (stack / gather of ground truth, the pinhole projection of 42 joints and
+the 20-bone direction term on [2,B,21,2]) is left to aten.  The step is sync-free, so it is hipGraph-capturable.
 Differences from the reference are host-side only: no `.cpu()` debug dumps (simplified.py:527-596) and the
 focal loss' `if num_pos.sum() == 0` host branch (lib/models/losses.py:161) is a device-side select.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as TF
 
 from .. import functional as F
 
@@ -20,17 +21,6 @@ _BONES = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 5), (5, 6), (6, 7), (7, 8), (0, 9)
 def sigmoid_clamped(x):
     """lib/models/utils.py:8-10 `_sigmoid` (out-of-place: the caller's logits stay intact)."""
     return torch.clamp(torch.sigmoid(x), min=1e-4, max=1 - 1e-4)
-
-
-def focal_loss(pred, gt):
-    """lib/models/losses.py:138-165 `_neg_loss`, per-sample [B]."""
-    pos = gt.eq(1).float()
-    neg = gt.lt(1).float()
-    negw = torch.pow(1 - gt, 4)
-    pos_loss = (torch.log(pred) * torch.pow(1 - pred, 2) * pos).sum(dim=(1, 2, 3))
-    neg_loss = (torch.log(1 - pred) * torch.pow(pred, 2) * negw * neg).sum(dim=(1, 2, 3))
-    num_pos = pos.sum(dim=(1, 2, 3))
-    return torch.where(num_pos.sum() == 0, -neg_loss, -(pos_loss + neg_loss) / (num_pos + 1e-3))
 
 
 def bone_direction_loss(j2d, gt2d, a, c):
@@ -110,10 +100,11 @@ class CtdetLoss(nn.Module):
         return self.total(t, epoch)
 
     def dense_terms(self, otherInfo, batch):
-        """The terms on the encoder's dense maps: hand masks (:368), joint heat-maps (:374), centre heat-map (:376,391)."""
-        return {'mask_loss': TF.smooth_l1_loss(otherInfo['mask'], batch['mask']),
-                'hms_loss': TF.mse_loss(otherInfo['hms'], batch['hms']),
-                'hm_loss': focal_loss(sigmoid_clamped(otherInfo['ret']['hm']), batch['hm'])}
+        """The terms on the encoder's dense maps: hand masks (:368), joint heat-maps (:374), centre heat-map (:376,391) --
+        SmoothL1, MSE and the focal loss on the clamped sigmoid, all in `F.dense_loss` (csrc/loss.hip)."""
+        mask_loss, hms_loss, hm_loss = F.dense_loss(otherInfo['mask'], batch['mask'], otherInfo['hms'], batch['hms'],
+                                                    otherInfo['ret']['hm'], batch['hm'])
+        return {'mask_loss': mask_loss, 'hms_loss': hms_loss, 'hm_loss': hm_loss}
 
     def dense_part(self, t):
         """What dense_terms contribute to the total ([B]); total == dense_part + mesh_part up to summation order."""
@@ -170,7 +161,7 @@ class CtdetLoss(nn.Module):
         jp_off = F.regress_joints_pair(*regs, vp)                                                           # :431-432
         jg_off = F.regress_joints_pair(*regs, vgt_off)
         joints_loss = (F.rowloss(jp_off, jg_off, 2, 'l1') * hv).sum(0)                                      # :435-436
-        alpha = 0 if epoch < 20 else 1                                                                      # :610
+        alpha = 0 if (epoch is None or epoch < 20) else 1                                                   # :610 (test mode passes None)
         # edge term: weighted by alpha in `total`; while alpha == 0 it is reported but its (exactly zero) gradient is skipped
         nl, el = F.face_loss(vp, vgt_off, self.faces_pair, edge_grad=alpha != 0)                            # :452-453
         norm_loss, edge_loss = nl.sum(), el.sum()

@@ -26,13 +26,15 @@ def load_model(model, model_path, optimizer=None, resume=False, lr=None, lr_step
     start_epoch = 0
     if optimizer is not None and resume:
         if 'optimizer' in ckpt:
-            optimizer.load_state_dict(ckpt['optimizer'])
+            optimizer.load_state_dict(ckpt['optimizer'])       # torch.optim.Adam layout on both sides (FlatAdam.state_dict)
             start_epoch = ckpt['epoch']
-            start_lr = lr
-            for step in (lr_step or []):
-                if start_epoch >= step:
-                    start_lr *= 0.1
-            optimizer.lr = start_lr
+            if lr is not None:                                  # lib/utils/utils.py:88-94; lr=None keeps the checkpoint's rate
+                start_lr = lr
+                for step in (lr_step or []):
+                    if start_epoch >= step:
+                        start_lr *= 0.1
+                for group in optimizer.param_groups:
+                    group['lr'] = start_lr
         elif verbose:
             print('No optimizer parameters in checkpoint.')
     return (model, optimizer, start_epoch) if optimizer is not None else model

@@ -88,3 +88,18 @@ def test_checkpoint_roundtrip_with_reference_conventions(tmp_path):
             assert torch.equal(sb[k], keep)
         else:
             assert torch.equal(sa[k], sb[k]), k
+
+
+def test_never_used_parameter_rule_matches_the_reference_golden(golden_dir):
+    """Trainer lays the parameters no autograd path reaches behind the reduced / optimised range.  The static
+    name rule must select exactly the tensors that got no gradient when the reference model was run with a loss touching
+    every output (tests/golden/params_without_grad.txt, written by oracle/make_goldens.py from the reference itself)."""
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.trains.base_trainer import split_parameters
+    m = load_model_intag(make_opt(256))
+    named = list(m.named_parameters())
+    early, late, dead = split_parameters(named)
+    want = {l.strip() for l in open(os.path.join(golden_dir, "params_without_grad.txt")) if l.strip()}
+    assert {n for n, _ in dead} == want
+    assert len(early) + len(late) + len(dead) == len(named)
+    assert sum(p.numel() for _, p in dead) == 12_387_365          # 49.5 MB of the 401 MB stay out of the all-reduce (SURVEY 8e)

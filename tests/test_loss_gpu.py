@@ -66,3 +66,84 @@ def test_loss_gradient_flows_to_every_trained_output():
         assert t.grad is not None and torch.isfinite(t.grad).all() and t.grad.abs().sum() > 0
     # wh / params heads get no loss term in the reference (simplified.py:397-399,613-614)
     assert other['ret']['wh'].grad is None and other['ret']['params'].grad is None
+
+
+def _aten_dense(mask, mask_gt, hms, hms_gt, hm, hm_gt):
+    """The reference's formulas with aten ops (checker): simplified.py:368,374,376,391; losses.py:138-165."""
+    import torch.nn.functional as TF
+    p = torch.clamp(torch.sigmoid(hm), 1e-4, 1 - 1e-4)
+    pos, neg = hm_gt.eq(1).float(), hm_gt.lt(1).float()
+    pl = (torch.log(p) * (1 - p) ** 2 * pos).sum((1, 2, 3))
+    nl = (torch.log(1 - p) * p ** 2 * (1 - hm_gt) ** 4 * neg).sum((1, 2, 3))
+    npos = pos.sum((1, 2, 3))
+    focal = -nl if float(npos.sum()) == 0 else -(pl + nl) / (npos + 1e-3)
+    return TF.smooth_l1_loss(mask, mask_gt), TF.mse_loss(hms, hms_gt), focal
+
+
+@pytest.mark.parametrize("positives", [True, False])
+def test_dense_loss_kernels_match_aten_formulas(positives):
+    from pdfnet_amd import functional as F
+    g = torch.Generator().manual_seed(3)
+    B, R = 3, 64
+    CL = torch.channels_last
+    mask = (torch.randn(B, 2, R, R, generator=g) * 1.5).cuda().contiguous(memory_format=CL)        # |d| on both sides of 1
+    mask_gt = (torch.rand(B, 2, R, R, generator=g) < 0.5).float().cuda()
+    hms = torch.randn(B, 42, R // 4, R // 4, generator=g).cuda().contiguous(memory_format=CL)
+    hms_gt = torch.rand(B, 42, R // 4, R // 4, generator=g).cuda()
+    hm = (torch.randn(B, 2, R // 4, R // 4, generator=g) * 4).cuda().contiguous(memory_format=CL)  # some logits beyond the clamp
+    hm[0, 0, 0, 0] = 30.0
+    hm[0, 1, 0, 1] = -30.0
+    hm_gt = (torch.rand(B, 2, R // 4, R // 4, generator=g) * 0.9).cuda()
+    if positives:
+        hm_gt[0, 0, 3, 4] = 1.0
+        hm_gt[2, 1, 5, 5] = 1.0
+        hm_gt[2, 0, 0, 0] = 1.0                                                                   # sample 1 has no positive
+    w = torch.tensor([0.7, -1.3, 2.0], device='cuda')
+    outs = []
+    for fn in (F.dense_loss, _aten_dense):
+        leaves = [t.clone().requires_grad_() for t in (mask, hms, hm)]
+        a, b, c = fn(leaves[0], mask_gt, leaves[1], hms_gt, leaves[2], hm_gt)
+        (3.0 * a + 5.0 * b + (c * w).sum()).backward()
+        outs.append(([a.detach(), b.detach(), c.detach()], [t.grad for t in leaves]))
+    for x, y in zip(outs[0][0], outs[1][0]):
+        assert torch.allclose(x, y, rtol=2e-5, atol=1e-6), (x, y)
+    for x, y in zip(outs[0][1], outs[1][1]):
+        assert x.shape == y.shape
+        assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max()) + 1e-9
+    # a term without an upstream gradient is skipped
+    leaves = [t.clone().requires_grad_() for t in (mask, hms, hm)]
+    F.dense_loss(leaves[0], mask_gt, leaves[1], hms_gt, leaves[2], hm_gt)[1].backward()
+    assert leaves[0].grad is None and leaves[2].grad is None and leaves[1].grad is not None
+
+
+def test_evaluation_loop_matches_the_reference_metric_formula():
+    """Trainer.evaluation (counterpart of base_trainer.py:207-429): two batches through the test-mode pass; the device-side
+    accumulation must equal the reference's per-batch formula (oracle/loss_cpu.evaluation_metrics) averaged over batches."""
+    from oracle import loss_cpu as LC
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch
+    from pdfnet_amd.trains.base_trainer import Trainer, mpjpe_mm
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    R, B = 128, 3
+    dev = torch.device('cuda')
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    torch.manual_seed(5)
+    m = load_model_intag(opt).to(dev)
+    tr = Trainer(opt, m, CtdetLoss(opt, consts).to(dev))
+    loader = [synthetic_train_batch(B, R, seed=s, consts=consts) for s in (21, 22)]
+    loader[0]['meta'] = {'not': 'a tensor'}                   # the reference's loader carries one (base_trainer.py:234-236)
+    got = tr.evaluation(loader)
+    assert got['samples'] == 2 * B and m.training
+    want = {}
+    tr.model_with_loss.eval()
+    with torch.no_grad():
+        for b in loader:
+            bd = tree_to({k: v for k, v in b.items() if torch.is_tensor(v)}, dev)
+            tup = tuple(t.cpu() for t in tr.model_with_loss(bd, 'test', None))
+            for k, v in LC.evaluation_metrics(tup, (b['lms_left_gt'], b['lms_right_gt'])).items():
+                want[k] = want.get(k, 0.0) + v / len(loader)
+            assert abs(mpjpe_mm(tup[1].cuda(), tup[3].cuda()) - float(torch.norm(tup[1] - tup[3], dim=-1).mean()) * 1000) < 1e-2
+    for k, v in want.items():
+        assert abs(got[k] - v) <= 1e-4 * abs(v) + 1e-6, (k, got[k], v)
+    assert abs(got['mpjpe_mm'] - (want['abs_left_joints'] + want['abs_right_joints']) / 2) <= 1e-4 * got['mpjpe_mm']

@@ -168,3 +168,73 @@ def test_fps_matches_reference_helper():
         order = O.fps_order(g["pts_" + name], int(g["S_" + name][0]), int(g["start_" + name][0]))
         assert np.array_equal(np.unique(order), g["unique_" + name]), name
 
+
+
+def _loss_fixture_inputs(B=3, R=256):
+    from oracle import loss_cpu as LC
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch
+    from tests.util import synthetic_model_outputs, ROOT
+    import os
+    consts = synthetic_loss_constants()
+    z = np.load(os.path.join(ROOT, "pdfnet_amd", "data", "gcn_core.npz"))
+    conv = {h: LC.Converter(z['graph_perm_' + h], z['graph_perm_reverse_' + h]) for h in ('left', 'right')}
+    batch = synthetic_train_batch(B, R, seed=5, consts=consts)
+    batch['valid'][1, 1] = 0.0
+
+    def outputs():
+        result, params, hand, other = synthetic_model_outputs(B, R, 9)
+        other['converter_left'], other['converter_right'] = conv['left'], conv['right']
+        return result, params, hand, other
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    return opt, consts, batch, outputs
+
+
+def test_loss_oracle_matches_reference_golden():
+    """oracle/loss_cpu.py against the reference's own CtdetLoss.forward (fixture written by oracle/make_goldens.py
+    loss_golden): per-sample loss, all 16 statistics at alpha = 0 and 1, and the test-mode 9-tuple."""
+    from oracle import loss_cpu as LC
+    g = gold("loss_ctdet_B3_R256")
+    opt, consts, batch, outputs = _loss_fixture_inputs()
+    for epoch in (0, 25):
+        loss, stats = LC.ctdet_loss(opt, consts, *outputs(), batch, 'train', epoch)
+        assert np.allclose(loss.numpy(), g["loss_e%d" % epoch], rtol=1e-6, atol=1e-5), epoch
+        n = 0
+        for k, v in g.items():
+            if k.startswith("stat_e%d::" % epoch):
+                got = torch.as_tensor(stats[k.split("::")[1]]).reshape(-1).numpy()
+                assert np.allclose(got, v, rtol=1e-6, atol=1e-7), (epoch, k)
+                n += 1
+        assert n == 16
+    tup = LC.ctdet_loss(opt, consts, *outputs(), batch, 'test', 0)
+    assert len(tup) == 9
+    for i, t in enumerate(tup):
+        assert np.allclose(t.numpy(), g["test%d" % i], rtol=1e-6, atol=1e-6), i
+    # evaluation metric (base_trainer.py:244-323): the formula on the golden tuple itself
+    m = LC.evaluation_metrics(tuple(T(g["test%d" % i]) for i in range(9)), (batch['lms_left_gt'], batch['lms_right_gt']))
+    ref = np.linalg.norm(g["test1"][:, 0] - g["test3"][:, 0], axis=-1).mean() * 1000
+    assert abs(m['abs_left_joints'] - ref) < 1e-3 * ref
+
+
+def test_demo_asset_pair_config1():
+    """BASELINE config 1: the reference's demo forward on its own asset pair assets/H2O/{color,depth}/000002.png
+    (fixture = network input + the reference's outputs, oracle/make_demo_golden.py).  The CPU oracle on the same input and
+    the clouds the reference's depth2pcl drew must reproduce the reference's outputs; its own front end must draw from the
+    same candidate set."""
+    from tests.util import demo_fixture_inputs, demo_state_dict, pack_demo
+    g, b = demo_fixture_inputs()
+    o = O.load_model_cpu(make_opt(256))
+    o.load_state_dict(demo_state_dict(o.state_dict(), g))
+    o.eval()
+    with torch.no_grad():
+        res = o(b['input'], b['choose'], b['cloud'], b['depth'], None, b['K_new'], b['valid'])
+    assert np.array_equal(res[3]['ind'].numpy(), g["pred_ind"])                     # centres picked from the heat-map: bit-exact
+    check_packed(pack_demo(res), g, abs_tol=1e-4, rel_tol=1e-5)
+    mask = res[3]['mask']
+    assert [(mask[0, c] > 0.5).sum().item() for c in range(2)] == g["mask_pos_count"].tolist()
+    # the clouds are real depth: 1024 distinct pixels per hand, each inside the predicted mask and the +-8 cm window
+    for hi, ch in ((0, 1), (1, 0)):                                                # hand 0 = left = mask channel 1 (:376-377)
+        pix = g["choose"][hi]
+        assert len(np.unique(pix)) == 1024
+        assert (mask[0, ch].flatten()[torch.from_numpy(pix)] > 0.5).all()
+        z = g["cloud"][hi][:, 2]
+        assert z.max() - z.min() < 0.16 + 1e-6 and z.min() > 0.2

@@ -1,0 +1,151 @@
+"""GPU tests of the train-loop counterpart (pdfnet_amd/trains/base_trainer.py): optimizer checkpoints interchangeable with
+torch.optim.Adam (the reference's optimizer, main.py:63), hipGraph replay across the loss schedule switch at epoch 20
+(simplified.py:610), gradient views that survive `model.zero_grad()`."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import make_opt
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(R=128, B=2, seed=7, dropout=False):
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch, to_device
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    dev = torch.device('cuda')
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    batch = to_device(synthetic_train_batch(B, R, seed=3, consts=consts), dev)
+    torch.manual_seed(seed)
+    m = load_model_intag(opt).to(dev)
+    if not dropout:
+        for mod in m.modules():
+            if hasattr(mod, 'p') and isinstance(getattr(mod, 'p'), float):
+                mod.p = 0.0
+    return opt, m, CtdetLoss(opt, consts).to(dev), batch
+
+
+def test_optimizer_checkpoint_is_torch_adam_format_both_ways(tmp_path):
+    """save_model / load_model(resume=True) (lib/utils/utils.py:37-119): the optimizer entry is torch.optim.Adam's
+    state_dict.  (a) ours -> torch.optim.Adam over the same parameters continues identically to ours;
+    (b) a torch.optim.Adam checkpoint resumes into FlatAdam."""
+    from pdfnet_amd import functional as F
+    from pdfnet_amd.trains.base_trainer import ModleWithLoss, Trainer
+    from pdfnet_amd.utils import load_model, save_model
+    opt, ma, crit, batch = _setup()
+    tr = Trainer(opt, ma, crit, lr=1e-4)
+    for _ in range(2):
+        tr.train_step(batch, 0)
+    torch.cuda.synchronize()
+    p = str(tmp_path / "model_3.pth")
+    save_model(p, 3, ma, tr.optimizer)
+    ck = torch.load(p)
+    assert set(ck['optimizer']) == {'state', 'param_groups'}
+    n_par = len(list(ma.parameters()))
+    assert ck['optimizer']['param_groups'][0]['params'] == list(range(n_par))
+    assert all(v['exp_avg'].is_contiguous() and tuple(v['exp_avg'].shape) == tuple(q.shape)
+               for v, q in zip(ck['optimizer']['state'].values(), ma.parameters()))
+
+    # (a) the textbook loop resumes from our checkpoint
+    opt2, mb, _, _ = _setup(seed=99)
+    adam = torch.optim.Adam(mb.parameters(), lr=1e-4)
+    mb, adam, ep = load_model(mb, p, adam, resume=True, lr=1e-4, lr_step=[], verbose=False)
+    assert ep == 3
+    mwl = ModleWithLoss(mb, crit).train()
+    adam.zero_grad()
+    loss_b = mwl(batch, 'train', 0)[0].mean()
+    loss_b.backward()
+    F.join_wgrad()
+    adam.step()
+    loss_a = tr.train_step(batch, 0)
+    torch.cuda.synchronize()
+    assert abs(float(loss_a) - float(loss_b.detach())) <= 1e-5 * abs(float(loss_b.detach()))
+    # moments after the resumed step agree tensor by tensor; parameters agree wherever the update is well conditioned (an
+    # element whose gradient is rounding noise -- e.g. a conv bias in front of a BatchNorm -- moves by +-lr at random)
+    pa = dict(ma.named_parameters())
+    st_b = adam.state_dict()['state']
+    o = tr.optimizer
+    checked = 0
+    for ci, (n, q) in enumerate(mb.named_parameters()):
+        if ci not in st_b or q.dim() < 2:                     # biases in front of a normalisation hold rounding noise only
+            continue
+        i = o.ckpt_index[ci]
+        ma_m, mb_m = o._view(o.flat_m, i), st_b[ci]['exp_avg']
+        scale = float(mb_m.abs().max())
+        assert float((ma_m - mb_m).abs().max()) <= 1e-4 * scale + 1e-12, n
+        big = mb_m.abs() > 1e-2 * scale
+        if scale > 1e-7 and big.any():
+            assert float((pa[n].detach() - q.detach())[big].abs().max()) <= 5e-6, n
+            checked += 1
+    assert checked > 200
+
+    # (b) FlatAdam resumes from torch.optim.Adam's checkpoint
+    p2 = str(tmp_path / "model_4.pth")
+    save_model(p2, 4, mb, adam)
+    opt3, mc, _, _ = _setup(seed=5)
+    tr3 = Trainer(opt3, mc, crit, lr=3e-4)
+    load_model(mc, p2, tr3.optimizer, resume=True, lr=None, verbose=False)           # lr=None keeps the checkpoint's rate
+    assert abs(tr3.optimizer.lr - 1e-4) < 1e-12
+    assert float(tr3.optimizer.step_t) == 3.0
+    st = adam.state_dict()['state']
+    for ci, q in enumerate(mc.parameters()):
+        if ci in st:
+            i = tr3.optimizer.ckpt_index[ci]
+            assert torch.equal(tr3.optimizer._view(tr3.optimizer.flat_m, i).cpu(), st[ci]['exp_avg'].cpu()), ci
+    with pytest.raises(ValueError):
+        tr3.optimizer.load_state_dict({'step': 1})           # round-1 flat layout is refused, not misread
+
+
+def test_graph_replay_follows_the_loss_schedule_across_epoch_20():
+    """alpha = 0 if epoch < 20 else 1 (simplified.py:610) is host state baked into a captured step: the trainer keys its
+    graphs on it, so graph mode and eager mode agree on both sides of the switch.  Weights are frozen (lr = 0) so that the
+    four steps of the two modes see the same function (train-mode BatchNorm uses batch statistics)."""
+    from pdfnet_amd import functional as F
+    from pdfnet_amd.trains.base_trainer import Trainer
+    res = {}
+    for mode in ('eager', 'graph'):
+        opt, m, crit, batch = _setup()
+        tr = Trainer(opt, m, crit, lr=0.0, use_graph=(mode == 'graph'))
+        old, F.ASYNC_WGRAD = F.ASYNC_WGRAD, (mode != 'graph')
+        try:
+            out = []
+            for ep in (19, 19, 20, 20):
+                loss = tr.train_step(batch, ep)
+                torch.cuda.synchronize()
+                out.append((float(loss), tr.optimizer.flat_g[:tr.n_live].clone()))
+        finally:
+            F.ASYNC_WGRAD = old
+        res[mode] = out
+        if mode == 'graph':
+            assert len(tr._graphs) == 2
+    for i in range(4):
+        (le, ge), (lg, gg) = res['eager'][i], res['graph'][i]
+        assert abs(le - lg) <= 1e-5 * abs(le), (i, le, lg)
+        assert float((ge - gg).abs().max()) <= 1e-4 * float(ge.abs().max()), i
+    for mode in ('eager', 'graph'):
+        r = res[mode]
+        assert r[2][0] > r[1][0] * 1.0001, mode                                   # alpha = 1 adds 2000*edge + 1000*joints2d
+        assert float((r[2][1] - r[1][1]).abs().max()) > 1e-3 * float(r[1][1].abs().max()), mode   # and their gradients
+        assert torch.equal(r[0][1], r[1][1]) or float((r[0][1] - r[1][1]).abs().max()) <= 1e-5 * float(r[0][1].abs().max())
+
+
+def test_gradient_views_survive_module_zero_grad():
+    """`model.zero_grad()` sets p.grad = None; the trainer re-attaches its flat views before the next backward, so the
+    HIP kernels keep accumulating where Adam reads (silent stall otherwise)."""
+    from pdfnet_amd.trains.base_trainer import Trainer
+    opt, m, crit, batch = _setup()
+    tr = Trainer(opt, m, crit, lr=1e-4)
+    tr.train_step(batch, 0)
+    m.zero_grad()                                            # set_to_none=True by default
+    assert all(p.grad is None for p in m.parameters())
+    before = tr.optimizer.flat_p.clone()
+    tr.train_step(batch, 0)
+    torch.cuda.synchronize()
+    assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(tr.optimizer.params, tr.optimizer._grad_views))
+    assert float(tr.optimizer.flat_g[:tr.n_live].abs().sum()) > 0
+    assert float((tr.optimizer.flat_p - before).abs().max()) > 1e-5
+    # the never-used tail is neither reduced nor stepped
+    assert float(tr.optimizer.flat_g[tr.n_live:].abs().max()) == 0.0
+    assert torch.equal(tr.optimizer.flat_p[tr.n_live:], before[tr.n_live:])

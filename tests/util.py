@@ -114,3 +114,45 @@ def tree_to(obj, device):
     if isinstance(obj, (list, tuple)):
         return type(obj)(tree_to(v, device) for v in obj)
     return obj
+
+
+def demo_fixture_inputs(device='cpu'):
+    """BASELINE config 1: the network input of the reference's demo (demo.py:117-202) rebuilt from
+    tests/golden/demo_H2O_000002_R256.npz -- uint8 BGR image -> ImageNet-normalised NCHW, uint16 millimetres -> metres --
+    plus the clouds the reference's own depth2pcl produced.  -> (golden dict, batch dict)."""
+    g = gold("demo_H2O_000002_R256")
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(1, 1, 3)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(1, 1, 3)
+    pre = ((g["image_u8"].astype(np.float32) / 255. - mean) / std).astype(np.float32)
+    b = {'input': torch.from_numpy(pre).permute(2, 0, 1).unsqueeze(0).contiguous(),
+         'depth': torch.from_numpy(g["depth_mm_u16"].astype(np.float32) / 1000.).reshape(1, 1, 256, 256),
+         'K_new': torch.from_numpy(g["K_img"].astype(np.float32)).reshape(1, 3, 3),
+         'valid': torch.ones(1, 2), 'choose': torch.from_numpy(g["choose"]).unsqueeze(0), 'cloud': torch.from_numpy(g["cloud"]).unsqueeze(0)}
+    return g, {k: v.to(device) for k, v in b.items()}
+
+
+def demo_state_dict(template, g):
+    """Generator weights + the mask-head bias shift the fixture was made with (oracle/make_demo_golden.py)."""
+    from oracle import synth
+    sd = synth.det_state_dict(template)
+    sd['encoder.dp_decoder.final_layer.1.bias'] = sd['encoder.dp_decoder.final_layer.1.bias'] + torch.from_numpy(g["dp_bias_add"])
+    return sd
+
+
+def pack_demo(res):
+    result, params, hand, other = res
+    o = {}
+    for h in ("left", "right"):
+        o["verts3d_" + h] = result['verts3d'][h]
+        o["verts2d_" + h] = result['verts2d'][h]
+        o["scale_" + h] = params['scale'][h]
+        o["trans2d_" + h] = params['trans2d'][h]
+        o["root_" + h] = params['root'][h]
+        o["gcn_verts3d_" + h] = hand[0]['verts3d'][h]
+    o["hm"] = other['ret']['hm']
+    for k in ("hms", "mask"):
+        t = other[k]
+        o[k + "_sum"] = t.double().sum().reshape(1)
+        o[k + "_abs_sum"] = t.double().abs().sum().reshape(1)
+        o[k + "_crop"] = t[:, :, 8:24, 8:24]
+    return o
