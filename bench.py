@@ -24,6 +24,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md:42
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # /opt/skills/guides/MI355X_MICROARCH.md:43 (dense)
 ALGO_GFLOP_PER_IMG_STEP_DENSE = 358.0  # 119.46 GF/img forward x3 (reference formulation)
 
 
@@ -306,6 +307,9 @@ def main():
                     help="full: BASELINE configs[2] (the headline); rgb-encoder: configs[1], B=8 RGB-only ResNet encoder fwd/bwd")
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 32; rgb-encoder: 8)')
     ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="f32: BASELINE configs[2] (headline). bf16: configs[3]/[4] per-GPU step -- bf16-input MFMA GEMMs with fp32 accumulation, "
+                         "fp32 master weights / statistics / loss, bf16 gradient all-reduce")
     ap.add_argument('--graph', action='store_true', help='replay forward+loss+backward as one hipGraph (default: eager launches with\n'
                     'side-stream overlap of the weight-gradient kernels, measured faster on MI355X)')
     ap.add_argument('--no-graph', action='store_true', help='(default) kept for compatibility')
@@ -337,6 +341,9 @@ def main():
         return rgb_encoder_bench(args, dev, rank, world)
     R, B = args.res, args.batch
     opt = make_opt(R)
+    bf16 = args.dtype == 'bf16'
+    if bf16:
+        F.set_gemm_precision('bf16')
     torch.manual_seed(0)
     F.manual_seed(1234 + rank)
     model = load_model_intag(opt).to(dev)
@@ -344,7 +351,8 @@ def main():
     loss = CtdetLoss(opt, consts).to(dev)
     if args.graph:
         F.ASYNC_WGRAD = False              # hipGraph replay of the forked wgrad stream measured slower than the plain graph
-    trainer = Trainer(opt, model, loss, lr=1e-4, use_graph=args.graph, broadcast_buffers=args.broadcast_buffers)   # world > 1: replicas synced from rank 0
+    trainer = Trainer(opt, model, loss, lr=1e-4, use_graph=args.graph, broadcast_buffers=args.broadcast_buffers,
+                      grad_comm_dtype=torch.bfloat16 if bf16 else None)   # world > 1: replicas synced from rank 0
     batch = to_device(synthetic_train_batch(B, R, seed=1 + rank, consts=consts), dev)
     rccl_ranks = 1
     if world > 1:
@@ -376,9 +384,9 @@ def main():
         "metric": "train-step images/sec @256x256 RGB-D B=32", "value": round(world * B * args.steps / dt, 2),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[2]: B=%d/GPU full RGB-D pyramid fusion + PointNet++ + GCN decoder fwd + CtdetLoss + bwd + Adam, "
-                               "fp32, %dx%d" % (B, R, R), "global_batch": world * B, "parallelism": "dp%d" % world,
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[%s]: B=%d/GPU full RGB-D pyramid fusion + PointNet++ + GCN decoder fwd + CtdetLoss + bwd + Adam, "
+                               "%s, %dx%d" % ("3/4" if bf16 else "2", B, "bf16 MFMA GEMMs (fp32 accumulate, fp32 master weights / statistics / loss)" if bf16 else "fp32", R, R), "global_batch": world * B, "parallelism": "dp%d" % world,
                    "launch": "hipGraph(fwd+loss+bwd) + fused Adam" if args.graph else "eager, weight-gradient kernels overlapped on a side HIP stream, fused Adam", "final_loss": round(loss_val, 4),
                    "rccl_ranks": rccl_ranks, "allreduce_mb_per_step": round(trainer.n_live * 4 / 1e6, 1) if world > 1 else 0.0,
                    "broadcast_buffers": bool(args.broadcast_buffers)},
@@ -404,19 +412,21 @@ def main():
         flops = sum(v[1] for v in per.values())
         secs = sum(v[2] for v in per.values())
         tiles = prof.by_tile()
-        tname = {128128: "igemm_nt<128,128>", 128064: "igemm_nt<128,64>", 64064: "igemm_nt<64,64>", 0: "small_k_gemm", -1: "wgemm_tn*"}
-        dom = tiles.get(128128, [0, 0.0, 1e-9])          # the kernel with the most time per step
-        traffic, traffic_all, traffic_src = pmc_traffic()
+        tname = {128128: "igemm_nt<128,128>", 128064: "igemm_nt<128,64>", 64064: "igemm_nt<64,64>", 0: "small_k_gemm", -1: "wgemm_*", 16: "igemm_bf16_kernel"}
+        dom = tiles.get(16 if bf16 else 128128, [0, 0.0, 1e-9])          # the kernel with the most time per step
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        traffic, traffic_all, traffic_src = pmc_traffic() if not bf16 else (None, None, 'no PMC profile of the bf16 kernels')
         out["roofline"] = {
-            "bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "kernel": "igemm_nt<128,128,2,2> (csrc/gemm.hip: fp32 MFMA implicit GEMM, forward / backward-data / transposed-conv passes "
-                      "of the large layers; the kernel with the most time per step)",
-            "achieved": round(dom[1] / dom[2] / 1e12, 2), "frac": round(dom[1] / dom[2] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+            "kernel": ("igemm_bf16_kernel (csrc/gemm_bf16.hip: bf16 MFMA implicit GEMM, all forward / backward-data passes)" if bf16 else
+                       "igemm_nt<128,128,2,2> (csrc/gemm.hip: fp32 MFMA implicit GEMM, forward / backward-data / transposed-conv passes "
+                       "of the large layers; the kernel with the most time per step)"),
+            "achieved": round(dom[1] / dom[2] / 1e12, 2), "frac": round(dom[1] / dom[2] / 1e12 / peak, 4),
             "launches_per_step": dom[0], "ms_per_step": round(dom[2] * 1e3, 2),
             "algorithmic_gflop_per_launch": round(dom[1] / max(dom[0], 1) / 1e9, 1), "avg_launch_ms": round(dom[2] / max(dom[0], 1) * 1e3, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "all_gemm_kernels": {
-                "achieved": round(flops / secs / 1e12, 2), "frac": round(flops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "achieved": round(flops / secs / 1e12, 2), "frac": round(flops / secs / 1e12 / peak, 4),
                 "launches_per_step": calls, "algorithmic_gflop_per_step": round(flops / 1e9, 1), "gemm_ms_per_step": round(secs * 1e3, 2),
                 "traffic": traffic_all,
                 "per_tile": {tname.get(k, str(k)): {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
@@ -429,7 +439,7 @@ def main():
                            "tflops_reference_formulation": round(ALGO_GFLOP_PER_IMG_STEP_DENSE * out["value"] / world / 1e3, 2),
                            "gflop_per_img_step_executed": round(flops / 1e9 / B, 1),
                            "tflops_executed": round(flops / 1e9 / B * out["value"] / world / 1e3, 2),
-                           "frac_of_fp32_mfma_peak": round(flops / 1e9 / B * out["value"] / world / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                           "frac_of_mfma_peak": round(flops / 1e9 / B * out["value"] / world / 1e3 / peak, 4)},
         }
         F.USE_SIDE_STREAMS = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

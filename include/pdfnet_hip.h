@@ -39,6 +39,11 @@ int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* db,
 long pdf_wgrad_workspace_floats(int M, int NI, int NJ);
 /* measurement aids (bench.py): BM*1000+BN of the calling thread's last implicit-GEMM launch (0 = streaming small-K
  * kernel), and the number of implicit-GEMM kernels it has launched so far (one entry point may launch several) */
+/* Operand precision of every GEMM-family entry point below: 0 (default) = fp32-input MFMA, exact fp32; 1 = operands rounded
+ * to bf16 (RNE) while staged into LDS, bf16 MFMA with fp32 accumulation (BASELINE configs 4 / 5: bf16 compute, fp32 master
+ * weights and fp32 normalisation / loss statistics).  Process-wide; set before the first step. */
+int pdf_set_gemm_precision(int bf16);
+int pdf_debug_gemm_precision(void);
 int pdf_debug_last_tile(void);
 int pdf_debug_igemm_launches(void);
 /* dx[M][K] = dy[M][N] w[N][K] (autograd of nn.Linear wrt its input); w is read in its forward storage */

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpdfnet_hip.so")
-SOURCES = ["gemm.hip", "pointops.hip", "norm.hip", "elementwise.hip", "graph.hip", "mano.hip", "frontend.hip", "loss.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "pointops.hip", "norm.hip", "elementwise.hip", "graph.hip", "mano.hip", "frontend.hip", "loss.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wno-unused-result"]
 
 
@@ -20,13 +20,13 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdr = os.path.join(CSRC, "common.h")
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src, hdr]):
+        if force or _stale(obj, [src] + hdrs):
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
 
     def run(cmd):

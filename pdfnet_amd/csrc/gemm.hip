@@ -11,38 +11,7 @@
 // fp32-input MFMA is bit-for-bit an fmaf chain (guide: FP32-input MFMA), so results are exact fp32.
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define MAX_TAPS 64
-
-struct IGemm {
-    const float* A; const float* B; float* C; const float* bias;
-    int M, N, K, Cin;
-    int lda, ldb;
-    int H, W, QH, QW, sy, sx, T;
-    int plain_in, plain_out;
-    int OH, OW, osy, osx, ooy, oox, ldc;
-    int ps_cout, ps_kw;
-    int act;                                  // 0 none, 1 relu, 2 leaky-relu(0.1)
-    // B layout: 0 = [N][K] rows (element (n, tap, ci) at n*ldb + wt[tap]*Cin + ci);  1 = [K][N] rows (element at
-    // ci*ldb + wt[tap]*btap + n): the backward-data / transposed-conv contractions read the weight in its forward storage
-    int b_kn, btap;
-    // group 1 of a paired launch (blockIdx.y == 1): same shapes, own weight/bias, A and C advanced by gsA / gsC floats
-    const float* B1; const float* bias1; long gsA, gsC;
-    short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
-};
-
-// the word masked lanes read instead of branching around their load
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
-
-__device__ __forceinline__ void xcd_tile(int bid, int nblk, int ntn, int& tm, int& tn) {
-    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous chunk of the
-    // tile list so the n-tiles that re-read one A panel hit the same L2 (guide T1, bijective form)
-    int q = nblk >> 3, r = nblk & 7, x = bid & 7;
-    int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-    tn = lin % ntn;
-    tm = lin / ntn;
-}
+#include "gemm_common.h"
 
 template <int BM, int BN, int WM, int WN, bool FAST, bool KN, int BKT = 16>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
@@ -257,23 +226,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-struct WGemm {
-    const float* P; const float* Q; float* slab;
-    int M, NI, Cq, T;
-    int ldp, ldq, ldw;
-    int H, W, QH, QW, sy, sx;
-    int plain_q;
-    int rows_per_split;
-    int tap_major;                            // tile order: channel-block major, taps inner (same XCD re-reads the same pixels)
-    int beta;                                 // single-split launches write dW directly: dW = beta*dW + acc
-    // group 1 of a paired launch (blockIdx.z == 1): P, Q advanced by gsP / gsQ floats, own slab (or output when one split)
-    long gsP, gsQ; float* slab1;
-    // optional bias gradient (column sums of P) riding along: per-split partials [split][NI] (or the output itself when one
-    // split), accumulated by the j-tile-0 blocks from the P tiles they stage anyway
-    float* bslab; float* bslab1;
-    short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
-};
-
 template <int BI, int BJ, int WM, int WN, bool FAST, int BKT = 16>
 __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     constexpr int BK = BKT;
@@ -747,6 +699,13 @@ static void launch_igemm_tile(const IGemm& g, bool fast, dim3 grid, hipStream_t 
     else hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, false>), grid, dim3(NT), 0, s, g);
 }
 
+// GEMM operand precision of the whole library: 0 = fp32 MFMA (exact fp32), 1 = bf16 MFMA with fp32 accumulation
+// (gemm_bf16.hip; BASELINE configs 4 / 5).  Set once before training; shapes the bf16 kernels do not take (rows that are not
+// 16-byte aligned, 3-channel stem) keep using the fp32 kernels.
+static int g_gemm_bf16 = 0;
+PDF_API int pdf_set_gemm_precision(int bf16) { g_gemm_bf16 = bf16 ? 1 : 0; return 0; }
+PDF_API int pdf_debug_gemm_precision() { return g_gemm_bf16; }
+
 static thread_local int g_last_tile = 0;            // BM * 1000 + BN of this thread's last implicit-GEMM launch (0: streaming small-K kernel)
 static thread_local int g_igemm_launches = 0;       // implicit-GEMM kernel launches of this thread so far
 PDF_API int pdf_debug_last_tile() { return g_last_tile; }
@@ -766,6 +725,11 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
         g_last_tile = 0;
         PDF_LAUNCH_CHECK();
         return 0;
+    }
+    if (g_gemm_bf16 && fast) {
+        const int rc = launch_igemm_bf16(g, s, groups);
+        if (rc < 0) return -rc;
+        if (rc == 1) { g_last_tile = 16; return 0; }
     }
     // tile choice: wide tiles when there are enough of them to fill 256 CUs, else smaller ones
     long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;
@@ -919,7 +883,8 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     const long perb = db ? g.NI : 0;
     if ((long)splits * (per + perb) * groups > ws_floats) splits = (int)(ws_floats / ((per + perb) * groups));
     if (splits < 1) splits = 1;
-    int rps = cdiv(cdiv(g.M, splits), 16) * 16;
+    const bool bf16 = g_gemm_bf16 && fast;
+    int rps = bf16 ? cdiv(cdiv(g.M, splits), 64) * 64 : cdiv(cdiv(g.M, splits), 16) * 16;
     splits = cdiv(g.M, rps);
     g.rows_per_split = rps;
     g.tap_major = (!g.plain_q && g.T > 1 && g.Cq % BJ == 0 && env_int(ENV_WG_TAPMAJOR, 1)) ? 1 : 0;
@@ -930,7 +895,13 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     g.bslab1 = db ? (splits == 1 ? db1 : bws + (long)splits * perb) : nullptr;
     g.beta = splits == 1 ? accumulate : 0;
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
-    if (small) {
+    int brc = 0;
+    if (bf16) {
+        brc = launch_wgemm_bf16(g, splits, groups, small ? 1 : 0, s);
+        if (brc < 0) return -brc;
+    }
+    if (brc == 1) {
+    } else if (small) {
         if (fast && env_int(ENV_WG_BK32, 1)) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);

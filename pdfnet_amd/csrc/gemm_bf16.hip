@@ -1,0 +1,438 @@
+// bf16-input MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate) forms of the two GEMM kernels of gemm.hip -- BASELINE configs 4/5
+// (mixed precision: fp32 master weights and fp32 activations in HBM, operands rounded to bf16 -- round-to-nearest-even,
+// v_cvt_pk_bf16_f32 -- while they are staged into LDS; 16x the fp32 MFMA rate, so these kernels are L2 / HBM bound).
+//
+// LDS images (bf16), K-step 64:
+//   ROW operand (contiguous along k in HBM: NHWC pixels, [N][K] weights): tile[row][k], row stride 144 B; a lane reads its
+//       MFMA fragment (8 consecutive k of row lane&31, k-offset 8*(lane>>5)) with one ds_read_b128 -- the 16 lanes of a
+//       read group hit 16 different 16-byte slots of the 256-byte bank row (conflict-free, guide section 2).
+//       Staging: 2 x float4 -> 8 bf16 -> one ds_write_b128.
+//   COL operand (contiguous along the tile-row index: [K][N] weights, both operands of a weight gradient): tile[k][row]
+//       exactly as it lies in HBM, row stride 2*rows + 64 B (consecutive k rows start 16 banks apart); staging is one
+//       float4 -> 4 bf16 -> one coalesced ds_write_b64, and the fragment is fetched with two ds_read_b64_tr_b16 (the
+//       CDNA4 transposing LDS read, guide T10: lane l receives column l&31, k = 8*(l>>5) + 0..3; tools/probe/tr_probe.hip).
+//       (A first version transposed in registers and wrote tile[row][k] with ds_write_b64: 16-way bank conflicts -- the
+//       weight-gradient kernel ran at 54-80 TFLOP/s, below the fp32 kernel.)
+#include "gemm_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+static __device__ __attribute__((aligned(32))) float g_zero32[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    f32x2 f = {a, b};
+    bf16x2 v = __builtin_convertvector(f, bf16x2);
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+
+constexpr int BK16 = 64;                         // K-step (bf16 elements)
+constexpr int LROW = BK16 * 2 + 16;              // ROW image: row stride in bytes
+constexpr int col_stride(int C) { return C * 2 + 64; }          // COL image [k][C]: row stride in bytes
+
+// fragment of a ROW image: rows r0 .. r0+31, k-sub-step ks (16 k each)
+__device__ __forceinline__ bf16x8 frag_row(const unsigned char* img, int r0, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8*>(img + (r0 + (lane & 31)) * LROW + ks * 32 + (lane >> 5) * 16);
+}
+// fragment of a COL image with C columns: columns c0 .. c0+31, k-sub-step ks (two transposing reads of 4 k each)
+template <int C>
+__device__ __forceinline__ bf16x8 frag_col(const unsigned char* img, int c0, int ks, int lane) {
+    constexpr int S = col_stride(C);
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const unsigned char* a = img + (ks * 16 + 8 * (g >> 1) + q) * S + (c0 + 16 * (g & 1) + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * S));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return *reinterpret_cast<bf16x8*>(&v);
+}
+
+__device__ __forceinline__ void st_row8(unsigned char* dst, const float4& lo, const float4& hi) {
+    uint4 v = {pk_bf16(lo.x, lo.y), pk_bf16(lo.z, lo.w), pk_bf16(hi.x, hi.y), pk_bf16(hi.z, hi.w)};
+    *reinterpret_cast<uint4*>(dst) = v;
+}
+__device__ __forceinline__ void st_col4(unsigned char* dst, const float4& v) {
+    *reinterpret_cast<uint2*>(dst) = uint2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Implicit GEMM (see gemm.hip igemm_nt for the contraction and the descriptor).  Requires the FAST conditions of the fp32
+// kernel (16-byte aligned rows, Cin % 8 == 0); a tap's channels are walked in steps of 64, chunks past Cin read zeros.
+// A is always a ROW operand; B is ROW ([N][K] storage) or COL ([K][N] storage, KN).
+template <int BM, int BN, int WM, int WN, bool KN>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
+    constexpr int BK = BK16;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int CPR = BK / 8;                          // 8-float chunks per ROW tile row
+    constexpr int RA = BM * CPR / 256, RB = BN * CPR / 256;
+    constexpr int CG = BN / 4;                           // COL: float4 column groups per k row
+    constexpr int KPP = 256 / CG;                        // COL: k rows per pass of the block
+    constexpr int NCB = BK / KPP;                        // COL: passes (= float4 loads per thread)
+    constexpr int SB = col_stride(BN);
+    constexpr int ABYTES = BM * LROW;
+    constexpr int BBYTES = KN ? BK * SB : BN * LROW;
+    constexpr int TILE = ABYTES + BBYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const float* __restrict__ Ap = g.A; const float* __restrict__ Bp = g.B; const float* __restrict__ biasp = g.bias;
+    float* __restrict__ Cp = g.C;
+    if (blockIdx.y) { Ap += g.gsA; Cp += g.gsC; Bp = g.B1; biasp = g.bias1; }
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    int tmi, tni;
+    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
+    const int m0 = tmi * BM, n0 = tni * BN;
+
+    // ---- A: ROW staging.  chunk q = tid + 256 i -> (row q / CPR, chunk q % CPR)
+    const int arow = tid / CPR, ach = (tid % CPR) * 8;
+    long abase[RA]; int iy0[RA], ix0[RA]; bool aval[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int r = m0 + arow + i * (256 / CPR);
+        aval[i] = r < g.M;
+        if (g.plain_in) { abase[i] = (long)r * g.lda; iy0[i] = 0; ix0[i] = 0; }
+        else {
+            const int hw = g.QH * g.QW;
+            const int ni = r / hw, rem = r - ni * hw;
+            const int qy = rem / g.QW, qx = rem - qy * g.QW;
+            iy0[i] = qy * g.sy; ix0[i] = qx * g.sx;
+            abase[i] = (long)ni * g.H * g.W * g.lda;
+        }
+    }
+    // ---- B
+    long bbase[RB > 0 ? RB : 1]; bool bval[RB > 0 ? RB : 1];
+    const int bcg = (tid % CG) * 4, bk0 = tid / CG;      // COL: 4 columns n, k rows bk0 + KPP * pass
+    const bool bcol_ok = n0 + bcg < g.N;
+    if (!KN) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = n0 + arow + i * (256 / CPR);
+            bval[i] = n < g.N;
+            bbase[i] = (long)n * g.ldb;
+        }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int spt = (g.Cin + BK - 1) / BK;               // K-steps per tap
+    const int nk = g.T * spt;
+    float4 ra[RA][2];
+    float4 rb[KN ? 1 : (RB > 0 ? RB : 1)][2];
+    float4 rc[KN ? NCB : 1];
+    int nt_tap = 0, nt_ci = 0, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * (KN ? g.btap : g.Cin);
+    auto gload = [&]() {
+        const int ci0 = nt_ci + ach;
+        const bool kin = ci0 < g.Cin;                     // Cin % 8 == 0: a chunk is inside or outside as a whole
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const float* src;
+            if (g.plain_in) src = (aval[i] && kin) ? Ap + abase[i] + ci0 : g_zero32;
+            else {
+                const int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
+                const bool ok = aval[i] && kin && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                src = ok ? Ap + abase[i] + ((long)iy * g.W + ix) * g.lda + ci0 : g_zero32;
+            }
+            ra[i][0] = *reinterpret_cast<const float4*>(src);
+            ra[i][1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+        if (!KN) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const float* src = (bval[i] && kin) ? Bp + bbase[i] + wbase + ci0 : g_zero32;
+                rb[i][0] = *reinterpret_cast<const float4*>(src);
+                rb[i][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NCB; ++u) {
+                const int ci = nt_ci + bk0 + u * KPP;
+                const float* src = (bcol_ok && ci < g.Cin) ? Bp + (long)ci * g.ldb + wbase + n0 + bcg : g_zero32;
+                rc[u] = *reinterpret_cast<const float4*>(src);
+            }
+        }
+        nt_ci += BK;
+        if (nt_ci >= g.Cin && nt_tap + 1 < g.T) {
+            ++nt_tap; nt_ci = 0;
+            ddy = g.dy[nt_tap]; ddx = g.dx[nt_tap]; wbase = g.wt[nt_tap] * (KN ? g.btap : g.Cin);
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* as = smem + buf * TILE;
+        unsigned char* bs = as + ABYTES;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) st_row8(as + (arow + i * (256 / CPR)) * LROW + ach * 2, ra[i][0], ra[i][1]);
+        if (!KN) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) st_row8(bs + (arow + i * (256 / CPR)) * LROW + ach * 2, rb[i][0], rb[i][1]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NCB; ++u) st_col4(bs + (bk0 + u * KPP) * SB + bcg * 2, rc[u]);
+        }
+    };
+
+    gload();
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload();
+        const unsigned char* as = smem + cur * TILE;
+        const unsigned char* bs = as + ABYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = frag_row(as, (wm * TM + i) * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = KN ? frag_col<BN>(bs, (wn * TN + j) * 32, ks, lane) : frag_row(bs, (wn * TN + j) * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue (same as igemm_nt): lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        const bool cok = col < g.N;
+        int co = col, padd_y = 0, padd_x = 0;
+        if (g.ps_cout > 0) {
+            const int tap = col / g.ps_cout;
+            co = col - tap * g.ps_cout;
+            padd_y = tap / g.ps_kw;
+            padd_x = tap - padd_y * g.ps_kw;
+        }
+        const float bv = (biasp != nullptr && cok) ? biasp[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (cok && row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+                    long o;
+                    if (g.plain_out) o = (long)row * g.ldc + co;
+                    else {
+                        const int hw = g.QH * g.QW;
+                        const int ni = row / hw, rem = row - ni * hw;
+                        const int qy = rem / g.QW, qx = rem - qy * g.QW;
+                        const int oy = qy * g.osy + g.ooy + padd_y, ox = qx * g.osx + g.oox + padd_x;
+                        o = (((long)ni * g.OH + oy) * g.OW + ox) * g.ldc + co;
+                    }
+                    Cp[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_tile_bf16(const IGemm& g, dim3 grid, hipStream_t s) {
+    if (g.b_kn) hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, g);
+}
+
+int launch_igemm_bf16(const IGemm& g, hipStream_t s, int groups) {
+    if (g.Cin % 8 != 0 || g.lda % 4 != 0 || g.ldb % 4 != 0) return 0;
+    if (g.b_kn && (g.N % 4 != 0 || g.btap % 4 != 0)) return 0;
+    const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;
+    if (g.N > 64 && t128 >= 192) launch_tile_bf16<128, 128, 2, 2>(g, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
+    else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= 192) launch_tile_bf16<128, 64, 4, 1>(g, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s);
+    else launch_tile_bf16<64, 64, 2, 2>(g, dim3(cdiv(g.M, 64) * cdiv(g.N, 64), groups), s);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 1 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient (see gemm.hip wgemm_tn): dW[i][wt[t]*Cq + c] = sum_m P[m][i] * Q[pos(m,t)][c]; the reduction index m is
+// the slow axis of both operands in HBM, so both are COL operands (tile[m][i], tile[m][j]) read with transposing loads.
+// BI x BJ tile, K-step 64 pixels, M split over blockIdx.y into slabs (summed by reduce_slabs of gemm.hip).
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
+    constexpr int BK = BK16;
+    constexpr int WN = 2, TM = BI / 2 / 32, TN = BJ / 2 / 32;
+    constexpr int CGP = BI / 4, CGQ = BJ / 4;            // float4 column groups per k row
+    constexpr int KPP_P = 256 / CGP, KPP_Q = 256 / CGQ;  // k rows per pass
+    constexpr int NP = BK / KPP_P, NQ = BK / KPP_Q;      // float4 loads per thread and K-step
+    constexpr int SP = col_stride(BI), SQ = col_stride(BJ);
+    constexpr int PBYTES = BK * SP, TILE = PBYTES + BK * SQ;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE];
+    __shared__ float bred[KPP_P * BI];                   // bias partials: one row of BI columns per k row group
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab; float* bslabp = g.bslab;
+    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; bslabp = g.bslab1; }
+    const int wm = wave / WN, wn = wave % WN;
+    const int NJ = g.T * g.Cq;
+    const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
+    int ti, tj;
+    if (g.tap_major) {
+        const int nblk = nti * ntj, q = nblk >> 3, r = nblk & 7, x = blockIdx.x & 7;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+        const int nb = g.Cq / BJ, per_cb = g.T * nti;
+        const int cb = lin / per_cb, rem = lin - cb * per_cb;
+        const int tap = rem / nti;
+        ti = rem - tap * nti;
+        tj = tap * nb + cb;
+    } else {
+        xcd_tile(blockIdx.x, nti * ntj, ntj, ti, tj);
+    }
+    const int i0 = ti * BI, j0 = tj * BJ;
+    const bool do_bias = bslabp != nullptr && tj == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ms = blockIdx.y * g.rows_per_split;
+    const int me = min(g.M, ms + g.rows_per_split);
+
+    const int pcg = (tid % CGP) * 4, pk0 = tid / CGP;
+    const int qcg = (tid % CGQ) * 4, qk0 = tid / CGQ;
+    const bool pcol_ok = i0 + pcg < g.NI;
+    const int jcol = j0 + qcg;
+    const bool qcol_ok = jcol < NJ;
+    const int qtap = qcol_ok ? jcol / g.Cq : 0;
+    const int qch = jcol - qtap * g.Cq;
+    const int tdy = g.dy[qtap], tdx = g.dx[qtap];
+    // (image, qy, qx) of each Q row this thread loads, advanced by BK rows per step -- no divisions in the loop
+    int q_ni[NQ], q_y[NQ], q_x[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int m = ms + qk0 + u * KPP_Q, hw = g.QH * g.QW;
+        q_ni[u] = m / hw;
+        const int rem = m - q_ni[u] * hw;
+        q_y[u] = rem / g.QW;
+        q_x[u] = rem - q_y[u] * g.QW;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 rp[NP], rq[NQ];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int m = mb + pk0 + u * KPP_P;
+            const float* src = (m < me && pcol_ok) ? Pp + (long)m * g.ldp + i0 + pcg : g_zero32;
+            rp[u] = *reinterpret_cast<const float4*>(src);
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int m = mb + qk0 + u * KPP_Q;
+            const float* src = g_zero32;
+            if (g.plain_q) {
+                if (m < me && qcol_ok) src = Qp + (long)m * g.ldq + qch;
+            } else {
+                const int iy = q_y[u] * g.sy + tdy, ix = q_x[u] * g.sx + tdx;
+                if (m < me && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                    src = Qp + ((long)q_ni[u] * g.H * g.W + (long)iy * g.W + ix) * g.ldq + qch;
+                q_x[u] += BK;
+                while (q_x[u] >= g.QW) {
+                    q_x[u] -= g.QW;
+                    if (++q_y[u] == g.QH) { q_y[u] = 0; ++q_ni[u]; }
+                }
+            }
+            rq[u] = *reinterpret_cast<const float4*>(src);
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* ps = smem + buf * TILE;
+        unsigned char* qs = ps + PBYTES;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            st_col4(ps + (pk0 + u * KPP_P) * SP + pcg * 2, rp[u]);
+            if (do_bias) { bsum[0] += rp[u].x; bsum[1] += rp[u].y; bsum[2] += rp[u].z; bsum[3] += rp[u].w; }
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) st_col4(qs + (qk0 + u * KPP_Q) * SQ + qcg * 2, rq[u]);
+    };
+
+    if (ms < me) { gload(ms); lstore(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int mb = ms; mb < me; mb += BK) {
+        const bool more = mb + BK < me;
+        if (more) gload(mb + BK);
+        const unsigned char* ps = smem + cur * TILE;
+        const unsigned char* qs = ps + PBYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = frag_col<BI>(ps, (wm * TM + i) * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = frag_col<BJ>(qs, (wn * TN + j) * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (do_bias) {                                        // column sums of P (fp32, un-rounded): reduce the k-row groups' partials
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bred[pk0 * BI + pcg + e] = bsum[e];
+        __syncthreads();
+        if (tid < BI && i0 + tid < g.NI) {
+            float t = 0.f;
+            for (int k = 0; k < KPP_P; ++k) t += bred[k * BI + tid];
+            float* bo = bslabp + (long)blockIdx.y * g.NI + i0 + tid;
+            *bo = g.beta ? *bo + t : t;
+        }
+    }
+    float* out = slabp + (long)blockIdx.y * g.NI * g.ldw;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (col >= NJ) continue;
+        const int t = col / g.Cq;
+        const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.NI) {
+                    float* o = out + (long)row * g.ldw + wcol;
+                    *o = g.beta ? *o + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+    }
+}
+
+// g carries the split / slab plan of launch_wgemm (gemm.hip); `small` = its 64 x 64 tile choice
+int launch_wgemm_bf16(const WGemm& g, int splits, int groups, int small, hipStream_t s) {
+    const int NJ = g.T * g.Cq;
+    if (g.NI % 4 != 0 || g.Cq % 4 != 0 || g.ldp % 4 != 0 || g.ldq % 4 != 0 || g.rows_per_split % BK16 != 0) return 0;
+    if (small) {
+        dim3 grid((unsigned)(cdiv(g.NI, 64) * cdiv(NJ, 64)), (unsigned)splits, (unsigned)groups);
+        hipLaunchKernelGGL((wgemm_bf16_kernel<64, 64>), grid, dim3(256), 0, s, g);
+    } else {
+        dim3 grid((unsigned)(cdiv(g.NI, 128) * cdiv(NJ, 128)), (unsigned)splits, (unsigned)groups);
+        hipLaunchKernelGGL((wgemm_bf16_kernel<128, 128>), grid, dim3(256), 0, s, g);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 1 : -(int)e;
+}

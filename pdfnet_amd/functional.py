@@ -89,6 +89,19 @@ def parallel(*fns):
 CL = torch.channels_last
 
 
+def set_gemm_precision(dtype):
+    """'fp32' (default): every contraction on the exact fp32-input MFMA.  'bf16': operands of the conv / transposed-conv /
+    linear kernels (forward, backward-data, weight gradient) are rounded to bf16 as they are staged, bf16 MFMA with fp32
+    accumulation; weights, activations, normalisation statistics, losses and the optimizer stay fp32 (BASELINE configs 4-5)."""
+    if dtype not in ('fp32', 'bf16'):
+        raise ValueError("pdfnet_amd: gemm precision must be 'fp32' or 'bf16'")
+    hip.lib().pdf_set_gemm_precision(1 if dtype == 'bf16' else 0)
+
+
+def gemm_precision():
+    return 'bf16' if hip.lib().pdf_debug_gemm_precision() else 'fp32'
+
+
 def _L():
     return hip.lib()
 

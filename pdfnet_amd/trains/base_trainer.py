@@ -158,21 +158,75 @@ class FlatAdam:
         self._b.copy_(torch.tensor(self.betas))
 
 
-def allreduce_flat_grads(flat_g, chunks=4, wait=True, force=False):
+class _Reduction:
+    """One outstanding gradient all-reduce; `finish()` waits for it (and, when the gradients travel in a narrower dtype,
+    widens the reduced values back into the flat buffer)."""
+
+    def __init__(self, work, dst=None, buf=None):
+        self.work, self.dst, self.buf = work, dst, buf
+
+    def finish(self):
+        self.work.wait()
+        if self.buf is not None:
+            self.dst.copy_(self.buf)
+
+
+def allreduce_flat_grads(flat_g, chunks=4, wait=True, force=False, comm_dtype=None):
     """Gradient SUM across ranks (the mean's 1/world is folded into the optimizer's grad_scale).  A few large
     RCCL all-reduces on the contiguous buffer: xGMI rings are per-link bound, so fewer/larger beats many/small.
-    wait=False returns the outstanding work handles instead of waiting for them; force=True issues the collectives on
-    a one-rank group too (tests: exercises the RCCL calls on a one-GPU box)."""
+    wait=False returns the outstanding reductions instead of finishing them; force=True issues the collectives on
+    a one-rank group too (tests: exercises the RCCL calls on a one-GPU box).  comm_dtype=torch.bfloat16 sends the gradients
+    as bf16 (half the bytes over xGMI; BASELINE configs 4-5) and accumulates the result back into the fp32 buffer."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force) or flat_g.numel() == 0:
         return []
     n = flat_g.numel()
     per = (n + chunks - 1) // chunks
-    works = [dist.all_reduce(flat_g[i:min(n, i + per)], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, n, per)]
+    reds = []
+    for i in range(0, n, per):
+        piece = flat_g[i:min(n, i + per)]
+        if comm_dtype is not None and comm_dtype != piece.dtype:
+            buf = piece.to(comm_dtype)
+            reds.append(_Reduction(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), piece, buf))
+        else:
+            reds.append(_Reduction(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)))
     if not wait:
-        return works
-    for w in works:
-        w.wait()
+        return reds
+    for r in reds:
+        r.finish()
     return []
+
+
+class GradReducer:
+    """The data-parallel gradient reduction of one step over the flat gradient buffer laid out [early | late | never used]:
+    `early_ready()` is called from inside the backward as soon as the early slice is complete (autograd hook on the trunk
+    output) and starts its all-reduce while the rest of the backward runs; `finish()` is called after the backward, reduces
+    the late slice and waits for everything.  The never-used tail [n_live, numel) is not sent.  Device-agnostic (the CPU
+    tests drive it over gloo; the trainer over RCCL)."""
+
+    def __init__(self, flat_g, n_early, n_live, comm_dtype=None):
+        self.flat_g, self.n_early, self.n_live, self.comm_dtype = flat_g, n_early, n_live, comm_dtype
+        self.force = False
+        self.early = None
+        self.bytes_sent = 0
+
+    def reset(self):
+        self.early = None
+
+    def early_ready(self):
+        if self.early is not None:
+            return
+        self.early = allreduce_flat_grads(self.flat_g[:self.n_early], chunks=3, wait=False, force=self.force, comm_dtype=self.comm_dtype)
+
+    def finish(self):
+        live = self.flat_g[:self.n_live]
+        esz = torch.empty(0, dtype=self.comm_dtype or live.dtype).element_size()
+        self.bytes_sent = live.numel() * esz
+        if self.early is not None:                            # early part already in flight
+            allreduce_flat_grads(live[self.n_early:], chunks=2, force=self.force, comm_dtype=self.comm_dtype)
+            for r in self.early:
+                r.finish()
+        else:
+            allreduce_flat_grads(live, force=self.force, comm_dtype=self.comm_dtype)
 
 
 # Parameters whose gradients are complete only at the very end of the backward: the ResNet trunk and what hangs off the
@@ -201,7 +255,7 @@ def split_parameters(named):
 class Trainer:
     """train(epoch, loader) / train_step(batch) for `HandNET_GCN` + `CtdetLoss`."""
 
-    def __init__(self, opt, model, loss, lr=1e-4, use_graph=False, broadcast_buffers=False):
+    def __init__(self, opt, model, loss, lr=1e-4, use_graph=False, broadcast_buffers=False, grad_comm_dtype=None):
         self.opt = opt
         self.model = model
         self.model_with_loss = ModleWithLoss(model, loss)
@@ -212,7 +266,7 @@ class Trainer:
         self.n_early = self.optimizer.offsets[len(early)] if late else self.optimizer.n_live
         self.n_live = self.optimizer.n_live
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self._early_works = None
+        self.reducer = GradReducer(self.optimizer.flat_g, self.n_early, self.n_live, grad_comm_dtype)
         self.force_collectives = False                         # tests: run the all-reduces on a one-rank group as well
         self.collectives = True                                # False: a rank-local step (bench.py's instrumented step on rank 0)
         self.early_probe = None                                # test hook: called with the early gradient slice when it is complete
@@ -238,17 +292,17 @@ class Trainer:
     def _early_grads_ready(self):
         """Runs inside the backward, when d loss / d x1 is complete: start the all-reduce of the early part of the flat
         gradient buffer while the trunk's backward (~a third of the step) still runs."""
-        if self.use_graph or self._early_works is not None or not self.collectives or \
+        if self.use_graph or self.reducer.early is not None or not self.collectives or \
                 (self.world == 1 and self.early_probe is None and not self.force_collectives):
             return
         F.join_wgrad()                                         # the side-stream kernels issued so far wrote into this part
-        early = self.optimizer.flat_g[:self.n_early]
         if self.early_probe is not None:
-            self.early_probe(early)
-        self._early_works = allreduce_flat_grads(early, chunks=3, wait=False, force=self.force_collectives)
+            self.early_probe(self.optimizer.flat_g[:self.n_early])
+        self.reducer.force = self.force_collectives
+        self.reducer.early_ready()
 
     def _fwd_bwd(self, batch, epoch):
-        self._early_works = None
+        self.reducer.reset()
         self.optimizer.zero_grad()
         loss, stats, _, _ = self.model_with_loss(batch, 'train', epoch)
         loss = loss.mean()                                     # base_trainer.py:144
@@ -267,15 +321,9 @@ class Trainer:
             loss = self._graph_step(batch, epoch)
         else:
             loss, _ = self._fwd_bwd(batch, epoch)
-        live = self.optimizer.flat_g[:self.n_live]             # the never-used tail is not reduced (its gradient is zero on every rank)
-        if not self.collectives:
-            pass
-        elif self._early_works is not None:                    # early part already in flight (or nothing to do at world 1)
-            allreduce_flat_grads(live[self.n_early:], chunks=2, force=self.force_collectives)
-            for w in self._early_works:
-                w.wait()
-        else:
-            allreduce_flat_grads(live, force=self.force_collectives)
+        if self.collectives:                                   # the never-used tail is not reduced (zero on every rank)
+            self.reducer.force = self.force_collectives
+            self.reducer.finish()
         self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0)
         return loss
 

@@ -31,7 +31,7 @@ def _worker(rank, world, port, q):
     assert len(early) == 3
     assert allreduce_flat_grads(g[n_early:], chunks=2) == []
     for w in early:
-        w.wait()
+        w.finish()
     g *= 1.0 / world                             # FlatAdam's grad_scale
     gathered = [torch.empty(n) for _ in range(world)]
     dist.all_gather(gathered, mine)
@@ -60,3 +60,61 @@ def test_single_process_is_a_noop():
     g = torch.arange(10.0)
     allreduce_flat_grads(g)
     assert torch.equal(g, torch.arange(10.0))
+
+
+def _reducer_worker(rank, world, port, q, comm):
+    """The trainer's own reduction object (GradReducer: what Trainer._early_grads_ready / train_step drive) on a fake
+    backward: the early slice is complete when the hook fires, the late slice is written afterwards, the never-used tail
+    never; with and without bf16 transport."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pdfnet_amd.trains.base_trainer import GradReducer
+    torch.manual_seed(7 + rank)
+    n, n_early, n_live = 50000, 30016, 44032
+    flat = torch.zeros(n)
+    red = GradReducer(flat, n_early, n_live, comm_dtype=torch.bfloat16 if comm == 'bf16' else None)
+    errs = []
+    for step in range(2):                                    # the reducer re-arms every step
+        red.reset()
+        flat.zero_()
+        mine = torch.zeros(n)
+        mine[:n_live] = torch.randn(n_live)
+        mine[n_live:] = 0.0                                  # parameters no autograd path reaches
+        flat[:n_early] = mine[:n_early]                      # ... backward of everything above the trunk
+        red.early_ready()                                    # hook on the trunk output's gradient
+        red.early_ready()                                    # (firing twice must not send twice)
+        flat[n_early:n_live] = mine[n_early:n_live]          # ... trunk backward, while the early slice is in flight
+        red.finish()
+        gathered = [torch.empty(n) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        ref = sum(gathered)
+        errs.append(float((flat - ref).abs().max() / ref.abs().max()))
+        assert float(flat[n_live:].abs().max()) == 0.0
+    q.put((rank, max(errs), red.bytes_sent))
+    dist.destroy_process_group()
+
+
+def _run_reducer(comm):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q, comm)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_trainer_reduction_object_world2_fp32():
+    res = _run_reducer('fp32')
+    assert all(e < 1e-6 for _, e, _ in res), res
+    assert all(b == 44032 * 4 for _, _, b in res)            # the never-used tail is not sent
+
+
+def test_trainer_reduction_object_world2_bf16_transport():
+    res = _run_reducer('bf16')
+    assert all(e < 1e-2 for _, e, _ in res), res             # bf16 rounding of the summands: 2^-8 relative
+    assert all(b == 44032 * 2 for _, _, b in res)

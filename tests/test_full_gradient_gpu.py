@@ -1,0 +1,109 @@
+"""The gradient truth of the HIP path: EVERY parameter gradient, every BatchNorm running statistic and the full dense
+outputs of one train step, against the pinned CPU oracle (model: oracle/pdfnet_cpu.py, loss: oracle/loss_cpu.py -- both
+checked against fixtures of the reference itself in tests/test_oracle_vs_golden.py) evaluated in float64 on the same
+batch.  Replaces spot checks on a few named tensors and HIP-vs-HIP comparisons as the gradient reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import make_opt, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_every_gradient_and_every_bn_statistic_against_the_fp64_oracle():
+    from oracle import loss_cpu as LC
+    from oracle import pdfnet_cpu as O
+    from oracle import synth
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    from pdfnet_amd import functional as F
+    R, B = 256, 2
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    batch = synthetic_train_batch(B, R, seed=41, consts=consts)
+    m = load_model_intag(opt)
+    sd = synth.det_state_dict(m.state_dict())
+    # ---- oracle, float64
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    o = O.load_model_cpu(opt)
+    o.load_state_dict(sd)
+    for mod in o.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    o.double().train()
+    bd = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+    z = np.load(os.path.join(ROOT, "pdfnet_amd", "data", "gcn_core.npz"))
+    result, params, hand, other = o(bd['input'], bd['choose'], bd['cloud'], bd['depth'], bd['ind'], bd['K_new'], bd['valid'])
+    for h in ('left', 'right'):
+        other['converter_' + h] = LC.Converter(z['graph_perm_' + h], z['graph_perm_reverse_' + h])
+    loss_o, stats_o = LC.ctdet_loss(opt, consts, result, params, hand, other, bd, 'train', 25)
+    # wh / params heads have no term in CtdetLoss (simplified.py:397-399): add one so that every live parameter is covered
+    extra = lambda oth: oth['ret']['wh'].pow(2).mean() + oth['ret']['params'].pow(2).mean()
+    (loss_o.mean() + extra(other)).backward()
+    hms_o, mask_o = other['hms'].detach(), other['mask'].detach()
+    # ---- HIP, float32
+    m.load_state_dict(sd)
+    m.cuda().train()
+    for mod in m.modules():
+        if isinstance(getattr(mod, 'p', None), float):
+            mod.p = 0.0
+    crit = CtdetLoss(opt, consts).cuda()
+    bg = {k: v.cuda() for k, v in batch.items()}
+    res = m(bg['input'], bg['choose'], bg['cloud'], bg['depth'], bg['ind'], bg['K_new'], bg['valid'])
+    loss_g, stats_g, _, _ = crit(*res, bg, 'train', 25)
+    (loss_g.mean() + extra(res[3])).backward()
+    F.join_wgrad()
+    torch.cuda.synchronize()
+
+    # loss terms: 16 statistics
+    for k, v in stats_o.items():
+        a, b = torch.as_tensor(stats_g[k]).detach().cpu().double().reshape(-1), torch.as_tensor(v).detach().reshape(-1)
+        assert torch.allclose(a, b, rtol=2e-4, atol=1e-6), (k, a, b)
+    # full dense outputs (train mode: SURVEY App. C noise floor 2e-3 abs on values up to ~8)
+    for name, a, b in (('hms', res[3]['hms'], hms_o), ('mask', res[3]['mask'], mask_o)):
+        err = float((a.detach().cpu().double() - b).abs().max())
+        assert err <= 1e-3 + 1e-4 * float(b.abs().max()), (name, err)
+    # every gradient
+    go = dict(o.named_parameters())
+    bad, checked, none_o = [], 0, 0
+    for n, p in m.named_parameters():
+        g64 = go[n].grad
+        if g64 is None:
+            none_o += 1
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        g = p.grad.detach().cpu().double()
+        na, nb = float(g64.norm()), float(g.norm())
+        cos = float((g64 * g).sum()) / (na * nb + 1e-300)
+        # norm within 1.5e-3 (2.5e-3 for sums with heavy cancellation over ~10^6 rows: the 3-channel SFT layer on the raw
+        # cloud, |g| ~ 5e3 from terms ~1e6 times larger in total) and cosine >= 0.9999
+        tol = 2.5e-3 if 'pointnet_plus.sft0' in n else 1.5e-3
+        if abs(na - nb) <= tol * na + 1e-12 and cos >= 0.9999:
+            checked += 1
+            continue
+        # a bias in front of a train-mode BatchNorm has an exactly-zero gradient (fp64: ~1e-9): the fp32 path holds the
+        # rounding noise of a sum over up to 2M rows.  Judge it against its layer's weight gradient.
+        wn = n[:-4] + 'weight'
+        if n.endswith('.bias') and wn in go and go[wn].grad is not None and na <= 1e-6 * float(go[wn].grad.norm()) \
+                and nb <= 1e-2 * float(go[wn].grad.norm()):
+            checked += 1
+            continue
+        bad.append((n, tuple(g.shape), na, nb, cos))
+    assert not bad, "\n".join("%s %s |g64|=%.4e |g32|=%.4e cos=%.6f" % b for b in bad[:20])
+    assert none_o == 324 and checked == len(go) - 324            # tests/golden/params_without_grad.txt
+    # every BatchNorm running statistic after the step
+    so = o.state_dict()
+    sg = m.state_dict()
+    nstat = 0
+    for k, v in so.items():
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            a = sg[k].detach().cpu().double()
+            assert float((a - v).abs().max()) <= 2e-5 + 1e-4 * float(v.abs().max()), k
+            nstat += 1
+        elif k.endswith('num_batches_tracked'):
+            assert int(sg[k]) == int(v), k
+    assert nstat > 150

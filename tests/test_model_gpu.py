@@ -345,7 +345,7 @@ def test_trainer_collectives_on_a_one_rank_rccl_group():
             g1 = tr.optimizer.flat_g.clone()                  # first-step gradients: later steps diverge chaotically (Adam)
             losses.append(float(tr.train_step(batch, 0)))     # the trigger re-arms every step
             torch.cuda.synchronize()
-            assert (tr._early_works is not None and len(tr._early_works) == 3) == force
+            assert (tr.reducer.early is not None and len(tr.reducer.early) == 3) == force
             out.append((losses, g1))
         assert abs(out[0][0][0] - out[1][0][0]) <= 1e-5 * abs(out[0][0][0])
         ga, gb = out[0][1], out[1][1]
