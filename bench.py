@@ -412,7 +412,7 @@ def main():
         flops = sum(v[1] for v in per.values())
         secs = sum(v[2] for v in per.values())
         tiles = prof.by_tile()
-        tname = {128128: "igemm_nt<128,128>", 128064: "igemm_nt<128,64>", 64064: "igemm_nt<64,64>", 0: "small_k_gemm", -1: "wgemm_*", 16: "igemm_bf16_kernel"}
+        tname = {128128: "igemm_nt<128,128>", 128064: "igemm_nt<128,64>", 64064: "igemm_nt<64,64>", 32032: "igemm_nt<32,32>", 0: "small_k_gemm", -1: "wgemm_*", 16: "igemm_bf16_kernel"}
         dom = tiles.get(16 if bf16 else 128128, [0, 0.0, 1e-9])          # the kernel with the most time per step
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         traffic, traffic_all, traffic_src = pmc_traffic() if not bf16 else (None, None, 'no PMC profile of the bf16 kernels')

@@ -639,10 +639,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_SPLITK, ENV_IG_HALO, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_SPLITK, ENV_IG_HALO, ENV_IG_T32, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_SPLITK", "PDF_IG_HALO"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_SPLITK", "PDF_IG_HALO", "PDF_IG_T32"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -661,9 +661,16 @@ __global__ __launch_bounds__(256) void small_k_gemm(const IGemm g) {
     __shared__ float bt[SMALLK_MAX][260];                    // [k][n] for this block's <= 256 columns
     const int n0 = blockIdx.y * 256;
     const int nn = min(256, g.N - n0);
-    for (int i = threadIdx.x; i < nn * g.K; i += 256) {
-        const int n = i / g.K, k = i - n * g.K;
-        bt[k][n] = g.B[(long)(n0 + n) * g.ldb + k];
+    if (g.b_kn) {                                            // [K][N] storage (backward-data of a 2- / 42-channel output conv)
+        for (int i = threadIdx.x; i < nn * g.K; i += 256) {
+            const int k = i / nn, n = i - k * nn;
+            bt[k][n] = g.B[(long)k * g.ldb + n0 + n];
+        }
+    } else {
+        for (int i = threadIdx.x; i < nn * g.K; i += 256) {
+            const int n = i / g.K, k = i - n * g.K;
+            bt[k][n] = g.B[(long)(n0 + n) * g.ldb + k];
+        }
     }
     __syncthreads();
     const int nq = (nn + 3) / 4;
@@ -718,7 +725,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
     if (g.b_kn) fast = fast && (g.N % 4 == 0) && (g.btap % 4 == 0);
     if (groups > 1) fast = fast && aligned16(g.B1) && (g.gsA % 4 == 0);
-    if (!fast && groups == 1 && !g.b_kn && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
+    if (!fast && groups == 1 && (!g.b_kn || (g.T == 1 && g.wt[0] == 0)) && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
         (long)g.M * g.N >= (1L << 20)) {
         dim3 grid(grid_for((long)g.M * ((min(g.N, 256) + 3) / 4)), cdiv(g.N, 256));
         hipLaunchKernelGGL(small_k_gemm, grid, dim3(256), 0, s, g);
@@ -741,6 +748,11 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
         launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s), g_last_tile = 128128;
     else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int(ENV_IG_T128, 600))
         launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s), g_last_tile = 128064;   // (K-step 32: no gain here)
+    else if (fast && (long)cdiv(g.M, 64) * cdiv(g.N, 64) * groups < 96 && g.K >= 512 && env_int(ENV_IG_T32, 1)) {
+        // a handful of 64x64 tiles with a long reduction (M = 64 centre windows, the mesh decoder's 1024-wide layers): latency
+        // bound on a few CUs -- 32x32 tiles put 4x as many blocks on the chip (one wave each)
+        launch_igemm_tile<32, 32, 1, 1>(g, fast, dim3(cdiv(g.M, 32) * cdiv(g.N, 32), groups), s), g_last_tile = 32032;
+    }
     else
     {
         const dim3 grid(cdiv(g.M, 64) * cdiv(g.N, 64), groups);
@@ -801,12 +813,147 @@ PDF_API int pdf_linear_bwd_data_pair(const float* dy, const float* w0, const flo
     return launch_igemm(g, s, 2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tiny-channel layers: HBM-bound streaming kernels instead of 128-wide MFMA tiles that would be > 95 % padding.
+// e_conv1 (intaghand_encoder.py:711: Conv2d(3, 3, 3, padding=1) on the full-resolution image): one thread per output pixel.
+template <int CI, int CO, int KH, int KW>
+__global__ __launch_bounds__(256) void tiny_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int N, int H, int W, int ldx, int pad, int OH, int OW, int ldy, int act) {
+    __shared__ float ws[CO * KH * KW * CI];
+    for (int i = threadIdx.x; i < CO * KH * KW * CI; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long total = (long)N * OH * OW;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+        const int ox = (int)(p % OW), oy = (int)((p / OW) % OH);
+        const long n = p / ((long)OW * OH);
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int iy = oy + ky - pad, ix = ox + kx - pad;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const float* xp = x + ((n * H + iy) * W + ix) * ldx;
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    const float v = xp[ci];
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) acc[c] = fmaf(v, ws[((c * KH + ky) * KW + kx) * CI + ci], acc[c]);
+                }
+            }
+        float* yp = y + p * ldy;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            float v = acc[c];
+            if (act == 1) v = fmaxf(v, 0.f); else if (act == 2) v = v > 0.f ? v : 0.1f * v;
+            yp[c] = v;
+        }
+    }
+}
+// its weight gradient: every thread keeps all CO*KH*KW*CI sums in registers over a grid-stride loop of pixels; one partial
+// row per block in the workspace, summed by reduce_slabs (fixed order: deterministic)
+template <int CI, int CO, int KH, int KW>
+__global__ __launch_bounds__(256) void tiny_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                              int N, int H, int W, int ldx, int pad, int OH, int OW, int lddy) {
+    constexpr int NW = CO * KH * KW * CI;
+    __shared__ float red[4][NW];
+    float acc[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) acc[i] = 0.f;
+    const long total = (long)N * OH * OW;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+        const int ox = (int)(p % OW), oy = (int)((p / OW) % OH);
+        const long n = p / ((long)OW * OH);
+        float g[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) g[c] = dy[p * lddy + c];
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int iy = oy + ky - pad, ix = ox + kx - pad;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float* xp = x + ((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * ldx;
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    const float v = ok ? xp[ci] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) acc[((c * KH + ky) * KW + kx) * CI + ci] = fmaf(g[c], v, acc[((c * KH + ky) * KW + kx) * CI + ci]);
+                }
+            }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NW; i += 256) part[(long)blockIdx.x * NW + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// Weight (and bias) gradient of a layer with <= 4 output channels on plain rows (the 2-channel hm / mask heads):
+// dW[i][j] = sum_m P[m][i] Q[m][j], K = NJ <= 1024 columns, one float4 column group per thread, the block's row lanes reduced
+// through LDS; per-block partials [blk][NI*NJ (+NI)] in the workspace, summed by reduce_slabs.
+__global__ __launch_bounds__(256) void narrow_wgrad_kernel(const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ part, float* __restrict__ bpart,
+                                                           int M, int NI, int NJ, int ldp, int ldq, int rows_per_block) {
+    __shared__ float red[256 * 16];
+    __shared__ float bred[256 * 4];
+    const int cgs = NJ / 4, rl = 256 / cgs;                  // column groups, row lanes
+    const int cg = threadIdx.x % cgs, lr = threadIdx.x / cgs;
+    float acc[4][4] = {}, bs[4] = {};
+    const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    if (lr < rl) {
+        for (int m = m0 + lr; m < m1; m += rl) {
+            const float4 q = *reinterpret_cast<const float4*>(Q + (long)m * ldq + cg * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < NI) {
+                    const float p = P[(long)m * ldp + i];
+                    acc[i][0] = fmaf(p, q.x, acc[i][0]); acc[i][1] = fmaf(p, q.y, acc[i][1]);
+                    acc[i][2] = fmaf(p, q.z, acc[i][2]); acc[i][3] = fmaf(p, q.w, acc[i][3]);
+                    if (cg == 0) bs[i] += p;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[threadIdx.x * 16 + i * 4 + e] = acc[i][e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bred[threadIdx.x * 4 + i] = bs[i];
+    __syncthreads();
+    if (lr == 0) {
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = 0.f;
+                for (int r = 0; r < rl; ++r) t += red[(r * cgs + cg) * 16 + i * 4 + e];
+                part[(long)blockIdx.x * NI * NJ + (long)i * NJ + cg * 4 + e] = t;
+            }
+        if (cg == 0 && bpart != nullptr)
+            for (int i = 0; i < NI; ++i) {
+                float t = 0.f;
+                for (int r = 0; r < rl; ++r) t += bred[(r * cgs) * 4 + i];
+                bpart[(long)blockIdx.x * NI + i] = t;
+            }
+    }
+}
+
 // Conv2d forward on NHWC.  w is [Cout][KH][KW][Cin] (the channels_last storage of an OIHW weight).
 // Replaces nn.Conv2d.forward at intaghand_encoder.py:711-772,790-791 and resnet.py:202-218.
 PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                            int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                            int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s) {
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && (long)N * OH * OW >= (1L << 16)) {
+        hipLaunchKernelGGL((tiny_conv_fwd_kernel<3, 3, 3, 3>), dim3(grid_for((long)N * OH * OW)), dim3(256), 0, s, x, w, bias, y, N, H, W, ldx, pad, OH, OW, ldy, act);
+        PDF_LAUNCH_CHECK();
+        return 0;
+    }
     IGemm g = {};
     g.A = x; g.B = w; g.C = y; g.bias = bias;
     g.M = N * OH * OW; g.N = Cout; g.K = KH * KW * Cin; g.Cin = Cin; g.lda = ldx; g.ldb = KH * KW * Cin; g.ldc = ldy;
@@ -965,6 +1112,30 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
                                   int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                                   int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && db == nullptr && (long)N * OH * OW >= (1L << 16) && ws_floats >= 81L * 64) {
+        const int nblk = (int)min((long)1024, ws_floats / 81);
+        hipLaunchKernelGGL((tiny_conv_wgrad_kernel<3, 3, 3, 3>), dim3(nblk), dim3(256), 0, s, x, dy, ws, N, H, W, ldx, pad, OH, OW, lddy);
+        Reduce r = {ws, dw, nullptr, 81, nullptr, nullptr, nullptr, 0, nblk, accumulate};
+        hipLaunchKernelGGL(reduce_slabs_2d, dim3(2, 1), dim3(256), 0, s, r, 2);
+        PDF_LAUNCH_CHECK();
+        return 0;
+    }
+    if (Cout <= 4 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && Cin % 4 == 0 && Cin <= 1024 && 256 % (Cin / 4) == 0 && ldx % 4 == 0 && aligned16(x)) {
+        const long per = (long)Cout * Cin, perb = db ? Cout : 0;
+        const int M = N * OH * OW;
+        int nblk = (int)min((long)1024, ws_floats / (per + perb));
+        if (nblk >= 1) {
+            const int rpb = cdiv(M, nblk);
+            nblk = cdiv(M, rpb);
+            float* bws = ws + (long)nblk * per;
+            hipLaunchKernelGGL(narrow_wgrad_kernel, dim3(nblk), dim3(256), 0, s, dy, x, ws, db ? bws : nullptr, M, Cout, Cin, lddy, ldx, rpb);
+            Reduce r = {ws, dw, nullptr, per, bws, db, nullptr, (int)perb, nblk, accumulate};
+            const int mb = (int)((per + 63) / 64);
+            hipLaunchKernelGGL(reduce_slabs_2d, dim3(mb + (int)((perb + 63) / 64), 1), dim3(256), 0, s, r, mb);
+            PDF_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     WGemm g = {};
     g.P = dy; g.Q = x; g.M = N * OH * OW; g.NI = Cout; g.Cq = Cin; g.T = KH * KW;
     g.ldp = lddy; g.ldq = ldx; g.ldw = KH * KW * Cin;

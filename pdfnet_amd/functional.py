@@ -198,7 +198,9 @@ def _main_grad(param, like):
     (FlatAdam tags its parameters): skips autograd's separate `grad += dw` pass and the dw allocation."""
     if param is None or not getattr(param, '_pdf_main_grad', False):
         return None
-    g = param.grad
+    g = getattr(param, '_pdf_grad_alias', None)            # a re-shaped view of a parameter carries the matching view of its gradient
+    if g is None:
+        g = param.grad
     if g is None or g.shape != like.shape or g.stride() != like.stride():
         return None
     return g
@@ -398,6 +400,17 @@ class _Linear(Function):
 
 def linear(x, w, b=None, act=ACT_NONE):
     return _Linear.apply(x, w, b, act)
+
+
+def as_matrix(weight):
+    """A conv weight [Cout, Cin, KH, KW] in channels_last storage IS the row-major matrix [Cout, KH*KW*Cin]: return that
+    view (no copy) for `linear`, carrying the same view of the trainer's flat gradient so that the weight gradient is still
+    accumulated in place."""
+    w2 = weight.permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+    if getattr(weight, '_pdf_main_grad', False) and weight.grad is not None:
+        w2._pdf_main_grad = True
+        w2._pdf_grad_alias = weight.grad.permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+    return w2
 
 
 class _LinearPair(Function):

@@ -228,7 +228,9 @@ class ResNetSimple(nn.Module):
         win = F.window_gather(x0, ind, 2)                                                  # [B*2,256,5,5]
         u0 = F.conv2d(win, up0.weight, None, 1, 0)                                         # [B*2,512,3,3] (valid conv)
         u0 = F.window_mask(u0, ind, H, W, 1)
-        u1 = F.conv2d(u0, up1.weight, None, 1, 0)                                          # [B*2,1024,1,1]
+        # a valid 3x3 convolution of a 3x3 map is one full contraction: a plain [B*2, 9*512] x [1024, 9*512]^T GEMM on the NHWC
+        # rows (as a convolution the backward-data pass walks 9 taps of which 8 are masked per position)
+        u1 = F.linear(u0.permute(0, 2, 3, 1).reshape(B * 2, -1), F.as_matrix(up1.weight))  # [B*2,1024]
         return u1.reshape(B, 2, 1024)
 
     def forward(self, img, ind, choose, cloud, depth=None, K_new=None, valid=None):

@@ -36,7 +36,8 @@ def rnd(*shape, seed=0, scale=1.0):
 
 @pytest.mark.parametrize("M,K,N,act,bias", [
     (2016, 512, 256, 0, True), (300, 131, 128, 1, True), (64, 252, 778, 0, False), (8064, 64, 3, 0, True),
-    (1000, 16, 64, 2, True), (37, 1024, 509, 0, True), (40000, 2, 128, 0, False), (33000, 42, 130, 2, True), (70000, 16, 64, 1, True), (32768, 64, 64, 1, False), (40000, 256, 128, 0, True), (5, 3, 3, 2, True)])
+    (1000, 16, 64, 2, True), (37, 1024, 509, 0, True), (40000, 2, 128, 0, False), (33000, 42, 130, 2, True), (70000, 16, 64, 1, True), (32768, 64, 64, 1, False), (40000, 256, 128, 0, True), (5, 3, 3, 2, True),
+    (64, 4608, 1024, 0, False), (64, 1024, 1024, 0, True), (32, 1024, 512, 1, True)])       # few rows, long reduction: 32x32 tiles
 def test_linear(F, M, K, N, act, bias):
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3) if bias else None
     xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
@@ -61,7 +62,11 @@ CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, act, bias
     (2, 3, 32, 32, 64, 7, 2, 3, 0, False), (2, 3, 17, 19, 3, 3, 1, 1, 1, False), (2, 64, 16, 16, 64, 3, 1, 1, 0, False),
     (2, 128, 13, 13, 128, 3, 2, 1, 0, False), (2, 256, 16, 16, 128, 1, 2, 0, 0, False), (2, 64, 16, 16, 256, 1, 1, 0, 0, False),
     (3, 32, 9, 11, 48, 3, 1, 1, 1, True), (1, 256, 64, 64, 256, 3, 1, 1, 1, True), (2, 256, 8, 8, 122, 1, 1, 0, 0, True),
-    (4, 1024, 16, 16, 256, 3, 1, 1, 0, False)]
+    (4, 1024, 16, 16, 256, 3, 1, 1, 0, False),
+    # streaming kernels for tiny channel counts: e_conv1 (3 -> 3, full resolution), the 2-channel hm / mask heads
+    (2, 3, 192, 200, 3, 3, 1, 1, 1, False), (2, 256, 64, 64, 2, 1, 1, 0, 0, True), (2, 128, 128, 128, 2, 1, 1, 0, 0, True),
+    # valid 3x3 on the 5x5 / 3x3 centre windows (few rows, long reduction: 32x32 tiles)
+    (64, 256, 5, 5, 512, 3, 1, 0, 0, False), (64, 512, 3, 3, 1024, 3, 1, 0, 0, False)]
 
 
 @pytest.mark.parametrize("cfg", CONVS)
