@@ -117,6 +117,19 @@ int pdf_nms_top1(const float* hm, int BC, int H, int W, long* ind, float* score,
 /* nn.MaxPool2d((1,K)) / ((S2,1)) of netR_1/2/3 (intaghand_encoder.py:62,82,100): x [R][K][ldx] -> y [R][ldy], arg [R][C] */
 int pdf_maxk_fwd(const float* x, int ldx, int C, long R, int K, float* y, int ldy, int* arg, void* stream);
 int pdf_maxk_bwd(const float* dy, int ldy, const int* arg, int C, long R, int K, float* dx, int ldx, void* stream);
+/* BatchNorm2d -> ReLU -> MaxPool2d over the K neighbours, the tail of every set-abstraction MLP (intaghand_encoder.py:59-62,
+ * 79-82,97-100), on the convolution output y [R][K][ldy] without writing the normalised tensor: out [R][ldo], arg int32 [R][C].
+ * training: batch statistics over the R*K rows (+ running-statistics update); else running statistics.  save_mean / save_rstd /
+ * scale / shift [C] feed the backward, which rebuilds d y [R][K][lddy] from (dout [R][lddo], arg, y) -- the two BatchNorm sums
+ * only involve the R*C selected elements -- and (accumulates) dgamma / dbeta.  C % 4 == 0.
+ * ws: pdf_bn_workspace_floats(C, R*K) floats (fwd), pdf_bn_workspace_floats(C, R) + 3*C (bwd). */
+int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, int training,
+                         float* out, int ldo, int* arg, float* save_mean, float* save_rstd, float* scale, float* shift,
+                         float* ws, void* stream);
+int pdf_bn_relu_maxk_bwd(const float* dout, int lddo, const int* arg, const float* y, int ldy, const float* save_mean, const float* save_rstd,
+                         const float* gamma, const float* scale, const float* shift, int C, long R, int K,
+                         float* dy, int lddy, float* dgamma, float* dbeta, int accumulate, float* ws, void* stream);
 
 /* ---- normalisation (csrc/norm.hip) ------------------------------------------------------------ */
 

@@ -431,6 +431,142 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Set-abstraction tail (intaghand_encoder.py:59-62,79-82,97-100: BatchNorm2d -> ReLU -> MaxPool2d over the K neighbours) in
+// one pass over the convolution output y [R][K][C]: out[r][c] = max_k relu(fma(y, scale, shift)), arg = first k attaining it.
+// The normalised tensor (537 MB per hand at level 1) is never written; the backward rebuilds the gradient of y from
+// (dout, arg, y): its two BatchNorm sums only involve the R*C selected elements.
+__global__ __launch_bounds__(256) void bn_relu_maxk_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int C, int K, float* __restrict__ out, int ldo,
+                                                               int* __restrict__ arg, long total /* R * C/4 */) {
+    const int cq = C / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cq;
+        const int c0 = (int)(i - r * cq) * 4;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c0), sh = *reinterpret_cast<const float4*>(shift + c0);
+        const float* p = y + r * K * ldy + c0;
+        float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);            // relu output is >= 0: the first k always wins against -1
+        int4 bi = make_int4(0, 0, 0, 0);
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (long)k * ldy);
+            const float zx = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), zy = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+            const float zz = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), zw = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+            if (zx > best.x) { best.x = zx; bi.x = k; }
+            if (zy > best.y) { best.y = zy; bi.y = k; }
+            if (zz > best.z) { best.z = zz; bi.z = k; }
+            if (zw > best.w) { best.w = zw; bi.w = k; }
+        }
+        *reinterpret_cast<float4*>(out + r * ldo + c0) = best;
+        *reinterpret_cast<int4*>(arg + r * C + c0) = bi;
+    }
+}
+// partial sums over the rows r of g = dout * [z > 0] and g * xhat at the selected neighbour (same [chunks][C][2] layout as
+// bn_bwd_partial_v4_kernel, so bn_bwd_finalize_kernel finishes them)
+__global__ __launch_bounds__(256) void bn_maxk_bwd_partial_kernel(const float* __restrict__ dm, int lddm, const int* __restrict__ arg,
+                                                                  const float* __restrict__ y, int ldy, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int C, int K, long R, long rows_per_chunk,
+                                                                  float* __restrict__ part) {
+    __shared__ float4 sa[V4_TY][V4_TX], sb[V4_TY][V4_TX];
+    const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
+    const int c0 = blockIdx.x * BN_CT + tx * 4;
+    const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (c0 < C) {
+        const float4 m = *reinterpret_cast<const float4*>(mean + c0), rs = *reinterpret_cast<const float4*>(rstd + c0);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c0), sh = *reinterpret_cast<const float4*>(shift + c0);
+        for (long r = r0 + ty; r < r1; r += V4_TY) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dm + r * lddm + c0);
+            const int4 k4 = *reinterpret_cast<const int4*>(arg + r * C + c0);
+            const float* base = y + r * K * ldy + c0;
+            const float vx = base[(long)k4.x * ldy], vy = base[(long)k4.y * ldy + 1], vz = base[(long)k4.z * ldy + 2], vw = base[(long)k4.w * ldy + 3];
+            const float gx = fmaf(vx, sc.x, sh.x) > 0.f ? g4.x : 0.f, gy = fmaf(vy, sc.y, sh.y) > 0.f ? g4.y : 0.f;
+            const float gz = fmaf(vz, sc.z, sh.z) > 0.f ? g4.z : 0.f, gw = fmaf(vw, sc.w, sh.w) > 0.f ? g4.w : 0.f;
+            a.x += gx; a.y += gy; a.z += gz; a.w += gw;
+            b.x += gx * (vx - m.x) * rs.x; b.y += gy * (vy - m.y) * rs.y; b.z += gz * (vz - m.z) * rs.z; b.w += gw * (vw - m.w) * rs.w;
+        }
+    }
+    v4_block_reduce(a, b, sa, sb, part, C, c0, true);
+}
+// dy[r][k][c] = a * (g - c1 - xhat * c2), g = dout[r][c] where k == arg[r][c] and the ReLU was active, else 0
+__global__ __launch_bounds__(256) void bn_maxk_bwd_apply_kernel(const float* __restrict__ dm, int lddm, const int* __restrict__ arg,
+                                                                const float* __restrict__ y, int ldy, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ coef,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift, int C, int K,
+                                                                float* __restrict__ dy, int lddy, long total /* R * C/4 */) {
+    const int cq = C / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cq;
+        const int c0 = (int)(i - r * cq) * 4;
+        const float4 m = *reinterpret_cast<const float4*>(mean + c0), rs = *reinterpret_cast<const float4*>(rstd + c0);
+        const float4 ka = *reinterpret_cast<const float4*>(coef + c0), k1 = *reinterpret_cast<const float4*>(coef + C + c0),
+                     k2 = *reinterpret_cast<const float4*>(coef + 2 * C + c0);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c0), sh = *reinterpret_cast<const float4*>(shift + c0);
+        const float4 g4 = *reinterpret_cast<const float4*>(dm + r * lddm + c0);
+        const int4 k4 = *reinterpret_cast<const int4*>(arg + r * C + c0);
+        const float* p = y + r * K * ldy + c0;
+        float* q = dy + r * K * lddy + c0;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (long)k * ldy);
+            const float gx = (k == k4.x && fmaf(v.x, sc.x, sh.x) > 0.f) ? g4.x : 0.f, gy = (k == k4.y && fmaf(v.y, sc.y, sh.y) > 0.f) ? g4.y : 0.f;
+            const float gz = (k == k4.z && fmaf(v.z, sc.z, sh.z) > 0.f) ? g4.z : 0.f, gw = (k == k4.w && fmaf(v.w, sc.w, sh.w) > 0.f) ? g4.w : 0.f;
+            float4 o;
+            o.x = ka.x * (gx - k1.x - (v.x - m.x) * rs.x * k2.x);
+            o.y = ka.y * (gy - k1.y - (v.y - m.y) * rs.y * k2.y);
+            o.z = ka.z * (gz - k1.z - (v.z - m.z) * rs.z * k2.z);
+            o.w = ka.w * (gw - k1.w - (v.w - m.w) * rs.w * k2.w);
+            *reinterpret_cast<float4*>(q + (long)k * lddy) = o;
+        }
+    }
+}
+// training != 0: batch statistics over all R*K rows (running statistics updated with `momentum`); else running statistics.
+// C % 4 == 0, 16-byte aligned rows.  ws: pdf_bn_workspace_floats(C, R*K) floats.
+PDF_API int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, int training,
+                                 float* out, int ldo, int* arg, float* save_mean, float* save_rstd, float* scale, float* shift,
+                                 float* ws, hipStream_t s) {
+    if (R <= 0 || C <= 0 || K <= 0) return 0;
+    if (!v4_ok(C, {ldy, ldo}, {y, out, arg, scale, shift})) return PDF_E_BADARG;
+    const long rows = R * K;
+    if (training) {
+        long chunks = bn_chunks(C, rows);
+        long rpc = (rows + chunks - 1) / chunks;
+        chunks = (rows + rpc - 1) / rpc;
+        hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, y, ldy, C, rows, rpc, ws);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, y, C, rows, gamma, beta,
+                           running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+    } else {
+        hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, C, gamma, beta, running_mean, running_var, eps, scale, shift);
+    }
+    PDF_LAUNCH_CHECK();
+    const long total = R * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxk_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, y, ldy, scale, shift, C, K, out, ldo, arg, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// ws: pdf_bn_workspace_floats(C, R) + 3*C floats
+PDF_API int pdf_bn_relu_maxk_bwd(const float* dout, int lddo, const int* arg, const float* y, int ldy, const float* save_mean, const float* save_rstd,
+                                 const float* gamma, const float* scale, const float* shift, int C, long R, int K,
+                                 float* dy, int lddy, float* dgamma, float* dbeta, int accumulate, float* ws, hipStream_t s) {
+    if (R <= 0 || C <= 0 || K <= 0) return 0;
+    if (!v4_ok(C, {ldy, lddo, lddy}, {y, dout, dy, arg, save_mean, save_rstd, scale, shift, ws})) return PDF_E_BADARG;
+    long chunks = bn_chunks(C, R);
+    long rpc = (R + chunks - 1) / chunks;
+    chunks = (R + rpc - 1) / rpc;
+    float* coef = ws + pdf_bn_workspace_floats(C, R);
+    hipLaunchKernelGGL(bn_maxk_bwd_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dout, lddo, arg, y, ldy, save_mean, save_rstd,
+                       scale, shift, C, K, R, rpc, ws);
+    // the statistics were taken over R*K rows: the means of the backward are over R*K as well
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, R * K, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
+    const long total = R * (C / 4);
+    hipLaunchKernelGGL(bn_maxk_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dout, lddo, arg, y, ldy, save_mean, save_rstd, coef,
+                       scale, shift, C, K, dy, lddy, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
 // column sums: out[c] (+)= sum_r g[r][c]   (conv / linear bias gradients), optional relu mask by y
 __global__ __launch_bounds__(FIN_TX * FIN_TY) void colsum_finalize_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ out,
                                                                           float* __restrict__ out1, int accumulate) {

@@ -1003,6 +1003,55 @@ def max_over_k(x):
     return _MaxK.apply(x)
 
 
+class _BnReluMaxK(Function):
+    """BatchNorm -> ReLU -> max over the K neighbours of x [R*K, C] (rows r*K + k) in one pass: -> [R, C].
+    The normalised [R*K, C] tensor is never materialised (set-abstraction tail, intaghand_encoder.py:59-62,79-82,97-100)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, K, training, momentum, eps):
+        hip.require_gpu(x)
+        x = x.contiguous()
+        C = x.shape[-1]
+        R = x.numel() // (C * K)
+        dev = x.device
+        out = torch.empty((R, C), device=dev)
+        arg = torch.empty((R, C), dtype=torch.int32, device=dev)
+        mean, rstd, scale, shift = (torch.empty(C, device=dev) for _ in range(4))
+        L = _L()
+        ws = _ws(L.pdf_bn_workspace_floats(C, R * K), dev)
+        L.pdf_bn_relu_maxk_fwd(ptr(x), C, C, R, K, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps, int(training),
+                               ptr(out), C, ptr(arg), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
+        ctx.save_for_backward(x, gamma, arg, mean, rstd, scale, shift)
+        ctx.cfg = (R, K, C, training)
+        ctx.params = (gamma, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, arg, mean, rstd, scale, shift = ctx.saved_tensors
+        R, K, C, training = ctx.cfg
+        if not training:
+            raise RuntimeError("pdfnet_amd: BatchNorm backward in eval mode is not implemented")
+        g = dout.contiguous()
+        dx = torch.empty_like(x)
+        g_par, b_par = ctx.params
+        mg_g, mg_b = _main_grad(g_par, g_par), _main_grad(b_par, b_par)
+        direct = mg_g is not None and mg_b is not None
+        dgamma = mg_g if direct else torch.empty(C, device=x.device)
+        dbeta = mg_b if direct else torch.empty(C, device=x.device)
+        L = _L()
+        ws = _ws(L.pdf_bn_workspace_floats(C, R) + 3 * C, x.device)
+        L.pdf_bn_relu_maxk_bwd(ptr(g), C, ptr(arg), ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R, K,
+                               ptr(dx), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream())
+        if direct:
+            dgamma = dbeta = None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_relu_max_over_k(x, gamma, beta, rmean, rvar, K, training, momentum=0.1, eps=1e-5):
+    return _BnReluMaxK.apply(x, gamma, beta, rmean, rvar, K, training, momentum, eps)
+
+
 # ----------------------------------------------------------------------------------------------
 class _Cheby2(Function):
     """x [B,V,F] -> [B,V,2F] = interleave(x, L x); ell = (col, val, colT, valT, width)."""

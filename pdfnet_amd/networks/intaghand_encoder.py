@@ -106,11 +106,13 @@ class PointNet_Plus(nn.Module):
                                      Linear(512, opt.PCA_SZ))          # constructed, unused (:155)
 
     @staticmethod
-    def _mlp(seq, x):
+    def _mlp_max(seq, x, K):
+        """3 x (1x1 conv -> BatchNorm -> ReLU) then MaxPool over the K neighbours (:48-65,67-103).  The last BatchNorm, its
+        ReLU and the pooling are one pass over the last convolution's output (F.bn_relu_max_over_k)."""
         x = x.reshape(-1, x.shape[-1])            # point rows [cloud*centroid*neighbour, channel]
-        for i in (0, 3, 6):
+        for i in (0, 3):
             x = seq[i + 1](seq[i](x), relu=True)
-        return x
+        return seq[7].relu_max_over_k(seq[6](x), K)
 
     def forward(self, cloud, emb, choose):
         return self.stage_b(*self.stage_a(cloud, emb[0], emb[1], choose), emb[2], choose)
@@ -123,12 +125,12 @@ class PointNet_Plus(nn.Module):
         B = cloud.shape[0]
         pts = self.sft0(cloud, F.gather_rows(emb0, choose))                                # [B,1024,3]   (:120-122)
         g1, _ = F.knn_ball_group(pts, 3, S1, K, o.ball_radius, _pad16(3))                  # [B,S1,K,16]  (:123)
-        x = F.max_over_k(self._mlp(self.netR_1, g1).view(B * S1, K, 128))                  # [B*S1,128]   (:132)
+        x = self._mlp_max(self.netR_1, g1, K)                                               # [B*S1,128]   (:132)
         e1 = F.gather_rows(emb1, choose[:, :S1], R, 1)                                     # [B,S1,64]    (:125-127)
         x = torch.cat((pts[:, :S1], x.view(B, S1, 128)), 2)                                # [B,S1,131]   (:134)
         x = self.sft1(x, e1)                                                               #              (:137)
         g2, _ = F.knn_ball_group(x, 131, S2, K, o.ball_radius2, _pad16(131))               # [B,S2,K,144] (:139)
-        y = F.max_over_k(self._mlp(self.netR_2, g2).view(B * S2, K, 256))                  # [B*S2,256]
+        y = self._mlp_max(self.netR_2, g2, K)                                               # [B*S2,256]
         return x, y
 
     def stage_b(self, x, y, emb2, choose):
@@ -140,7 +142,7 @@ class PointNet_Plus(nn.Module):
         y = torch.cat((x[:, :S2, :3], y.view(B, S2, 256)), 2)                              # [B,S2,259]
         y = self.sft2(y, e2)                                                               #              (:147)
         y = torch.nn.functional.pad(y, (0, _pad16(259) - 259))
-        y = F.max_over_k(self._mlp(self.netR_3, y).view(B, S2, 1024))                      # [B,1024]     (:152)
+        y = self._mlp_max(self.netR_3, y, S2)                                               # [B,1024]     (:152)
         return y.view(B, 1, 1024)
 
 

@@ -119,6 +119,15 @@ class BatchNorm(nn.Module):
                             self.training, self.momentum, self.eps, relu, res)
 
 
+    def relu_max_over_k(self, x, K):
+        """relu(self(x)) followed by the max over groups of K consecutive rows, fused (F.bn_relu_max_over_k)."""
+        if self.training:
+            if self._pending == 0:
+                BatchNorm._dirty.append(self)
+            self._pending += 1
+        return F.bn_relu_max_over_k(x, self.weight, self.bias, self.running_mean, self.running_var, K, self.training, self.momentum, self.eps)
+
+
 class LayerNorm(nn.Module):
     def __init__(self, d, eps=1e-6):
         super().__init__()

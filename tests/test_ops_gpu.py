@@ -156,6 +156,34 @@ def test_batchnorm(F, shape, relu, res):
                 close(rd.grad, rr.grad, 1e-6, what="bn dres")
 
 
+@pytest.mark.parametrize("R,K,C", [(96, 64, 128), (40, 128, 1024), (300, 64, 256), (7, 5, 8)])
+def test_fused_batchnorm_relu_max_over_neighbours(F, R, K, C):
+    """Set-abstraction tail (intaghand_encoder.py:59-62): BatchNorm2d -> ReLU -> MaxPool over K in one pass, forward and
+    backward (gradient of the convolution output, dgamma, dbeta), train and eval mode, against the unfused torch ops."""
+    x = rnd(R * K, C, seed=1) * 1.5 + 0.3
+    g, b = torch.rand(C) + 0.5, rnd(C, seed=2) * 0.5
+    g[::7] *= -1.0                                           # negative scales: the max then sits on the smallest input
+    rm0, rv0 = rnd(C, seed=3), torch.rand(C) + 0.5
+    for training in (True, False):
+        xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+        rm, rv = rm0.clone(), rv0.clone()
+        z = TF.relu(TF.batch_norm(xr, rm, rv, gr, br, training, 0.1, 1e-5))
+        ref = z.view(R, K, C).max(1)[0]
+        xd, gd, bd = dev(x).requires_grad_(), dev(g).requires_grad_(), dev(b).requires_grad_()
+        rmd, rvd = dev(rm0.clone()), dev(rv0.clone())
+        out = F.bn_relu_max_over_k(xd, gd, bd, rmd, rvd, K, training, 0.1, 1e-5)
+        close(out, ref, 2e-5, what="fused bn-relu-max fwd train=%s" % training)
+        if training:
+            close(rmd, rm, 1e-5, what="running_mean")
+            close(rvd, rv, 1e-5, what="running_var")
+            gy = rnd(R, C, seed=4)
+            ref.backward(gy)
+            out.backward(dev(gy))
+            close(xd.grad, xr.grad, 5e-5, rtol=5e-5, what="fused dx")
+            close(gd.grad, gr.grad, 2e-4, rtol=5e-5, what="fused dgamma")
+            close(bd.grad, br.grad, 2e-4, rtol=5e-5, what="fused dbeta")
+
+
 def test_pool_upsample_relu(F):
     x = rnd(2, 16, 13, 14, seed=1)
     xr = x.clone().requires_grad_()
