@@ -100,6 +100,14 @@ int pdf_knn_ball_group(const float* pts, int ldp, int C, int Bc, int N, int S, i
 /* autograd of the gather (values only; indices carry no gradient): dpts must be zero-filled */
 int pdf_group_bwd(const float* dg, int ldg, const int* idx, float* dpts, int ldd, int C,
                   int Bc, int N, int S, int K, void* stream);
+/* First 1x1 convolution of a set-abstraction MLP applied BEFORE the grouping (group_points + netR_*[0], lib/utils/utils.py:
+ * 134-188 + intaghand_encoder.py:48-52): with u = conv(points) [Bc][N][ldu] (bias included) and v = W[:, :3] centre_xyz
+ * [Bc][S][ldv], y[b,s,k,:] = u[b, idx[b,s,k], :] - v[b,s,:] equals the convolution of the centre-subtracted grouped block,
+ * which is never materialised.  bwd: du (caller zero-fills) += scatter of dy, dv = -sum_k dy.  C % 4 == 0, C <= 256. */
+int pdf_gather_sub_fwd(const float* u, int ldu, const float* v, int ldv, const int* idx, int Bc, int N, int S, int K, int C,
+                       float* y, int ldy, void* stream);
+int pdf_gather_sub_bwd(const float* dy, int lddy, const int* idx, float* du, int ldu, float* dv, int ldv,
+                       int Bc, int N, int S, int K, int C, void* stream);
 /* _tranpose_and_gather_feat (lib/models/utils.py:22-26) on an NHWC map: out[b][m][:] = feat[b][ind'[b][m]][:],
  * ind' = pyramid index of intaghand_encoder.py:125-126 when shift > 0.  ind is int64 [B][>=M] with batch stride. */
 int pdf_gather_rows(const float* feat, int ldf, int C, long HW, const long* ind, long ind_bstride,

@@ -160,6 +160,77 @@ PDF_API int pdf_group_bwd(const float* dg, int ldg, const int* idx, float* dpts,
 }
 
 // ---------------------------------------------------------------------------------------------
+// First layer of a set-abstraction MLP without the grouped tensor.  The reference gathers K neighbours per centroid, subtracts
+// the centre from xyz (utils.py:153-160,181-186) and applies a 1x1 convolution to the [C, S, K] block; a 1x1 convolution is
+// linear, so  W (p_idx - c_pad) + b = (W p + b)[idx] - W c_pad:  the convolution runs ONCE PER POINT (N rows instead of
+// S*K = 32x / 16x as many) and this kernel gathers its rows:  y[b,s,k,:] = u[b, idx[b,s,k], :] - v[b,s,:].
+// The [Bc,S,K,C_in] grouped tensor (2.1 / 4.7 MB per cloud) is never written or read.
+__global__ __launch_bounds__(256) void gather_sub_fwd_kernel(const float* __restrict__ u, int ldu, const float* __restrict__ v, int ldv,
+                                                             const int* __restrict__ idx, int N, int S, int K, int C,
+                                                             float* __restrict__ y, int ldy, long total /* rows * C/4 */) {
+    const int cq = C / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / cq;                             // (b*S + s)*K + k
+        const int c0 = (int)(i - row * cq) * 4;
+        const long bs = row / K;
+        const long b = bs / S;
+        const float4 a = *reinterpret_cast<const float4*>(u + (b * N + idx[row]) * ldu + c0);
+        const float4 c = *reinterpret_cast<const float4*>(v + bs * ldv + c0);
+        *reinterpret_cast<float4*>(y + row * ldy + c0) = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
+    }
+}
+PDF_API int pdf_gather_sub_fwd(const float* u, int ldu, const float* v, int ldv, const int* idx, int Bc, int N, int S, int K, int C,
+                               float* y, int ldy, hipStream_t s) {
+    if (C % 4 != 0 || ldu % 4 != 0 || ldv % 4 != 0 || ldy % 4 != 0) return PDF_E_BADARG;
+    const long total = (long)Bc * S * K * (C / 4);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(gather_sub_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, u, ldu, v, ldv, idx, N, S, K, C, y, ldy, total);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// backward: du (zero-filled by the caller) [Bc][N][ldu] += dy rows scattered by idx (float atomics at the memory side);
+// dv[b,s,:] = -sum_k dy[b,s,k,:] (one wave owns a centroid: plain store)
+__global__ __launch_bounds__(256) void gather_sub_bwd_kernel(const float* __restrict__ dy, int lddy, const int* __restrict__ idx,
+                                                             float* __restrict__ du, int ldu, float* __restrict__ dv, int ldv,
+                                                             int N, int S, int K, int C, long total_rows) {
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long row = w0; row < total_rows; row += nw) {       // row = b*S + s
+        const long b = row / S;
+        float* base = du + b * N * ldu;
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};                  // up to 256 channels
+        for (int k = 0; k < K; ++k) {
+            const int j = idx[row * K + k];
+            const float* g = dy + (row * K + k) * lddy;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = lane + 64 * t;
+                if (c < C) {
+                    const float x = g[c];
+                    atomicAdd(base + (long)j * ldu + c, x);
+                    cs[t] += x;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = lane + 64 * t;
+            if (c < C) dv[row * ldv + c] = -cs[t];
+        }
+    }
+}
+PDF_API int pdf_gather_sub_bwd(const float* dy, int lddy, const int* idx, float* du, int ldu, float* dv, int ldv,
+                               int Bc, int N, int S, int K, int C, hipStream_t s) {
+    if (C > 256) return PDF_E_BADARG;
+    const long rows = (long)Bc * S;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(gather_sub_bwd_kernel, dim3(grid_for(rows * 64)), dim3(256), 0, s, dy, lddy, idx, du, ldu, dv, ldv, N, S, K, C, rows);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // gather_rows: replaces _tranpose_and_gather_feat (lib/models/utils.py:22-26) without the full-map
 // permute: feat is already NHWC, so a gathered pixel is one contiguous row.
 // shift > 0 applies the pyramid index math of intaghand_encoder.py:125-126:

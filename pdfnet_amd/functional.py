@@ -964,6 +964,45 @@ def knn_ball_group(pts, C, S, K, r2, ldg):
     return _KnnGroup.apply(pts, C, S, K, float(r2), ldg)
 
 
+def knn_ball_indices(pts, S, K, r2):
+    """Neighbour indices only (kNN + ball rule of group_points, lib/utils/utils.py:140-151): pts [Bc,N,>=3] -> int32 [Bc,S,K]."""
+    hip.require_gpu(pts)
+    p = pts.detach().contiguous()
+    Bc, N, ldp = p.shape
+    idx = torch.empty((Bc, S, K), dtype=torch.int32, device=p.device)
+    _L().pdf_knn_ball_group(ptr(p), ldp, 3, Bc, N, S, K, float(r2), ptr(idx), None, 0, stream())
+    return idx
+
+
+class _GatherSub(Function):
+    """y[b,s,k,:] = u[b, idx[b,s,k], :] - v[b,s,:]   (u [Bc,N,C], v [Bc,S,C], idx int32 [Bc,S,K]) -> [Bc,S,K,C]."""
+
+    @staticmethod
+    def forward(ctx, u, v, idx):
+        hip.require_gpu(u, v, idx)
+        u, v = u.contiguous(), v.contiguous()
+        Bc, N, C = u.shape
+        S, K = idx.shape[1], idx.shape[2]
+        y = torch.empty((Bc, S, K, C), device=u.device)
+        _L().pdf_gather_sub_fwd(ptr(u), C, ptr(v), C, ptr(idx), Bc, N, S, K, C, ptr(y), C, stream())
+        ctx.save_for_backward(idx)
+        ctx.cfg = (Bc, N, S, K, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        Bc, N, S, K, C = ctx.cfg
+        du = torch.zeros((Bc, N, C), device=dy.device)
+        dv = torch.empty((Bc, S, C), device=dy.device)
+        _L().pdf_gather_sub_bwd(ptr(dy.contiguous()), C, ptr(idx), ptr(du), C, ptr(dv), C, Bc, N, S, K, C, stream())
+        return du, dv, None
+
+
+def gather_sub(u, v, idx):
+    return _GatherSub.apply(u, v, idx)
+
+
 def fps(xyz, S, start=None):
     """Farthest point sampling (the reference's `farthest_point_sampling_fast`, lib/datasets/interhand.py:147-178):
     xyz [Bc,N,>=3] -> int32 [Bc,S] picks in order; start int32 [Bc] (first pick, default 0).  No gradient."""

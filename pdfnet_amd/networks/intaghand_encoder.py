@@ -106,13 +106,25 @@ class PointNet_Plus(nn.Module):
                                      Linear(512, opt.PCA_SZ))          # constructed, unused (:155)
 
     @staticmethod
-    def _mlp_max(seq, x, K):
-        """3 x (1x1 conv -> BatchNorm -> ReLU) then MaxPool over the K neighbours (:48-65,67-103).  The last BatchNorm, its
-        ReLU and the pooling are one pass over the last convolution's output (F.bn_relu_max_over_k)."""
-        x = x.reshape(-1, x.shape[-1])            # point rows [cloud*centroid*neighbour, channel]
-        for i in (0, 3):
-            x = seq[i + 1](seq[i](x), relu=True)
+    def _mlp_max(seq, y1, K):
+        """Rest of a set-abstraction MLP after its first 1x1 convolution (:48-65,67-103): BN -> ReLU, 2 x (conv -> BN -> ReLU),
+        MaxPool over the K neighbours.  y1: rows [cloud*centroid*neighbour, channel].  The last BatchNorm, its ReLU and the
+        pooling are one pass over the last convolution's output (F.bn_relu_max_over_k)."""
+        x = seq[1](y1.reshape(-1, y1.shape[-1]), relu=True)
+        x = seq[4](seq[3](x), relu=True)
         return seq[7].relu_max_over_k(seq[6](x), K)
+
+    @staticmethod
+    def _group_conv(conv, rows, S, K, r2):
+        """group_points / group_points_2 (lib/utils/utils.py:134-188) followed by the MLP's first 1x1 convolution, without the
+        grouped tensor: the convolution is linear, so it is applied once per POINT and its rows are gathered --
+        conv(p_idx - centre_xyz) = conv(p)[idx] - W[:, :3] centre_xyz (F.gather_sub).  rows [B,N,Cpad]: xyz first, zero-padded to
+        a multiple of 16 channels.  -> [B,S,K,Cout] (pre-BatchNorm)."""
+        idx = F.knn_ball_indices(rows, S, K, r2)                                           # kNN + ball rule on (modulated) xyz
+        w = conv.matrix(rows.shape[-1])
+        u = F.linear(rows, w, conv.bias)                                                   # [B,N,Cout]
+        ctr = torch.nn.functional.pad(rows[:, :S, :3], (0, rows.shape[-1] - 3))            # centres = the first S points
+        return F.gather_sub(u, F.linear(ctr, w), idx)
 
     def forward(self, cloud, emb, choose):
         return self.stage_b(*self.stage_a(cloud, emb[0], emb[1], choose), emb[2], choose)
@@ -124,13 +136,13 @@ class PointNet_Plus(nn.Module):
         R, S1, S2, K = o.default_resolution, o.sample_num_level1, o.sample_num_level2, o.knn_K
         B = cloud.shape[0]
         pts = self.sft0(cloud, F.gather_rows(emb0, choose))                                # [B,1024,3]   (:120-122)
-        g1, _ = F.knn_ball_group(pts, 3, S1, K, o.ball_radius, _pad16(3))                  # [B,S1,K,16]  (:123)
-        x = self._mlp_max(self.netR_1, g1, K)                                               # [B*S1,128]   (:132)
+        y1 = self._group_conv(self.netR_1[0], torch.nn.functional.pad(pts, (0, _pad16(3) - 3)), S1, K, o.ball_radius)   # (:123,:49)
+        x = self._mlp_max(self.netR_1, y1, K)                                               # [B*S1,128]   (:132)
         e1 = F.gather_rows(emb1, choose[:, :S1], R, 1)                                     # [B,S1,64]    (:125-127)
         x = torch.cat((pts[:, :S1], x.view(B, S1, 128)), 2)                                # [B,S1,131]   (:134)
         x = self.sft1(x, e1)                                                               #              (:137)
-        g2, _ = F.knn_ball_group(x, 131, S2, K, o.ball_radius2, _pad16(131))               # [B,S2,K,144] (:139)
-        y = self._mlp_max(self.netR_2, g2, K)                                               # [B*S2,256]
+        y1 = self._group_conv(self.netR_2[0], torch.nn.functional.pad(x, (0, _pad16(131) - 131)), S2, K, o.ball_radius2)   # (:139,:68)
+        y = self._mlp_max(self.netR_2, y1, K)                                               # [B*S2,256]
         return x, y
 
     def stage_b(self, x, y, emb2, choose):
@@ -142,7 +154,7 @@ class PointNet_Plus(nn.Module):
         y = torch.cat((x[:, :S2, :3], y.view(B, S2, 256)), 2)                              # [B,S2,259]
         y = self.sft2(y, e2)                                                               #              (:147)
         y = torch.nn.functional.pad(y, (0, _pad16(259) - 259))
-        y = self._mlp_max(self.netR_3, y, S2)                                               # [B,1024]     (:152)
+        y = self._mlp_max(self.netR_3, self.netR_3[0](y), S2)                               # [B,1024]     (:152)
         return y.view(B, 1, 1024)
 
 

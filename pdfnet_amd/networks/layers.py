@@ -73,12 +73,15 @@ class PointConv(nn.Module):
         bound = 1.0 / math.sqrt(cin)
         self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
 
-    def forward(self, x, act=F.ACT_NONE):
+    def matrix(self, kpad):
+        """[Cout, kpad] weight matrix (zero columns for the padded channels)."""
         w = self.weight.flatten(1)
-        kpad = x.shape[-1]
         if kpad != w.shape[1]:
             w = torch.nn.functional.pad(w, (0, kpad - w.shape[1]))
-        return F.linear(x, w, self.bias, act)
+        return w
+
+    def forward(self, x, act=F.ACT_NONE):
+        return F.linear(x, self.matrix(x.shape[-1]), self.bias, act)
 
 
 class BatchNorm(nn.Module):

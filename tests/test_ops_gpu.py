@@ -184,6 +184,39 @@ def test_fused_batchnorm_relu_max_over_neighbours(F, R, K, C):
             close(bd.grad, br.grad, 2e-4, rtol=5e-5, what="fused dbeta")
 
 
+@pytest.mark.parametrize("N,S,K,Cin,Cout", [(1024, 512, 64, 3, 64), (512, 128, 64, 131, 128)])
+def test_group_then_conv_equals_conv_then_gather(F, N, S, K, Cin, Cout):
+    """group_points(_2) + the set-abstraction MLP's first 1x1 convolution (lib/utils/utils.py:134-188 +
+    intaghand_encoder.py:48-52,67-71) evaluated without the grouped tensor: conv(p)[idx] - W[:, :3] centre must equal the
+    convolution of the gathered, centre-subtracted block -- values and the gradients wrt points, weight and bias."""
+    B = 3
+    pad = (Cin + 15) // 16 * 16
+    g = torch.Generator().manual_seed(N + Cin)
+    pts = torch.cat([torch.rand(B, N, 2, generator=g) * 0.2 - 0.1, torch.rand(B, N, 1, generator=g) * 0.1 + 0.4,
+                     torch.randn(B, N, Cin - 3, generator=g)], 2)
+    w = torch.randn(Cout, Cin, generator=g) * Cin ** -0.5
+    b = torch.randn(Cout, generator=g)
+    rows = dev(torch.nn.functional.pad(pts, (0, pad - Cin))).requires_grad_()
+    wd, bd = dev(torch.nn.functional.pad(w, (0, pad - Cin))).requires_grad_(), dev(b).requires_grad_()
+    idx = F.knn_ball_indices(rows, S, K, 0.0225 if Cin == 3 else 0.04)
+    u = F.linear(rows, wd, bd)
+    ctr = torch.nn.functional.pad(rows[:, :S, :3], (0, pad - 3))
+    y = F.gather_sub(u, F.linear(ctr, wd), idx)
+    # reference: gather, subtract the centre from xyz, convolve (float64 on the CPU)
+    pr, wr, br = pts.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    ii = idx.cpu().long()
+    grouped = torch.gather(pr.unsqueeze(1).expand(B, S, N, Cin), 2, ii.unsqueeze(-1).expand(B, S, K, Cin))
+    sub = torch.cat([pr[:, :S, None, :3], torch.zeros(B, S, 1, Cin - 3, dtype=torch.float64)], 3)
+    ref = (grouped - sub) @ wr.t() + br
+    close(y, ref.float(), 2e-5, rtol=2e-5, what="gather_sub fwd")
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy.double())
+    y.backward(dev(gy))
+    close(rows.grad[..., :Cin], pr.grad.float(), 2e-4, rtol=5e-5, what="d points")
+    close(wd.grad[:, :Cin], wr.grad.float(), 2e-3, rtol=1e-4, what="d weight")
+    close(bd.grad, br.grad.float(), 2e-3, rtol=1e-4, what="d bias")
+
+
 def test_pool_upsample_relu(F):
     x = rnd(2, 16, 13, 14, seed=1)
     xr = x.clone().requires_grad_()
