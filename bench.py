@@ -123,6 +123,115 @@ class GemmProfiler:
         return sorted(sh.items(), key=lambda kv: -kv[1][2])
 
 
+def _isnull(v):
+    return v is None or getattr(v, 'value', 1) in (None, 0)
+
+
+class HbmProfiler:
+    """The HBM-bound kernel family of the path (kNN / ball-query / grouping, gathers, set-abstraction tail,
+    BatchNorm, L2Norm, bilinear x2, Adam; plus FPS, timed on its own because the live path never calls it): events on the
+    launch stream around each C-ABI call, ALGORITHMIC bytes (every operand read / written once) from the call's own arguments."""
+    PEAK_GBS = 8000.0                                    # /opt/skills/guides/MI355X_MICROARCH.md:36 (spec; 6.29 TB/s measured copy)
+
+    @staticmethod
+    def nbytes(name, a):
+        f = 4
+        if name == 'pdf_knn_ball_group':                 # pts, ldp, C, Bc, N, S, K, r2, idx, grouped, ldg
+            _, ldp, C, Bc, N, S, K, _, _, grouped, ldg = a[:11]
+            return Bc * (N * 3 * f + S * K * 4 + (0 if _isnull(grouped) else S * K * ldg * f + N * C * f))
+        if name == 'pdf_gather_sub_fwd':                 # u, ldu, v, ldv, idx, Bc, N, S, K, C, y, ldy
+            Bc, N, S, K, C = a[5:10]
+            return Bc * (S * K * C * f + S * K * 4 + N * C * f + S * C * f)
+        if name == 'pdf_gather_sub_bwd':                 # dy, lddy, idx, du, ldu, dv, ldv, Bc, N, S, K, C
+            Bc, N, S, K, C = a[7:12]
+            return Bc * (S * K * C * f + S * K * 4 + N * C * f + S * C * f)
+        if name == 'pdf_bn_relu_maxk_fwd':               # y, ldy, C, R, K, ..., training at 11
+            C, R, K = a[2:5]
+            return R * K * C * f * (2 if a[11] else 1) + R * C * 8
+        if name == 'pdf_bn_relu_maxk_bwd':               # dout, lddo, arg, y, ldy, mean, rstd, gamma, scale, shift, C, R, K
+            C, R, K = a[10:13]
+            return 2 * R * K * C * f + 3 * R * C * f
+        if name == 'pdf_bn_train_fwd':                   # x, ldx, C, R, ..., res at 10
+            C, R = a[2], a[3]
+            return R * C * f * (3 + (0 if _isnull(a[10]) else 1))
+        if name == 'pdf_bn_train_bwd':                   # dy, lddy, y, ldy, relu, x, ldx, ..., C at 12, R at 13, dx, lddx, dres
+            C, R = a[12], a[13]
+            return R * C * f * (5 + (0 if _isnull(a[16]) else 3))
+        if name == 'pdf_gather_rows':                    # feat, ldf, C, HW, ind, stride, B, M, R, shift, out, ldo
+            C, B, M, ldo = a[2], a[6], a[7], a[11]
+            return B * M * (C * f + ldo * f + 8)
+        if name == 'pdf_scatter_rows_add':
+            ldo, C, B, M = a[1], a[2], a[6], a[7]
+            return B * M * (2 * C * f + ldo * f + 8)
+        if name in ('pdf_l2norm_fwd',):                  # x, ldx, C, R
+            return a[2] * a[3] * f * 2
+        if name in ('pdf_l2norm_bwd',):                  # dy, lddy, x, ldx, C, R
+            return a[4] * a[5] * f * 3
+        if name in ('pdf_upsample2x_fwd', 'pdf_upsample2x_bwd'):     # x, N, H, W, C
+            return a[1] * a[2] * a[3] * a[4] * f * 5
+        if name == 'pdf_adam_step':                      # p, g, m, v, n
+            return a[4] * f * 7
+        return 0
+
+    NAMES = ('pdf_knn_ball_group', 'pdf_gather_sub_fwd', 'pdf_gather_sub_bwd', 'pdf_bn_relu_maxk_fwd', 'pdf_bn_relu_maxk_bwd',
+             'pdf_bn_train_fwd', 'pdf_bn_train_bwd', 'pdf_gather_rows', 'pdf_scatter_rows_add', 'pdf_l2norm_fwd', 'pdf_l2norm_bwd',
+             'pdf_upsample2x_fwd', 'pdf_upsample2x_bwd', 'pdf_adam_step')
+
+    def __init__(self):
+        from pdfnet_amd import hip
+        self.lib = hip.lib()
+        self.records, self.saved = [], {}
+
+    def __enter__(self):
+        for n in self.NAMES:
+            fn = getattr(self.lib, n)
+            self.saved[n] = fn
+
+            def wrapped(*a, _fn=fn, _n=n):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _fn(*a)
+                e1.record()
+                self.records.append((_n, float(self.nbytes(_n, a)), e0, e1))
+                return r
+            setattr(self.lib, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for n, fn in self.saved.items():
+            setattr(self.lib, n, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        per = {}
+        for n, b, e0, e1 in self.records:
+            d = per.setdefault(n, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += b
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        return per
+
+
+def fps_hbm(dev, Bc=64, N=4096, S=1024):
+    """Farthest point sampling (pdf_fps; reference helper interhand.py:147-178) on its own: the live path never calls it
+    (SURVEY 0.1).  One block per cloud keeps points and running distances in registers: 2 x N x 12 B read + S x 4 B written
+    per cloud are ALL its HBM bytes, so its time is S dependent arg-max picks -- latency, not bandwidth (stated, not hidden)."""
+    from pdfnet_amd import functional as F
+    x = torch.rand(Bc, N, 3, device=dev)
+    for _ in range(2):
+        F.fps(x, S)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        F.fps(x, S)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / 3
+    nb = Bc * (N * 12 + S * 4)
+    return {"clouds": Bc, "points": N, "picks": S, "ms": round(t * 1e3, 3), "us_per_pick": round(t / S * 1e6, 3),
+            "algorithmic_MB": round(nb / 1e6, 2), "achieved_GBs": round(nb / t / 1e9, 2), "bound": "latency (S dependent arg-max rounds per cloud)"}
+
+
 def _flush_c_stdout():
     try:
         import ctypes
@@ -151,6 +260,27 @@ def pmc_traffic():
                 "%s (rocprofv3 --pmc, %s)" % (os.path.basename(p), d.get("tag", "")))
     except Exception as e:                                     # noqa: BLE001
         return None, None, "unreadable profile: %s" % e
+
+
+def pmc_traffic_hbm():
+    """HBM bytes per step of the PointNet++ data-movement kernels from the last committed PMC profile (same staleness rule
+    as pmc_traffic, keyed on csrc/pointops.hip + csrc/norm.hip)."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, "no PMC profile committed"
+    p = files[-1]
+    try:
+        d = json.load(open(p))
+        h = hashlib.sha256()
+        for f in ("pointops.hip", "norm.hip"):
+            h.update(open(os.path.join(ROOT, "pdfnet_amd", "csrc", f), "rb").read())
+        if d.get("hbm_src_sha256") != h.hexdigest():
+            return None, "%s is older than csrc/pointops.hip / norm.hip (withheld)" % os.path.basename(p)
+        return round(d["hbm_family"]["pointnet_bytes_per_step"]), "%s (rocprofv3 --pmc, %s)" % (os.path.basename(p), d.get("tag", ""))
+    except Exception as e:                                     # noqa: BLE001
+        return None, "unreadable profile: %s" % e
 
 
 def oracle_with_loss(R, state_dict=None):
@@ -401,9 +531,10 @@ def main():
         trainer.use_graph = False
         trainer.collectives = False        # rank-local step: the other ranks are already past their last collective
         F.USE_SIDE_STREAMS = False         # exclusive per-launch durations (no overlapped branches)
-        with GemmProfiler() as prof:
+        with GemmProfiler() as prof, HbmProfiler() as hprof:
             trainer.train_step(batch)
         per = prof.summary()
+        hper = hprof.summary()
         if args.gemm_shapes:
             with open(args.gemm_shapes, 'w') as f:
                 for (n, ints), (c, fl, sec) in prof.by_shape():
@@ -440,6 +571,23 @@ def main():
                            "gflop_per_img_step_executed": round(flops / 1e9 / B, 1),
                            "tflops_executed": round(flops / 1e9 / B * out["value"] / world / 1e3, 2),
                            "frac_of_mfma_peak": round(flops / 1e9 / B * out["value"] / world / 1e3 / peak, 4)},
+        }
+        hb, hs = sum(v[1] for v in hper.values()), sum(v[2] for v in hper.values())
+        pn = ('pdf_knn_ball_group', 'pdf_gather_sub_fwd', 'pdf_gather_sub_bwd', 'pdf_bn_relu_maxk_fwd', 'pdf_bn_relu_maxk_bwd', 'pdf_gather_rows', 'pdf_scatter_rows_add')
+        pb, ps = sum(hper[k][1] for k in pn if k in hper), sum(hper[k][2] for k in pn if k in hper)
+        htraffic, htraffic_src = pmc_traffic_hbm()
+        out["roofline_hbm"] = {
+            "bound": "hbm", "peak": HbmProfiler.PEAK_GBS, "unit": "GB/s",
+            "kernel": "PointNet++ data movement: kNN + ball query (indices only), per-point conv gather (gather_sub), set-abstraction tail "
+                      "(BatchNorm + ReLU + max over K in one pass), pyramid row gathers -- csrc/pointops.hip, csrc/norm.hip",
+            "achieved": round(pb / max(ps, 1e-9) / 1e9, 1), "frac": round(pb / max(ps, 1e-9) / 1e9 / HbmProfiler.PEAK_GBS, 4),
+            "launches_per_step": sum(hper[k][0] for k in pn if k in hper), "ms_per_step": round(ps * 1e3, 3),
+            "algorithmic_MB_per_step": round(pb / 1e6, 1), "traffic": htraffic, "traffic_source": htraffic_src,
+            "all_hbm_bound_entry_points": {"achieved": round(hb / max(hs, 1e-9) / 1e9, 1), "frac": round(hb / max(hs, 1e-9) / 1e9 / HbmProfiler.PEAK_GBS, 4),
+                                           "ms_per_step": round(hs * 1e3, 2), "algorithmic_GB_per_step": round(hb / 1e9, 2)},
+            "per_entry_point": {k: {"calls": v[0], "MB": round(v[1] / 1e6, 1), "ms": round(v[2] * 1e3, 3), "GBs": round(v[1] / max(v[2], 1e-9) / 1e9, 1)}
+                                for k, v in sorted(hper.items())},
+            "fps": fps_hbm(dev),
         }
         F.USE_SIDE_STREAMS = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

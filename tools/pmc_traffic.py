@@ -3,7 +3,13 @@ family (profiles/rNN_pmc_traffic.json).  Units and corrections per /opt/skills/g
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half the bytes of wide coalesced reads, so it
 is doubled; WRITE_SIZE is taken as is.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_in_trace> <out.json>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_in_trace> <out.json> [tag]
+
+Besides the GEMM family the file carries `hbm_family`: the HBM-bound kernels (PointNet++ data movement, BatchNorm, gathers,
+FPS when traced) with counter bytes per launch and, from the dispatch timestamps of the same (serialised) PMC run, the
+achieved counter-GB/s -- the north_star's "rocprof counters evidence achieved HBM GB/s on FPS / ball-query".
+`gemm_hip_sha256` / `hbm_src_sha256` tie the numbers to the kernel sources they were measured with (bench.py withholds
+them when the sources have changed since).
 """
 import collections
 import csv
@@ -11,6 +17,8 @@ import glob
 import json
 import re
 import sys
+import hashlib
+import os
 
 
 def tile_name(k):
@@ -40,6 +48,46 @@ def load(d, counter, by_tile=False):
     return agg
 
 
+HBM_KERNELS = ("knn_ball_group_kernel", "gather_sub_fwd_kernel", "gather_sub_bwd_kernel", "bn_relu_maxk_fwd_kernel", "bn_maxk_bwd_partial_kernel",
+               "bn_maxk_bwd_apply_kernel", "gather_rows_kernel", "scatter_rows_kernel", "bn_partial_v4_kernel", "affine_apply_v4_kernel",
+               "bn_bwd_partial_v4_kernel", "bn_bwd_apply_v4_kernel", "l2norm_fwd_kernel", "l2norm_bwd_kernel", "up2_fwd_v4_kernel", "up2_bwd_v4_kernel",
+               "adam_kernel", "fps_kernel", "maxk_fwd_kernel", "maxk_bwd_kernel", "group_bwd_kernel")
+POINTNET = HBM_KERNELS[:8]
+
+
+def hbm_family(fdir, wdir, steps):
+    def per_kernel(d, counter):
+        f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
+        agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            m = re.match(r"(?:void )?(\w+)", r["Kernel_Name"])
+            k = m.group(1) if m else r["Kernel_Name"]
+            if k not in HBM_KERNELS:
+                continue
+            a = agg[k]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            if "Start_Timestamp" in r and "End_Timestamp" in r:
+                a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+        return agg
+    fe, wr = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
+    out = {"kernels": {}}
+    pn = 0.0
+    for k in sorted(set(fe) | set(wr)):
+        n = fe[k][0] or wr[k][0]
+        rb, wb = fe[k][1] * 1024 * 2, wr[k][1] * 1024
+        secs = (fe[k][2] + wr[k][2]) / 2.0 if fe[k][2] and wr[k][2] else (fe[k][2] or wr[k][2])
+        out["kernels"][k] = {"launches_per_step": n / steps, "read_MB_per_launch": rb / max(n, 1) / 1e6, "write_MB_per_launch": wb / max(n, 1) / 1e6,
+                             "bytes_per_launch": (rb + wb) / max(n, 1), "avg_us": secs / max(n, 1) * 1e6,
+                             "counter_GBs": (rb + wb) / secs / 1e9 if secs > 0 else None}
+        if k in POINTNET:
+            pn += rb + wb
+    out["pointnet_bytes_per_step"] = pn / steps
+    return out
+
+
 def main():
     fdir, wdir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     fe, wr = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
@@ -63,8 +111,18 @@ def main():
         n = fk[k][0] or wk[k][0]
         b = fk[k][1] * 1024 * 2 + wk[k][1] * 1024
         res["kernels"][k] = {"launches_per_step": n / steps, "hbm_GB_per_step": b / steps / 1e9, "bytes_per_launch": b / max(n, 1)}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res["tag"] = sys.argv[5] if len(sys.argv) > 5 else ""
+    res["gemm_hip_sha256"] = hashlib.sha256(open(os.path.join(root, "pdfnet_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
+    h = hashlib.sha256()
+    for f in ("pointops.hip", "norm.hip"):
+        h.update(open(os.path.join(root, "pdfnet_amd", "csrc", f), "rb").read())
+    res["hbm_src_sha256"] = h.hexdigest()
+    res["hbm_family"] = hbm_family(fdir, wdir, steps)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["gemm_family"]), json.dumps(res["families"]))
+    for k, v in res["hbm_family"]["kernels"].items():
+        print("%-34s %6.1f launches/step %9.2f MB/launch %8.1f us  %7.1f GB/s (counters)" % (k, v["launches_per_step"], v["bytes_per_launch"] / 1e6, v["avg_us"], v["counter_GBs"]))
     # the heaviest single dispatches (reads), for tile-order / reuse work
     f = (glob.glob(fdir + "/*counter_collection.csv") + glob.glob(fdir + "/*/*counter_collection.csv"))[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE"]
