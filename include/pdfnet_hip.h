@@ -278,6 +278,20 @@ int pdf_depth2pcl(const float* depth, const float* mask, const float* K, const f
 int pdf_mano_lbs_fwd(const float* root_aa, const float* pose_aa, const float* shape, const float* trans,
                      const float* v_template, const float* shapedirs, const float* posedirs, const float* J_reg,
                      const float* weights, int B, int left_side, int center_idx, float* verts, float* joints, void* stream);
+/* autograd of the above: gradients of (verts [B][778][3], joints [B][21][3]) w.r.t. root / pose axis-angles, shape and trans.
+ * dverts / djoints may be NULL (no gradient from that output); dshape / dtrans may be NULL (not wanted). */
+int pdf_mano_lbs_bwd(const float* root_aa, const float* pose_aa, const float* shape,
+                     const float* v_template, const float* shapedirs, const float* posedirs, const float* J_reg,
+                     const float* weights, int B, int left_side, int center_idx, const float* dverts, const float* djoints,
+                     float* droot, float* dpose, float* dshape, float* dtrans, void* stream);
+/* ManoRender.Split_coeff (lib/models/hand3d/Mano_render.py:145-194; call site lib/trains/simplified.py:730-736): decode of the
+ * 122-channel `params` head at each hand's centre pixel -- per hand [orient 3 | pose 45 | shape 10 (x 0) | trans 3], trans z += 0.6,
+ * x / y un-projected from the centre pixel with K.  params NHWC [B][HW][ldp], ind int64 [B][2] (left, right), K [B][3][3].
+ * Outputs [2][B][3], [2][B][45], [2][B][10], [2][B][3] feed pdf_mano_lbs_fwd.  bwd scatters into dparams (caller zero-fills). */
+int pdf_mano_split_coeff(const float* params, int ldp, long HW, const long* ind, const float* K, int B, int input_res, int down,
+                         float* orient, float* pose, float* shape, float* trans, void* stream);
+int pdf_mano_split_coeff_bwd(const float* params, float* dparams, int ldp, long HW, const long* ind, const float* K, int B, int input_res, int down,
+                             const float* dorient, const float* dpose, const float* dtrans, void* stream);
 
 #ifdef __cplusplus
 }

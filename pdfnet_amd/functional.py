@@ -1213,19 +1213,83 @@ def nms_top1(hm):
     return ind, score
 
 
+class _ManoLBS(Function):
+    """ManoLayer.forward (manolayer.py:257-334, use_pca=False) with its backward: (root_aa [B,3], pose_aa [B,45], shape [B,10],
+    trans [B,3] | None) -> (verts [B,778,3], joints [B,21,3])."""
+
+    @staticmethod
+    def forward(ctx, root_aa, pose_aa, shape, trans, consts, left, center_idx):
+        hip.require_gpu(root_aa)
+        root_aa, pose_aa, shape = root_aa.contiguous(), pose_aa.contiguous(), shape.contiguous()
+        trans = trans.contiguous() if trans is not None else None
+        B = root_aa.shape[0]
+        verts = torch.empty((B, 778, 3), device=root_aa.device)
+        joints = torch.empty((B, 21, 3), device=root_aa.device)
+        _L().pdf_mano_lbs_fwd(ptr(root_aa), ptr(pose_aa), ptr(shape), ptr(trans),
+                              ptr(consts['v_template']), ptr(consts['shapedirs']), ptr(consts['posedirs']),
+                              ptr(consts['J_regressor']), ptr(consts['weights']), B, int(left), center_idx, ptr(verts), ptr(joints), stream())
+        ctx.save_for_backward(root_aa, pose_aa, shape)
+        ctx.cfg = (consts, left, center_idx, trans is not None)
+        ctx.set_materialize_grads(False)
+        return verts, joints
+
+    @staticmethod
+    def backward(ctx, dverts, djoints):
+        root_aa, pose_aa, shape = ctx.saved_tensors
+        consts, left, center_idx, has_trans = ctx.cfg
+        B = root_aa.shape[0]
+        dev = root_aa.device
+        droot, dpose = torch.empty((B, 3), device=dev), torch.empty((B, 45), device=dev)
+        dshape = torch.empty((B, 10), device=dev) if ctx.needs_input_grad[2] else None
+        dtrans = torch.empty((B, 3), device=dev) if has_trans and ctx.needs_input_grad[3] else None
+        _L().pdf_mano_lbs_bwd(ptr(root_aa), ptr(pose_aa), ptr(shape), ptr(consts['v_template']), ptr(consts['shapedirs']), ptr(consts['posedirs']),
+                              ptr(consts['J_regressor']), ptr(consts['weights']), B, int(left), center_idx,
+                              ptr(dverts.contiguous() if dverts is not None else None), ptr(djoints.contiguous() if djoints is not None else None),
+                              ptr(droot), ptr(dpose), ptr(dshape), ptr(dtrans), stream())
+        return droot, dpose, dshape, dtrans, None, None, None
+
+
 def mano_lbs(consts, root_aa, pose_aa, shape, trans=None, side='left', center_idx=None):
-    """ManoLayer.forward (manolayer.py:257-334, use_pca=False). Forward only (the training loss uses
-    the joint regressor, not LBS -- SURVEY.md 0.5)."""
-    hip.require_gpu(root_aa)
-    B = root_aa.shape[0]
-    verts = torch.empty((B, 778, 3), device=root_aa.device)
-    joints = torch.empty((B, 21, 3), device=root_aa.device)
-    _L().pdf_mano_lbs_fwd(ptr(root_aa.contiguous()), ptr(pose_aa.contiguous()), ptr(shape.contiguous()),
-                          ptr(trans.contiguous()) if trans is not None else None,
-                          ptr(consts['v_template']), ptr(consts['shapedirs']), ptr(consts['posedirs']),
-                          ptr(consts['J_regressor']), ptr(consts['weights']), B, int(side == 'left'),
-                          -1 if center_idx is None else int(center_idx), ptr(verts), ptr(joints), stream())
-    return verts, joints
+    """ManoLayer.forward (manolayer.py:257-334, use_pca=False), differentiable w.r.t. root / pose / shape / trans."""
+    return _ManoLBS.apply(root_aa, pose_aa, shape, trans, consts, side == 'left', -1 if center_idx is None else int(center_idx))
+
+
+class _ManoSplitCoeff(Function):
+    """ManoRender.Split_coeff (Mano_render.py:145-194) for both hands: params map [B,122,H,W] (channels_last), ind [B,2], K [B,3,3]
+    -> orient [2,B,3], pose [2,B,45], shape [2,B,10] (zeros), trans [2,B,3]."""
+
+    @staticmethod
+    def forward(ctx, params, ind, K, input_res, down):
+        hip.require_gpu(params, ind)
+        params = cl(params)
+        B, C, H, W = params.shape
+        if C != 122:
+            raise ValueError("pdfnet_amd: the params head has 122 channels, got %d" % C)
+        ind, K = ind.contiguous(), K.detach().float().contiguous()
+        dev = params.device
+        orient, pose = torch.empty((2, B, 3), device=dev), torch.empty((2, B, 45), device=dev)
+        shape, trans = torch.empty((2, B, 10), device=dev), torch.empty((2, B, 3), device=dev)
+        _L().pdf_mano_split_coeff(ptr(params), C, H * W, ptr(ind), ptr(K), B, input_res, down, ptr(orient), ptr(pose), ptr(shape), ptr(trans), stream())
+        ctx.save_for_backward(params, ind, K)
+        ctx.cfg = (input_res, down)
+        ctx.mark_non_differentiable(shape)
+        ctx.set_materialize_grads(False)
+        return orient, pose, shape, trans
+
+    @staticmethod
+    def backward(ctx, do, dp, _ds, dt):
+        params, ind, K = ctx.saved_tensors
+        input_res, down = ctx.cfg
+        B, C, H, W = params.shape
+        z = lambda t, n: t.contiguous() if t is not None else torch.zeros((2, B, n), device=params.device)
+        dparams = _zeros_cl(params.shape, params.device)
+        _L().pdf_mano_split_coeff_bwd(ptr(params), ptr(dparams), C, H * W, ptr(ind), ptr(K), B, input_res, down,
+                                      ptr(z(do, 3)), ptr(z(dp, 45)), ptr(z(dt, 3)), stream())
+        return dparams, None, None, None, None
+
+
+def mano_split_coeff(params, ind, K, input_res, down_ratio=4):
+    return _ManoSplitCoeff.apply(params, ind, K, int(input_res), int(down_ratio))
 
 
 class _RegressJoints(Function):

@@ -62,3 +62,23 @@ def mano_gt_from_coeff(mano_consts, mano_coeff, K):
         proj = lambda x: (x @ K.transpose(1, 2))[..., :2] / (x @ K.transpose(1, 2))[..., 2:]
         out[hand] = {'verts3d': v, 'joints3d': j, 'verts2d': proj(v), 'joints2d': proj(j)}
     return out
+
+
+def fix_shape(mano_consts):
+    """lib/datasets/interhand.py:120-123: the released MANO_LEFT.pkl carries the right hand's x-sign in its shape blend
+    shapes; if left and right `shapedirs[:, 0, :]` (x rows, [778,3,10]) are (nearly) identical, flip the left one in place.
+    The reference applies this to the loss module's layers (simplified.py:52) but not to the dataset's (interhand.py:460-461)
+    nor to ManoRender's (Mano_render.py:61-66) -- callers choose, as there.  Returns True when it flipped."""
+    l, r = mano_consts['left']['shapedirs'], mano_consts['right']['shapedirs']
+    if float(torch.sum(torch.abs(l[:, 0, :] - r[:, 0, :]))) < 1:
+        l[:, 0, :] *= -1
+        return True
+    return False
+
+
+def mano_from_params(mano_consts, params_map, ind, K, input_res, down_ratio=4):
+    """The legacy MANO branch of the loss (simplified.py:730-736): decode the 122-channel params head at the two centre pixels
+    (`Split_coeff`) and run both MANO layers (no translation, like the reference call) -> verts [2,B,778,3], joints [2,B,21,3], trans."""
+    orient, pose, shape, trans = F.mano_split_coeff(params_map, ind, K, input_res, down_ratio)
+    out = [F.mano_lbs(mano_consts[h], orient[i], pose[i], shape[i], None, side=h) for i, h in enumerate(('left', 'right'))]
+    return torch.stack([o[0] for o in out]), torch.stack([o[1] for o in out]), trans

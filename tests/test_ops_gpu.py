@@ -452,6 +452,93 @@ def test_mano_regressor(F):
         close(j2, jo, 5e-6, what="mano centered joints")
 
 
+@pytest.mark.parametrize("side,center", [("left", None), ("right", 9)])
+def test_mano_lbs_backward_against_the_oracle_autograd(F, side, center):
+    """pdf_mano_lbs_bwd: gradients of (verts, joints) w.r.t. root / pose axis-angles, shape and translation against autograd
+    through the float64 oracle restatement of ManoLayer.forward (manolayer.py:257-334) -- incl. a zero rotation (|a| = 0)."""
+    from oracle import pdfnet_cpu as O
+    from oracle import synth
+    c = synth.synthetic_mano_consts(side)
+    c64 = {k: v.double() for k, v in c.items()}
+    g = torch.Generator().manual_seed(11)
+    B = 4
+    rot, pose = torch.randn(B, 3, generator=g) * 0.8, torch.randn(B, 45, generator=g) * 0.4
+    pose[0, 6:9] = 0.0                                       # an exactly-zero joint rotation
+    shape, trans = torch.randn(B, 10, generator=g), torch.randn(B, 3, generator=g) * 0.1
+    gv, gj = torch.randn(B, 778, 3, generator=g), torch.randn(B, 21, 3, generator=g)
+    leaves = [t.double().requires_grad_() for t in (rot, pose, shape, trans)]
+    # the oracle helper builds float32 identity matrices: run it in float64 by default dtype
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        vo, jo = O.mano_lbs(c64, leaves[0], leaves[1], leaves[2], trans=leaves[3], side=side, center_idx=center)
+        ((vo * gv.double()).sum() + (jo * gj.double()).sum()).backward()
+    finally:
+        torch.set_default_dtype(old)
+    cd = {k: dev(v.contiguous()) for k, v in c.items()}
+    dl = [dev(t).requires_grad_() for t in (rot, pose, shape, trans)]
+    v, j = F.mano_lbs(cd, dl[0], dl[1], dl[2], trans=dl[3], side=side, center_idx=center)
+    close(v, vo.float(), 1e-5, what="mano verts")
+    ((v * dev(gv)).sum() + (j * dev(gj)).sum()).backward()
+    for name, a, b in zip(("d root", "d pose", "d shape", "d trans"), dl, leaves):
+        close(a.grad, b.grad.float(), 1e-4, rtol=2e-4, what=name)
+    # only one output used, shape / trans not wanted
+    d2 = [dev(t).requires_grad_() for t in (rot, pose)]
+    v2, _ = F.mano_lbs(cd, d2[0], d2[1], dev(shape), side=side, center_idx=center)
+    (v2 * dev(gv)).sum().backward()
+    l2 = [t.double().requires_grad_() for t in (rot, pose)]
+    torch.set_default_dtype(torch.float64)
+    try:
+        vo2, _ = O.mano_lbs(c64, l2[0], l2[1], shape.double(), side=side, center_idx=center)
+        (vo2 * gv.double()).sum().backward()
+    finally:
+        torch.set_default_dtype(old)
+    close(d2[0].grad, l2[0].grad.float(), 1e-4, rtol=2e-4, what="d root (verts only)")
+    close(d2[1].grad, l2[1].grad.float(), 1e-4, rtol=2e-4, what="d pose (verts only)")
+
+
+def test_mano_split_coeff_decode_and_fix_shape(F):
+    """ManoRender.Split_coeff (Mano_render.py:145-194): the decode of the 122-channel params head that feeds the MANO layers in
+    the reference's legacy branch (simplified.py:730-736), values and gradient; `fix_shape` (interhand.py:120-123)."""
+    from oracle import synth
+    from pdfnet_amd.utils import fix_shape, mano_from_params
+    B, R, down = 3, 64, 4
+    g = torch.Generator().manual_seed(5)
+    P = torch.randn(B, 122, R // down, R // down, generator=g)
+    ind = torch.tensor([[0, 255], [17, 200], [100, 3]])
+    K = torch.tensor([[[70.0, 0, 30], [0, 66, 34], [0, 0, 1]]]).repeat(B, 1, 1) + torch.rand(B, 3, 3, generator=g)
+    Pr = P.clone().requires_grad_()
+    gsz = R // down
+    ref = {}
+    for h in range(2):                                       # the reference's formulas, per hand
+        th = Pr.reshape(B, 122, -1)[torch.arange(B), :, ind[:, h]]
+        t = th[:, 61 * h + 58:61 * h + 61]
+        tz = t[:, 2] + 0.6
+        cx, cy = (ind[:, h] % gsz) * down, (ind[:, h] // gsz) * down
+        ref[h] = (th[:, 61 * h:61 * h + 3], th[:, 61 * h + 3:61 * h + 48], th[:, 61 * h + 48:61 * h + 58] * 0,
+                  torch.stack((tz * (t[:, 0] + cx - K[:, 0, 2]) / K[:, 0, 0], tz * (t[:, 1] + cy - K[:, 1, 2]) / K[:, 1, 1], tz), 1))
+    Pd = dev(P).contiguous(memory_format=torch.channels_last).requires_grad_()
+    o, p, s, t = F.mano_split_coeff(Pd, dev(ind), dev(K), R, down)
+    for h in range(2):
+        for a, b, w in zip((o[h], p[h], s[h], t[h]), ref[h], ("orient", "pose", "shape", "trans")):
+            close(a, b.detach(), 1e-6, rtol=1e-6, what="split_coeff " + w)
+    go, gp, gt = torch.randn(2, B, 3, generator=g), torch.randn(2, B, 45, generator=g), torch.randn(2, B, 3, generator=g)
+    ((o * dev(go)).sum() + (p * dev(gp)).sum() + (t * dev(gt)).sum()).backward()
+    sum((ref[h][0] * go[h]).sum() + (ref[h][1] * gp[h]).sum() + (ref[h][3] * gt[h]).sum() for h in range(2)).backward()
+    close(Pd.grad, Pr.grad, 1e-6, rtol=1e-5, what="split_coeff bwd")
+    # the decoded parameters drive both MANO layers
+    consts = {h: {k: dev(v.contiguous()) for k, v in synth.synthetic_mano_consts(h).items()} for h in ("left", "right")}
+    v, j, tr = mano_from_params(consts, Pd.detach(), dev(ind), dev(K), R, down)
+    assert v.shape == (2, B, 778, 3) and j.shape == (2, B, 21, 3) and torch.isfinite(v).all()
+    # fix_shape: flips the left x-rows exactly when left and right agree there
+    c2 = {h: {k: v.clone() for k, v in consts[h].items()} for h in consts}
+    c2['left']['shapedirs'][:, 0, :] = c2['right']['shapedirs'][:, 0, :]
+    before = c2['left']['shapedirs'].clone()
+    assert fix_shape(c2)
+    assert torch.equal(c2['left']['shapedirs'][:, 0, :], -before[:, 0, :]) and torch.equal(c2['left']['shapedirs'][:, 1:, :], before[:, 1:, :])
+    assert not fix_shape(c2)                                 # now they differ: left alone
+
+
 def test_adam(F):
     from pdfnet_amd import hip
     p0, g = rnd(10000, seed=1), rnd(10000, seed=2)
