@@ -226,6 +226,146 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// igemm_halo3x3: the 128x128 implicit GEMM for 3x3 stride-1 convolutions (forward, and backward-data, which is a 3x3
+// stride-1 convolution of dy with the taps mirrored) that re-uses its input from LDS.  igemm_nt gathers the A tile from global
+// memory once per tap: every input pixel is fetched 9 times, and because the 9 visits of a block are 1.5 MB of streaming
+// apart (x 96 resident blocks per XCD) none of them hits L2 -- 5.7 GB of fetch for `feat` against 0.55 GB of input.  Here a
+// block's 128 output pixels are R = 128 / W whole image rows; per 16-channel chunk the (R + 2) x (W + 2) halo of input pixels
+// (zero-padded at the image border) is staged in LDS ONCE and the 9 taps read it at shifted row offsets, so the input is
+// fetched (R + 2)(W + 2) / (R W) = 2.06x (W = 64) instead of 9x, with 4.4x fewer global-load instructions for A.
+// K order: channel chunk outer, tap inner (B tile = 128 x 16 weights per (chunk, tap) as before).
+// LDS: A halo [2][264][17] + B [2][128][17] floats = 53 KB -> 3 blocks / CU like igemm_nt<128,128>.
+#define HALO_MAX_PIX 264
+template <bool KN>
+__global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
+    constexpr int BM = 128, BN = 128, WN = 2, BK = 16, LD = 17, TM = 2, TN = 2;
+    constexpr int NH = (HALO_MAX_PIX * 4 + 255) / 256;                    // float4 halo loads per thread and chunk (5)
+    __shared__ float As[2][HALO_MAX_PIX * LD];
+    __shared__ float Bs[2][BN * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const float* __restrict__ Ap = g.A; const float* __restrict__ Bp = g.B; const float* __restrict__ biasp = g.bias;
+    float* __restrict__ Cp = g.C;
+    const int ntm = g.M / BM, ntn = (g.N + BN - 1) / BN;
+    int tmi, tni;
+    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
+    const int m0 = tmi * BM, n0 = tni * BN;
+    const int W = g.W, H = g.H, HC = W + 2, R = BM / W, HP = (R + 2) * HC;
+    const int img = m0 / (H * W), y0 = (m0 - img * H * W) / W;
+    // halo staging plan of this thread: float4 q = tid + 256 i -> (halo pixel q / 4, channel quad q % 4)
+    long hsrc[NH]; int hdst[NH]; bool hok[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int q = tid + i * 256, hp = q >> 2, part = q & 3;
+        const int hy = hp / HC, hx = hp - hy * HC;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        hok[i] = hp < HP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        hsrc[i] = (((long)img * H + iy) * W + ix) * g.lda + part * 4;
+        hdst[i] = hp < HP ? hp * LD + part * 4 : -1;
+    }
+    // B staging (as igemm_nt FAST): [N][K]: thread -> (row n, 4 consecutive k);  [K][N]: thread -> (k row, 4 consecutive n)
+    const int lrow = tid >> 2, kq = (tid & 3) * 4;
+    const int nq4 = (tid & 31) * 4;
+    long bbase[2]; bool bval[2]; int kb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (KN) { kb[i] = (tid + i * 256) >> 5; bval[i] = n0 + nq4 < g.N; bbase[i] = (long)kb[i] * g.ldb + n0 + nq4; }
+        else { const int n = n0 + lrow + i * 64; kb[i] = 0; bval[i] = n < g.N; bbase[i] = (long)n * g.ldb; }
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[NH], rb[2];
+    auto hload = [&](int ci0) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) ra[i] = *reinterpret_cast<const float4*>(hok[i] ? Ap + hsrc[i] + ci0 : g_zero16);
+    };
+    auto hstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+            if (hdst[i] >= 0) { float* p = &As[buf][hdst[i]]; p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w; }
+    };
+    auto bload = [&](int ci0, int tap) {
+        const int wb = g.wt[tap] * (KN ? g.btap : g.Cin);
+        const long wofs = KN ? (long)ci0 * g.ldb + wb : (long)(wb + ci0 + kq);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const float4*>(bval[i] ? Bp + bbase[i] + wofs : g_zero16);
+    };
+    auto bstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (KN) { float* p = &Bs[buf][nq4 * LD + kb[i]]; p[0] = rb[i].x; p[LD] = rb[i].y; p[2 * LD] = rb[i].z; p[3 * LD] = rb[i].w; }
+            else { float* p = &Bs[buf][(lrow + i * 64) * LD + kq]; p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w; }
+        }
+    };
+    // A fragment rows: output pixel p = (wm*2 + i)*32 + (lane & 31) -> image row r = p / W, column c = p % W -> halo pixel (r+1, c+1)
+    int arow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = (wm * TM + i) * 32 + (lane & 31), r = p / W, c = p - r * W;
+        arow[i] = ((r + 1) * HC + c + 1) * LD + (lane >> 5);
+    }
+    const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5);
+
+    const int nchunks = g.Cin / BK, nsteps = nchunks * 9;
+    hload(0); hstore(0);
+    bload(0, 0); bstore(0);
+    __syncthreads();
+    int abuf = 0, bbuf = 0, chunk = 0, tap = 0;
+    for (int st = 0; st < nsteps; ++st) {
+        const bool more = st + 1 < nsteps;
+        const int ntap = tap == 8 ? 0 : tap + 1, nchunk = tap == 8 ? chunk + 1 : chunk;
+        if (more) bload(nchunk * BK, ntap);
+        const bool stage_a = tap == 0 && chunk + 1 < nchunks;             // next chunk's halo: loaded during tap 0, written after its MFMAs
+        if (stage_a) hload((chunk + 1) * BK);
+        const int toff = (g.dy[tap] * HC + g.dx[tap]) * LD;
+        const float* as = As[abuf] + toff;
+        const float* bs = Bs[bbuf];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[arow[i] + kk * 2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[brow + j * 32 * LD + kk * 2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) bstore(bbuf ^ 1);
+        if (stage_a) hstore(abuf ^ 1);
+        __syncthreads();
+        bbuf ^= 1;
+        if (tap == 8) abuf ^= 1;
+        tap = ntap; chunk = nchunk;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        const bool cok = col < g.N;
+        const float bv = (biasp != nullptr && cok) ? biasp[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (cok) {
+                    float v = acc[i][j][r] + bv;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+                    Cp[(long)row * g.ldc + col] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int BI, int BJ, int WM, int WN, bool FAST, int BKT = 16>
 __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     constexpr int BK = BKT;
@@ -744,7 +884,17 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     // (a 256x128 tile -- 128 accumulator registers, one wave per SIMD -- was measured: 104 vs 123 TFLOP/s on the largest conv)
     // (also measured for this tile: 8 waves per block with K-step 32 -- <128,128,4,2,..,32>, 4 waves/SIMD, half the barriers
     // per flop: +1 % alone (125.5 vs 124.2 TFLOP/s on the largest conv), -0.3 % inside the step)
-    if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600))
+    bool halo = fast && groups == 1 && g.T == 9 && !g.plain_in && g.plain_out && g.ps_cout == 0 && g.sy == 1 && g.sx == 1 && g.QW == g.W && g.QH == g.H &&
+                (g.W == 64 || g.W == 32 || g.W == 16) && (g.H * g.W) % 128 == 0 && g.M % 128 == 0 && g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) &&
+                env_int(ENV_IG_HALO, 1);
+    for (int t = 0; halo && t < 9; ++t) halo = g.dy[t] >= -1 && g.dy[t] <= 1 && g.dx[t] >= -1 && g.dx[t] <= 1;
+    if (halo) {
+        const dim3 grid((g.M / 128) * cdiv(g.N, 128));
+        if (g.b_kn) hipLaunchKernelGGL(igemm_halo3x3<true>, grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(igemm_halo3x3<false>, grid, dim3(256), 0, s, g);
+        g_last_tile = 128128;
+    }
+    else if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600))
         launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s), g_last_tile = 128128;
     else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int(ENV_IG_T128, 600))
         launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s), g_last_tile = 128064;   // (K-step 32: no gain here)
