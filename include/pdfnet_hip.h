@@ -39,6 +39,10 @@ int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* db,
 long pdf_wgrad_workspace_floats(int M, int NI, int NJ);
 /* measurement aids (bench.py): BM*1000+BN of the calling thread's last implicit-GEMM launch (0 = streaming small-K
  * kernel), and the number of implicit-GEMM kernels it has launched so far (one entry point may launch several) */
+/* Allocates the library's ticket-counter ring (csrc/common.h pdf_last_block_arrives: in-launch finalisation of BatchNorm
+ * statistics and weight-gradient slabs).  Called once per process after the device is selected, outside any stream capture;
+ * the entry points call it lazily otherwise. */
+int pdf_init(void);
 /* Operand precision of every GEMM-family entry point below: 0 (default) = fp32-input MFMA, exact fp32; 1 = operands rounded
  * to bf16 (RNE) while staged into LDS, bf16 MFMA with fp32 accumulation (BASELINE configs 4 / 5: bf16 compute, fp32 master
  * weights and fp32 normalisation / loss statistics).  Process-wide; set before the first step. */

@@ -50,3 +50,44 @@ __device__ __forceinline__ float pdf_uniform(uint64_t seed, uint64_t idx) {
     uint32_t h = pdf_hash32((uint32_t)idx ^ pdf_hash32((uint32_t)(idx >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9E3779B9U);
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// "Last block finishes the job": the blocks of one launch that contribute partials to the same output each take a ticket
+// from a device counter after publishing their partials; the block that draws the last ticket sees everybody's partials and
+// reduces them in a FIXED order (deterministic), which removes the separate reduce launch and its kernel boundary.
+// Protocol = the guide's split-K recipe (cdna_hip_programming.md section 5, "In-launch split-K reduction"; Guideline 16):
+// producer: every storing wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, lane 0 agent-scope RELEASE fence,
+// explicit s_waitcnt vmcnt(0) (ROCm 7.2 may drop the fence's own wait), relaxed agent-scope fetch_add;
+// consumer (the last arriver): lane 0 agent-scope ACQUIRE fence, s_waitcnt vmcnt(0), workgroup barrier, plain loads.
+// Correct for any placement of the blocks on XCDs / CUs.  The last arriver resets the counter, so counters only need to be
+// zero once (hipMemset at allocation).  `flag` is a word of LDS.
+// `release`: true = the partials were written with plain stores (agent-scope release fence: writes back the XCD's dirty L2
+// lines -- expensive when the L2 holds megabytes of a previous kernel's output, so use it for a few blocks per launch only);
+// false = the partials were written with pdf_store_wt (write-through stores, no fence needed: Guideline 16 R1).
+__device__ __forceinline__ void pdf_store_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool pdf_last_block_arrives(int* counter, int expected, int* flag, bool release = true) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (release) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == expected - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+// Ticket counters: a zero-initialised device ring shared by every launch of the library; each launch takes a fresh region, and
+// a region is only handed out again after PDF_COUNTER_RING / (counters per step) steps -- long after the launch that used it
+// (and reset it) has finished.  Defined in elementwise.hip.
+#define PDF_COUNTER_RING (1 << 22)
+int* pdf_ticket_counters(int n);

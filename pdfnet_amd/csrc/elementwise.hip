@@ -299,3 +299,28 @@ PDF_API int pdf_adam_step(float* p, const float* g, float* m, float* v, long n, 
     PDF_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// ticket-counter ring of common.h (pdf_last_block_arrives)
+#include <atomic>
+#include <mutex>
+int* pdf_ticket_counters(int n) {
+    static int* base = nullptr;
+    static std::once_flag once;
+    static std::atomic<long> next{0};
+    std::call_once(once, [] {
+        if (hipMalloc(&base, sizeof(int) * PDF_COUNTER_RING) != hipSuccess) { base = nullptr; return; }
+        if (hipMemset(base, 0, sizeof(int) * PDF_COUNTER_RING) != hipSuccess || hipDeviceSynchronize() != hipSuccess) base = nullptr;
+    });
+    if (base == nullptr || n <= 0 || n > PDF_COUNTER_RING) return nullptr;
+    long o = next.fetch_add(n);
+    long start = o % PDF_COUNTER_RING;
+    if (start + n > PDF_COUNTER_RING) {                      // do not straddle the end: take the region at the start of the ring instead
+        o = next.fetch_add(n + (PDF_COUNTER_RING - start)) + (PDF_COUNTER_RING - start);
+        start = o % PDF_COUNTER_RING;
+        if (start + n > PDF_COUNTER_RING) start = 0;
+    }
+    return base + start;
+}
+PDF_API int pdf_init(void) { return pdf_ticket_counters(1) != nullptr ? 0 : PDF_E_WORKSPACE; }

@@ -779,10 +779,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_SPLITK, ENV_IG_HALO, ENV_IG_T32, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_SPLITK", "PDF_IG_HALO", "PDF_IG_T32"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -886,6 +886,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     // per flop: +1 % alone (125.5 vs 124.2 TFLOP/s on the largest conv), -0.3 % inside the step)
     bool halo = fast && groups == 1 && g.T == 9 && !g.plain_in && g.plain_out && g.ps_cout == 0 && g.sy == 1 && g.sx == 1 && g.QW == g.W && g.QH == g.H &&
                 (g.W == 64 || g.W == 32 || g.W == 16) && (g.H * g.W) % 128 == 0 && g.M % 128 == 0 && g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) &&
+                g.Cin >= env_int(ENV_IG_HALO_MINC, 256) &&      // measured: 128-channel layers lose (94 vs 107 TFLOP/s forward), 256+ gain 2-3 %
                 env_int(ENV_IG_HALO, 1);
     for (int t = 0; halo && t < 9; ++t) halo = g.dy[t] >= -1 && g.dy[t] <= 1 && g.dx[t] >= -1 && g.dx[t] <= 1;
     if (halo) {

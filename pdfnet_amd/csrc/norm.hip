@@ -53,6 +53,61 @@ __device__ __forceinline__ void reduce_chunks(const float* __restrict__ part, in
     for (int j = 0; j < FIN_TY; ++j) { a += s1[j][tx]; b += s2[j][tx]; }
 }
 
+// ---- finalize inside the partial kernels (pdf_last_block_arrives): the last block of a 64-channel tile sums the chunk
+// partials part[chunk][C][2] in a fixed order -- 64 channels x 4 chunk lanes, doubles -- and writes the per-channel results.
+// Saves one launch and one dependent kernel boundary per BatchNorm call (152 per step, on the critical path).
+__device__ __forceinline__ bool tile_sums(const float* __restrict__ part, int chunks, int C, int c_tile, double* red /*[2][4][64]*/, double& a, double& b) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = c_tile * BN_CT + tx;
+    a = 0.0; b = 0.0;
+    if (c < C) {
+        const float2* p2 = reinterpret_cast<const float2*>(part) + c;
+        for (int k = ty; k < chunks; k += 4) { const float2 v = p2[(long)k * C]; a += v.x; b += v.y; }
+    }
+    red[ty * 64 + tx] = a; red[256 + ty * 64 + tx] = b;
+    __syncthreads();
+    a = (red[tx] + red[64 + tx]) + (red[128 + tx] + red[192 + tx]);
+    b = (red[256 + tx] + red[320 + tx]) + (red[384 + tx] + red[448 + tx]);
+    return ty == 0 && c < C;
+}
+struct BnFin {                                              // forward finalize arguments
+    const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps;
+    float* save_mean; float* save_rstd; float* scale; float* shift; int* counters;
+};
+__device__ __forceinline__ void bn_finalize_tile(const float* __restrict__ part, int chunks, const float* __restrict__ x, int C, long R, const BnFin& f,
+                                                 int c_tile, double* red) {
+    double a, b;
+    if (!tile_sums(part, chunks, C, c_tile, red, a, b)) return;
+    const int c = c_tile * BN_CT + (threadIdx.x & 63);
+    const double n = (double)R;
+    const double dm = a / n;
+    double var = b / n - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const double mean = dm + (double)x[c];
+    const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    f.save_mean[c] = (float)mean;
+    f.save_rstd[c] = rstd;
+    if (f.running_mean != nullptr) {
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+        const double unb = R > 1 ? var * n / (n - 1.0) : var;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
+    }
+    const float sc = f.gamma[c] * rstd;
+    f.scale[c] = sc;
+    f.shift[c] = f.beta[c] - (float)mean * sc;
+}
+struct BnBwdFin { const float* gamma; const float* rstd; float* dgamma; float* dbeta; int accumulate; float* coef; int* counters; };
+__device__ __forceinline__ void bn_bwd_finalize_tile(const float* __restrict__ part, int chunks, int C, long R, const BnBwdFin& f, int c_tile, double* red) {
+    double a, b;
+    if (!tile_sums(part, chunks, C, c_tile, red, a, b)) return;
+    const int c = c_tile * BN_CT + (threadIdx.x & 63);
+    if (f.accumulate) { f.dbeta[c] += (float)a; f.dgamma[c] += (float)b; }
+    else { f.dbeta[c] = (float)a; f.dgamma[c] = (float)b; }
+    f.coef[c] = f.gamma[c] * f.rstd[c];
+    f.coef[C + c] = (float)(a / (double)R);
+    f.coef[2 * C + c] = (float)(b / (double)R);
+}
+
 __global__ __launch_bounds__(FIN_TX * FIN_TY) void bn_finalize_kernel(const float* __restrict__ part, int chunks, const float* __restrict__ x, int C, long R,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
@@ -111,7 +166,7 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
 #define V4_TX 16
 #define V4_TY 16
 __device__ __forceinline__ void v4_block_reduce(float4 a, float4 b, float4 (&sa)[V4_TY][V4_TX], float4 (&sb)[V4_TY][V4_TX],
-                                                float* __restrict__ part, int C, int c0, bool two) {
+                                                float* __restrict__ part, int C, int c0, bool two, bool wt = false) {
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     sa[ty][tx] = a; sb[ty][tx] = b;
     __syncthreads();
@@ -123,13 +178,19 @@ __device__ __forceinline__ void v4_block_reduce(float4 a, float4 b, float4 (&sa)
             y.x += v.x; y.y += v.y; y.z += v.z; y.w += v.w;
         }
         float* o = part + ((long)blockIdx.y * C + c0) * 2;
-        o[0] = x.x; o[1] = two ? y.x : 0.f; o[2] = x.y; o[3] = two ? y.y : 0.f;
-        o[4] = x.z; o[5] = two ? y.z : 0.f; o[6] = x.w; o[7] = two ? y.w : 0.f;
+        const float v[8] = {x.x, two ? y.x : 0.f, x.y, two ? y.y : 0.f, x.z, two ? y.z : 0.f, x.w, two ? y.w : 0.f};
+        if (wt) {                                            // consumed by another block of this launch: write-through stores
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pdf_store_wt(o + e, v[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[e];
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restrict__ x, int ldx, int C, long R, long rows_per_chunk,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, const BnFin fin) {
     __shared__ float4 sa[V4_TY][V4_TX], sb[V4_TY][V4_TX];
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
@@ -145,7 +206,12 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
             b.x += v.x * v.x; b.y += v.y * v.y; b.z += v.z * v.z; b.w += v.w * v.w;
         }
     }
-    v4_block_reduce(a, b, sa, sb, part, C, c0, true);
+    v4_block_reduce(a, b, sa, sb, part, C, c0, true, fin.counters != nullptr);
+    if (fin.counters != nullptr) {
+        __shared__ double red[512];
+        __shared__ int flag;
+        if (pdf_last_block_arrives(fin.counters + blockIdx.x, gridDim.y, &flag, false)) bn_finalize_tile(part, gridDim.y, x, C, R, fin, blockIdx.x, red);
+    }
 }
 
 // relu == 2: no residual went into the ReLU, so its mask is recomputed from x as fmaf(x, scale, shift) > 0 -- the exact
@@ -154,8 +220,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
                                                                 const float* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int C, long R, long rows_per_chunk,
-                                                                float* __restrict__ part) {
+                                                                float* __restrict__ part, const BnBwdFin fin) {
     __shared__ float4 sa[V4_TY][V4_TX], sb[V4_TY][V4_TX];
+    const long RT = R;
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
     const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
@@ -181,7 +248,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
             b.z += g.z * (xv.z - m.z) * rs.z; b.w += g.w * (xv.w - m.w) * rs.w;
         }
     }
-    v4_block_reduce(a, b, sa, sb, part, C, c0, true);
+    v4_block_reduce(a, b, sa, sb, part, C, c0, true, fin.counters != nullptr);
+    if (fin.counters != nullptr) {
+        __shared__ double red[512];
+        __shared__ int flag;
+        if (pdf_last_block_arrives(fin.counters + blockIdx.x, gridDim.y, &flag, false)) bn_bwd_finalize_tile(part, gridDim.y, C, RT, fin, blockIdx.x, red);
+    }
 }
 
 // (colsum kernels: blockIdx.z == 1 is group 1 of a paired call -- rows [R, 2R), partials after group 0's)
@@ -311,14 +383,18 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
     long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
-    if (v4_ok(C, {ldx}, {x}))
-        hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws);
-    else
+    BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, nullptr};
+    if (v4_ok(C, {ldx}, {x})) {
+        fin.counters = pdf_ticket_counters(cdiv(C, BN_CT));          // finalize in the last block of each channel tile
+        hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws, fin);
+    } else
         hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, x, C, R, gamma, beta,
-                       running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
-    PDF_LAUNCH_CHECK();
+    if (fin.counters == nullptr) {
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, x, C, R, gamma, beta,
+                           running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+        PDF_LAUNCH_CHECK();
+    }
     launch_affine_apply(x, ldx, scale, shift, res, ldr, y, ldy, C, R, relu, s);
     PDF_LAUNCH_CHECK();
     return 0;
@@ -411,15 +487,19 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
     float* coef = ws + pdf_bn_workspace_floats(C, R);
     const bool vec = v4_ok(C, {lddy, ldx, lddx, relu == 1 ? ldy : 0, dres ? lddr : 0},
                            {dy, x, dx, dres, relu == 1 ? y : nullptr, save_mean, save_rstd, coef, relu == 2 ? scale : nullptr, relu == 2 ? shift : nullptr});
-    if (vec)
+    BnBwdFin fin = {gamma, save_rstd, dgamma, dbeta, accumulate, coef, nullptr};
+    if (vec) {
+        fin.counters = pdf_ticket_counters(cdiv(C, BN_CT));
         hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
-                           save_mean, save_rstd, scale, shift, C, R, rpc, ws);
-    else
+                           save_mean, save_rstd, scale, shift, C, R, rpc, ws, fin);
+    } else
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
                            save_mean, save_rstd, scale, shift, C, R, rpc, ws);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, R, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
-    PDF_LAUNCH_CHECK();
+    if (fin.counters == nullptr) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, R, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
+        PDF_LAUNCH_CHECK();
+    }
     if (vec) {
         const long arpc = apply_rows_per_chunk(C, R);
         hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)((R + arpc - 1) / arpc)), dim3(256), 0, s, dy, lddy, y, ldy, relu,
@@ -467,7 +547,8 @@ __global__ __launch_bounds__(256) void bn_maxk_bwd_partial_kernel(const float* _
                                                                   const float* __restrict__ y, int ldy, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, int C, int K, long R, long rows_per_chunk,
-                                                                  float* __restrict__ part) {
+                                                                  float* __restrict__ part, const BnBwdFin fin) {
+    const long RT = R * K;                                   // the statistics were taken over R*K rows: so are the backward's means
     __shared__ float4 sa[V4_TY][V4_TX], sb[V4_TY][V4_TX];
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
@@ -487,7 +568,12 @@ __global__ __launch_bounds__(256) void bn_maxk_bwd_partial_kernel(const float* _
             b.x += gx * (vx - m.x) * rs.x; b.y += gy * (vy - m.y) * rs.y; b.z += gz * (vz - m.z) * rs.z; b.w += gw * (vw - m.w) * rs.w;
         }
     }
-    v4_block_reduce(a, b, sa, sb, part, C, c0, true);
+    v4_block_reduce(a, b, sa, sb, part, C, c0, true, fin.counters != nullptr);
+    if (fin.counters != nullptr) {
+        __shared__ double red[512];
+        __shared__ int flag;
+        if (pdf_last_block_arrives(fin.counters + blockIdx.x, gridDim.y, &flag, false)) bn_bwd_finalize_tile(part, gridDim.y, C, RT, fin, blockIdx.x, red);
+    }
 }
 // dy[r][k][c] = a * (g - c1 - xhat * c2), g = dout[r][c] where k == arg[r][c] and the ReLU was active, else 0
 __global__ __launch_bounds__(256) void bn_maxk_bwd_apply_kernel(const float* __restrict__ dm, int lddm, const int* __restrict__ arg,
@@ -534,9 +620,11 @@ PDF_API int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, 
         long chunks = bn_chunks(C, rows);
         long rpc = (rows + chunks - 1) / chunks;
         chunks = (rows + rpc - 1) / rpc;
-        hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, y, ldy, C, rows, rpc, ws);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, y, C, rows, gamma, beta,
-                           running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+        BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, pdf_ticket_counters(cdiv(C, BN_CT))};
+        hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, y, ldy, C, rows, rpc, ws, fin);
+        if (fin.counters == nullptr)
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, y, C, rows, gamma, beta,
+                               running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
     } else {
         hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, C, gamma, beta, running_mean, running_var, eps, scale, shift);
     }
@@ -556,10 +644,11 @@ PDF_API int pdf_bn_relu_maxk_bwd(const float* dout, int lddo, const int* arg, co
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
     float* coef = ws + pdf_bn_workspace_floats(C, R);
+    BnBwdFin fin = {gamma, save_rstd, dgamma, dbeta, accumulate, coef, pdf_ticket_counters(cdiv(C, BN_CT))};
     hipLaunchKernelGGL(bn_maxk_bwd_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dout, lddo, arg, y, ldy, save_mean, save_rstd,
-                       scale, shift, C, K, R, rpc, ws);
-    // the statistics were taken over R*K rows: the means of the backward are over R*K as well
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, R * K, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
+                       scale, shift, C, K, R, rpc, ws, fin);
+    if (fin.counters == nullptr)      // the statistics were taken over R*K rows: the means of the backward are over R*K as well
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, C, R * K, gamma, save_rstd, dgamma, dbeta, accumulate, coef);
     const long total = R * (C / 4);
     hipLaunchKernelGGL(bn_maxk_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dout, lddo, arg, y, ldy, save_mean, save_rstd, coef,
                        scale, shift, C, K, dy, lddy, total);

@@ -73,6 +73,8 @@ def lib():
     global _lib
     if _lib is None:
         _lib = _Lib()
+        if torch.cuda.is_available():
+            _lib.pdf_init()                # device-side ticket counters: allocate now, never inside a stream capture
     return _lib
 
 
