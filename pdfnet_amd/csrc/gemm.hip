@@ -537,28 +537,8 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
         cur ^= 1;
     }
 
-    if (do_bias && i0 + tid < g.NI) {
-        float* bo = bslabp + (long)blockIdx.y * g.NI + i0 + tid;
-        *bo = g.beta ? *bo + bsum : bsum;
-    }
-    float* out = slabp + (long)blockIdx.y * g.NI * g.ldw;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
-        if (col >= NJ) continue;
-        const int t = col / g.Cq;
-        const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.NI) {
-                    float* o = out + (long)row * g.ldw + wcol;
-                    *o = g.beta ? *o + acc[i][j][r] : acc[i][j][r];
-                }
-            }
-    }
+    // (the ticket flag lives in the staging array: a second __shared__ object can de-pipeline LDS-DMA kernels, guide section 5 item 4a)
+    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && i0 + tid < g.NI, bsum, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(&Ps[0][0]));
 }
 
 
@@ -707,28 +687,7 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
 
-    if (do_bias && i0 + tid < g.NI) {
-        float* bo = bslabp + (long)blockIdx.y * g.NI + i0 + tid;
-        *bo = g.beta ? *bo + bsum : bsum;
-    }
-    float* out = slabp + (long)blockIdx.y * g.NI * g.ldw;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
-        if (col >= NJ) continue;
-        const int t = col / g.Cq;
-        const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.NI) {
-                    float* o = out + (long)row * g.ldw + wcol;
-                    *o = g.beta ? *o + acc[i][j][r] : acc[i][j][r];
-                }
-            }
-    }
+    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && i0 + tid < g.NI, bsum, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(smem));
 }
 
 // Slab reducers.  blockIdx.y == 1 is group 1 of a paired launch (slabs after group 0's, own outputs).  A launch may carry a
@@ -779,10 +738,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1192,6 +1151,12 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     g.bslab = db ? (splits == 1 ? db : bws) : nullptr;
     g.bslab1 = db ? (splits == 1 ? db1 : bws + (long)splits * perb) : nullptr;
     g.beta = splits == 1 ? accumulate : 0;
+    g.out = out; g.out1 = out1; g.bout = db; g.bout1 = db1; g.accumulate = accumulate;
+    // In-launch reduction (PDF_WG_INLAUNCH=1) is OFF by default: measured 245 vs 395 img/s.  Every block's agent-scope release
+    // fence (buffer_wbl2) writes back the whole XCD L2, which holds megabytes of slabs and of the main stream's fresh outputs;
+    // write-through slab stores would need 16-byte stores from a re-laid-out accumulator (4-byte sc1 stores are ~6x slower).
+    // BatchNorm's in-launch finalisation (norm.hip) publishes 32 bytes per block and does use the write-through form.
+    g.counters = (splits > 1 && env_int(ENV_WG_INLAUNCH, 0)) ? pdf_ticket_counters((int)tiles * groups) : nullptr;
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     int brc = 0;
     if (bf16) {
@@ -1211,7 +1176,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         else hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, false>), grid, dim3(256), 0, s, g);
     }
     PDF_LAUNCH_CHECK();
-    if (splits > 1) {
+    if (splits > 1 && g.counters == nullptr) {
         Reduce r = {ws, out, out1, per, bws, db, db1, (int)perb, splits, accumulate};
         if (splits >= 16 && per <= (1L << 20)) {
             const int mb = (int)((per + 63) / 64);

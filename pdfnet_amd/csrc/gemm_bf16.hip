@@ -391,35 +391,14 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
         cur ^= 1;
     }
 
+    float bval = 0.f;
     if (do_bias) {                                        // column sums of P (fp32, un-rounded): reduce the k-row groups' partials
 #pragma unroll
         for (int e = 0; e < 4; ++e) bred[pk0 * BI + pcg + e] = bsum[e];
         __syncthreads();
-        if (tid < BI && i0 + tid < g.NI) {
-            float t = 0.f;
-            for (int k = 0; k < KPP_P; ++k) t += bred[k * BI + tid];
-            float* bo = bslabp + (long)blockIdx.y * g.NI + i0 + tid;
-            *bo = g.beta ? *bo + t : t;
-        }
+        if (tid < BI) for (int k = 0; k < KPP_P; ++k) bval += bred[k * BI + tid];
     }
-    float* out = slabp + (long)blockIdx.y * g.NI * g.ldw;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
-        if (col >= NJ) continue;
-        const int t = col / g.Cq;
-        const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.NI) {
-                    float* o = out + (long)row * g.ldw + wcol;
-                    *o = g.beta ? *o + acc[i][j][r] : acc[i][j][r];
-                }
-            }
-    }
+    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && tid < BI && i0 + tid < g.NI, bval, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(smem));
 }
 
 // g carries the split / slab plan of launch_wgemm (gemm.hip); `small` = its 64 x 64 tile choice

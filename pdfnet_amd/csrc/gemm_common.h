@@ -49,9 +49,75 @@ struct WGemm {
     // optional bias gradient (column sums of P) riding along: per-split partials [split][NI] (or the output itself when one
     // split), accumulated by the j-tile-0 blocks from the P tiles they stage anyway
     float* bslab; float* bslab1;
+    // in-launch reduction of the split slabs (pdf_last_block_arrives): the last block of every output tile sums the slabs in split
+    // order into out / out1 (+= when accumulate) and the bias partials into bout / bout1; counters == NULL: reduce_slabs launch
+    float* out; float* out1; float* bout; float* bout1; int accumulate; int* counters;
     short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
 };
 
+
+// Epilogue shared by the weight-gradient kernels: this block's partial tile -> its split's slab (or the output itself when there
+// is one split), the bias partial, and -- in-launch -- the reduction over the splits by the tile's last-arriving block.
+// bias_thread: this thread carries the bias partial `bval` of output row i0 + threadIdx.x.
+template <int TM, int TN>
+__device__ __forceinline__ void wgemm_finish(const WGemm& g, const f32x16 (&acc)[TM][TN], int i0, int j0, int wm, int wn, int lane,
+                                             bool bias_thread, float bval, int tile_id, int ntiles, int* lds_flag) {
+    const int grp = blockIdx.z, split = blockIdx.y, splits = gridDim.y;
+    float* slabp = grp ? g.slab1 : g.slab;
+    float* bslabp = grp ? g.bslab1 : g.bslab;
+    const int NJ = g.T * g.Cq;
+    if (bias_thread) {
+        float* bo = bslabp + (long)split * g.NI + i0 + threadIdx.x;
+        *bo = g.beta ? *bo + bval : bval;
+    }
+    float* out = slabp + (long)split * g.NI * g.ldw;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (col >= NJ) continue;
+        const int t = col / g.Cq;
+        const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.NI) {
+                    float* o = out + (long)row * g.ldw + wcol;
+                    *o = g.beta ? *o + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+    }
+    if (g.counters == nullptr || splits == 1) return;
+    if (!pdf_last_block_arrives(g.counters + grp * ntiles + tile_id, splits, lds_flag, true)) return;
+    float* dst = grp ? g.out1 : g.out;
+    const long per = (long)g.NI * g.ldw;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (col >= NJ) continue;
+        const int t = col / g.Cq;
+        const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.NI) {
+                    const long pos = (long)row * g.ldw + wcol;
+                    float sum = g.accumulate ? dst[pos] : 0.f;
+                    for (int z = 0; z < splits; ++z) sum += slabp[z * per + pos];
+                    dst[pos] = sum;
+                }
+            }
+    }
+    if (bslabp != nullptr && j0 == 0 && threadIdx.x < TM * 64 && i0 + (int)threadIdx.x < g.NI) {      // TM * 64 = BI rows of this tile
+        float* bdst = grp ? g.bout1 : g.bout;
+        float sum = g.accumulate ? bdst[i0 + threadIdx.x] : 0.f;
+        for (int z = 0; z < splits; ++z) sum += bslabp[(long)z * g.NI + i0 + threadIdx.x];
+        bdst[i0 + threadIdx.x] = sum;
+    }
+}
 
 // bf16-input MFMA path (gemm_bf16.hip): same descriptors, operands rounded to bf16 while they are staged into LDS,
 // fp32 accumulation.  Return 1 if the launch was issued, 0 if the shape is not supported there (the caller then uses the

@@ -102,6 +102,22 @@ def gemm_precision():
     return 'bf16' if hip.lib().pdf_debug_gemm_precision() else 'fp32'
 
 
+class _forced_fp32:
+    """Launches issued inside run on the fp32 kernels even in bf16 mode (the precision flag is read on the host at launch)."""
+
+    def __init__(self, on):
+        self.on = on and hip.lib().pdf_debug_gemm_precision() != 0
+
+    def __enter__(self):
+        if self.on:
+            hip.lib().pdf_set_gemm_precision(0)
+
+    def __exit__(self, *exc):
+        if self.on:
+            hip.lib().pdf_set_gemm_precision(1)
+        return False
+
+
 def _L():
     return hip.lib()
 
@@ -360,7 +376,7 @@ class _Linear(Function):
     """y[..., N] = act(x[..., K] w[N, K]^T + b)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    def forward(ctx, x, w, b, act, fp32=False):
         hip.require_gpu(x, w)
         w_in = w
         x, w = x.contiguous(), w.contiguous()
@@ -368,8 +384,10 @@ class _Linear(Function):
         M = x.numel() // K
         Nn = w.shape[0]
         y = torch.empty(x.shape[:-1] + (Nn,), dtype=torch.float32, device=x.device)
-        _L().pdf_linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), M, Nn, K, K, K, Nn, act, stream())
+        with _forced_fp32(fp32):
+            _L().pdf_linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), M, Nn, K, K, K, Nn, act, stream())
         ctx.save_for_backward(x, w, y if act else None)
+        ctx.fp32 = fp32
         ctx.cfg = (act, b is not None)
         ctx.params = (w_in, b)
         return y
@@ -388,18 +406,22 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.pdf_linear_bwd_data(ptr(g), ptr(w), ptr(dx), M, Nn, K, Nn, K, K, stream())
+            with _forced_fp32(ctx.fp32):
+                L.pdf_linear_bwd_data(ptr(g), ptr(w), ptr(dx), M, Nn, K, Nn, K, K, stream())
         w_par, b_par = ctx.params
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(M, Nn, K, x.device)
-            L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
+            with _forced_fp32(ctx.fp32):
+                L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K, fused_bias=True)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE):
-    return _Linear.apply(x, w, b, act)
+def linear(x, w, b=None, act=ACT_NONE, fp32=False):
+    """fp32=True: keep this layer on the exact fp32 kernels when the library runs in bf16 mode (layers whose INPUT must not
+    be rounded -- absolute point coordinates that are only meaningful as differences)."""
+    return _Linear.apply(x, w, b, act, fp32)
 
 
 def as_matrix(weight):

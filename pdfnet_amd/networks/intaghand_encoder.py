@@ -122,9 +122,11 @@ class PointNet_Plus(nn.Module):
         a multiple of 16 channels.  -> [B,S,K,Cout] (pre-BatchNorm)."""
         idx = F.knn_ball_indices(rows, S, K, r2)                                           # kNN + ball rule on (modulated) xyz
         w = conv.matrix(rows.shape[-1])
-        u = F.linear(rows, w, conv.bias)                                                   # [B,N,Cout]
+        # fp32 also in bf16 mode: the layer sees ABSOLUTE coordinates (0.45 +- 0.1 m) whose differences (centimetres) carry the
+        # signal; rounding them to bf16 (2 mm steps) before the subtraction would destroy it.  N rows: the cost is nothing.
+        u = F.linear(rows, w, conv.bias, fp32=True)                                        # [B,N,Cout]
         ctr = torch.nn.functional.pad(rows[:, :S, :3], (0, rows.shape[-1] - 3))            # centres = the first S points
-        return F.gather_sub(u, F.linear(ctr, w), idx)
+        return F.gather_sub(u, F.linear(ctr, w, fp32=True), idx)
 
     def forward(self, cloud, emb, choose):
         return self.stage_b(*self.stage_a(cloud, emb[0], emb[1], choose), emb[2], choose)
