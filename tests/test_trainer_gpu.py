@@ -149,3 +149,35 @@ def test_gradient_views_survive_module_zero_grad():
     # the never-used tail is neither reduced nor stepped
     assert float(tr.optimizer.flat_g[tr.n_live:].abs().max()) == 0.0
     assert torch.equal(tr.optimizer.flat_p[tr.n_live:], before[tr.n_live:])
+
+
+def test_headline_batch_32_properties():
+    """BASELINE config 3 at its real size (B = 32, 256x256; what bench.py times): size-independent properties -- every output
+    finite and of the reference's shape, predicted centre indices inside the R/4 grid, the loss finite and falling over 3
+    steps on a fixed batch, gradients present for every live parameter and absent for the never-used tail."""
+    from pdfnet_amd.trains.base_trainer import Trainer
+    R, B = 256, 32
+    opt, m, crit, batch = _setup(R=R, B=B, dropout=True)
+    m.eval()
+    with torch.no_grad():
+        result, params, hand, other = m(batch['input'], batch['choose'], batch['cloud'], batch['depth'], None, batch['K_new'], batch['valid'])
+    for h in ('left', 'right'):
+        assert result['verts3d'][h].shape == (B, 778, 3) and result['verts2d'][h].shape == (B, 778, 2)
+        assert hand[0]['verts3d'][h].shape == (B, 252, 3)
+        assert params['scale'][h].shape == (B,) and params['trans2d'][h].shape == (B, 2) and params['root'][h].shape == (B, 3)
+        for t in (result['verts3d'][h], result['verts2d'][h], hand[0]['verts3d'][h], params['root'][h]):
+            assert torch.isfinite(t).all()
+    assert other['hms'].shape == (B, 42, R // 4, R // 4) and other['mask'].shape == (B, 2, R, R)
+    assert other['ret']['hm'].shape == (B, 2, R // 4, R // 4) and other['ret']['params'].shape == (B, 122, R // 4, R // 4)
+    ind = other['ind']
+    assert ind.dtype == torch.int64 and ind.shape == (B, 2) and int(ind.min()) >= 0 and int(ind.max()) < (R // 4) ** 2
+    tr = Trainer(opt, m, crit, lr=1e-4)
+    losses = [float(tr.train_step(batch, 0)) for _ in range(3)]
+    assert all(np.isfinite(losses)) and losses[2] < losses[0], losses
+    g = tr.optimizer.flat_g
+    assert torch.isfinite(g).all() and float(g[tr.n_live:].abs().max()) == 0.0
+    live_zero = [n for (n, p) in m.named_parameters() if p.grad is not None and float(p.grad.abs().max()) == 0.0]
+    from pdfnet_amd.trains.base_trainer import DEAD_PATTERN
+    # besides the structurally dead tensors only the wh / params heads (no loss term, simplified.py:397-399) stay at zero
+    assert all(DEAD_PATTERN.match(n) or n.startswith(('encoder.wh.', 'encoder.params.')) for n in live_zero), \
+        [n for n in live_zero if not DEAD_PATTERN.match(n) and not n.startswith(('encoder.wh.', 'encoder.params.'))][:5]
