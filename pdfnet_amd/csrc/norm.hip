@@ -3,6 +3,7 @@
 // one streaming pass; channels are the contiguous axis so every access is coalesced.
 #include "common.h"
 #include <initializer_list>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm2d / BatchNorm1d over rows.  Statistics are accumulated as shifted sums
@@ -53,9 +54,18 @@ __device__ __forceinline__ void reduce_chunks(const float* __restrict__ part, in
     for (int j = 0; j < FIN_TY; ++j) { a += s1[j][tx]; b += s2[j][tx]; }
 }
 
+static bool bn_inlaunch(int C, long R) {
+    static long maxb = -2;
+    if (maxb == -2) { const char* e = getenv("PDF_BN_INLAUNCH_MAXMB"); maxb = e ? atol(e) : 0; }
+    return maxb < 0 || (long)C * R * 4 <= maxb * (1L << 20);
+}
+
 // ---- finalize inside the partial kernels (pdf_last_block_arrives): the last block of a 64-channel tile sums the chunk
 // partials part[chunk][C][2] in a fixed order -- 64 channels x 4 chunk lanes, doubles -- and writes the per-channel results.
-// Saves one launch and one dependent kernel boundary per BatchNorm call (152 per step, on the critical path).
+// Saves one launch per BatchNorm call (164 per step) but every block then waits for its write-through stores and the ticket
+// before it retires, and the tile's last block adds the serial sum: measured on MI355X the partial kernels run 1.3-1.4 ms
+// per step longer than the finalize launches they replace (fp32 B=32 393 vs 399 img/s, bf16 652 vs 664), so it is opt-in:
+// PDF_BN_INLAUNCH_MAXMB=<n> enables it for tensors up to n MiB (-1: always).
 __device__ __forceinline__ bool tile_sums(const float* __restrict__ part, int chunks, int C, int c_tile, double* red /*[2][4][64]*/, double& a, double& b) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = c_tile * BN_CT + tx;
@@ -385,7 +395,7 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
     chunks = (R + rpc - 1) / rpc;
     BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, nullptr};
     if (v4_ok(C, {ldx}, {x})) {
-        fin.counters = pdf_ticket_counters(cdiv(C, BN_CT));          // finalize in the last block of each channel tile
+        fin.counters = bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr;          // finalize in the last block of each channel tile
         hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws, fin);
     } else
         hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws);
@@ -489,7 +499,7 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
                            {dy, x, dx, dres, relu == 1 ? y : nullptr, save_mean, save_rstd, coef, relu == 2 ? scale : nullptr, relu == 2 ? shift : nullptr});
     BnBwdFin fin = {gamma, save_rstd, dgamma, dbeta, accumulate, coef, nullptr};
     if (vec) {
-        fin.counters = pdf_ticket_counters(cdiv(C, BN_CT));
+        fin.counters = bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr;
         hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
                            save_mean, save_rstd, scale, shift, C, R, rpc, ws, fin);
     } else
@@ -620,7 +630,7 @@ PDF_API int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, 
         long chunks = bn_chunks(C, rows);
         long rpc = (rows + chunks - 1) / chunks;
         chunks = (rows + rpc - 1) / rpc;
-        BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, pdf_ticket_counters(cdiv(C, BN_CT))};
+        BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, bn_inlaunch(C, rows) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr};
         hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, y, ldy, C, rows, rpc, ws, fin);
         if (fin.counters == nullptr)
             hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, y, C, rows, gamma, beta,
@@ -644,7 +654,7 @@ PDF_API int pdf_bn_relu_maxk_bwd(const float* dout, int lddo, const int* arg, co
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
     float* coef = ws + pdf_bn_workspace_floats(C, R);
-    BnBwdFin fin = {gamma, save_rstd, dgamma, dbeta, accumulate, coef, pdf_ticket_counters(cdiv(C, BN_CT))};
+    BnBwdFin fin = {gamma, save_rstd, dgamma, dbeta, accumulate, coef, bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr};
     hipLaunchKernelGGL(bn_maxk_bwd_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dout, lddo, arg, y, ldy, save_mean, save_rstd,
                        scale, shift, C, K, R, rpc, ws, fin);
     if (fin.counters == nullptr)      // the statistics were taken over R*K rows: the means of the backward are over R*K as well
