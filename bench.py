@@ -479,7 +479,7 @@ def main():
     model = load_model_intag(opt).to(dev)
     consts = synthetic_loss_constants()
     loss = CtdetLoss(opt, consts).to(dev)
-    if args.graph:
+    if args.graph and not os.environ.get('PDF_GRAPH_WGRAD_STREAM'):
         F.ASYNC_WGRAD = False              # hipGraph replay of the forked wgrad stream measured slower than the plain graph
     trainer = Trainer(opt, model, loss, lr=1e-4, use_graph=args.graph, broadcast_buffers=args.broadcast_buffers,
                       grad_comm_dtype=torch.bfloat16 if bf16 else None)   # world > 1: replicas synced from rank 0

@@ -738,10 +738,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -880,7 +880,7 @@ static void conv_taps(IGemm& g, int KH, int KW, int pad, int dil) {
     for (int ky = 0; ky < KH; ++ky)
         for (int kx = 0; kx < KW; ++kx) {
             int t = ky * KW + kx;
-            g.dy[t] = (short)(ky * dil - pad); g.dx[t] = (short)(kx * dil - pad); g.wt[t] = (short)t;
+            g.dy[t] = (int)(ky * dil - pad); g.dx[t] = (int)(kx * dil - pad); g.wt[t] = t;
         }
 }
 
@@ -1099,9 +1099,9 @@ PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
                     if ((px + pad - kx) % stride != 0) continue;
                     // oy = qy + (py + pad - ky)/stride  (exact division, may be negative)
                     int ny = py + pad - ky, nx = px + pad - kx;
-                    g.dy[T] = (short)(ny >= 0 ? ny / stride : -((-ny) / stride));
-                    g.dx[T] = (short)(nx >= 0 ? nx / stride : -((-nx) / stride));
-                    g.wt[T] = (short)(ky * KW + kx);
+                    g.dy[T] = (int)(ny >= 0 ? ny / stride : -((-ny) / stride));
+                    g.dx[T] = (int)(nx >= 0 ? nx / stride : -((-nx) / stride));
+                    g.wt[T] = (int)(ky * KW + kx);
                     ++T;
                 }
             }
@@ -1141,7 +1141,21 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     if ((long)splits * (per + perb) * groups > ws_floats) splits = (int)(ws_floats / ((per + perb) * groups));
     if (splits < 1) splits = 1;
     const bool bf16 = g_gemm_bf16 && fast;
-    int rps = bf16 ? cdiv(cdiv(g.M, splits), 64) * 64 : cdiv(cdiv(g.M, splits), 16) * 16;
+    const int rq = bf16 ? 64 : 16;
+    // The blocks all run equally long and the chip retires them CU by CU: 1044 blocks on 256 CUs leave most CUs idle for the
+    // fifth pass (82 % busy).  Among split counts down to 3/4 of the target, take the one whose block count fills whole
+    // passes best (never more splits than the workspace was sized for).
+    if (splits > 1 && env_int(ENV_WG_QUANT, 1)) {
+        int best = splits; double beste = -1.0;
+        for (int sp = splits; sp >= 1 && sp * 4 >= splits * 3; --sp) {
+            const int r = cdiv(cdiv(g.M, sp), rq) * rq;
+            const long blocks = tiles * groups * cdiv(g.M, r);
+            const double e = (double)blocks / (256.0 * (double)((blocks + 255) / 256));
+            if (e > beste + 0.02) { beste = e; best = sp; }
+        }
+        splits = best;
+    }
+    int rps = cdiv(cdiv(g.M, splits), rq) * rq;
     splits = cdiv(g.M, rps);
     g.rows_per_split = rps;
     g.tap_major = (!g.plain_q && g.T > 1 && g.Cq % BJ == 0 && env_int(ENV_WG_TAPMAJOR, 1)) ? 1 : 0;
@@ -1260,7 +1274,7 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
     for (int ky = 0; ky < KH; ++ky)
         for (int kx = 0; kx < KW; ++kx) {
             int t = ky * KW + kx;
-            g.dy[t] = (short)(ky - pad); g.dx[t] = (short)(kx - pad); g.wt[t] = (short)t;
+            g.dy[t] = (int)(ky - pad); g.dx[t] = (int)(kx - pad); g.wt[t] = t;
         }
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s, nullptr, db);
 }
@@ -1301,9 +1315,9 @@ PDF_API int pdf_deconv2d_fwd(const float* x, const float* w, const float* bias, 
                 for (int kx = 0; kx < KW; ++kx) {
                     if ((px + pad - kx) % stride != 0) continue;
                     int ny = py + pad - ky, nx = px + pad - kx;      // iy = qy + ny/stride
-                    g.dy[T] = (short)(ny >= 0 ? ny / stride : -((-ny) / stride));
-                    g.dx[T] = (short)(nx >= 0 ? nx / stride : -((-nx) / stride));
-                    g.wt[T] = (short)(ky * KW + kx);
+                    g.dy[T] = (int)(ny >= 0 ? ny / stride : -((-ny) / stride));
+                    g.dx[T] = (int)(nx >= 0 ? nx / stride : -((-nx) / stride));
+                    g.wt[T] = (int)(ky * KW + kx);
                     ++T;
                 }
             }
@@ -1344,7 +1358,7 @@ PDF_API int pdf_deconv2d_bwd_weight(const float* x, const float* dy, float* dw, 
     for (int ky = 0; ky < KH; ++ky)
         for (int kx = 0; kx < KW; ++kx) {
             int t = ky * KW + kx;
-            g.dy[t] = (short)(ky - pad); g.dx[t] = (short)(kx - pad); g.wt[t] = (short)t;
+            g.dy[t] = (int)(ky - pad); g.dx[t] = (int)(kx - pad); g.wt[t] = t;
         }
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s);
 }

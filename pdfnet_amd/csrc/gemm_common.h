@@ -20,7 +20,7 @@ struct IGemm {
     int b_kn, btap;
     // group 1 of a paired launch (blockIdx.y == 1): same shapes, own weight/bias, A and C advanced by gsA / gsC floats
     const float* B1; const float* bias1; long gsA, gsC;
-    short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
+    int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
 // the word masked lanes read instead of branching around their load
@@ -52,7 +52,7 @@ struct WGemm {
     // in-launch reduction of the split slabs (pdf_last_block_arrives): the last block of every output tile sums the slabs in split
     // order into out / out1 (+= when accumulate) and the bias partials into bout / bout1; counters == NULL: reduce_slabs launch
     float* out; float* out1; float* bout; float* bout1; int accumulate; int* counters;
-    short dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];
+    int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
 
