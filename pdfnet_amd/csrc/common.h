@@ -91,3 +91,9 @@ __device__ __forceinline__ bool pdf_last_block_arrives(int* counter, int expecte
 // (and reset it) has finished.  Defined in elementwise.hip.
 #define PDF_COUNTER_RING (1 << 22)
 int* pdf_ticket_counters(int n);
+// Scratch for the split-K partial sums of the small-M GEMMs (entry points without a workspace argument): a 256 MiB ring
+// allocated once (pdf_init), handed out in launch order.  One use takes at most 16 MiB and a train step a few tens of MiB, so
+// a region comes round again only several steps later -- far beyond what the launch queue can hold in flight.
+#define PDF_SCRATCH_RING (1L << 26)
+#define PDF_SCRATCH_MAX (1L << 22)
+float* pdf_scratch(long floats);

@@ -323,4 +323,21 @@ int* pdf_ticket_counters(int n) {
     }
     return base + start;
 }
-PDF_API int pdf_init(void) { return pdf_ticket_counters(1) != nullptr ? 0 : PDF_E_WORKSPACE; }
+// split-K scratch ring of common.h (pdf_scratch)
+float* pdf_scratch(long floats) {
+    static float* base = nullptr;
+    static std::once_flag once;
+    static std::atomic<long> next{0};
+    std::call_once(once, [] { if (hipMalloc(&base, sizeof(float) * PDF_SCRATCH_RING) != hipSuccess) base = nullptr; });
+    floats = (floats + 63) & ~63L;                            // 256-byte granules
+    if (base == nullptr || floats <= 0 || floats > PDF_SCRATCH_MAX) return nullptr;
+    long o = next.fetch_add(floats);
+    long start = o % PDF_SCRATCH_RING;
+    if (start + floats > PDF_SCRATCH_RING) {
+        o = next.fetch_add(floats + (PDF_SCRATCH_RING - start)) + (PDF_SCRATCH_RING - start);
+        start = o % PDF_SCRATCH_RING;
+        if (start + floats > PDF_SCRATCH_RING) start = 0;
+    }
+    return base + start;
+}
+PDF_API int pdf_init(void) { return (pdf_ticket_counters(1) != nullptr && pdf_scratch(64) != nullptr) ? 0 : PDF_E_WORKSPACE; }

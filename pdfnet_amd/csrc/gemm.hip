@@ -76,11 +76,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = (g.K + BK - 1) / BK;
+    int kt0 = 0, kt1 = nk;                               // split-K launch: this block's K-steps (T == 1 only)
+    if (g.ksteps > 0) { kt0 = blockIdx.z * g.ksteps; kt1 = min(nk, kt0 + g.ksteps); }
 
     float4 ra[RA], rb[RB];
     // tap state of the NEXT tile to load (tiles are loaded strictly in order): no per-tile division and the
     // tap table (scalar loads that share lgkmcnt with the LDS traffic) is read only when the tap changes
-    int nt_tap = 0, nt_ci = 0, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * (KN ? g.btap : g.Cin);
+    int nt_tap = 0, nt_ci = kt0 * BK, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * (KN ? g.btap : g.Cin);
     auto gload = [&](int kt) {
         if (FAST) {
             const int ci0 = nt_ci + kq;
@@ -159,14 +161,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
         }
     };
 
-    gload(0);
+    gload(kt0);
     lstore(0);
     __syncthreads();
     int cur = 0;
     const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5);
     const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt + 1 < kt1) gload(kt + 1);
         const float* as = As[cur];
         const float* bs = Bs[cur];
 #pragma unroll
@@ -182,11 +184,26 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+        if (kt + 1 < kt1) lstore(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
+    if (g.ksteps > 0) {                                  // split-K: raw partial tile -> part[split][M][N]
+        float* pp = g.part + (long)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (col < g.N && row < g.M) pp[(long)row * g.N + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -738,10 +755,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -796,6 +813,20 @@ __global__ __launch_bounds__(256) void small_k_gemm(const IGemm g) {
     }
 }
 
+// C[m][n] = act(bias[n] + sum over splits of part[z][m][n]) in split order (deterministic)
+__global__ __launch_bounds__(256) void splitk_finish(const float* __restrict__ part, int splits, int M, int N, const float* __restrict__ bias,
+                                                     int act, float* __restrict__ C, int ldc) {
+    const long total = (long)M * N;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / N;
+        const int n = (int)(i - m * N);
+        float v = bias ? bias[n] : 0.f;
+        for (int z = 0; z < splits; ++z) v += part[(long)z * total + i];
+        if (act == 1) v = fmaxf(v, 0.f); else if (act == 2) v = v > 0.f ? v : 0.1f * v;
+        C[m * ldc + n] = v;
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BKF = 16>
 static void launch_igemm_tile(const IGemm& g, bool fast, dim3 grid, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
@@ -836,6 +867,32 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
         const int rc = launch_igemm_bf16(g, s, groups);
         if (rc < 0) return -rc;
         if (rc == 1) { g_last_tile = 16; return 0; }
+    }
+    // Few output tiles under a long reduction (the M = 64 centre-window layers, 8x8-map 1x1 convs, the mesh decoder's vertex
+    // up-projections): a handful of CUs would walk K step by step at load latency.  Split K over blockIdx.z so that ~320 blocks
+    // run, partial tiles through the scratch ring, bias / activation in splitk_finish.
+    const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
+    if (groups == 1 && g.T == 1 && g.plain_in && g.plain_out && g.ps_cout == 0 && t64 <= 128 && g.K >= 512 && env_int(ENV_IG_SPLITK, 1)) {
+        const bool bk32 = fast && g.Cin % 32 == 0;
+        const int bk = bk32 ? 32 : 16, nk = cdiv(g.K, bk);
+        int splits = (int)min((long)cdiv(320, (int)t64), (long)(g.K / 128));
+        while (splits > 1 && (long)splits * g.M * g.N > PDF_SCRATCH_MAX) --splits;
+        if (splits >= 2) {
+            const int ksteps = cdiv(nk, splits);
+            splits = cdiv(nk, ksteps);
+            float* part = splits >= 2 ? pdf_scratch((long)splits * g.M * g.N) : nullptr;
+            if (part != nullptr) {
+                IGemm gs = g;
+                gs.ksteps = ksteps; gs.part = part;
+                const dim3 grid((unsigned)t64, 1, (unsigned)splits);
+                if (bk32) launch_igemm_tile<64, 64, 2, 2, 32>(gs, fast, grid, s);
+                else launch_igemm_tile<64, 64, 2, 2>(gs, fast, grid, s);
+                hipLaunchKernelGGL(splitk_finish, dim3(grid_for((long)g.M * g.N)), dim3(256), 0, s, part, splits, g.M, g.N, g.bias, g.act, g.C, g.ldc);
+                g_last_tile = 64064;
+                PDF_LAUNCH_CHECK();
+                return 0;
+            }
+        }
     }
     // tile choice: wide tiles when there are enough of them to fill 256 CUs, else smaller ones
     long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;

@@ -20,6 +20,9 @@ struct IGemm {
     int b_kn, btap;
     // group 1 of a paired launch (blockIdx.y == 1): same shapes, own weight/bias, A and C advanced by gsA / gsC floats
     const float* B1; const float* bias1; long gsA, gsC;
+    // split-K (blockIdx.z = split): K-steps [z*ksteps, (z+1)*ksteps) of this launch's BK, raw partial sums to
+    // part[z][M][N] (no bias / activation -- splitk_finish applies them).  ksteps == 0: no split.
+    int ksteps; float* part;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 

@@ -37,7 +37,9 @@ def rnd(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("M,K,N,act,bias", [
     (2016, 512, 256, 0, True), (300, 131, 128, 1, True), (64, 252, 778, 0, False), (8064, 64, 3, 0, True),
     (1000, 16, 64, 2, True), (37, 1024, 509, 0, True), (40000, 2, 128, 0, False), (33000, 42, 130, 2, True), (70000, 16, 64, 1, True), (32768, 64, 64, 1, False), (40000, 256, 128, 0, True), (5, 3, 3, 2, True),
-    (64, 4608, 1024, 0, False), (64, 1024, 1024, 0, True), (32, 1024, 512, 1, True)])       # few rows, long reduction: 32x32 tiles
+    # few output tiles under a long reduction: split-K (partials through the scratch ring + splitk_finish), odd widths included
+    (64, 4608, 1024, 0, False), (64, 1024, 1024, 0, True), (32, 1024, 512, 1, True), (192, 252, 778, 2, True), (2048, 2048, 128, 1, True),
+    (100, 777, 130, 0, True)])
 def test_linear(F, M, K, N, act, bias):
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3) if bias else None
     xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
