@@ -72,6 +72,11 @@ int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
 int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
                         int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
                         int stride, int pad, int OH, int OW, int lddy, void* stream);
+/* dx += ... (stride 1): accumulates into an existing gradient -- the autograd add of a two-consumer tensor (a ResNet block input:
+ * resnet.py:100-122, `out += identity`) done by the second producer's epilogue */
+int pdf_conv2d_bwd_data_add(const float* dy, const float* w, float* dx,
+                        int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                        int stride, int pad, int OH, int OW, int lddy, void* stream);
 int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                           int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                           int stride, int pad, int OH, int OW, int lddy, int accumulate, void* stream);
@@ -198,6 +203,19 @@ int pdf_sft_fwd(const float* fea, int ldf, const float* scale, int lds, const fl
                 float* out, int ldo, int C, long R, void* stream);
 int pdf_sft_bwd(const float* g, int ldg, const float* fea, int ldf, const float* scale, int lds,
                 float* dfea, int lddf, float* dscale, int ldds, int C, long R, void* stream);
+/* SFTLayer(3, 3) -- the four 3->3 point convolutions, the LeakyReLU(0.1) pair and the modulation of sft0
+ * (intaghand_encoder.py:120-122 calling :205-219) in one launch per direction.  Weights [3][3] row-major, biases [3].
+ * bwd: ws = 48*256 floats; parameter gradients (NULL = not wanted) are written, or added to when accumulate != 0. */
+int pdf_sft3_fwd(const float* fea, int ldf, const float* cond, int ldc, const float* w_scale0, const float* b_scale0,
+                 const float* w_scale1, const float* b_scale1, const float* w_shift0, const float* b_shift0,
+                 const float* w_shift1, const float* b_shift1, float* out, int ldo, long R, void* stream);
+int pdf_sft3_bwd(const float* g, int ldg, const float* fea, int ldf, const float* cond, int ldc,
+                 const float* w_scale0, const float* b_scale0, const float* w_scale1, const float* b_scale1,
+                 const float* w_shift0, const float* b_shift0, const float* w_shift1, const float* b_shift1,
+                 float* dfea, int lddf, float* dcond, int lddc,
+                 float* dw_scale0, float* db_scale0, float* dw_scale1, float* db_scale1,
+                 float* dw_shift0, float* db_shift0, float* dw_shift1, float* db_shift1, int accumulate,
+                 float* ws, long R, void* stream);
 /* nn.Dropout(p) with a stateless (seed, index) mask: the same call is its own backward (gcn.py:96, self_attn.py:51-52).
  * step: optional DEVICE counter mixed into the seed so a replayed hipGraph draws a fresh mask every step. */
 int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long seed, const unsigned long long* step, void* stream);

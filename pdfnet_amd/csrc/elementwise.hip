@@ -69,6 +69,134 @@ PDF_API int pdf_sft_bwd(const float* g, int ldg, const float* fea, int ldf, cons
     return 0;
 }
 
+// ---- SFTLayer(3, 3) as ONE kernel (sft0, intaghand_encoder.py:120-122 with :205-219): the four 3 -> 3 point convolutions,
+// the two LeakyReLU(0.1) and the modulation for one point per thread.  As separate launches the layer is 10 forward and
+// ~30 backward launches over 32 K x 3 floats (the 3 x 3 weight gradients alone took 47 us each).
+struct Sft3Params { const float* w[4]; const float* b[4]; };      // scale_conv0, scale_conv1, shift_conv0, shift_conv1: [3][3], [3]
+__device__ __forceinline__ void mat3(const float* __restrict__ w, const float* __restrict__ b, const float (&x)[3], float (&y)[3]) {
+#pragma unroll
+    for (int o = 0; o < 3; ++o) y[o] = fmaf(w[o * 3 + 2], x[2], fmaf(w[o * 3 + 1], x[1], fmaf(w[o * 3], x[0], b[o])));
+}
+__global__ __launch_bounds__(256) void sft3_fwd_kernel(const float* __restrict__ fea, int ldf, const float* __restrict__ cond, int ldc, const Sft3Params p,
+                                                        float* __restrict__ out, int ldo, long R) {
+    GRID_STRIDE(r, R) {
+        const float c[3] = {cond[r * ldc], cond[r * ldc + 1], cond[r * ldc + 2]};
+        float zs[3], zh[3], sc[3], sh[3];
+        mat3(p.w[0], p.b[0], c, zs);
+        mat3(p.w[2], p.b[2], c, zh);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { zs[i] = zs[i] > 0.f ? zs[i] : 0.1f * zs[i]; zh[i] = zh[i] > 0.f ? zh[i] : 0.1f * zh[i]; }
+        mat3(p.w[1], p.b[1], zs, sc);
+        mat3(p.w[3], p.b[3], zh, sh);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[r * ldo + i] = fea[r * ldf + i] * (sc[i] + 1.f) + sh[i];
+    }
+}
+PDF_API int pdf_sft3_fwd(const float* fea, int ldf, const float* cond, int ldc, const float* w_scale0, const float* b_scale0,
+                         const float* w_scale1, const float* b_scale1, const float* w_shift0, const float* b_shift0,
+                         const float* w_shift1, const float* b_shift1, float* out, int ldo, long R, hipStream_t s) {
+    if (R <= 0) return 0;
+    Sft3Params p = {{w_scale0, w_scale1, w_shift0, w_shift1}, {b_scale0, b_scale1, b_shift0, b_shift1}};
+    hipLaunchKernelGGL(sft3_fwd_kernel, dim3(grid_for(R)), dim3(256), 0, s, fea, ldf, cond, ldc, p, out, ldo, R);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// backward: dfea, dcond per point; the 48 parameter-gradient sums (per conv: dW [3][3] then db [3], in Sft3Params order) as
+// per-block partials part[block][48] (fixed order: lane tree, 4 waves), summed by sft3_bwd_finish in block order.
+#define SFT3_BLOCKS 256
+__global__ __launch_bounds__(256) void sft3_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ fea, int ldf,
+                                                        const float* __restrict__ cond, int ldc, const Sft3Params p,
+                                                        float* __restrict__ dfea, int lddf, float* __restrict__ dcond, int lddc,
+                                                        float* __restrict__ part, long R) {
+    __shared__ float red[4][48];
+    float acc[48];
+#pragma unroll
+    for (int i = 0; i < 48; ++i) acc[i] = 0.f;
+    GRID_STRIDE(r, R) {
+        const float c[3] = {cond[r * ldc], cond[r * ldc + 1], cond[r * ldc + 2]};
+        const float gv[3] = {g[r * ldg], g[r * ldg + 1], g[r * ldg + 2]};
+        const float f[3] = {fea[r * ldf], fea[r * ldf + 1], fea[r * ldf + 2]};
+        float z[2][3], h[2][3], sc[3], dc[3] = {0.f, 0.f, 0.f};
+        mat3(p.w[0], p.b[0], c, z[0]);
+        mat3(p.w[2], p.b[2], c, z[1]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { h[0][i] = z[0][i] > 0.f ? z[0][i] : 0.1f * z[0][i]; h[1][i] = z[1][i] > 0.f ? z[1][i] : 0.1f * z[1][i]; }
+        mat3(p.w[1], p.b[1], h[0], sc);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dfea[r * lddf + i] = gv[i] * (sc[i] + 1.f);
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {                     // 0: scale branch (d scale = g * fea), 1: shift branch (d shift = g)
+            float d1[3], dz[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) d1[i] = br == 0 ? gv[i] * f[i] : gv[i];
+            float* a1 = acc + (br * 2 + 1) * 12;             // conv1 of this branch
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a1[o * 3 + k] += d1[o] * h[br][k];
+                a1[9 + o] += d1[o];
+            }
+            const float* w1 = p.w[br * 2 + 1];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float dh = w1[k] * d1[0] + w1[3 + k] * d1[1] + w1[6 + k] * d1[2];
+                dz[k] = z[br][k] > 0.f ? dh : 0.1f * dh;
+            }
+            float* a0 = acc + (br * 2) * 12;                 // conv0 of this branch
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a0[o * 3 + k] += dz[o] * c[k];
+                a0[9 + o] += dz[o];
+            }
+            const float* w0 = p.w[br * 2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dc[k] += w0[k] * dz[0] + w0[3 + k] * dz[1] + w0[6 + k] * dz[2];
+        }
+        if (dcond != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dcond[r * lddc + k] = dc[k];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 48) part[blockIdx.x * 48 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+struct Sft3Grads { float* w[4]; float* b[4]; };
+__global__ void sft3_bwd_finish(const float* __restrict__ part, int nblk, const Sft3Grads d, int accumulate) {
+    const int i = threadIdx.x;
+    if (i >= 48) return;
+    float v = 0.f;
+    for (int b = 0; b < nblk; ++b) v += part[b * 48 + i];
+    const int conv = i / 12, e = i - conv * 12;
+    float* base = e < 9 ? d.w[conv] : d.b[conv];
+    if (base != nullptr) { float* o = base + (e < 9 ? e : e - 9); *o = accumulate ? *o + v : v; }
+}
+// ws: 48 * 256 floats.  d*: the eight parameter gradients (any may be NULL), += when accumulate.  dcond may be NULL.
+PDF_API int pdf_sft3_bwd(const float* g, int ldg, const float* fea, int ldf, const float* cond, int ldc,
+                         const float* w_scale0, const float* b_scale0, const float* w_scale1, const float* b_scale1,
+                         const float* w_shift0, const float* b_shift0, const float* w_shift1, const float* b_shift1,
+                         float* dfea, int lddf, float* dcond, int lddc,
+                         float* dw_scale0, float* db_scale0, float* dw_scale1, float* db_scale1,
+                         float* dw_shift0, float* db_shift0, float* dw_shift1, float* db_shift1, int accumulate,
+                         float* ws, long R, hipStream_t s) {
+    if (R <= 0) return 0;
+    Sft3Params p = {{w_scale0, w_scale1, w_shift0, w_shift1}, {b_scale0, b_scale1, b_shift0, b_shift1}};
+    Sft3Grads d = {{dw_scale0, dw_scale1, dw_shift0, dw_shift1}, {db_scale0, db_scale1, db_shift0, db_shift1}};
+    const int nblk = (int)min((long)SFT3_BLOCKS, (R + 255) / 256);
+    hipLaunchKernelGGL(sft3_bwd_kernel, dim3(nblk), dim3(256), 0, s, g, ldg, fea, ldf, cond, ldc, p, dfea, lddf, dcond, lddc, ws, R);
+    hipLaunchKernelGGL(sft3_bwd_finish, dim3(1), dim3(64), 0, s, ws, nblk, d, accumulate);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
 // dropout with a stateless mask: keep iff u(seed, i) >= p ; y = x * keep / (1-p).  Same call serves
 // forward and backward (the mask is a pure function of seed and element index).
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p, unsigned long long seed,

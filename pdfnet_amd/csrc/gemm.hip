@@ -235,6 +235,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
                         int oy = qy * g.osy + g.ooy + padd_y, ox = qx * g.osx + g.oox + padd_x;
                         o = (((long)ni * g.OH + oy) * g.OW + ox) * g.ldc + co;
                     }
+                    if (g.accum) v += Cp[o];
                     Cp[o] = v;
                 }
             }
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
                     float v = acc[i][j][r] + bv;
                     if (g.act == 1) v = fmaxf(v, 0.f);
                     else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+                    if (g.accum) v += Cp[(long)row * g.ldc + col];
                     Cp[(long)row * g.ldc + col] = v;
                 }
             }
@@ -855,7 +857,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
     if (g.b_kn) fast = fast && (g.N % 4 == 0) && (g.btap % 4 == 0);
     if (groups > 1) fast = fast && aligned16(g.B1) && (g.gsA % 4 == 0);
-    if (!fast && groups == 1 && (!g.b_kn || (g.T == 1 && g.wt[0] == 0)) && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
+    if (!fast && groups == 1 && !g.accum && (!g.b_kn || (g.T == 1 && g.wt[0] == 0)) && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
         (long)g.M * g.N >= (1L << 20)) {
         dim3 grid(grid_for((long)g.M * ((min(g.N, 256) + 3) / 4)), cdiv(g.N, 256));
         hipLaunchKernelGGL(small_k_gemm, grid, dim3(256), 0, s, g);
@@ -872,7 +874,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     // up-projections): a handful of CUs would walk K step by step at load latency.  Split K over blockIdx.z so that ~320 blocks
     // run, partial tiles through the scratch ring, bias / activation in splitk_finish.
     const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
-    if (groups == 1 && g.T == 1 && g.plain_in && g.plain_out && g.ps_cout == 0 && t64 <= 128 && g.K >= 512 && env_int(ENV_IG_SPLITK, 1)) {
+    if (groups == 1 && g.T == 1 && g.plain_in && g.plain_out && g.ps_cout == 0 && !g.accum && t64 <= 128 && g.K >= 512 && env_int(ENV_IG_SPLITK, 1)) {
         const bool bk32 = fast && g.Cin % 32 == 0;
         const int bk = bk32 ? 32 : 16, nk = cdiv(g.K, bk);
         int splits = (int)min((long)cdiv(320, (int)t64), (long)(g.K / 128));
@@ -1134,10 +1136,11 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
 // Conv2d backward-data: dx[N,H,W,Cin] from dy[N,OH,OW,Cout] and the FORWARD weight w = [Cout][KH][KW][Cin], read as
 // the [K = (tap, co)][N = ci] operand it is.  One launch per input-parity class so a stride-s conv
 // never multiplies zeros.  dx must be zero-filled by the caller when stride > kernel (1x1 s2).
-PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
-                                int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
-                                int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
+static int conv2d_bwd_data(const float* dy, const float* w, float* dx,
+                           int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                           int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    if (accumulate && stride > 1) return PDF_E_BADARG;       // (every dx element must be written by exactly one launch)
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {
             IGemm g = {};
@@ -1147,7 +1150,7 @@ PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
             g.QH = (H - py + stride - 1) / stride; g.QW = (W - px + stride - 1) / stride;
             if (g.QH <= 0 || g.QW <= 0) continue;
             g.M = N * g.QH * g.QW;
-            g.sy = 1; g.sx = 1;
+            g.sy = 1; g.sx = 1; g.accum = accumulate;
             // input row iy = qy*stride + py; contributing taps: (iy + pad - ky) % stride == 0, oy = (iy+pad-ky)/stride
             int T = 0;
             for (int ky = 0; ky < KH; ++ky) {
@@ -1171,6 +1174,19 @@ PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
             if (rc) return rc;
         }
     return 0;
+}
+
+PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
+                                int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
+    return conv2d_bwd_data(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, 0, s);
+}
+// dx += the same (stride 1): the gradient of a tensor with two consumers -- a ResNet block input feeds conv1 and the shortcut --
+// is accumulated by the second producer's epilogue instead of a separate add pass over both gradients
+PDF_API int pdf_conv2d_bwd_data_add(const float* dy, const float* w, float* dx,
+                                    int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                    int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
+    return conv2d_bwd_data(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, 1, s);
 }
 
 // out1 != nullptr: paired launch (see WGemm::gsP); ws then holds both groups' slabs

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
                         const int oy = qy * g.osy + g.ooy + padd_y, ox = qx * g.osx + g.oox + padd_x;
                         o = (((long)ni * g.OH + oy) * g.OW + ox) * g.ldc + co;
                     }
+                    if (g.accum) v += Cp[o];
                     Cp[o] = v;
                 }
             }

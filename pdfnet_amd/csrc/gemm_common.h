@@ -23,6 +23,7 @@ struct IGemm {
     // split-K (blockIdx.z = split): K-steps [z*ksteps, (z+1)*ksteps) of this launch's BK, raw partial sums to
     // part[z][M][N] (no bias / activation -- splitk_finish applies them).  ksteps == 0: no split.
     int ksteps; float* part;
+    int accum;                                // C += result (after bias / activation): a gradient accumulated into an existing one
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 

@@ -276,10 +276,15 @@ def _act_bwd(dy, y, act):
 
 # ----------------------------------------------------------------------------------------------
 class _Conv2d(Function):
+    """skip=True: also returns the input as a second output (the identity shortcut of a ResNet block).  The two gradients of
+    the block input then meet in THIS backward, where the backward-data GEMM adds its result onto the shortcut's gradient in
+    its epilogue (pdf_conv2d_bwd_data_add) -- instead of autograd's separate add pass over both tensors."""
+
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act):
+    def forward(ctx, x, w, b, stride, pad, act, skip=False):
         hip.require_gpu(x, w)
         w_in = w
+        x_in = x
         x, w = cl(x), cl(w)
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = w.shape
@@ -290,10 +295,12 @@ class _Conv2d(Function):
         ctx.save_for_backward(x, w, y if act else None)
         ctx.cfg = (stride, pad, act, b is not None)
         ctx.params = (w_in, b)
+        if skip:
+            return y, x_in.view_as(x_in)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, w, y = ctx.saved_tensors
         stride, pad, act, has_b = ctx.cfg
         N, Cin, H, W = x.shape
@@ -305,11 +312,14 @@ class _Conv2d(Function):
         dx = dw = db = None
         L = _L()
         if ctx.needs_input_grad[0]:
-            if stride > KH:
-                dx = torch.zeros_like(x)
+            if dskip is not None and stride == 1 and dskip.shape == x.shape and dskip.is_contiguous(memory_format=CL):
+                dx = dskip                                  # the shortcut's gradient (sole consumer: this node); += in the epilogue
+                L.pdf_conv2d_bwd_data_add(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
             else:
-                dx = torch.empty_like(x)
-            L.pdf_conv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+                dx = torch.zeros_like(x) if stride > KH else torch.empty_like(x)
+                L.pdf_conv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+                if dskip is not None:
+                    dx = dx + dskip
         w_par, b_par = ctx.params
         R = N * OH * OW
 
@@ -318,11 +328,16 @@ class _Conv2d(Function):
             L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
                                     stride, pad, OH, OW, Cout, acc, stream())
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE):
     return _Conv2d.apply(x, w, b, stride, pad, act)
+
+
+def conv2d_with_skip(x, w, b=None, stride=1, pad=0, act=ACT_NONE):
+    """-> (conv2d(x), x): use the second output as the block's identity shortcut (see _Conv2d)."""
+    return _Conv2d.apply(x, w, b, stride, pad, act, True)
 
 
 class _Deconv2d(Function):
@@ -669,6 +684,54 @@ def l2norm(x, w, eps=1e-10):
     return _L2Norm.apply(x, w, eps)
 
 
+class _L2NormCat(Function):
+    """torch.cat([l2norm(x_i, w_i)], 1) without the concatenation pass: every L2Norm writes its channels straight into the
+    concatenated NHWC buffer (row stride = the total channel count), and the backward reads its channel slice of the incoming
+    gradient in place (no slice copies).  The pyramid of intaghand_encoder.py:724-739."""
+
+    @staticmethod
+    def forward(ctx, eps, *args):
+        n = len(args) // 2
+        xs, ws = [cl(x) for x in args[:n]], list(args[n:])
+        hip.require_gpu(*xs)
+        B, _, H, W = xs[0].shape
+        if any(x.shape[0] != B or x.shape[2:] != xs[0].shape[2:] for x in xs):
+            raise ValueError("pdfnet_amd: l2norm_cat wants maps of one batch and resolution")
+        Cs = [x.shape[1] for x in xs]
+        Ct, R = sum(Cs), B * H * W
+        out = torch.empty((B, Ct, H, W), dtype=torch.float32, device=xs[0].device, memory_format=CL)
+        norms, off = [], 0
+        for x, w, C in zip(xs, ws, Cs):
+            norm = torch.empty(R, device=x.device)
+            _L().pdf_l2norm_fwd(ptr(x), C, C, R, ptr(w), eps, hip.ptr_at(out, off), Ct, ptr(norm), stream())
+            norms.append(norm)
+            off += C
+        ctx.save_for_backward(*xs, *ws, *norms)
+        ctx.cfg = (eps, n, Cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        eps, n, Cs = ctx.cfg
+        t = ctx.saved_tensors
+        xs, ws, norms = t[:n], t[n:2 * n], t[2 * n:]
+        g = cl(dy)
+        Ct = sum(Cs)
+        dxs, dws, off = [], [], 0
+        for x, w, norm, C in zip(xs, ws, norms, Cs):
+            R = x.numel() // C
+            dx, dw = torch.empty_like(x), torch.zeros_like(w)
+            _L().pdf_l2norm_bwd(hip.ptr_at(g, off), Ct, ptr(x), C, C, R, ptr(w), eps, ptr(norm), ptr(dx), C, ptr(dw), stream())
+            dxs.append(dx)
+            dws.append(dw)
+            off += C
+        return (None,) + tuple(dxs) + tuple(dws)
+
+
+def l2norm_cat(xs, ws, eps=1e-10):
+    return _L2NormCat.apply(eps, *xs, *ws)
+
+
 class _LayerNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -873,6 +936,49 @@ class _SFTModulate(Function):
 
 def sft_modulate(fea, scale, shift):
     return _SFTModulate.apply(fea, scale, shift)
+
+
+class _SFT3(Function):
+    """SFTLayer(3, 3) in one launch per direction (pdf_sft3_fwd / pdf_sft3_bwd): fea, cond [..., 3]; params = the layer's
+    (weight [3,3,1,1], bias [3]) pairs in the order scale_conv0, scale_conv1, shift_conv0, shift_conv1."""
+
+    @staticmethod
+    def forward(ctx, fea, cond, *params):
+        hip.require_gpu(fea, cond)
+        fea, cond = fea.contiguous(), cond.contiguous()
+        if fea.shape[-1] != 3 or cond.shape[-1] != 3 or len(params) != 8:
+            raise ValueError("pdfnet_amd: sft3 wants 3-channel rows and four (weight, bias) pairs")
+        pc = [p.contiguous() for p in params]
+        R = fea.numel() // 3
+        out = torch.empty_like(fea)
+        _L().pdf_sft3_fwd(ptr(fea), 3, ptr(cond), 3, *[ptr(p) for p in pc], ptr(out), 3, R, stream())
+        ctx.save_for_backward(fea, cond, *pc)
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fea, cond = ctx.saved_tensors[:2]
+        pc = ctx.saved_tensors[2:]
+        g = g.contiguous()
+        R = fea.numel() // 3
+        dfea = torch.empty_like(fea)
+        dcond = torch.empty_like(cond) if ctx.needs_input_grad[1] else None
+        ws = _ws(48 * 256, g.device)
+        mg = [_main_grad(p, p) if ctx.needs_input_grad[2 + i] else None for i, p in enumerate(ctx.params)]
+        direct = all(m is not None for m in mg)
+        if direct:                                             # straight into the trainer's flat gradient buffer
+            outs, ret = mg, [None] * 8
+        else:
+            outs = [torch.empty_like(p) if ctx.needs_input_grad[2 + i] else None for i, p in enumerate(pc)]
+            ret = outs
+        _L().pdf_sft3_bwd(ptr(g), 3, ptr(fea), 3, ptr(cond), 3, *[ptr(p) for p in pc], ptr(dfea), 3, ptr(dcond), 3,
+                          *[ptr(o) for o in outs], 1 if direct else 0, ptr(ws), R, stream())
+        return (dfea, dcond) + tuple(ret)
+
+
+def sft3(fea, cond, params):
+    return _SFT3.apply(fea, cond, *params)
 
 
 class _GatherRows(Function):

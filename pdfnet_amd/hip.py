@@ -87,6 +87,11 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def ptr_at(t, elements):
+    """Device pointer `elements` elements into `t` (a channel offset inside an NHWC row)."""
+    return ctypes.c_void_p(t.data_ptr() + elements * t.element_size())
+
+
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

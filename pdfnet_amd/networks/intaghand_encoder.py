@@ -32,10 +32,17 @@ class Bottleneck(nn.Module):
             self.downsample = nn.Sequential(Conv2d(cin, width * 4, 1, stride, 0, bias=False), BatchNorm(width * 4))
 
     def forward(self, x):
-        y = self.bn1(self.conv1(x), relu=True)
+        if self.downsample is None and x.requires_grad:
+            # identity block: conv1 hands the input back as the shortcut so both gradients of x meet in conv1's backward,
+            # which accumulates onto the shortcut's gradient in the GEMM epilogue (no separate add pass)
+            y, sc = F.conv2d_with_skip(x, self.conv1.weight, None, 1, 0)
+        else:
+            y, sc = self.conv1(x), x
+        y = self.bn1(y, relu=True)
         y = self.bn2(self.conv2(y), relu=True)
         y = self.conv3(y)
-        sc = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        if self.downsample is not None:
+            sc = self.downsample[1](self.downsample[0](x))
         return self.bn3(y, relu=True, res=sc)          # relu(bn3(y) + shortcut) in one pass
 
 
@@ -77,8 +84,14 @@ class SFTLayer(nn.Module):
         self.SFT_shift_conv1 = PointConv(c_cond, c_fea)
 
     def forward(self, fea, cond):
-        scale = self.SFT_scale_conv1(self.SFT_scale_conv0(cond, F.ACT_LRELU))
-        shift = self.SFT_shift_conv1(self.SFT_shift_conv0(cond, F.ACT_LRELU))
+        if fea.shape[-1] == 3 and cond.shape[-1] == 3:           # sft0: one kernel per direction for the whole layer
+            convs = (self.SFT_scale_conv0, self.SFT_scale_conv1, self.SFT_shift_conv0, self.SFT_shift_conv1)
+            return F.sft3(fea, cond, [t for c in convs for t in (c.weight, c.bias)])
+        # fea may arrive zero-padded to a multiple of 16 channels: scale / shift are produced at that width (zero in the padding,
+        # so the padding stays zero) and every GEMM of the layer keeps 16-byte aligned rows
+        npad = fea.shape[-1]
+        scale = self.SFT_scale_conv1(self.SFT_scale_conv0(cond, F.ACT_LRELU), npad=npad)
+        shift = self.SFT_shift_conv1(self.SFT_shift_conv0(cond, F.ACT_LRELU), npad=npad)
         return F.sft_modulate(fea, scale, shift)
 
 
@@ -141,9 +154,9 @@ class PointNet_Plus(nn.Module):
         y1 = self._group_conv(self.netR_1[0], torch.nn.functional.pad(pts, (0, _pad16(3) - 3)), S1, K, o.ball_radius)   # (:123,:49)
         x = self._mlp_max(self.netR_1, y1, K)                                               # [B*S1,128]   (:132)
         e1 = F.gather_rows(emb1, choose[:, :S1], R, 1)                                     # [B,S1,64]    (:125-127)
-        x = torch.cat((pts[:, :S1], x.view(B, S1, 128)), 2)                                # [B,S1,131]   (:134)
+        x = torch.cat((pts[:, :S1], x.view(B, S1, 128), x.new_zeros(B, S1, _pad16(131) - 131)), 2)   # [B,S1,131 | 0]   (:134)
         x = self.sft1(x, e1)                                                               #              (:137)
-        y1 = self._group_conv(self.netR_2[0], torch.nn.functional.pad(x, (0, _pad16(131) - 131)), S2, K, o.ball_radius2)   # (:139,:68)
+        y1 = self._group_conv(self.netR_2[0], x, S2, K, o.ball_radius2)                    # (:139,:68)
         y = self._mlp_max(self.netR_2, y1, K)                                               # [B*S2,256]
         return x, y
 
@@ -153,9 +166,8 @@ class PointNet_Plus(nn.Module):
         R, S2 = o.default_resolution, o.sample_num_level2
         B = x.shape[0]
         e2 = F.gather_rows(emb2, choose[:, :S2], R, 2)                                     # [B,S2,256]   (:126,128)
-        y = torch.cat((x[:, :S2, :3], y.view(B, S2, 256)), 2)                              # [B,S2,259]
+        y = torch.cat((x[:, :S2, :3], y.view(B, S2, 256), y.new_zeros(B, S2, _pad16(259) - 259)), 2)   # [B,S2,259 | 0]
         y = self.sft2(y, e2)                                                               #              (:147)
-        y = torch.nn.functional.pad(y, (0, _pad16(259) - 259))
         y = self._mlp_max(self.netR_3, self.netR_3[0](y), S2)                               # [B,1024]     (:152)
         return y.view(B, 1, 1024)
 
@@ -267,7 +279,8 @@ class ResNetSimple(nn.Module):
         x3 = r.layer2(x4)
         x2 = r.layer3(x3)
         x1 = r.layer4(x2)
-        pyr = torch.cat([self.p2_l2(self.p2(x4)), self.p3_l2(self.p3(x3)), self.p4_l2(self.p4(x2)), self.p5_l2(self.p5(x1))], 1)
+        pyr = F.l2norm_cat([self.p2(x4), self.p3(x3), self.p4(x2), self.p5(x1)],         # NHWC channel concat, written in place
+                           [self.p2_l2.weight, self.p3_l2.weight, self.p4_l2.weight, self.p5_l2.weight])
         return self.feat_bn(self.feat(pyr), relu=True), emb0, x1                          # :740-744
 
     def trunk(self, img, ind, choose, cloud, depth=None, K_new=None, valid=None):
@@ -291,8 +304,8 @@ class ResNetSimple(nn.Module):
             cb = self.on_trunk_output_grad
             x1.register_hook(lambda g: cb())
         st = {'x1': x1, 'ret': {}}
-        pyr = torch.cat([self.p2_l2(self.p2(x4)), self.p3_l2(self.p3(x3)),
-                         self.p4_l2(self.p4(x2)), self.p5_l2(self.p5(x1))], 1)            # NHWC channel concat
+        pyr = F.l2norm_cat([self.p2(x4), self.p3(x3), self.p4(x2), self.p5(x1)],         # NHWC channel concat, written in place
+                           [self.p2_l2.weight, self.p3_l2.weight, self.p4_l2.weight, self.p5_l2.weight])
         x0 = self.feat_bn(self.feat(pyr), relu=True)                                      # :740-744
         st['x0'] = x0
         hm_fc = self.hm

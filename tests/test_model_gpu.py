@@ -431,7 +431,9 @@ def test_demo_asset_pair_config1_on_the_gpu():
     assert np.array_equal(res[3]['ind'].cpu().numpy(), g["pred_ind"])
     check_packed(pack_demo(res), g, abs_tol=1e-4, rel_tol=1e-5)
     mask = res[3]['mask']
-    assert [(mask[0, c] > 0.5).sum().item() for c in range(2)] == g["mask_pos_count"].tolist()
+    for c in range(2):                  # the count of mask > 0.5, up to the pixels that sit within the 1e-4 tolerance of the threshold
+        lo, hi = (mask[0, c] > 0.5 + 1e-4).sum().item(), (mask[0, c] > 0.5 - 1e-4).sum().item()
+        assert lo <= int(g["mask_pos_count"][c]) <= hi, (c, lo, hi, int(g["mask_pos_count"][c]))
     # (b) the GPU front end
     from pdfnet_amd import functional as F
     F.manual_seed(317)

@@ -393,6 +393,64 @@ def _ell(D):
     return col, val
 
 
+def test_sft3_layer_in_one_kernel_equals_the_four_convs(F):
+    """SFTLayer(3, 3) (sft0, reference intaghand_encoder.py:205-219): fused kernel vs the layer written out in torch --
+    output, d fea, d cond and the eight parameter gradients."""
+    R = 5000
+    fea, cond, gy = rnd(2, R // 2, 3, seed=1), rnd(2, R // 2, 3, seed=2), rnd(2, R // 2, 3, seed=3)
+    params = [rnd(3, 3, 1, 1, seed=10 + i, scale=0.6) if i % 2 == 0 else rnd(3, seed=10 + i, scale=0.3) for i in range(8)]
+    fr, cr = fea.clone().requires_grad_(), cond.clone().requires_grad_()
+    pr = [p.clone().requires_grad_() for p in params]
+
+    def conv(x, w, b):
+        return x @ w.flatten(1).t() + b
+    scale = conv(TF.leaky_relu(conv(cr, pr[0], pr[1]), 0.1), pr[2], pr[3])
+    shift = conv(TF.leaky_relu(conv(cr, pr[4], pr[5]), 0.1), pr[6], pr[7])
+    ref = fr * (scale + 1) + shift
+    ref.backward(gy)
+    fd, cd = dev(fea).requires_grad_(), dev(cond).requires_grad_()
+    pd = [dev(p).requires_grad_() for p in params]
+    out = F.sft3(fd, cd, pd)
+    out.backward(dev(gy))
+    close(out, ref, 2e-6, what="sft3 fwd")
+    close(fd.grad, fr.grad, 2e-6, what="sft3 dfea")
+    close(cd.grad, cr.grad, 5e-6, what="sft3 dcond")
+    for i, (a, b) in enumerate(zip(pd, pr)):
+        close(a.grad, b.grad, 2e-4, rtol=2e-5, what="sft3 dparam %d" % i)
+
+
+def test_conv_with_skip_accumulates_the_shortcut_gradient_in_the_epilogue(F):
+    """ResNet identity block input: conv1's backward-data adds onto the shortcut's gradient (pdf_conv2d_bwd_data_add) -- same dx
+    and dw as the plain graph, with a channels_last shortcut gradient (in place) and a strided one (fallback add)."""
+    x, w = rnd(3, 64, 12, 10, seed=1), rnd(32, 64, 1, 1, seed=2, scale=0.1)
+    a = rnd(3, 32, 12, 10, seed=3)
+    for b in (rnd(3, 64, 12, 10, seed=4).contiguous(memory_format=torch.channels_last), rnd(3, 64, 12, 10, seed=5)):
+        xr, wr = dev(x).requires_grad_(), dev(w).requires_grad_()
+        ((F.conv2d(xr, wr) * dev(a)).sum() + (xr * dev(b)).sum()).backward()
+        xd, wd = dev(x).requires_grad_(), dev(w).requires_grad_()
+        y, sc = F.conv2d_with_skip(xd, wd)
+        ((y * dev(a)).sum() + (sc * dev(b)).sum()).backward()
+        close(xd.grad, xr.grad, 1e-6, what="skip dx")
+        close(wd.grad, wr.grad, 1e-6, what="skip dw")
+
+
+def test_l2norm_cat_writes_the_pyramid_in_place(F):
+    """F.l2norm_cat == torch.cat([F.l2norm(x_i, w_i)], 1), forward and all gradients."""
+    Cs = (16, 32, 8, 24)
+    xs = [rnd(2, C, 6, 5, seed=10 + i) for i, C in enumerate(Cs)]
+    ws = [rnd(C, seed=20 + i).abs() + 0.5 for i, C in enumerate(Cs)]
+    gy = rnd(2, sum(Cs), 6, 5, seed=30)
+    a = [dev(x).requires_grad_() for x in xs] + [dev(w).requires_grad_() for w in ws]
+    b = [dev(x).requires_grad_() for x in xs] + [dev(w).requires_grad_() for w in ws]
+    ref = torch.cat([F.l2norm(x, w) for x, w in zip(a[:4], a[4:])], 1)
+    ref.backward(dev(gy))
+    out = F.l2norm_cat(b[:4], b[4:])
+    out.backward(dev(gy))
+    close(out, ref, 0.0, rtol=0.0, what="l2norm_cat fwd")
+    for u, v in zip(b, a):
+        close(u.grad, v.grad, 1e-6, what="l2norm_cat grad")
+
+
 def test_cheby_attention(F):
     from oracle import pdfnet_cpu as O
     Ls = O.load_graph_constants()['L_right']

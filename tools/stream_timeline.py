@@ -52,3 +52,51 @@ for t, d in ev:
     lvl += d
 nog += t1 - last
 print("time with no GEMM kernel resident: %.2f ms of %.2f" % (nog / 1e6, (t1 - t0) / 1e6))
+
+# ---- the busiest stream's idle gaps: where the dependent chain waits (for a forked branch, the weight-gradient stream, the host)
+main = max(per.items(), key=lambda kv: kv[1][0])[0]
+mk = [k for k in step if k[3] == main]
+others = [k for k in step if k[3] != main]
+gaps = []
+for a, b in zip(mk, mk[1:]):
+    if b[0] - a[1] >= 20000:
+        busy = sum(max(0, min(o[1], b[0]) - max(o[0], a[1])) for o in others)
+        gaps.append((b[0] - a[1], (a[1] - t0) / 1e6, a[2][:40], b[2][:40], busy / (b[0] - a[1])))
+print("stream %s idle gaps >= 20 us: %d, total %.2f ms (all gaps %.2f ms)" % (main, len(gaps), sum(g[0] for g in gaps) / 1e6,
+      sum(b[0] - a[1] for a, b in zip(mk, mk[1:]) if b[0] > a[1]) / 1e6))
+for g in sorted(gaps, reverse=True)[:25]:
+    print("  at %6.2f ms  gap %7.1f us  other streams busy x%.2f   after %-40s before %s" % (g[1], g[0] / 1e3, g[4], g[2], g[3]))
+# 4 ms buckets: busy fraction of the main stream and of everything else
+nb = int((t1 - t0) / 4e6) + 1
+bm, bo = [0] * nb, [0] * nb
+for s, e, n, q in step:
+    tgt = bm if q == main else bo
+    b = int((s - t0) / 4e6)
+    while s < e:
+        end = min(e, t0 + (b + 1) * 4000000)
+        tgt[b] += end - s
+        s = end
+        b += 1
+print("4 ms buckets, main stream busy: " + ' '.join("%.2f" % (v / 4e6) for v in bm))
+print("4 ms buckets, other streams  : " + ' '.join("%.2f" % (v / 4e6) for v in bo))
+# small side streams kernel by kernel (forked branches: what the main stream's joins wait for)
+for q, (b, c, cc) in sorted(per.items(), key=lambda kv: -kv[1][0]):
+    if q == main or c > 70:
+        continue
+    print("stream %s:" % q)
+    for s, e, n, qq in step:
+        if qq == q and e - s >= 30000:
+            print("   at %6.2f ms  %8.1f us  %s" % ((s - t0) / 1e6, (e - s) / 1e3, n[:100]))
+# aten kernels on the main stream (glue the library could absorb), by kernel name
+ac = collections.defaultdict(lambda: [0, 0])
+for s, e, n, q in mk:
+    if cls(n) == 'aten' or 'rocclr' in n:
+        key = re.sub(r'\s+', ' ', n)[:150]
+        ac[key][0] += 1; ac[key][1] += e - s
+print("aten / runtime-copy kernels on stream %s: %d launches, %.2f ms" % (main, sum(v[0] for v in ac.values()), sum(v[1] for v in ac.values()) / 1e6))
+for k, v in sorted(ac.items(), key=lambda kv: -kv[1][1])[:14]:
+    print("  %4d  %7.3f ms  %s" % (v[0], v[1] / 1e6, k))
+# the largest of them one by one
+big = sorted(((e - s, (s - t0) / 1e6, n) for s, e, n, q in mk if (cls(n) == 'aten' or 'rocclr' in n) and e - s >= 40000), reverse=True)
+for d, at, n in big[:40]:
+    print("     at %6.2f ms  %7.1f us  %s" % (at, d / 1e3, re.sub(r'\s+', ' ', n)[:110]))
