@@ -78,8 +78,17 @@ def lib():
     return _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
-    """hipStream_t of torch's current stream (launches are captured when that stream is capturing)."""
+    """hipStream_t of torch's current stream (launches are captured when that stream is capturing).
+    Called once per kernel launch (~2,000 times a step): the raw-handle query costs ~0.3 us where
+    `torch.cuda.current_stream()` builds a Stream object through the device-index helpers (~9 us, a fifth of the step's
+    host time)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -25,7 +25,8 @@ class HandNET_GCN(nn.Module):
         img_fmaps, ind = st['img_fmaps'], st['ind']
         # The dense branches are issued BEFORE the launch-bound mesh decoder.  Issuing them after it (so that their heavy
         # convolutions overlap the decoder's small kernels in forward and backward) was measured: 267-272 vs 314 img/s in
-        # one session -- the big kernels starve the critical decoder -> PointNet++ -> trunk backward chain.
+        # one session -- the big kernels starve the critical decoder -> PointNet++ -> trunk backward chain.  Round 2 re-measured it
+        # with the branches waiting on a post-trunk event only: 388 vs 407 img/s; with the decoder on a high-priority stream: 283.
         hms, mask, ret, hms_fmaps, dp_fmaps = self.encoder.dense_branches(st)
         gl, gr = img_fmaps[0][:, 0], img_fmaps[0][:, 1]                 # what mid_model hands on (intaghand_encoder.py:881)
         result, paramsDict, handDictList, otherInfo = self.decoder(gl, gr)
