@@ -757,10 +757,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1257,8 +1257,9 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);
     } else {
         const int dma = env_int(ENV_WG_DMA, 3);
-        if (fast && dma == 4) hipLaunchKernelGGL(wgemm_tn_dma<4>, grid, dim3(256), 0, s, g);
-        else if (fast && dma == 3) hipLaunchKernelGGL(wgemm_tn_dma<3>, grid, dim3(256), 0, s, g);
+        const int pad = env_int(ENV_WG_LDSPAD, 0) * 1024;
+        if (fast && dma == 4) hipLaunchKernelGGL(wgemm_tn_dma<4>, grid, dim3(256), pad, s, g);
+        else if (fast && dma == 3) hipLaunchKernelGGL(wgemm_tn_dma<3>, grid, dim3(256), pad, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, false>), grid, dim3(256), 0, s, g);
     }

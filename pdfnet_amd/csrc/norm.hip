@@ -979,3 +979,111 @@ PDF_API int pdf_l2norm_bwd(const float* dy, int lddy, const float* x, int ldx, i
     PDF_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- the pyramid form (intaghand_encoder.py:724-739): up to 4 maps L2-normalised into / out of ONE concatenated NHWC buffer
+// in ONE launch (blockIdx.y = part).  One launch per part reads a 1 KB slice of every 4 KB row of the concatenated gradient,
+// i.e. a quarter of the HBM channels at a time: measured 529 us per part against 87 us on contiguous rows.
+#define L2_MAXPARTS 4
+struct L2Parts {
+    const float* x[L2_MAXPARTS]; const float* w[L2_MAXPARTS]; float* norm[L2_MAXPARTS]; float* dx[L2_MAXPARTS]; float* dw[L2_MAXPARTS];
+    int C[L2_MAXPARTS], off[L2_MAXPARTS];
+};
+__global__ __launch_bounds__(256) void l2norm_cat_fwd_kernel(const L2Parts p, long R, float eps, float* __restrict__ y, int ldy) {
+    const int part = blockIdx.y, C = p.C[part], lane = threadIdx.x & 63;
+    const float* __restrict__ x = p.x[part]; const float* __restrict__ w = p.w[part];
+    float* __restrict__ yo = y + p.off[part];
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = w0; r < R; r += nw) {
+        float sq = 0.f;
+        for (int c = lane; c < C; c += 64) { float v = x[r * C + c]; sq += v * v; }
+        const float n = sqrtf(wave_sum(sq)) + eps;
+        for (int c = lane; c < C; c += 64) yo[r * ldy + c] = w[c] * (x[r * C + c] / n);
+        if (lane == 0) p.norm[part][r] = n;
+    }
+}
+__global__ __launch_bounds__(256) void l2norm_cat_bwd_kernel(const L2Parts p, int nparts, long R, float eps, const float* __restrict__ dy, int lddy) {
+    // one wave per pixel, the parts one after the other: the wave walks its whole concatenated gradient row (a launch or a
+    // block per part reads 1 KB out of every 4 KB row -- measured 6x slower than contiguous rows)
+    __shared__ float sw[L2_MAXPARTS][64 * L2_MAXV];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < L2_MAXPARTS * 64 * L2_MAXV; i += 256) (&sw[0][0])[i] = 0.f;
+    __syncthreads();
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    float acc[L2_MAXPARTS][L2_MAXV];
+#pragma unroll
+    for (int q = 0; q < L2_MAXPARTS; ++q)
+#pragma unroll
+        for (int i = 0; i < L2_MAXV; ++i) acc[q][i] = 0.f;
+    for (long r = w0; r < R; r += nw) {
+#pragma unroll
+        for (int q = 0; q < L2_MAXPARTS; ++q) {
+            if (q >= nparts) continue;                       // (no break: the loop must unroll so that acc[][] stays in registers)
+            const int C = p.C[q];
+            const float* __restrict__ x = p.x[q] + r * C; const float* __restrict__ w = p.w[q];
+            const float* __restrict__ g0 = dy + r * lddy + p.off[q];
+            float* __restrict__ dx = p.dx[q] + r * C;
+            const float n = p.norm[q][r];
+            float g[L2_MAXV], xv[L2_MAXV], wv[L2_MAXV];
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < L2_MAXV; ++i) {
+                const int c = lane + 64 * i;
+                g[i] = c < C ? g0[c] : 0.f;
+                xv[i] = c < C ? x[c] : 0.f;
+                wv[i] = c < C ? w[c] : 0.f;
+                dot += wv[i] * g[i] * xv[i];
+            }
+            dot = wave_sum(dot);
+            const float nn = n - eps;
+            const float k = nn > 0.f ? dot / (n * n * nn) : 0.f;
+            const float in = 1.f / n;
+#pragma unroll
+            for (int i = 0; i < L2_MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < C) dx[c] = wv[i] * g[i] * in - xv[i] * k;
+                acc[q][i] += g[i] * xv[i] * in;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < L2_MAXPARTS; ++q)
+#pragma unroll
+        for (int i = 0; i < L2_MAXV; ++i) { const int c = lane + 64 * i; if (q < nparts && c < p.C[q]) atomicAdd(&sw[q][c], acc[q][i]); }
+    __syncthreads();
+    for (int q = 0; q < nparts; ++q)
+        for (int i = threadIdx.x; i < p.C[q]; i += 256) atomicAdd(&p.dw[q][i], sw[q][i]);
+}
+static int l2_parts(L2Parts& p, int nparts, const float* const* x, const float* const* w, float* const* norm, float* const* dx, float* const* dw,
+                    const int* C) {
+    if (nparts < 1 || nparts > L2_MAXPARTS) return PDF_E_BADARG;
+    int off = 0;
+    for (int i = 0; i < nparts; ++i) {
+        if (C[i] <= 0 || C[i] > 64 * L2_MAXV) return PDF_E_BADARG;
+        p.x[i] = x[i]; p.w[i] = w[i]; p.norm[i] = norm[i]; p.dx[i] = dx ? dx[i] : nullptr; p.dw[i] = dw ? dw[i] : nullptr;
+        p.C[i] = C[i]; p.off[i] = off;
+        off += C[i];
+    }
+    return 0;
+}
+// x[i]: [R][C[i]] contiguous rows; y: [R][ldy] with part i at channel offset C[0] + ... + C[i-1]; norm[i]: [R]
+PDF_API int pdf_l2norm_cat_fwd(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R,
+                               float* y, int ldy, float* const* norm, hipStream_t s) {
+    if (R <= 0) return 0;
+    L2Parts p = {};
+    if (int rc = l2_parts(p, nparts, x, w, norm, nullptr, nullptr, C)) return rc;
+    hipLaunchKernelGGL(l2norm_cat_fwd_kernel, dim3(grid_for(R * 64, 256, 2048), nparts), dim3(256), 0, s, p, R, eps, y, ldy);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// dw[i] must be zero-filled (atomically accumulated)
+PDF_API int pdf_l2norm_cat_bwd(int nparts, const float* dy, int lddy, const float* const* x, const int* C, const float* const* w, float eps, long R,
+                               float* const* norm, float* const* dx, float* const* dw, hipStream_t s) {
+    if (R <= 0) return 0;
+    L2Parts p = {};
+    if (int rc = l2_parts(p, nparts, x, w, norm, dx, dw, C)) return rc;
+    hipLaunchKernelGGL(l2norm_cat_bwd_kernel, dim3(grid_for(R * 64, 256, 2048)), dim3(256), 0, s, p, nparts, R, eps, dy, lddy);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}

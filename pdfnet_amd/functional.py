@@ -684,6 +684,16 @@ def l2norm(x, w, eps=1e-10):
     return _L2Norm.apply(x, w, eps)
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(values):
+    import ctypes
+    return (ctypes.c_int * len(values))(*values)
+
+
 class _L2NormCat(Function):
     """torch.cat([l2norm(x_i, w_i)], 1) without the concatenation pass: every L2Norm writes its channels straight into the
     concatenated NHWC buffer (row stride = the total channel count), and the backward reads its channel slice of the incoming
@@ -700,12 +710,8 @@ class _L2NormCat(Function):
         Cs = [x.shape[1] for x in xs]
         Ct, R = sum(Cs), B * H * W
         out = torch.empty((B, Ct, H, W), dtype=torch.float32, device=xs[0].device, memory_format=CL)
-        norms, off = [], 0
-        for x, w, C in zip(xs, ws, Cs):
-            norm = torch.empty(R, device=x.device)
-            _L().pdf_l2norm_fwd(ptr(x), C, C, R, ptr(w), eps, hip.ptr_at(out, off), Ct, ptr(norm), stream())
-            norms.append(norm)
-            off += C
+        norms = [torch.empty(R, device=out.device) for _ in xs]
+        _L().pdf_l2norm_cat_fwd(n, _ptr_array(xs), _int_array(Cs), _ptr_array(ws), eps, R, ptr(out), Ct, _ptr_array(norms), stream())
         ctx.save_for_backward(*xs, *ws, *norms)
         ctx.cfg = (eps, n, Cs)
         return out
@@ -717,14 +723,10 @@ class _L2NormCat(Function):
         xs, ws, norms = t[:n], t[n:2 * n], t[2 * n:]
         g = cl(dy)
         Ct = sum(Cs)
-        dxs, dws, off = [], [], 0
-        for x, w, norm, C in zip(xs, ws, norms, Cs):
-            R = x.numel() // C
-            dx, dw = torch.empty_like(x), torch.zeros_like(w)
-            _L().pdf_l2norm_bwd(hip.ptr_at(g, off), Ct, ptr(x), C, C, R, ptr(w), eps, ptr(norm), ptr(dx), C, ptr(dw), stream())
-            dxs.append(dx)
-            dws.append(dw)
-            off += C
+        R = xs[0].numel() // Cs[0]
+        dxs, dws = [torch.empty_like(x) for x in xs], [torch.zeros_like(w) for w in ws]
+        _L().pdf_l2norm_cat_bwd(n, ptr(g), Ct, _ptr_array(xs), _int_array(Cs), _ptr_array(ws), eps, R, _ptr_array(norms),
+                                _ptr_array(dxs), _ptr_array(dws), stream())
         return (None,) + tuple(dxs) + tuple(dws)
 
 

@@ -337,7 +337,7 @@ class ResNetSimple(nn.Module):
         st['ind'] = ind
         return st
 
-    def dense_branches(self, st):
+    def dense_branches(self, st, defer=False):
         """The two up-sampling decoders (need only x1) and the wh / params heads (need only x0; no loss term): heavy
         convolutions with few launches, each on its own side stream, joined right away.  (Starting them as early as their
         inputs exist, next to the pyramid / feat convolutions, was measured: 346 vs 366 img/s -- MFMA-bound work gains
@@ -354,14 +354,16 @@ class ResNetSimple(nn.Module):
                     out[head] = fc[2](fc[0](x0, F.ACT_RELU))
             return out
         f_heads = F.fork(other_heads)
-        ret = dict(st['ret'])
-        for head in self.opt.heads:                                                        # keep the reference's key order
-            if head != 'hm':
-                ret[head] = None
-        ret.update(f_heads.join())
-        hms, hms_f = f_hms.join()
-        mask, dp_f = f_dp.join() if f_dp is not None else st['dp']
-        return hms, mask, ret, hms_f, dp_f
+        def join():
+            ret = dict(st['ret'])
+            for head in self.opt.heads:                                                    # keep the reference's key order
+                if head != 'hm':
+                    ret[head] = None
+            ret.update(f_heads.join())
+            hms, hms_f = f_hms.join()
+            mask, dp_f = f_dp.join() if f_dp is not None else st['dp']
+            return hms, mask, ret, hms_f, dp_f
+        return join if defer else join()
 
 
 class resnet_mid(nn.Module):

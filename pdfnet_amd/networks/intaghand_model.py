@@ -27,9 +27,12 @@ class HandNET_GCN(nn.Module):
         # convolutions overlap the decoder's small kernels in forward and backward) was measured: 267-272 vs 314 img/s in
         # one session -- the big kernels starve the critical decoder -> PointNet++ -> trunk backward chain.  Round 2 re-measured it
         # with the branches waiting on a post-trunk event only: 388 vs 407 img/s; with the decoder on a high-priority stream: 283.
-        hms, mask, ret, hms_fmaps, dp_fmaps = self.encoder.dense_branches(st)
         gl, gr = img_fmaps[0][:, 0], img_fmaps[0][:, 1]                 # what mid_model hands on (intaghand_encoder.py:881)
+        # ... and joined only AFTER the mesh decoder has been issued: in the forward the decoder's small kernels run next to
+        # the branches' convolutions (404.5 -> 406.8 img/s), while the autograd order of the backward stays as it was.
+        join_dense = self.encoder.dense_branches(st, defer=True)
         result, paramsDict, handDictList, otherInfo = self.decoder(gl, gr)
+        hms, mask, ret, hms_fmaps, dp_fmaps = join_dense()
         if self.run_mid_model:
             with torch.no_grad():
                 self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)          # live state: its BN running statistics only

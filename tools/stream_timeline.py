@@ -100,3 +100,12 @@ for k, v in sorted(ac.items(), key=lambda kv: -kv[1][1])[:14]:
 big = sorted(((e - s, (s - t0) / 1e6, n) for s, e, n, q in mk if (cls(n) == 'aten' or 'rocclr' in n) and e - s >= 40000), reverse=True)
 for d, at, n in big[:40]:
     print("     at %6.2f ms  %7.1f us  %s" % (at, d / 1e3, re.sub(r'\s+', ' ', n)[:110]))
+# main-stream kernels that are neither GEMM nor BatchNorm nor aten, by name (the latency-bound part of the dependent chain)
+oc = collections.defaultdict(lambda: [0, 0])
+for s, e, n, q in mk:
+    if cls(n) in ('other hip', 'attention', 'layernorm', 'cheby', 'maxk', 'knn/group', 'colsum'):
+        key = re.sub(r'\(.*', '', n)[:60]
+        oc[key][0] += 1; oc[key][1] += e - s
+print("other library kernels on stream %s: %d launches, %.2f ms" % (main, sum(v[0] for v in oc.values()), sum(v[1] for v in oc.values()) / 1e6))
+for k, v in sorted(oc.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("  %4d  %7.3f ms  avg %6.1f us  %s" % (v[0], v[1] / 1e6, v[1] / v[0] / 1e3, k))
