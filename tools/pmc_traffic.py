@@ -23,6 +23,8 @@ import os
 
 def tile_name(k):
     """'void igemm_nt<128, 128, 2, 2, true, false>(IGemm)' -> 'igemm_nt<128,128>' (tile shape; the B-layout / fast-path flags merged)."""
+    if "igemm_halo3x3" in k:                                   # the LDS-halo form of the 128x128 tile (same tile class as in bench.py)
+        return "igemm_nt<128,128>"
     m = re.search(r"(igemm_nt|wgemm_tn_dma|wgemm_tn)<([^>]*)>", k)
     if not m:
         return None
@@ -40,7 +42,8 @@ def load(d, counter, by_tile=False):
         if by_tile:
             fam = tile_name(k)
         else:
-            fam = "igemm_nt" if "igemm_nt" in k else "wgemm_tn" if "wgemm_tn" in k else "reduce_slabs" if "reduce_slabs" in k else None
+            fam = ("igemm_nt" if ("igemm_nt" in k or "igemm_halo3x3" in k or "small_k_gemm" in k) else "wgemm_tn" if "wgemm_tn" in k else
+                   "reduce_slabs" if ("reduce_slabs" in k or "splitk_finish" in k) else None)
         if fam is None:
             continue
         agg[fam][0] += 1
@@ -50,7 +53,7 @@ def load(d, counter, by_tile=False):
 
 HBM_KERNELS = ("knn_ball_group_kernel", "gather_sub_fwd_kernel", "gather_sub_bwd_kernel", "bn_relu_maxk_fwd_kernel", "bn_maxk_bwd_partial_kernel",
                "bn_maxk_bwd_apply_kernel", "gather_rows_kernel", "scatter_rows_kernel", "bn_partial_v4_kernel", "affine_apply_v4_kernel",
-               "bn_bwd_partial_v4_kernel", "bn_bwd_apply_v4_kernel", "l2norm_fwd_kernel", "l2norm_bwd_kernel", "up2_fwd_v4_kernel", "up2_bwd_v4_kernel",
+               "bn_bwd_partial_v4_kernel", "bn_bwd_apply_v4_kernel", "l2norm_fwd_kernel", "l2norm_bwd_kernel", "l2norm_cat_fwd_kernel", "l2norm_cat_bwd_kernel", "up2_fwd_v4_kernel", "up2_bwd_v4_kernel",
                "adam_kernel", "fps_kernel", "maxk_fwd_kernel", "maxk_bwd_kernel", "group_bwd_kernel")
 POINTNET = HBM_KERNELS[:8]
 
@@ -119,6 +122,18 @@ def main():
         h.update(open(os.path.join(root, "pdfnet_amd", "csrc", f), "rb").read())
     res["hbm_src_sha256"] = h.hexdigest()
     res["hbm_family"] = hbm_family(fdir, wdir, steps)
+    # per-dispatch reads of the 3x3 LDS-halo kernels (the layer VERDICT r01 singled out: `feat` forward fetched 5.75 GB with the
+    # per-tap gather) and the heaviest dispatches overall
+    f0 = (glob.glob(fdir + "/*counter_collection.csv") + glob.glob(fdir + "/*/*counter_collection.csv"))[0]
+    rows0 = [r for r in csv.DictReader(open(f0)) if r["Counter_Name"] == "FETCH_SIZE"]
+    halo = collections.defaultdict(list)
+    for r in rows0:
+        if "igemm_halo3x3" in r["Kernel_Name"]:
+            halo[re.sub(r"^void |\(.*$", "", r["Kernel_Name"])].append(round(float(r["Counter_Value"]) * 2 * 1024 / 1e6, 1))
+    res["halo3x3_read_MB_per_dispatch"] = {k: sorted(v, reverse=True)[:3 * 8] for k, v in halo.items()}
+    rows0.sort(key=lambda r: -float(r["Counter_Value"]))
+    res["largest_dispatches_read_MB"] = [[re.sub(r"^void |\(.*$", "", r["Kernel_Name"])[:60], r.get("Grid_Size", "?"),
+                                          round(float(r["Counter_Value"]) * 2 * 1024 / 1e6, 1)] for r in rows0[:24]]
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["gemm_family"]), json.dumps(res["families"]))
     for k, v in res["hbm_family"]["kernels"].items():
