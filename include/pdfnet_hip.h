@@ -224,6 +224,18 @@ int pdf_sft3_bwd(const float* g, int ldg, const float* fea, int ldf, const float
                  float* dw_scale0, float* db_scale0, float* dw_scale1, float* db_scale1,
                  float* dw_shift0, float* db_shift0, float* dw_shift1, float* db_shift1, int accumulate,
                  float* ws, long R, void* stream);
+/* bf16 shadows (bf16 mode of pdf_set_gemm_precision).  A producer can write the values of an fp32 tensor a second time, rounded to
+ * bf16 (RNE), same layout and leading dimensions; a GEMM-family consumer given that copy stages 2-byte operands (half the L2 -> LDS
+ * bytes of kernels bound by exactly those; results bit-identical to rounding while staging).  Passed through thread-local slots so
+ * the signatures above stay as they are: call the setter, then the entry point, on the same thread.
+ *   pdf_set_bf16_operands(op0, op1): shadows of the NEXT conv2d / deconv2d / linear call's operands -- forward: (x, w);
+ *     backward-data: (dy, w); backward-weight: (x, dy); NULL = none.  Every GEMM-family entry point clears them.
+ *   pdf_set_bf16_output(out): pdf_bn_train_fwd writes the shadow of y, pdf_bn_train_bwd of dx, pdf_l2norm_cat_fwd of y.
+ *   pdf_cast_bf16: dst[i] = bf16(src[i]), n % 4 == 0 (weight shadows from the flat fp32 master buffer). */
+int pdf_set_bf16_operands(const void* op0_bf16, const void* op1_bf16);
+int pdf_set_bf16_output(void* out_bf16);
+int pdf_cast_bf16(const float* src, void* dst, long n, void* stream);
+int pdf_debug_shadow_operands(void);      /* shadow operands consumed by bf16 GEMM launches so far (tests) */
 /* nn.Dropout(p) with a stateless (seed, index) mask: the same call is its own backward (gcn.py:96, self_attn.py:51-52).
  * step: optional DEVICE counter mixed into the seed so a replayed hipGraph draws a fresh mask every step. */
 int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long seed, const unsigned long long* step, void* stream);

@@ -97,3 +97,14 @@ int* pdf_ticket_counters(int n);
 #define PDF_SCRATCH_RING (1L << 26)
 #define PDF_SCRATCH_MAX (1L << 22)
 float* pdf_scratch(long floats);
+// bf16 shadows handed to the NEXT entry-point call of this thread (pdf_set_bf16_operands / pdf_set_bf16_output, elementwise.hip):
+// every GEMM-family entry point takes (and clears) the operand pair first thing, the BatchNorm / pyramid entry points the output.
+typedef __bf16 pdf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pdf_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pdf_pk_bf16(float a, float b) {      // two floats -> packed bf16 pair, round-to-nearest-even
+    pdf_f32x2 f = {a, b};
+    pdf_bf16x2 v = __builtin_convertvector(f, pdf_bf16x2);
+    return *reinterpret_cast<unsigned int*>(&v);
+}
+void pdf_tls_take_operands(const void** op0, const void** op1);
+void* pdf_tls_take_output();

@@ -468,4 +468,31 @@ float* pdf_scratch(long floats) {
     }
     return base + start;
 }
+// ---------------------------------------------------------------------------------------------
+// bf16 shadows (bf16 mode): a producer that writes an fp32 tensor the GEMMs will read can write the same values rounded to bf16
+// (RNE) beside it; the consumer passes that copy along and the bf16 GEMM kernels stage 2-byte operands -- half the L2 -> LDS bytes
+// of the kernels that are bound by exactly those, results bit-identical to rounding while staging.  Carried through
+// thread-local slots so that the existing signatures stay as they are: set, then call, on the same thread.
+static thread_local const void* tl_op0 = nullptr;
+static thread_local const void* tl_op1 = nullptr;
+static thread_local void* tl_out = nullptr;
+PDF_API int pdf_set_bf16_operands(const void* op0_bf16, const void* op1_bf16) { tl_op0 = op0_bf16; tl_op1 = op1_bf16; return 0; }
+PDF_API int pdf_set_bf16_output(void* out_bf16) { tl_out = out_bf16; return 0; }
+void pdf_tls_take_operands(const void** op0, const void** op1) { *op0 = tl_op0; *op1 = tl_op1; tl_op0 = tl_op1 = nullptr; }
+void* pdf_tls_take_output() { void* o = tl_out; tl_out = nullptr; return o; }
+// dst[i] = bf16(src[i]) (RNE): the weight shadows, refreshed from the flat fp32 master buffer once per step
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<uint2*>(dst)[i] = uint2{pdf_pk_bf16(v.x, v.y), pdf_pk_bf16(v.z, v.w)};
+    }
+}
+PDF_API int pdf_cast_bf16(const float* src, void* dst, long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (n % 4 != 0) return PDF_E_BADARG;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, src, reinterpret_cast<unsigned short*>(dst), n / 4);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
 PDF_API int pdf_init(void) { return (pdf_ticket_counters(1) != nullptr && pdf_scratch(64) != nullptr) ? 0 : PDF_E_WORKSPACE; }

@@ -846,7 +846,9 @@ PDF_API int pdf_set_gemm_precision(int bf16) { g_gemm_bf16 = bf16 ? 1 : 0; retur
 PDF_API int pdf_debug_gemm_precision() { return g_gemm_bf16; }
 
 static thread_local int g_last_tile = 0;            // BM * 1000 + BN of this thread's last implicit-GEMM launch (0: streaming small-K kernel)
-static thread_local int g_igemm_launches = 0;       // implicit-GEMM kernel launches of this thread so far
+static thread_local int g_igemm_launches = 0;
+static int g_shadow_operands = 0;                   // bf16 shadow operands consumed by GEMM launches so far (tests)
+PDF_API int pdf_debug_shadow_operands() { return g_shadow_operands; }       // implicit-GEMM kernel launches of this thread so far
 PDF_API int pdf_debug_last_tile() { return g_last_tile; }
 PDF_API int pdf_debug_igemm_launches() { return g_igemm_launches; }
 
@@ -865,7 +867,11 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
         PDF_LAUNCH_CHECK();
         return 0;
     }
+    if (!(g_gemm_bf16 && fast) || groups > 1) { g.A16 = nullptr; g.B16 = nullptr; }
+    if (g.A16 != nullptr && (g.lda % 8 != 0 || (reinterpret_cast<uintptr_t>(g.A16) & 15))) g.A16 = nullptr;      // 16-byte chunks of 8 bf16
+    if (g.B16 != nullptr && ((!g.b_kn && g.ldb % 8 != 0) || (reinterpret_cast<uintptr_t>(g.B16) & 15))) g.B16 = nullptr;
     if (g_gemm_bf16 && fast) {
+        g_shadow_operands += (g.A16 != nullptr) + (g.B16 != nullptr);
         const int rc = launch_igemm_bf16(g, s, groups);
         if (rc < 0) return -rc;
         if (rc == 1) { g_last_tile = 16; return 0; }
@@ -943,6 +949,9 @@ static void conv_taps(IGemm& g, int KH, int KW, int pad, int dil) {
         }
 }
 
+struct Shadows { const void* op0; const void* op1; };
+static Shadows take_shadows() { Shadows sh; pdf_tls_take_operands(&sh.op0, &sh.op1); return sh; }
+
 // Linear / 1x1: y[M][N] = act(x[M][K] w[N][K]^T + b).  Reference: nn.Linear / 1x1 nn.Conv2d call sites
 // (e.g. model_attn/gcn.py:66, intaghand_encoder.py:48-103 netR_*, :205-219 SFT convs).
 static IGemm linear_desc(const float* x, const float* w, const float* bias, float* y,
@@ -956,13 +965,16 @@ static IGemm linear_desc(const float* x, const float* w, const float* bias, floa
 }
 PDF_API int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
                            int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) {
+    const Shadows sh = take_shadows();
     IGemm g = linear_desc(x, w, bias, y, M, N, K, ldx, ldw, ldy, act);
+    g.A16 = sh.op0; g.B16 = sh.op1;
     return launch_igemm(g, s);
 }
 // Two same-shaped layers with their own parameters in ONE launch (the left / right hand branches of the mesh decoder,
 // DualGraph.py:83-84, inter_attn.py:66-67): rows [0, M) of x / y belong to (w0, b0), rows [M, 2M) to (w1, b1).
 PDF_API int pdf_linear_fwd_pair(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
                                 int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) {
+    take_shadows();
     IGemm g = linear_desc(x, w0, b0, y, M, N, K, ldx, ldw, ldy, act);
     g.B1 = w1; g.bias1 = b1; g.gsA = (long)M * ldx; g.gsC = (long)M * ldy;
     return launch_igemm(g, s, 2);
@@ -970,12 +982,15 @@ PDF_API int pdf_linear_fwd_pair(const float* x, const float* w0, const float* w1
 // dx[M][K] = dy[M][N] w[N][K]: the weight is read in its forward [N][K] storage (no transposed copy)
 PDF_API int pdf_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx,
                                 hipStream_t s) {
+    const Shadows sh = take_shadows();
     IGemm g = linear_desc(dy, w, nullptr, dx, M, K, N, lddy, ldw, lddx, 0);
     g.b_kn = 1; g.btap = 0;
+    g.A16 = sh.op0; g.B16 = sh.op1;
     return launch_igemm(g, s);
 }
 PDF_API int pdf_linear_bwd_data_pair(const float* dy, const float* w0, const float* w1, float* dx, int M, int N, int K,
                                      int lddy, int ldw, int lddx, hipStream_t s) {
+    take_shadows();
     IGemm g = linear_desc(dy, w0, nullptr, dx, M, K, N, lddy, ldw, lddx, 0);
     g.b_kn = 1; g.btap = 0;
     g.B1 = w1; g.bias1 = nullptr; g.gsA = (long)M * lddy; g.gsC = (long)M * lddx;
@@ -1117,6 +1132,7 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const float* __restri
 PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                            int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                            int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s) {
+    const Shadows sh = take_shadows();
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && (long)N * OH * OW >= (1L << 16)) {
         hipLaunchKernelGGL((tiny_conv_fwd_kernel<3, 3, 3, 3>), dim3(grid_for((long)N * OH * OW)), dim3(256), 0, s, x, w, bias, y, N, H, W, ldx, pad, OH, OW, ldy, act);
@@ -1130,6 +1146,7 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
     conv_taps(g, KH, KW, pad, 1);
     g.plain_in = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
     g.plain_out = 1; g.act = act;
+    g.A16 = sh.op0; g.B16 = sh.op1;
     return launch_igemm(g, s);
 }
 
@@ -1139,6 +1156,7 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
 static int conv2d_bwd_data(const float* dy, const float* w, float* dx,
                            int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
                            int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
+    const Shadows sh = take_shadows();
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (accumulate && stride > 1) return PDF_E_BADARG;       // (every dx element must be written by exactly one launch)
     for (int py = 0; py < stride; ++py)
@@ -1151,6 +1169,7 @@ static int conv2d_bwd_data(const float* dy, const float* w, float* dx,
             if (g.QH <= 0 || g.QW <= 0) continue;
             g.M = N * g.QH * g.QW;
             g.sy = 1; g.sx = 1; g.accum = accumulate;
+            g.A16 = sh.op0; g.B16 = sh.op1;
             // input row iy = qy*stride + py; contributing taps: (iy + pad - ky) % stride == 0, oy = (iy+pad-ky)/stride
             int T = 0;
             for (int ky = 0; ky < KH; ++ky) {
@@ -1214,6 +1233,11 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     if ((long)splits * (per + perb) * groups > ws_floats) splits = (int)(ws_floats / ((per + perb) * groups));
     if (splits < 1) splits = 1;
     const bool bf16 = g_gemm_bf16 && fast;
+    if (!bf16 || groups > 1) { g.P16 = nullptr; g.Q16 = nullptr; }
+    if (db != nullptr) g.P16 = nullptr;                     // the fused bias gradient sums the un-rounded rows of P
+    // (16-byte groups of 8 bf16 along the operand's columns)
+    if (g.P16 != nullptr && ((reinterpret_cast<uintptr_t>(g.P16) & 15) || g.ldp % 8 || g.NI % 8 || g.gsP % 8)) g.P16 = nullptr;
+    if (g.Q16 != nullptr && ((reinterpret_cast<uintptr_t>(g.Q16) & 15) || g.ldq % 8 || g.Cq % 8 || g.gsQ % 8)) g.Q16 = nullptr;
     const int rq = bf16 ? 64 : 16;
     // The blocks all run equally long and the chip retires them CU by CU: 1044 blocks on 256 CUs leave most CUs idle for the
     // fifth pass (82 % busy).  Among split counts down to 3/4 of the target, take the one whose block count fills whole
@@ -1247,6 +1271,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     int brc = 0;
     if (bf16) {
+        g_shadow_operands += (g.P16 != nullptr) + (g.Q16 != nullptr);
         brc = launch_wgemm_bf16(g, splits, groups, small ? 1 : 0, s);
         if (brc < 0) return -brc;
     }
@@ -1293,16 +1318,19 @@ PDF_API long pdf_wgrad_workspace_floats(int M, int NI, int NJ) {
 // dW[N][K] (+)= dy[M][N]^T x[M][K]   (Linear / 1x1 weight gradient)
 PDF_API int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) {
+    const Shadows sh = take_shadows();                       // op0: x, op1: dy
     WGemm g = {};
     g.P = dy; g.Q = x; g.M = M; g.NI = N; g.Cq = K; g.T = 1; g.ldp = lddy; g.ldq = ldx; g.ldw = K;
     g.plain_q = 1; g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
     g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
+    g.Q16 = sh.op0; g.P16 = sh.op1;
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s, nullptr, db);
 }
 
 // paired form of the above: rows [0, M) -> dw0, rows [M, 2M) -> dw1; ws >= 2 * pdf_wgrad_workspace_floats(M, N, K)
 PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* dw0, float* dw1, float* db0, float* db1,
                                        float* ws, long ws_floats, int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) {
+    take_shadows();
     WGemm g = {};
     g.P = dy; g.Q = x; g.M = M; g.NI = N; g.Cq = K; g.T = 1; g.ldp = lddy; g.ldq = ldx; g.ldw = K;
     g.plain_q = 1; g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
@@ -1315,6 +1343,7 @@ PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* d
 PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                                   int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
+    const Shadows sh = take_shadows();                       // op0: x, op1: dy
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && db == nullptr && (long)N * OH * OW >= (1L << 16) && ws_floats >= 81L * 64) {
         const int nblk = (int)min((long)1024, ws_floats / 81);
@@ -1350,6 +1379,7 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
             int t = ky * KW + kx;
             g.dy[t] = (int)(ky - pad); g.dx[t] = (int)(kx - pad); g.wt[t] = t;
         }
+    g.Q16 = sh.op0; g.P16 = sh.op1;
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s, nullptr, db);
 }
 
@@ -1360,10 +1390,11 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
 PDF_API int pdf_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                              int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                              int stride, int pad, int OH, int OW, int ldy, hipStream_t s) {
+    const Shadows sh = take_shadows();                       // op0: x, op1: w
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (KH == stride && KW == stride && pad == 0) {
         IGemm g = {};
-        g.A = x; g.B = w; g.C = y; g.bias = bias;
+        g.A = x; g.B = w; g.C = y; g.bias = bias; g.A16 = sh.op0; g.B16 = sh.op1;
         g.M = N * H * W; g.N = KH * KW * Cout; g.K = Cin; g.Cin = Cin; g.lda = ldx; g.ldc = ldy;
         // columns n = (tap, co): w[ci][tap][co] is exactly a [K = ci][N] matrix
         g.ldb = KH * KW * Cout; g.b_kn = 1; g.btap = 0;
@@ -1376,7 +1407,7 @@ PDF_API int pdf_deconv2d_fwd(const float* x, const float* w, const float* bias, 
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {
             IGemm g = {};
-            g.A = x; g.B = w; g.C = y; g.bias = bias;
+            g.A = x; g.B = w; g.C = y; g.bias = bias; g.A16 = sh.op0; g.B16 = sh.op1;
             g.N = Cout; g.Cin = Cin; g.lda = ldx; g.ldb = KH * KW * Cout; g.b_kn = 1; g.btap = Cout; g.ldc = ldy;
             g.H = H; g.W = W;
             g.QH = (OH - py + stride - 1) / stride; g.QW = (OW - px + stride - 1) / stride;
@@ -1410,9 +1441,10 @@ PDF_API int pdf_deconv2d_fwd(const float* x, const float* w, const float* bias, 
 PDF_API int pdf_deconv2d_bwd_data(const float* dy, const float* w, float* dx,
                                   int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
                                   int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
+    const Shadows sh = take_shadows();                       // op0: dy, op1: w
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     IGemm g = {};
-    g.A = dy; g.B = w; g.C = dx; g.bias = nullptr;
+    g.A = dy; g.B = w; g.C = dx; g.bias = nullptr; g.A16 = sh.op0; g.B16 = sh.op1;
     g.M = N * H * W; g.N = Cin; g.K = KH * KW * Cout; g.Cin = Cout; g.lda = lddy; g.ldb = KH * KW * Cout; g.ldc = lddx;
     g.H = OH; g.W = OW; g.QH = H; g.QW = W; g.sy = stride; g.sx = stride;
     conv_taps(g, KH, KW, pad, 1);
@@ -1424,9 +1456,10 @@ PDF_API int pdf_deconv2d_bwd_data(const float* dy, const float* w, float* dx,
 PDF_API int pdf_deconv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
                                     int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                                     int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
+    const Shadows sh = take_shadows();                       // op0: x, op1: dy
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     WGemm g = {};
-    g.P = x; g.Q = dy; g.M = N * H * W; g.NI = Cin; g.Cq = Cout; g.T = KH * KW;
+    g.P = x; g.Q = dy; g.P16 = sh.op0; g.Q16 = sh.op1; g.M = N * H * W; g.NI = Cin; g.Cq = Cout; g.T = KH * KW;
     g.ldp = ldx; g.ldq = lddy; g.ldw = KH * KW * Cout;
     g.H = OH; g.W = OW; g.QH = H; g.QW = W; g.sy = stride; g.sx = stride; g.plain_q = 0;
     for (int ky = 0; ky < KH; ++ky)

@@ -20,6 +20,8 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // raw bf16 bits of 8 / 4 elements (shadow operands)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static __device__ __attribute__((aligned(32))) float g_zero32[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -62,7 +64,9 @@ __device__ __forceinline__ void st_col4(unsigned char* dst, const float4& v) {
 // Implicit GEMM (see gemm.hip igemm_nt for the contraction and the descriptor).  Requires the FAST conditions of the fp32
 // kernel (16-byte aligned rows, Cin % 8 == 0); a tap's channels are walked in steps of 64, chunks past Cin read zeros.
 // A is always a ROW operand; B is ROW ([N][K] storage) or COL ([K][N] storage, KN).
-template <int BM, int BN, int WM, int WN, bool KN>
+// SA / SB: the A / B operand comes as a bf16 shadow (IGemm::A16 / B16) -- compile-time, because a run-time branch around the
+// operand loads makes the compiler drain them one by one (measured: 672 -> 376 img/s with `if (A16 != nullptr)` in the loop)
+template <int BM, int BN, int WM, int WN, bool KN, bool SHA, bool SHB>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
     constexpr int BK = BK16;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -81,7 +85,10 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
     const int wm = wave / WN, wn = wave % WN;
     const float* __restrict__ Ap = g.A; const float* __restrict__ Bp = g.B; const float* __restrict__ biasp = g.bias;
     float* __restrict__ Cp = g.C;
-    if (blockIdx.y) { Ap += g.gsA; Cp += g.gsC; Bp = g.B1; biasp = g.bias1; }
+    const unsigned short* __restrict__ A16 = reinterpret_cast<const unsigned short*>(g.A16);
+    const unsigned short* __restrict__ B16 = reinterpret_cast<const unsigned short*>(g.B16);
+    if (blockIdx.y) { Ap += g.gsA; Cp += g.gsC; Bp = g.B1; biasp = g.bias1; if (A16) A16 += g.gsA; B16 = reinterpret_cast<const unsigned short*>(g.B116); }
+    const unsigned short* const z16 = reinterpret_cast<const unsigned short*>(g_zero32);
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     int tmi, tni;
     xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
@@ -126,38 +133,57 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
 
     const int spt = (g.Cin + BK - 1) / BK;               // K-steps per tap
     const int nk = g.T * spt;
-    float4 ra[RA][2];
-    float4 rb[KN ? 1 : (RB > 0 ? RB : 1)][2];
-    float4 rc[KN ? NCB : 1];
+    float4 ra[SHA ? 1 : RA][2];
+    float4 rb[(KN || SHB) ? 1 : (RB > 0 ? RB : 1)][2];
+    float4 rc[(KN && !SHB) ? NCB : 1];
+    u32x4 ra16[SHA ? RA : 1];                            // shadow operands: raw bf16 bits, 8 (ROW) / 4 (COL) elements per load
+    u32x4 rb16[(!KN && SHB) ? (RB > 0 ? RB : 1) : 1];
+    u32x2 rc16[(KN && SHB) ? NCB : 1];
     int nt_tap = 0, nt_ci = 0, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * (KN ? g.btap : g.Cin);
     auto gload = [&]() {
         const int ci0 = nt_ci + ach;
         const bool kin = ci0 < g.Cin;                     // Cin % 8 == 0: a chunk is inside or outside as a whole
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const float* src;
-            if (g.plain_in) src = (aval[i] && kin) ? Ap + abase[i] + ci0 : g_zero32;
+            // branch-free: the element offset is computed for every lane, a masked lane SELECTS the zero word's address
+            bool ok; long off;
+            if (g.plain_in) { ok = aval[i] && kin; off = abase[i] + ci0; }
             else {
                 const int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
-                const bool ok = aval[i] && kin && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-                src = ok ? Ap + abase[i] + ((long)iy * g.W + ix) * g.lda + ci0 : g_zero32;
+                ok = aval[i] && kin && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                off = abase[i] + ((long)iy * g.W + ix) * g.lda + ci0;
             }
-            ra[i][0] = *reinterpret_cast<const float4*>(src);
-            ra[i][1] = *reinterpret_cast<const float4*>(src + 4);
+            if constexpr (SHA) {                            // 8 bf16 = one 16-byte load, stored to LDS as it is
+                const unsigned short* src = ok ? A16 + off : z16;
+                ra16[i] = *reinterpret_cast<const u32x4*>(src);
+            } else {
+                const float* src = ok ? Ap + off : g_zero32;
+                ra[i][0] = *reinterpret_cast<const float4*>(src);
+                ra[i][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
         }
         if (!KN) {
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                const float* src = (bval[i] && kin) ? Bp + bbase[i] + wbase + ci0 : g_zero32;
-                rb[i][0] = *reinterpret_cast<const float4*>(src);
-                rb[i][1] = *reinterpret_cast<const float4*>(src + 4);
+                const bool ok = bval[i] && kin;
+                if constexpr (SHB) {
+                    const unsigned short* src = ok ? B16 + bbase[i] + wbase + ci0 : z16;
+                    rb16[i] = *reinterpret_cast<const u32x4*>(src);
+                } else {
+                    const float* src = ok ? Bp + bbase[i] + wbase + ci0 : g_zero32;
+                    rb[i][0] = *reinterpret_cast<const float4*>(src);
+                    rb[i][1] = *reinterpret_cast<const float4*>(src + 4);
+                }
             }
         } else {
 #pragma unroll
             for (int u = 0; u < NCB; ++u) {
                 const int ci = nt_ci + bk0 + u * KPP;
-                const float* src = (bcol_ok && ci < g.Cin) ? Bp + (long)ci * g.ldb + wbase + n0 + bcg : g_zero32;
-                rc[u] = *reinterpret_cast<const float4*>(src);
+                const bool ok = bcol_ok && ci < g.Cin;
+                if constexpr (SHB) {                        // 4 bf16 = 8 bytes
+                    const unsigned short* src = ok ? B16 + (long)ci * g.ldb + wbase + n0 + bcg : z16;
+                    rc16[u] = *reinterpret_cast<const u32x2*>(src);
+                } else rc[u] = *reinterpret_cast<const float4*>(ok ? Bp + (long)ci * g.ldb + wbase + n0 + bcg : g_zero32);
             }
         }
         nt_ci += BK;
@@ -170,13 +196,23 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
         unsigned char* as = smem + buf * TILE;
         unsigned char* bs = as + ABYTES;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) st_row8(as + (arow + i * (256 / CPR)) * LROW + ach * 2, ra[i][0], ra[i][1]);
+        for (int i = 0; i < RA; ++i) {
+            unsigned char* d = as + (arow + i * (256 / CPR)) * LROW + ach * 2;
+            if constexpr (SHA) *reinterpret_cast<u32x4*>(d) = ra16[i]; else st_row8(d, ra[i][0], ra[i][1]);
+        }
         if (!KN) {
 #pragma unroll
-            for (int i = 0; i < RB; ++i) st_row8(bs + (arow + i * (256 / CPR)) * LROW + ach * 2, rb[i][0], rb[i][1]);
+            for (int i = 0; i < RB; ++i) {
+                unsigned char* d = bs + (arow + i * (256 / CPR)) * LROW + ach * 2;
+                if constexpr (SHB) *reinterpret_cast<u32x4*>(d) = rb16[i]; else st_row8(d, rb[i][0], rb[i][1]);
+            }
         } else {
 #pragma unroll
-            for (int u = 0; u < NCB; ++u) st_col4(bs + (bk0 + u * KPP) * SB + bcg * 2, rc[u]);
+            for (int u = 0; u < NCB; ++u) {
+                unsigned char* d = bs + (bk0 + u * KPP) * SB + bcg * 2;
+                if constexpr (SHB) *reinterpret_cast<u32x2*>(d) = rc16[u];
+                else st_col4(d, rc[u]);
+            }
         }
     };
 
@@ -244,10 +280,18 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
     }
 }
 
+template <int BM, int BN, int WM, int WN, bool SA_, bool SB_>
+static void launch_tile_bf16_s(const IGemm& g, dim3 grid, hipStream_t s) {
+    if (g.b_kn) hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, true, SA_, SB_>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, false, SA_, SB_>), grid, dim3(256), 0, s, g);
+}
 template <int BM, int BN, int WM, int WN>
 static void launch_tile_bf16(const IGemm& g, dim3 grid, hipStream_t s) {
-    if (g.b_kn) hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, g);
+    const bool sa = g.A16 != nullptr, sb = g.B16 != nullptr;
+    if (sa && sb) launch_tile_bf16_s<BM, BN, WM, WN, true, true>(g, grid, s);
+    else if (sa) launch_tile_bf16_s<BM, BN, WM, WN, true, false>(g, grid, s);
+    else if (sb) launch_tile_bf16_s<BM, BN, WM, WN, false, true>(g, grid, s);
+    else launch_tile_bf16_s<BM, BN, WM, WN, false, false>(g, grid, s);
 }
 
 int launch_igemm_bf16(const IGemm& g, hipStream_t s, int groups) {
@@ -265,13 +309,14 @@ int launch_igemm_bf16(const IGemm& g, hipStream_t s, int groups) {
 // Weight gradient (see gemm.hip wgemm_tn): dW[i][wt[t]*Cq + c] = sum_m P[m][i] * Q[pos(m,t)][c]; the reduction index m is
 // the slow axis of both operands in HBM, so both are COL operands (tile[m][i], tile[m][j]) read with transposing loads.
 // BI x BJ tile, K-step 64 pixels, M split over blockIdx.y into slabs (summed by reduce_slabs of gemm.hip).
-template <int BI, int BJ>
+template <int BI, int BJ, bool SP16, bool SQ16>
 __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
     constexpr int BK = BK16;
     constexpr int WN = 2, TM = BI / 2 / 32, TN = BJ / 2 / 32;
-    constexpr int CGP = BI / 4, CGQ = BJ / 4;            // float4 column groups per k row
+    constexpr int GP = SP16 ? 8 : 4, GQ = SQ16 ? 8 : 4;  // columns per 16-byte load: 4 fp32 or 8 bf16 (shadow operand)
+    constexpr int CGP = BI / GP, CGQ = BJ / GQ;          // column groups per k row
     constexpr int KPP_P = 256 / CGP, KPP_Q = 256 / CGQ;  // k rows per pass
-    constexpr int NP = BK / KPP_P, NQ = BK / KPP_Q;      // float4 loads per thread and K-step
+    constexpr int NP = BK / KPP_P, NQ = BK / KPP_Q;      // 16-byte loads per thread and K-step (a shadow operand needs half as many)
     constexpr int SP = col_stride(BI), SQ = col_stride(BJ);
     constexpr int PBYTES = BK * SP, TILE = PBYTES + BK * SQ;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE];
@@ -279,7 +324,10 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab; float* bslabp = g.bslab;
-    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; bslabp = g.bslab1; }
+    const unsigned short* __restrict__ P16 = reinterpret_cast<const unsigned short*>(g.P16);
+    const unsigned short* __restrict__ Q16 = reinterpret_cast<const unsigned short*>(g.Q16);
+    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; bslabp = g.bslab1; if (P16) P16 += g.gsP; if (Q16) Q16 += g.gsQ; }
+    const unsigned short* const z16 = reinterpret_cast<const unsigned short*>(g_zero32);
     const int wm = wave / WN, wn = wave % WN;
     const int NJ = g.T * g.Cq;
     const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
@@ -296,13 +344,13 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
         xcd_tile(blockIdx.x, nti * ntj, ntj, ti, tj);
     }
     const int i0 = ti * BI, j0 = tj * BJ;
-    const bool do_bias = bslabp != nullptr && tj == 0;
+    const bool do_bias = !SP16 && bslabp != nullptr && tj == 0;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     const int ms = blockIdx.y * g.rows_per_split;
     const int me = min(g.M, ms + g.rows_per_split);
 
-    const int pcg = (tid % CGP) * 4, pk0 = tid / CGP;
-    const int qcg = (tid % CGQ) * 4, qk0 = tid / CGQ;
+    const int pcg = (tid % CGP) * GP, pk0 = tid / CGP;
+    const int qcg = (tid % CGQ) * GQ, qk0 = tid / CGQ;
     const bool pcol_ok = i0 + pcg < g.NI;
     const int jcol = j0 + qcg;
     const bool qcol_ok = jcol < NJ;
@@ -328,31 +376,40 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 rp[NP], rq[NQ];
+    float4 rp[SP16 ? 1 : NP], rq[SQ16 ? 1 : NQ];
+    u32x4 rp16[SP16 ? NP : 1], rq16[SQ16 ? NQ : 1];        // 8 bf16 each
     auto gload = [&](int mb) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int m = mb + pk0 + u * KPP_P;
-            const float* src = (m < me && pcol_ok) ? Pp + (long)m * g.ldp + i0 + pcg : g_zero32;
-            rp[u] = *reinterpret_cast<const float4*>(src);
+            const bool ok = m < me && pcol_ok;
+            if constexpr (SP16) {                          // 4 bf16 = 8 bytes (the host never combines this with the bias partials)
+                const unsigned short* src = ok ? P16 + (long)m * g.ldp + i0 + pcg : z16;
+                rp16[u] = *reinterpret_cast<const u32x4*>(src);
+            } else rp[u] = *reinterpret_cast<const float4*>(ok ? Pp + (long)m * g.ldp + i0 + pcg : g_zero32);
         }
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int m = mb + qk0 + u * KPP_Q;
-            const float* src = g_zero32;
-            if (g.plain_q) {
-                if (m < me && qcol_ok) src = Qp + (long)m * g.ldq + qch;
-            } else {
+            bool ok; long off;
+            if (g.plain_q) { ok = m < me && qcol_ok; off = (long)m * g.ldq + qch; }
+            else {
                 const int iy = q_y[u] * g.sy + tdy, ix = q_x[u] * g.sx + tdx;
-                if (m < me && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                    src = Qp + ((long)q_ni[u] * g.H * g.W + (long)iy * g.W + ix) * g.ldq + qch;
+                ok = m < me && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                off = ((long)q_ni[u] * g.H * g.W + (long)iy * g.W + ix) * g.ldq + qch;
                 q_x[u] += BK;
                 while (q_x[u] >= g.QW) {
                     q_x[u] -= g.QW;
                     if (++q_y[u] == g.QH) { q_y[u] = 0; ++q_ni[u]; }
                 }
             }
-            rq[u] = *reinterpret_cast<const float4*>(src);
+            if constexpr (SQ16) {
+                const unsigned short* src = ok ? Q16 + off : z16;
+                rq16[u] = *reinterpret_cast<const u32x4*>(src);
+            } else {
+                const float* src = ok ? Qp + off : g_zero32;
+                rq[u] = *reinterpret_cast<const float4*>(src);
+            }
         }
     };
     auto lstore = [&](int buf) {
@@ -360,11 +417,20 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
         unsigned char* qs = ps + PBYTES;
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            st_col4(ps + (pk0 + u * KPP_P) * SP + pcg * 2, rp[u]);
-            if (do_bias) { bsum[0] += rp[u].x; bsum[1] += rp[u].y; bsum[2] += rp[u].z; bsum[3] += rp[u].w; }
+            unsigned char* d = ps + (pk0 + u * KPP_P) * SP + pcg * 2;
+            if constexpr (SP16) {
+                *reinterpret_cast<u32x4*>(d) = rp16[u];      // (never together with the bias partials: launch_wgemm drops P16 then)
+            } else {
+                st_col4(d, rp[u]);
+                if (do_bias) { bsum[0] += rp[u].x; bsum[1] += rp[u].y; bsum[2] += rp[u].z; bsum[3] += rp[u].w; }
+            }
         }
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) st_col4(qs + (qk0 + u * KPP_Q) * SQ + qcg * 2, rq[u]);
+        for (int u = 0; u < NQ; ++u) {
+            unsigned char* d = qs + (qk0 + u * KPP_Q) * SQ + qcg * 2;
+            if constexpr (SQ16) *reinterpret_cast<u32x4*>(d) = rq16[u];
+            else st_col4(d, rq[u]);
+        }
     };
 
     if (ms < me) { gload(ms); lstore(0); }
@@ -406,12 +472,19 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
 int launch_wgemm_bf16(const WGemm& g, int splits, int groups, int small, hipStream_t s) {
     const int NJ = g.T * g.Cq;
     if (g.NI % 4 != 0 || g.Cq % 4 != 0 || g.ldp % 4 != 0 || g.ldq % 4 != 0 || g.rows_per_split % BK16 != 0) return 0;
+    const bool sp = g.P16 != nullptr, sq = g.Q16 != nullptr;
     if (small) {
         dim3 grid((unsigned)(cdiv(g.NI, 64) * cdiv(NJ, 64)), (unsigned)splits, (unsigned)groups);
-        hipLaunchKernelGGL((wgemm_bf16_kernel<64, 64>), grid, dim3(256), 0, s, g);
+        if (sp && sq) hipLaunchKernelGGL((wgemm_bf16_kernel<64, 64, true, true>), grid, dim3(256), 0, s, g);
+        else if (sp) hipLaunchKernelGGL((wgemm_bf16_kernel<64, 64, true, false>), grid, dim3(256), 0, s, g);
+        else if (sq) hipLaunchKernelGGL((wgemm_bf16_kernel<64, 64, false, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((wgemm_bf16_kernel<64, 64, false, false>), grid, dim3(256), 0, s, g);
     } else {
         dim3 grid((unsigned)(cdiv(g.NI, 128) * cdiv(NJ, 128)), (unsigned)splits, (unsigned)groups);
-        hipLaunchKernelGGL((wgemm_bf16_kernel<128, 128>), grid, dim3(256), 0, s, g);
+        if (sp && sq) hipLaunchKernelGGL((wgemm_bf16_kernel<128, 128, true, true>), grid, dim3(256), 0, s, g);
+        else if (sp) hipLaunchKernelGGL((wgemm_bf16_kernel<128, 128, true, false>), grid, dim3(256), 0, s, g);
+        else if (sq) hipLaunchKernelGGL((wgemm_bf16_kernel<128, 128, false, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((wgemm_bf16_kernel<128, 128, false, false>), grid, dim3(256), 0, s, g);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : -(int)e;

@@ -23,6 +23,10 @@ struct IGemm {
     // split-K (blockIdx.z = split): K-steps [z*ksteps, (z+1)*ksteps) of this launch's BK, raw partial sums to
     // part[z][M][N] (no bias / activation -- splitk_finish applies them).  ksteps == 0: no split.
     int ksteps; float* part;
+    // bf16 shadows of the operands (bf16 mode, optional): the same elements as A / B (B1) already rounded to bf16 (RNE) by their
+    // producer, same layout with the same leading dimensions in ELEMENTS -- the bf16 kernels then stage 2-byte operands
+    // straight into LDS (half the L2 -> LDS bytes, no conversion); results are bit-identical to rounding while staging
+    const void* A16; const void* B16; const void* B116;
     int accum;                                // C += result (after bias / activation): a gradient accumulated into an existing one
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
@@ -56,6 +60,7 @@ struct WGemm {
     // in-launch reduction of the split slabs (pdf_last_block_arrives): the last block of every output tile sums the slabs in split
     // order into out / out1 (+= when accumulate) and the bias partials into bout / bout1; counters == NULL: reduce_slabs launch
     float* out; float* out1; float* bout; float* bout1; int accumulate; int* counters;
+    const void* P16; const void* Q16;         // bf16 shadows of P / Q (see IGemm::A16)
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 

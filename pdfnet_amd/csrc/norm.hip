@@ -289,7 +289,9 @@ __global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __r
 // registers, no index division, 4 independent 16-byte loads per operand in flight per thread.
 __global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ res, int ldr,
-                                                              float* __restrict__ y, int ldy, int C, long R, long rows_per_chunk, int relu) {
+                                                              float* __restrict__ y, int ldy, int C, long R, long rows_per_chunk, int relu,
+                                                              unsigned short* __restrict__ y16 = nullptr) {
+    // y16 (bf16 mode, optional): the same values rounded to bf16 beside y, same leading dimension -- the shadow the bf16 GEMMs read
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
     if (c0 >= C) return;
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __res
         }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<float4*>(y + r * ldy + c0) = v;
+        if (y16 != nullptr) *reinterpret_cast<uint2*>(y16 + r * ldy + c0) = uint2{pdf_pk_bf16(v.x, v.y), pdf_pk_bf16(v.z, v.w)};
     }
 }
 
@@ -312,7 +315,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
                                                               const float* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ coef,
                                                               const float* __restrict__ scale, const float* __restrict__ shift, int C, long R,
-                                                              long rows_per_chunk, float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddr) {
+                                                              long rows_per_chunk, float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddr,
+                                                              unsigned short* __restrict__ dx16 = nullptr) {
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
     if (c0 >= C) return;
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
         o.z = ka.z * (g.z - k1.z - (xv.z - m.z) * rs.z * k2.z);
         o.w = ka.w * (g.w - k1.w - (xv.w - m.w) * rs.w * k2.w);
         *reinterpret_cast<float4*>(dx + r * lddx + c0) = o;
+        if (dx16 != nullptr) *reinterpret_cast<uint2*>(dx16 + r * lddx + c0) = uint2{pdf_pk_bf16(o.x, o.y), pdf_pk_bf16(o.z, o.w)};
     }
 }
 
@@ -361,11 +366,11 @@ static bool v4_ok(int C, std::initializer_list<int> lds, std::initializer_list<c
 }
 
 static void launch_affine_apply(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldr,
-                                float* y, int ldy, int C, long R, int relu, hipStream_t s) {
+                                float* y, int ldy, int C, long R, int relu, hipStream_t s, void* y16 = nullptr) {
     if (v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift})) {
         const long rpc = apply_rows_per_chunk(C, R);
         hipLaunchKernelGGL(affine_apply_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)((R + rpc - 1) / rpc)), dim3(256), 0, s,
-                           x, ldx, scale, shift, res, ldr, y, ldy, C, R, rpc, relu);
+                           x, ldx, scale, shift, res, ldr, y, ldy, C, R, rpc, relu, reinterpret_cast<unsigned short*>(y16));
     } else
         hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
 }
@@ -389,6 +394,7 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
                              float* running_mean, float* running_var, float momentum, float eps,
                              const float* res, int ldr, int relu, float* y, int ldy,
                              float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, hipStream_t s) {
+    void* y16 = pdf_tls_take_output();                       // bf16 shadow of y (pdf_set_bf16_output), vectorised path only
     if (R <= 0 || C <= 0) return 0;
     long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
@@ -405,7 +411,8 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
                            running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
         PDF_LAUNCH_CHECK();
     }
-    launch_affine_apply(x, ldx, scale, shift, res, ldr, y, ldy, C, R, relu, s);
+    if (y16 != nullptr && !v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift, y16})) return PDF_E_BADARG;
+    launch_affine_apply(x, ldx, scale, shift, res, ldr, y, ldy, C, R, relu, s, y16);
     PDF_LAUNCH_CHECK();
     return 0;
 }
@@ -489,6 +496,7 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
                              const float* scale, const float* shift, int C, long R,
                              float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
                              float* ws, hipStream_t s) {
+    void* dx16 = pdf_tls_take_output();                      // bf16 shadow of dx
     if (R <= 0 || C <= 0) return 0;
     if ((relu == 1 && y == nullptr) || (relu == 2 && (scale == nullptr || shift == nullptr || dres != nullptr))) return PDF_E_BADARG;
     long chunks = bn_chunks(C, R);
@@ -513,8 +521,9 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
     if (vec) {
         const long arpc = apply_rows_per_chunk(C, R);
         hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)((R + arpc - 1) / arpc)), dim3(256), 0, s, dy, lddy, y, ldy, relu,
-                           x, ldx, save_mean, save_rstd, coef, scale, shift, C, R, arpc, dx, lddx, dres, lddr);
-    } else
+                           x, ldx, save_mean, save_rstd, coef, scale, shift, C, R, arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
+    } else if (dx16 != nullptr) return PDF_E_BADARG;
+    else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef,
                            scale, shift, C, R * C, dx, lddx, dres, lddr);
     PDF_LAUNCH_CHECK();
@@ -988,7 +997,8 @@ struct L2Parts {
     const float* x[L2_MAXPARTS]; const float* w[L2_MAXPARTS]; float* norm[L2_MAXPARTS]; float* dx[L2_MAXPARTS]; float* dw[L2_MAXPARTS];
     int C[L2_MAXPARTS], off[L2_MAXPARTS];
 };
-__global__ __launch_bounds__(256) void l2norm_cat_fwd_kernel(const L2Parts p, long R, float eps, float* __restrict__ y, int ldy) {
+__global__ __launch_bounds__(256) void l2norm_cat_fwd_kernel(const L2Parts p, long R, float eps, float* __restrict__ y, int ldy,
+                                                             unsigned short* __restrict__ y16) {
     const int part = blockIdx.y, C = p.C[part], lane = threadIdx.x & 63;
     const float* __restrict__ x = p.x[part]; const float* __restrict__ w = p.w[part];
     float* __restrict__ yo = y + p.off[part];
@@ -998,7 +1008,14 @@ __global__ __launch_bounds__(256) void l2norm_cat_fwd_kernel(const L2Parts p, lo
         float sq = 0.f;
         for (int c = lane; c < C; c += 64) { float v = x[r * C + c]; sq += v * v; }
         const float n = sqrtf(wave_sum(sq)) + eps;
-        for (int c = lane; c < C; c += 64) yo[r * ldy + c] = w[c] * (x[r * C + c] / n);
+        for (int c = lane; c < C; c += 64) {
+            const float v = w[c] * (x[r * C + c] / n);
+            yo[r * ldy + c] = v;
+            if (y16 != nullptr) {                            // bf16 shadow: lanes pair up so that 4-byte words are written
+                const float vn = __shfl_down(v, 1, 64);
+                if ((lane & 1) == 0) *reinterpret_cast<unsigned int*>(y16 + p.off[part] + r * ldy + c) = pdf_pk_bf16(v, vn);
+            }
+        }
         if (lane == 0) p.norm[part][r] = n;
     }
 }
@@ -1070,10 +1087,13 @@ static int l2_parts(L2Parts& p, int nparts, const float* const* x, const float* 
 // x[i]: [R][C[i]] contiguous rows; y: [R][ldy] with part i at channel offset C[0] + ... + C[i-1]; norm[i]: [R]
 PDF_API int pdf_l2norm_cat_fwd(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R,
                                float* y, int ldy, float* const* norm, hipStream_t s) {
+    void* y16 = pdf_tls_take_output();                       // bf16 shadow of y (needs even channel counts)
     if (R <= 0) return 0;
     L2Parts p = {};
     if (int rc = l2_parts(p, nparts, x, w, norm, nullptr, nullptr, C)) return rc;
-    hipLaunchKernelGGL(l2norm_cat_fwd_kernel, dim3(grid_for(R * 64, 256, 2048), nparts), dim3(256), 0, s, p, R, eps, y, ldy);
+    for (int i = 0; y16 != nullptr && i < nparts; ++i) if (C[i] % 64) return PDF_E_BADARG;
+    hipLaunchKernelGGL(l2norm_cat_fwd_kernel, dim3(grid_for(R * 64, 256, 2048), nparts), dim3(256), 0, s, p, R, eps, y, ldy,
+                       reinterpret_cast<unsigned short*>(y16));
     PDF_LAUNCH_CHECK();
     return 0;
 }

@@ -102,6 +102,43 @@ def gemm_precision():
     return 'bf16' if hip.lib().pdf_debug_gemm_precision() else 'fp32'
 
 
+# ---- bf16 shadows (bf16 mode): BatchNorm (forward output, backward dx), the pyramid L2Norm and the trainer (weights) write a bf16
+# copy of what they produce; the conv / deconv / linear launches that read those tensors hand the copy to the library
+# (pdf_set_bf16_operands), whose bf16 GEMM kernels then stage 2-byte operands.  Results are bit-identical to the plain bf16 mode
+# (same round-to-nearest-even, done by the producer instead of the consumer).  A shadow travels as an attribute of the tensor
+# it mirrors and is ignored once that tensor has been modified in place.
+BF16_SHADOWS = _os.environ.get("PDFNET_BF16_SHADOWS", "1") != "0"
+
+
+def shadows_on():
+    return BF16_SHADOWS and hip.lib().pdf_debug_gemm_precision() != 0
+
+
+def attach_shadow(t, s16):
+    t._pdf_bf16, t._pdf_bf16_ver = s16, t._version
+    return t
+
+
+def shadow_of(t):
+    """The bf16 copy of `t` if it has a valid one with the same layout, else None."""
+    if t is None:
+        return None
+    s16 = getattr(t, '_pdf_bf16', None)
+    if s16 is None or t._version != getattr(t, '_pdf_bf16_ver', -1) or s16.shape != t.shape or s16.stride() != t.stride():
+        return None
+    return s16
+
+
+def new_shadow(t):
+    return torch.empty_like(t, dtype=torch.bfloat16) if shadows_on() else None
+
+
+def _set_ops(a, b):
+    """Shadows of the next GEMM-family call's two operands (None = none)."""
+    if a is not None or b is not None:
+        _L().pdf_set_bf16_operands(ptr(a), ptr(b))
+
+
 class _forced_fp32:
     """Launches issued inside run on the fp32 kernels even in bf16 mode (the precision flag is read on the host at launch)."""
 
@@ -291,8 +328,11 @@ class _Conv2d(Function):
         OH = (H + 2 * pad - KH) // stride + 1
         OW = (W + 2 * pad - KW) // stride + 1
         y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
+        x16, w16 = shadow_of(x), shadow_of(w)
+        _set_ops(x16, w16)
         _L().pdf_conv2d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream())
         ctx.save_for_backward(x, w, y if act else None)
+        ctx.s16 = (x16, w16)
         ctx.cfg = (stride, pad, act, b is not None)
         ctx.params = (w_in, b)
         if skip:
@@ -309,9 +349,12 @@ class _Conv2d(Function):
         g = cl(dy)
         if act:
             g = _act_bwd(g, y, act)
+        x16, w16 = ctx.s16
+        g16 = shadow_of(g)
         dx = dw = db = None
         L = _L()
         if ctx.needs_input_grad[0]:
+            _set_ops(g16, w16)
             if dskip is not None and stride == 1 and dskip.shape == x.shape and dskip.is_contiguous(memory_format=CL):
                 dx = dskip                                  # the shortcut's gradient (sole consumer: this node); += in the epilogue
                 L.pdf_conv2d_bwd_data_add(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
@@ -325,6 +368,7 @@ class _Conv2d(Function):
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(R, Cout, KH * KW * Cin, x.device)
+            _set_ops(x16, g16)
             L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
                                     stride, pad, OH, OW, Cout, acc, stream())
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True)
@@ -354,8 +398,11 @@ class _Deconv2d(Function):
         OW = (W - 1) * stride - 2 * pad + KW
         L = _L()
         y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
+        x16, w16 = shadow_of(x), shadow_of(w)
+        _set_ops(x16, w16)
         L.pdf_deconv2d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
         ctx.save_for_backward(x, w)
+        ctx.s16 = (x16, w16)
         ctx.cfg = (stride, pad, b is not None)
         ctx.params = (w_in, b)
         return y
@@ -368,15 +415,19 @@ class _Deconv2d(Function):
         _, Cout, KH, KW = w.shape
         OH, OW = dy.shape[2], dy.shape[3]
         g = cl(dy)
+        x16, w16 = ctx.s16
+        g16 = shadow_of(g)
         L = _L()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            _set_ops(g16, w16)
             L.pdf_deconv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
         w_par, b_par = ctx.params
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
+            _set_ops(x16, g16)
             L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
                                       stride, pad, OH, OW, Cout, acc, stream())
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, N * OH * OW, 2.0 * N * H * W * Cin * KH * KW * Cout)
@@ -399,9 +450,12 @@ class _Linear(Function):
         M = x.numel() // K
         Nn = w.shape[0]
         y = torch.empty(x.shape[:-1] + (Nn,), dtype=torch.float32, device=x.device)
+        x16, w16 = (None, None) if fp32 else (shadow_of(x), shadow_of(w))
         with _forced_fp32(fp32):
+            _set_ops(x16, w16)
             _L().pdf_linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), M, Nn, K, K, K, Nn, act, stream())
         ctx.save_for_backward(x, w, y if act else None)
+        ctx.s16 = (x16, w16)
         ctx.fp32 = fp32
         ctx.cfg = (act, b is not None)
         ctx.params = (w_in, b)
@@ -417,17 +471,21 @@ class _Linear(Function):
         g = dy.contiguous()
         if act:
             g = _act_bwd(g, y, act)
+        x16, w16 = ctx.s16
+        g16 = None if ctx.fp32 else shadow_of(g)
         L = _L()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with _forced_fp32(ctx.fp32):
+                _set_ops(g16, w16)
                 L.pdf_linear_bwd_data(ptr(g), ptr(w), ptr(dx), M, Nn, K, Nn, K, K, stream())
         w_par, b_par = ctx.params
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(M, Nn, K, x.device)
             with _forced_fp32(ctx.fp32):
+                _set_ops(x16, g16)
                 L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K, fused_bias=True)
         return dx, dw, db, None, None
@@ -444,6 +502,9 @@ def as_matrix(weight):
     view (no copy) for `linear`, carrying the same view of the trainer's flat gradient so that the weight gradient is still
     accumulated in place."""
     w2 = weight.permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+    w16 = shadow_of(weight)
+    if w16 is not None:
+        attach_shadow(w2, w16.permute(0, 2, 3, 1).reshape(weight.shape[0], -1))
     if getattr(weight, '_pdf_main_grad', False) and weight.grad is not None:
         w2._pdf_main_grad = True
         w2._pdf_grad_alias = weight.grad.permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
@@ -543,8 +604,13 @@ class _BatchNorm(Function):
             mean = torch.empty(C, device=dev)
             rstd = torch.empty(C, device=dev)
             ws = _ws(L.pdf_bn_workspace_floats(C, R), dev)
+            y16 = new_shadow(y) if C % 4 == 0 else None
+            if y16 is not None:
+                L.pdf_set_bf16_output(ptr(y16))
             L.pdf_bn_train_fwd(ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
                                ptr(res), C, int(relu), ptr(y), C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
+            if y16 is not None:
+                attach_shadow(y, y16)
             # ReLU without a residual: the backward recomputes the mask from x with (scale, shift); y is not kept for it
             recompute = relu and res is None
             ctx.save_for_backward(x, gamma, mean, rstd, (scale if recompute else (y if relu else None)), (shift if recompute else None))
@@ -577,8 +643,13 @@ class _BatchNorm(Function):
         dbeta = mg_b if direct else torch.empty(C, device=x.device)
         L = _L()
         ws = _ws(L.pdf_bn_workspace_floats(C, R) + 3 * C, x.device)
+        dx16 = new_shadow(dx) if C % 4 == 0 else None
+        if dx16 is not None:
+            L.pdf_set_bf16_output(ptr(dx16))
         L.pdf_bn_train_bwd(ptr(g), C, ptr(y), C, mode, ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R,
                            ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream())
+        if dx16 is not None:
+            attach_shadow(dx, dx16)
         if direct:
             dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
@@ -711,6 +782,10 @@ class _L2NormCat(Function):
         Ct, R = sum(Cs), B * H * W
         out = torch.empty((B, Ct, H, W), dtype=torch.float32, device=xs[0].device, memory_format=CL)
         norms = [torch.empty(R, device=out.device) for _ in xs]
+        out16 = new_shadow(out) if all(C % 64 == 0 for C in Cs) else None
+        if out16 is not None:
+            _L().pdf_set_bf16_output(ptr(out16))
+            attach_shadow(out, out16)
         _L().pdf_l2norm_cat_fwd(n, _ptr_array(xs), _int_array(Cs), _ptr_array(ws), eps, R, ptr(out), Ct, _ptr_array(norms), stream())
         ctx.save_for_backward(*xs, *ws, *norms)
         ctx.cfg = (eps, n, Cs)

@@ -96,6 +96,19 @@ class FlatAdam:
     def eps(self):
         return self.param_groups[0]['eps']
 
+    def refresh_bf16_shadows(self):
+        """bf16 mode: one cast of the flat master buffer into a flat bf16 buffer whose per-parameter views (same shapes and
+        strides) ride on the parameters as their shadows (pdfnet_amd.functional.shadow_of): the GEMM kernels then read 2-byte
+        weights.  Called at the start of every train step, i.e. after whatever changed the parameters last."""
+        if getattr(self, 'flat_p16', None) is None:
+            self.flat_p16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat_p.device)
+            self._p16_views = [self.flat_p16[o:o + p.numel()].as_strided(p.shape, p.stride()) for p, o in zip(self.params, self.offsets)]
+        hip.lib().pdf_cast_bf16(hip.ptr(self.flat_p), hip.ptr(self.flat_p16), self.numel, hip.stream())
+        base = self.flat_p.data_ptr()
+        for p, v, o in zip(self.params, self._p16_views, self.offsets):
+            if p.data_ptr() == base + 4 * o:                  # still the view into the flat buffer
+                F.attach_shadow(p, v)
+
     def reattach_grads(self):
         """The HIP backward kernels accumulate into `p.grad` only while it is the view into the flat gradient buffer.
         `model.zero_grad()` (set_to_none=True), `p.grad = None` or an optimizer-style zero_grad replace it; autograd would
@@ -314,6 +327,8 @@ class Trainer:
     def train_step(self, batch, epoch=0):
         """batch: dict of device tensors. Returns the (device) scalar loss; no host sync."""
         self.model_with_loss.train()
+        if F.shadows_on():
+            self.optimizer.refresh_bf16_shadows()
         if self.broadcast_buffers and self.world > 1 and self.collectives:
             for b in self._float_buffers():
                 dist.broadcast(b, 0)
