@@ -197,11 +197,12 @@ int pdf_l2norm_bwd(const float* dy, int lddy, const float* x, int ldx, int C, lo
 /* The pyramid concat of L2Norm'd maps (intaghand_encoder.py:724-739: torch.cat of four L2Norm outputs) in one launch per
  * direction: part i = rows x[i] [R][C[i]] (contiguous), written to / read from channel offset C[0]+..+C[i-1] of the
  * concatenated rows y / dy [R][ld].  x, w, norm, dx, dw: HOST arrays of nparts (<= 4) device pointers; C: host array.
- * bwd: dw[i] zero-filled by the caller (atomically accumulated). */
+ * bwd: dw[i] zero-filled by the caller (atomically accumulated); dx16: optional host array of bf16 shadow outputs of dx (bf16 mode,
+ * channel counts multiples of 64), NULL or NULL entries = none. */
 int pdf_l2norm_cat_fwd(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R,
                        float* y, int ldy, float* const* norm, void* stream);
 int pdf_l2norm_cat_bwd(int nparts, const float* dy, int lddy, const float* const* x, const int* C, const float* const* w, float eps, long R,
-                       float* const* norm, float* const* dx, float* const* dw, void* stream);
+                       float* const* norm, float* const* dx, float* const* dw, void* const* dx16_or_null, void* stream);
 
 /* ---- elementwise / spatial (csrc/elementwise.hip) --------------------------------------------- */
 int pdf_act_fwd(const float* x, int ldx, float* y, int ldy, int C, long R, int act, void* stream);

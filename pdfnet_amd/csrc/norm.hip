@@ -995,6 +995,7 @@ PDF_API int pdf_l2norm_bwd(const float* dy, int lddy, const float* x, int ldx, i
 #define L2_MAXPARTS 4
 struct L2Parts {
     const float* x[L2_MAXPARTS]; const float* w[L2_MAXPARTS]; float* norm[L2_MAXPARTS]; float* dx[L2_MAXPARTS]; float* dw[L2_MAXPARTS];
+    unsigned short* dx16[L2_MAXPARTS];                   // optional bf16 shadows of dx (bf16 mode)
     int C[L2_MAXPARTS], off[L2_MAXPARTS];
 };
 __global__ __launch_bounds__(256) void l2norm_cat_fwd_kernel(const L2Parts p, long R, float eps, float* __restrict__ y, int ldy,
@@ -1056,10 +1057,16 @@ __global__ __launch_bounds__(256) void l2norm_cat_bwd_kernel(const L2Parts p, in
             const float nn = n - eps;
             const float k = nn > 0.f ? dot / (n * n * nn) : 0.f;
             const float in = 1.f / n;
+            unsigned short* dx16 = p.dx16[q];
 #pragma unroll
             for (int i = 0; i < L2_MAXV; ++i) {
                 const int c = lane + 64 * i;
-                if (c < C) dx[c] = wv[i] * g[i] * in - xv[i] * k;
+                const float o = wv[i] * g[i] * in - xv[i] * k;
+                if (c < C) dx[c] = o;
+                if (dx16 != nullptr) {                        // (C % 64 == 0 then: whole waves, lanes pair up for 4-byte words)
+                    const float on = __shfl_down(o, 1, 64);
+                    if (c < C && (lane & 1) == 0) *reinterpret_cast<unsigned int*>(dx16 + r * C + c) = pdf_pk_bf16(o, on);
+                }
                 acc[q][i] += g[i] * xv[i] * in;
             }
         }
@@ -1099,10 +1106,14 @@ PDF_API int pdf_l2norm_cat_fwd(int nparts, const float* const* x, const int* C, 
 }
 // dw[i] must be zero-filled (atomically accumulated)
 PDF_API int pdf_l2norm_cat_bwd(int nparts, const float* dy, int lddy, const float* const* x, const int* C, const float* const* w, float eps, long R,
-                               float* const* norm, float* const* dx, float* const* dw, hipStream_t s) {
+                               float* const* norm, float* const* dx, float* const* dw, void* const* dx16, hipStream_t s) {
     if (R <= 0) return 0;
     L2Parts p = {};
     if (int rc = l2_parts(p, nparts, x, w, norm, dx, dw, C)) return rc;
+    for (int i = 0; dx16 != nullptr && i < nparts; ++i) {
+        if (dx16[i] != nullptr && C[i] % 64) return PDF_E_BADARG;
+        p.dx16[i] = reinterpret_cast<unsigned short*>(dx16[i]);
+    }
     hipLaunchKernelGGL(l2norm_cat_bwd_kernel, dim3(grid_for(R * 64, 256, 2048)), dim3(256), 0, s, p, nparts, R, eps, dy, lddy);
     PDF_LAUNCH_CHECK();
     return 0;

@@ -19,6 +19,9 @@ _side = {}
 def _record(obj, stream_):
     if torch.is_tensor(obj):
         obj.record_stream(stream_)
+        s16 = getattr(obj, '_pdf_bf16', None)           # its bf16 shadow travels with it
+        if s16 is not None:
+            s16.record_stream(stream_)
     elif isinstance(obj, (list, tuple)):
         for o in obj:
             _record(o, stream_)
@@ -227,6 +230,9 @@ class wgrad_stream:
         for t in self.tensors:                      # produced / owned by the main stream, read on the side stream
             if t is not None:
                 t.record_stream(side)
+                s16 = getattr(t, '_pdf_bf16', None)
+                if s16 is not None:
+                    s16.record_stream(side)
         _wg_used.add(key)
         self._ctx = torch.cuda.stream(side)
         self._ctx.__enter__()
@@ -274,7 +280,7 @@ def _colsum(g, C, R, ldg):
 ASYNC_WGRAD_MIN_FLOP = float(_os.environ.get("PDFNET_ASYNC_WGRAD_MIN_GFLOP", "0")) * 1e9
 
 
-def _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, C, R, flops, fused_bias=False):
+def _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, C, R, flops, fused_bias=False, shadows=()):
     """Weight and bias gradients of a conv / transposed conv / linear layer.  Gradients that go straight into the
     trainer's flat buffer are issued together on the side stream (one stream switch for both).  A size threshold for the
     switch was measured (PDFNET_ASYNC_WGRAD_MIN_GFLOP = 0 / 0.5 / 4 -> 316 / 311 / 298 img/s): even the smallest layers
@@ -289,7 +295,9 @@ def _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, C, R, flops, fused
     dw = db = None
     ride = fused_bias and need_w and need_b and (mg_w is None) == (mg_b is None)      # same accumulate mode for both
     if mg_w is not None or mg_b is not None:
-        with wgrad_stream(flops >= ASYNC_WGRAD_MIN_FLOP, x, g, params=(w_par, b_par)):
+        # (the bf16 shadows the launch reads are side-stream inputs like x and g: recorded, or the allocator could hand their
+        # memory out again while the weight-gradient kernel still reads it)
+        with wgrad_stream(flops >= ASYNC_WGRAD_MIN_FLOP, x, g, *shadows, params=(w_par, b_par)):
             if mg_w is not None:
                 launch_w(mg_w, mg_b if ride else None, 1)
             if mg_b is not None and not ride:
@@ -371,7 +379,7 @@ class _Conv2d(Function):
             _set_ops(x16, g16)
             L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
                                     stride, pad, OH, OW, Cout, acc, stream())
-        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True)
+        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True, shadows=(x16, g16))
         return dx, dw, db, None, None, None, None
 
 
@@ -430,7 +438,7 @@ class _Deconv2d(Function):
             _set_ops(x16, g16)
             L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
                                       stride, pad, OH, OW, Cout, acc, stream())
-        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, N * OH * OW, 2.0 * N * H * W * Cin * KH * KW * Cout)
+        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, N * OH * OW, 2.0 * N * H * W * Cin * KH * KW * Cout, shadows=(x16, g16))
         return dx, dw, db, None, None
 
 
@@ -487,7 +495,7 @@ class _Linear(Function):
             with _forced_fp32(ctx.fp32):
                 _set_ops(x16, g16)
                 L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
-        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K, fused_bias=True)
+        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K, fused_bias=True, shadows=(x16, g16))
         return dx, dw, db, None, None
 
 
@@ -800,8 +808,14 @@ class _L2NormCat(Function):
         Ct = sum(Cs)
         R = xs[0].numel() // Cs[0]
         dxs, dws = [torch.empty_like(x) for x in xs], [torch.zeros_like(w) for w in ws]
+        d16 = [new_shadow(d) for d in dxs] if all(C % 64 == 0 for C in Cs) and _os.environ.get('PDFNET_L2_SHADOW', '1') != '0' else None
+        if d16 is not None and d16[0] is None:
+            d16 = None
         _L().pdf_l2norm_cat_bwd(n, ptr(g), Ct, _ptr_array(xs), _int_array(Cs), _ptr_array(ws), eps, R, _ptr_array(norms),
-                                _ptr_array(dxs), _ptr_array(dws), stream())
+                                _ptr_array(dxs), _ptr_array(dws), _ptr_array(d16) if d16 is not None else None, stream())
+        if d16 is not None:
+            for d, s16 in zip(dxs, d16):
+                attach_shadow(d, s16)
         return (None,) + tuple(dxs) + tuple(dws)
 
 
