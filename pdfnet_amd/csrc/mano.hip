@@ -449,13 +449,41 @@ __global__ void bmm_strided_kernel(const float* __restrict__ A, const float* __r
     }
 }
 
+// long reductions over few outputs (the 21 x 778 joint regressor applied to B x 2 meshes: 4,032 outputs, K = 778): one WAVE per
+// output element, lanes stride over k, shuffle reduction -- the thread-per-output form above walks K serially (100 us per call)
+__global__ __launch_bounds__(256) void bmm_strided_wave_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
+                                                                int M, int N, int K, int RB,
+                                                                long sab, long sar, long sam, long sak, long sbb, long sbr, long sbk, long sbn,
+                                                                long scb, long scm, long scn, int beta, long total) {
+    const int lane = threadIdx.x & 63;
+    for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6; i < total; i += ((long)gridDim.x * blockDim.x) >> 6) {
+        const int n = (int)(i % N); const long p = i / N;
+        const int m = (int)(p % M); const long b = p / M;
+        float acc = 0.f;
+        for (int r = 0; r < RB; ++r) {
+            const float* a = A + b * sab + r * sar + m * sam;
+            const float* bb = Bm + b * sbb + r * sbr + n * sbn;
+            for (int k = lane; k < K; k += 64) acc += a[k * sak] * bb[k * sbk];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float* c = C + b * scb + m * scm + n * scn;
+            *c = beta ? *c + acc : acc;
+        }
+    }
+}
+
 PDF_API int pdf_bmm_strided(const float* A, const float* Bm, float* C, int batch, int M, int N, int K, int RB,
                             long sab, long sar, long sam, long sak, long sbb, long sbr, long sbk, long sbn,
                             long scb, long scm, long scn, int beta, hipStream_t s) {
     long total = (long)batch * M * N;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(bmm_strided_kernel, dim3(grid_for(total)), dim3(256), 0, s, A, Bm, C, M, N, K, RB,
-                       sab, sar, sam, sak, sbb, sbr, sbk, sbn, scb, scm, scn, beta, total);
+    if ((long)K * RB >= 128 && total <= (1L << 16))
+        hipLaunchKernelGGL(bmm_strided_wave_kernel, dim3(grid_for(total * 64)), dim3(256), 0, s, A, Bm, C, M, N, K, RB,
+                           sab, sar, sam, sak, sbb, sbr, sbk, sbn, scb, scm, scn, beta, total);
+    else
+        hipLaunchKernelGGL(bmm_strided_kernel, dim3(grid_for(total)), dim3(256), 0, s, A, Bm, C, M, N, K, RB,
+                           sab, sar, sam, sak, sbb, sbr, sbk, sbn, scb, scm, scn, beta, total);
     PDF_LAUNCH_CHECK();
     return 0;
 }
