@@ -1020,64 +1020,57 @@ __global__ __launch_bounds__(256) void l2norm_cat_fwd_kernel(const L2Parts p, lo
         if (lane == 0) p.norm[part][r] = n;
     }
 }
-__global__ __launch_bounds__(256) void l2norm_cat_bwd_kernel(const L2Parts p, int nparts, long R, float eps, const float* __restrict__ dy, int lddy) {
-    // one wave per pixel, the parts one after the other: the wave walks its whole concatenated gradient row (a launch or a
-    // block per part reads 1 KB out of every 4 KB row -- measured 6x slower than contiguous rows)
-    __shared__ float sw[L2_MAXPARTS][64 * L2_MAXV];
-    const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < L2_MAXPARTS * 64 * L2_MAXV; i += 256) (&sw[0][0])[i] = 0.f;
+template <int MAXV>
+__global__ __launch_bounds__(256) void l2norm_cat_bwd_kernel(const L2Parts p, long R, float eps, const float* __restrict__ dy, int lddy) {
+    // blockIdx.y = part, one wave per pixel.  Kept light on registers (MAXV = channels per lane: 4 for the 256-channel pyramid):
+    // this kernel runs beside the `feat` weight gradient, whose three resident blocks per CU leave ~80 VGPRs per SIMD lane free -- a
+    // walk over all four parts per wave (96 VGPRs) could not co-reside at all and took 4.9 ms there (0.3 ms alone); this form 2.5.
+    // (The same trimming of the BatchNorm backward kernels -- 100 -> 54-80 VGPRs via unroll 2-3 -- was measured and is neutral in fp32,
+    // -2 % in bf16 where they run alone more often.)
+    __shared__ float sw[64 * MAXV];
+    const int q = blockIdx.y, C = p.C[q], lane = threadIdx.x & 63;
+    const float* __restrict__ x = p.x[q]; const float* __restrict__ w = p.w[q]; const float* __restrict__ norm = p.norm[q];
+    const float* __restrict__ g0 = dy + p.off[q];
+    float* __restrict__ dx = p.dx[q];
+    unsigned short* __restrict__ dx16 = p.dx16[q];
+    for (int i = threadIdx.x; i < C; i += 256) sw[i] = 0.f;
     __syncthreads();
     const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
     const long nw = ((long)gridDim.x * blockDim.x) >> 6;
-    float acc[L2_MAXPARTS][L2_MAXV];
+    float acc[MAXV], wv[MAXV];
 #pragma unroll
-    for (int q = 0; q < L2_MAXPARTS; ++q)
-#pragma unroll
-        for (int i = 0; i < L2_MAXV; ++i) acc[q][i] = 0.f;
+    for (int i = 0; i < MAXV; ++i) { acc[i] = 0.f; const int c = lane + 64 * i; wv[i] = c < C ? w[c] : 0.f; }
     for (long r = w0; r < R; r += nw) {
+        const float n = norm[r];
+        float g[MAXV], xv[MAXV];
+        float dot = 0.f;
 #pragma unroll
-        for (int q = 0; q < L2_MAXPARTS; ++q) {
-            if (q >= nparts) continue;                       // (no break: the loop must unroll so that acc[][] stays in registers)
-            const int C = p.C[q];
-            const float* __restrict__ x = p.x[q] + r * C; const float* __restrict__ w = p.w[q];
-            const float* __restrict__ g0 = dy + r * lddy + p.off[q];
-            float* __restrict__ dx = p.dx[q] + r * C;
-            const float n = p.norm[q][r];
-            float g[L2_MAXV], xv[L2_MAXV], wv[L2_MAXV];
-            float dot = 0.f;
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            g[i] = c < C ? g0[r * lddy + c] : 0.f;
+            xv[i] = c < C ? x[r * C + c] : 0.f;
+            dot += wv[i] * g[i] * xv[i];
+        }
+        dot = wave_sum(dot);
+        const float nn = n - eps;
+        const float k = nn > 0.f ? dot / (n * n * nn) : 0.f;
+        const float in = 1.f / n;
 #pragma unroll
-            for (int i = 0; i < L2_MAXV; ++i) {
-                const int c = lane + 64 * i;
-                g[i] = c < C ? g0[c] : 0.f;
-                xv[i] = c < C ? x[c] : 0.f;
-                wv[i] = c < C ? w[c] : 0.f;
-                dot += wv[i] * g[i] * xv[i];
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            const float o = wv[i] * g[i] * in - xv[i] * k;
+            if (c < C) dx[r * C + c] = o;
+            if (dx16 != nullptr) {                            // (C % 64 == 0 then: whole waves, lanes pair up for 4-byte words)
+                const float on = __shfl_down(o, 1, 64);
+                if (c < C && (lane & 1) == 0) *reinterpret_cast<unsigned int*>(dx16 + r * C + c) = pdf_pk_bf16(o, on);
             }
-            dot = wave_sum(dot);
-            const float nn = n - eps;
-            const float k = nn > 0.f ? dot / (n * n * nn) : 0.f;
-            const float in = 1.f / n;
-            unsigned short* dx16 = p.dx16[q];
-#pragma unroll
-            for (int i = 0; i < L2_MAXV; ++i) {
-                const int c = lane + 64 * i;
-                const float o = wv[i] * g[i] * in - xv[i] * k;
-                if (c < C) dx[c] = o;
-                if (dx16 != nullptr) {                        // (C % 64 == 0 then: whole waves, lanes pair up for 4-byte words)
-                    const float on = __shfl_down(o, 1, 64);
-                    if (c < C && (lane & 1) == 0) *reinterpret_cast<unsigned int*>(dx16 + r * C + c) = pdf_pk_bf16(o, on);
-                }
-                acc[q][i] += g[i] * xv[i] * in;
-            }
+            acc[i] += g[i] * xv[i] * in;
         }
     }
 #pragma unroll
-    for (int q = 0; q < L2_MAXPARTS; ++q)
-#pragma unroll
-        for (int i = 0; i < L2_MAXV; ++i) { const int c = lane + 64 * i; if (q < nparts && c < p.C[q]) atomicAdd(&sw[q][c], acc[q][i]); }
+    for (int i = 0; i < MAXV; ++i) { const int c = lane + 64 * i; if (c < C) atomicAdd(&sw[c], acc[i]); }
     __syncthreads();
-    for (int q = 0; q < nparts; ++q)
-        for (int i = threadIdx.x; i < p.C[q]; i += 256) atomicAdd(&p.dw[q][i], sw[q][i]);
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&p.dw[q][i], sw[i]);
 }
 static int l2_parts(L2Parts& p, int nparts, const float* const* x, const float* const* w, float* const* norm, float* const* dx, float* const* dw,
                     const int* C) {
@@ -1114,7 +1107,11 @@ PDF_API int pdf_l2norm_cat_bwd(int nparts, const float* dy, int lddy, const floa
         if (dx16[i] != nullptr && C[i] % 64) return PDF_E_BADARG;
         p.dx16[i] = reinterpret_cast<unsigned short*>(dx16[i]);
     }
-    hipLaunchKernelGGL(l2norm_cat_bwd_kernel, dim3(grid_for(R * 64, 256, 2048)), dim3(256), 0, s, p, nparts, R, eps, dy, lddy);
+    int cmax = 0;
+    for (int i = 0; i < nparts; ++i) cmax = max(cmax, C[i]);
+    const dim3 grid(grid_for(R * 64, 256, 1024), nparts);
+    if (cmax <= 256) hipLaunchKernelGGL(l2norm_cat_bwd_kernel<4>, grid, dim3(256), 0, s, p, R, eps, dy, lddy);
+    else hipLaunchKernelGGL(l2norm_cat_bwd_kernel<L2_MAXV>, grid, dim3(256), 0, s, p, R, eps, dy, lddy);
     PDF_LAUNCH_CHECK();
     return 0;
 }
