@@ -177,7 +177,8 @@ __global__ void sft3_bwd_finish(const float* __restrict__ part, int nblk, const 
     for (int b = 0; b < nblk; ++b) v += part[b * 48 + i];
     const int conv = i / 12, e = i - conv * 12;
     float* base = e < 9 ? d.w[conv] : d.b[conv];
-    if (base != nullptr) { float* o = base + (e < 9 ? e : e - 9); *o = accumulate ? *o + v : v; }
+    // accumulate: atomic, so two calls of the layer on different streams (sft0 serves both hands) cannot lose an update
+    if (base != nullptr) { float* o = base + (e < 9 ? e : e - 9); if (accumulate) atomicAdd(o, v); else *o = v; }
 }
 // ws: 48 * 256 floats.  d*: the eight parameter gradients (any may be NULL), += when accumulate.  dcond may be NULL.
 PDF_API int pdf_sft3_bwd(const float* g, int ldg, const float* fea, int ldf, const float* cond, int ldc,
