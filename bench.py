@@ -518,7 +518,7 @@ def main():
         "config": {"workload": "configs[%s]: B=%d/GPU full RGB-D pyramid fusion + PointNet++ + GCN decoder fwd + CtdetLoss + bwd + Adam, "
                                "%s, %dx%d" % ("3/4" if bf16 else "2", B, "bf16 MFMA GEMMs (fp32 accumulate, fp32 master weights / statistics / loss)" if bf16 else "fp32", R, R), "global_batch": world * B, "parallelism": "dp%d" % world,
                    "launch": "hipGraph(fwd+loss+bwd) + fused Adam" if args.graph else "eager, weight-gradient kernels overlapped on a side HIP stream, fused Adam", "final_loss": round(loss_val, 4),
-                   "rccl_ranks": rccl_ranks, "allreduce_mb_per_step": round(trainer.n_live * 4 / 1e6, 1) if world > 1 else 0.0,
+                   "rccl_ranks": rccl_ranks, "allreduce_mb_per_step": round(trainer.n_live * (2 if bf16 else 4) / 1e6, 1) if world > 1 else 0.0,
                    "broadcast_buffers": bool(args.broadcast_buffers)},
     }
     mp_batch = None
