@@ -98,7 +98,9 @@ def set_gemm_precision(dtype):
     accumulation; weights, activations, normalisation statistics, losses and the optimizer stay fp32 (BASELINE configs 4-5)."""
     if dtype not in ('fp32', 'bf16'):
         raise ValueError("pdfnet_amd: gemm precision must be 'fp32' or 'bf16'")
+    global _GEMM_BF16
     hip.lib().pdf_set_gemm_precision(1 if dtype == 'bf16' else 0)
+    _GEMM_BF16 = dtype == 'bf16'                          # cached for the per-launch checks (shadows_on)
 
 
 def gemm_precision():
@@ -113,8 +115,11 @@ def gemm_precision():
 BF16_SHADOWS = _os.environ.get("PDFNET_BF16_SHADOWS", "1") != "0"
 
 
+_GEMM_BF16 = False
+
+
 def shadows_on():
-    return BF16_SHADOWS and hip.lib().pdf_debug_gemm_precision() != 0
+    return BF16_SHADOWS and _GEMM_BF16
 
 
 def attach_shadow(t, s16):
