@@ -103,3 +103,21 @@ def test_never_used_parameter_rule_matches_the_reference_golden(golden_dir):
     assert {n for n, _ in dead} == want
     assert len(early) + len(late) + len(dead) == len(named)
     assert sum(p.numel() for _, p in dead) == 12_387_365          # 49.5 MB of the 401 MB stay out of the all-reduce
+
+
+def test_bf16_shadow_bookkeeping_ignores_stale_or_relaid_out_copies():
+    """functional.attach_shadow / shadow_of (host logic of the bf16 shadows): a copy is handed to the library only while the
+    tensor it mirrors is unmodified and has the same shape and strides."""
+    import torch
+    from pdfnet_amd import functional as F
+    t = torch.randn(2, 8, 4, 4).contiguous(memory_format=torch.channels_last)
+    assert F.shadow_of(t) is None and F.shadow_of(None) is None
+    s = t.to(torch.bfloat16)
+    F.attach_shadow(t, s)
+    assert F.shadow_of(t) is s
+    t.add_(1.0)                                            # modified in place: the copy is stale
+    assert F.shadow_of(t) is None
+    F.attach_shadow(t, s.contiguous())                     # NCHW-contiguous copy of a channels_last tensor: other strides
+    assert F.shadow_of(t) is None
+    u = t.clone()
+    assert F.shadow_of(u) is None                          # attributes do not travel to new tensors
