@@ -243,7 +243,8 @@ int pdf_dropout(const float* x, float* y, long n, float p, unsigned long long se
 /* y = res + dropout(x) (residual tails, self_attn.py:31-33,80-84); backward: d res = dy, dx = pdf_dropout(dy, same seed) */
 int pdf_dropout_add(const float* x, const float* res, float* y, long n, float p, unsigned long long seed,
                     const unsigned long long* step, void* stream);
-/* resnet.maxpool (resnet.py:206) */
+/* resnet.maxpool (resnet.py:206).  bwd: when C % 4 == 0 and the pointers are 16-byte aligned every dx element is written exactly once
+ * (gather over the <= 4 windows of an input element); otherwise dx must be zero-filled by the caller (atomic scatter). */
 int pdf_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* arg, void* stream);
 int pdf_maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, void* stream);
 /* nn.Upsample(scale_factor=2, bilinear, align_corners=True) (intaghand_encoder.py:287-302) */

@@ -250,10 +250,42 @@ __global__ void maxpool3s2_fwd_kernel(const float* __restrict__ x, int N, int H,
         y[i] = best; arg[i] = (unsigned char)bi;
     }
 }
+// four channels per thread (C % 4 == 0): 9 float4 loads instead of 36 scalar ones per output quad
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_v4_kernel(const float* __restrict__ x, int N, int H, int W, int C, int OH, int OW,
+                                                                 float* __restrict__ y, unsigned char* __restrict__ arg, long total4) {
+    const int C4 = C >> 2;
+    GRID_STRIDE(i, total4) {
+        const int c = (int)(i % C4) * 4; long p = i / C4;
+        const int ox = (int)(p % OW); p /= OW;
+        const int oy = (int)(p % OH); const int n = (int)(p / OH);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + (((long)n * H + iy) * W + ix) * C + c);
+                const int t = ky * 3 + kx;
+                if (v.x > best.x) { best.x = v.x; b0 = t; }
+                if (v.y > best.y) { best.y = v.y; b1 = t; }
+                if (v.z > best.z) { best.z = v.z; b2 = t; }
+                if (v.w > best.w) { best.w = v.w; b3 = t; }
+            }
+        }
+        *reinterpret_cast<float4*>(y + i * 4) = best;
+        *reinterpret_cast<uchar4*>(arg + i * 4) = make_uchar4((unsigned char)b0, (unsigned char)b1, (unsigned char)b2, (unsigned char)b3);
+    }
+}
 PDF_API int pdf_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* arg, hipStream_t s) {
     int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     long total = (long)N * OH * OW * C;
     if (total <= 0) return 0;
+    if (C % 4 == 0 && !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) && !(reinterpret_cast<uintptr_t>(arg) & 3))
+        hipLaunchKernelGGL(maxpool3s2_fwd_v4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, s, x, N, H, W, C, OH, OW, y, arg, total / 4);
+    else
     hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, N, H, W, C, OH, OW, y, arg, total);
     PDF_LAUNCH_CHECK();
     return 0;
@@ -270,10 +302,46 @@ __global__ void maxpool3s2_bwd_kernel(const float* __restrict__ dy, const unsign
         atomicAdd(&dx[(((long)n * H + iy) * W + ix) * C + c], dy[i]);
     }
 }
+// gather form: every INPUT element looks at the <= 4 windows that contain it and takes the gradient of those whose arg-max it
+// is -- writes every dx element exactly once (no zero fill, no atomics: 134 MB of memset + 8.4 M atomic adds at B = 32 before)
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_gather_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, int N, int H, int W, int C,
+                                                                     int OH, int OW, float* __restrict__ dx, long total4) {
+    const int C4 = C >> 2;
+    GRID_STRIDE(i, total4) {
+        const int c = (int)(i % C4) * 4; long p = i / C4;
+        const int ix = (int)(p % W); p /= W;
+        const int iy = (int)(p % H); const int n = (int)(p / H);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        // windows with oy * 2 - 1 + ky = iy, ky in 0..2:  oy in [ceil((iy - 1) / 2), floor((iy + 1) / 2)] = [iy / 2, (iy + 1) / 2]
+        for (int oy = iy / 2; oy <= min(OH - 1, (iy + 1) / 2); ++oy) {
+            const int ky = iy + 1 - 2 * oy;
+            if (ky < 0 || ky > 2) continue;
+            for (int ox = ix / 2; ox <= min(OW - 1, (ix + 1) / 2); ++ox) {
+                const int kx = ix + 1 - 2 * ox;
+                if (kx < 0 || kx > 2) continue;
+                const long o = (((long)n * OH + oy) * OW + ox) * C + c;
+                const uchar4 a = *reinterpret_cast<const uchar4*>(arg + o);
+                const float4 d = *reinterpret_cast<const float4*>(dy + o);
+                const unsigned char t = (unsigned char)(ky * 3 + kx);
+                if (a.x == t) g.x += d.x;
+                if (a.y == t) g.y += d.y;
+                if (a.z == t) g.z += d.z;
+                if (a.w == t) g.w += d.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + i * 4) = g;
+    }
+}
 PDF_API int pdf_maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, hipStream_t s) {
     int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     long total = (long)N * OH * OW * C;
     if (total <= 0) return 0;
+    if (C % 4 == 0 && !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) && !(reinterpret_cast<uintptr_t>(arg) & 3)) {
+        const long tin4 = (long)N * H * W * C / 4;          // (dx need not be zero-filled on this path; the caller's fill is harmless)
+        hipLaunchKernelGGL(maxpool3s2_bwd_gather_kernel, dim3(grid_for(tin4)), dim3(256), 0, s, dy, arg, N, H, W, C, OH, OW, dx, tin4);
+        PDF_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, arg, N, H, W, C, OH, OW, dx, total);
     PDF_LAUNCH_CHECK();
     return 0;

@@ -711,7 +711,8 @@ class _MaxPool3s2(Function):
     def backward(ctx, dy):
         (arg,) = ctx.saved_tensors
         N, C, H, W = ctx.shape
-        dx = _zeros_cl((N, C, H, W), dy.device)
+        # (C % 4 == 0: the gather kernel writes every element once; otherwise the atomic scatter needs a zero-filled dx)
+        dx = torch.empty((N, C, H, W), device=dy.device, memory_format=CL) if C % 4 == 0 else _zeros_cl((N, C, H, W), dy.device)
         _L().pdf_maxpool3s2_bwd(ptr(cl(dy)), ptr(arg), N, H, W, C, ptr(dx), stream())
         return dx
 
