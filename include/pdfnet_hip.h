@@ -43,6 +43,10 @@ long pdf_wgrad_workspace_floats(int M, int NI, int NJ);
  * statistics and weight-gradient slabs).  Called once per process after the device is selected, outside any stream capture;
  * the entry points call it lazily otherwise. */
 int pdf_init(void);
+/* Stream fork / join for the host layer: everything issued on `signaler` so far completes before anything issued on
+ * `waiter` afterwards (hipEventRecord + hipStreamWaitEvent on a ring of timing-disabled events created by pdf_init; valid
+ * inside a stream capture).  The reference has no counterpart -- it runs on one stream. */
+int pdf_stream_wait(void* waiter, void* signaler);
 /* Operand precision of every GEMM-family entry point below: 0 (default) = fp32-input MFMA, exact fp32; 1 = operands rounded
  * to bf16 (RNE) while staged into LDS, bf16 MFMA with fp32 accumulation (BASELINE configs 4 / 5: bf16 compute, fp32 master
  * weights and fp32 normalisation / loss statistics).  Process-wide; set before the first step. */

@@ -564,4 +564,33 @@ PDF_API int pdf_cast_bf16(const float* src, void* dst, long n, hipStream_t s) {
     return 0;
 }
 
-PDF_API int pdf_init(void) { return (pdf_ticket_counters(1) != nullptr && pdf_scratch(64) != nullptr) ? 0 : PDF_E_WORKSPACE; }
+// ---- stream fork / join without Python objects (the host layer switches to a side stream ~180 times a step)
+#define PDF_EVENT_RING 1024
+static hipEvent_t g_events[PDF_EVENT_RING];
+static std::atomic<unsigned> g_event_next{0};
+static std::atomic<int> g_events_ready{0};
+static int pdf_event_ring(void) {
+    if (g_events_ready.load(std::memory_order_acquire)) return 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_events_ready.load(std::memory_order_relaxed)) return 0;
+    for (int i = 0; i < PDF_EVENT_RING; ++i)
+        if (hipEventCreateWithFlags(&g_events[i], hipEventDisableTiming) != hipSuccess) return PDF_E_WORKSPACE;
+    g_events_ready.store(1, std::memory_order_release);
+    return 0;
+}
+// `waiter` waits for everything `signaler` has been given so far.  A wait captures the event's latest record when it is
+// issued, so re-recording a ring slot later does not disturb it.
+PDF_API int pdf_stream_wait(hipStream_t waiter, hipStream_t signaler) {
+    if (waiter == signaler) return 0;
+    if (int rc = pdf_event_ring()) return rc;
+    hipEvent_t e = g_events[g_event_next.fetch_add(1, std::memory_order_relaxed) % PDF_EVENT_RING];
+    if (hipError_t rc = hipEventRecord(e, signaler)) return (int)rc;
+    if (hipError_t rc = hipStreamWaitEvent(waiter, e, 0)) return (int)rc;
+    return 0;
+}
+
+PDF_API int pdf_init(void) {
+    if (int rc = pdf_event_ring()) return rc;
+    return (pdf_ticket_counters(1) != nullptr && pdf_scratch(64) != nullptr) ? 0 : PDF_E_WORKSPACE;
+}

@@ -4,6 +4,7 @@ device memory, the current stream and the autograd tape; every computation below
 Activation layout: 4-D maps are logical NCHW tensors in torch.channels_last memory (physically NHWC,
 rows = pixels, channels contiguous); everything else is row-major [..., channels].
 """
+import ctypes
 import torch
 from torch.autograd import Function
 
@@ -219,19 +220,25 @@ class wgrad_stream:
     def __enter__(self):
         if not self.enabled:
             return self
-        cur = torch.cuda.current_stream()
-        dev = torch.cuda.current_device()
-        key = (dev, cur.cuda_stream)
-        if key not in _wg_streams:
-            _wg_streams[key] = torch.cuda.Stream()
-        side = _wg_streams[key]
-        side.wait_stream(cur)
+        # raw handles + the library's event ring: the torch.cuda.stream() / Stream.wait_stream() route builds four Python
+        # Stream / Event objects per switch through the device-index helpers (~35 us, x180 per step = a sixth of the
+        # backward's host time)
+        dev = hip._raw_device()
+        cur_raw = hip._raw_stream(dev)
+        key = (dev, cur_raw)
+        ent = _wg_streams.get(key)
+        if ent is None:
+            s = torch.cuda.Stream()
+            ent = _wg_streams[key] = (s, ctypes.c_void_p(s.cuda_stream), s.stream_id, s.device_index, s.device_type)
+        side, side_raw = ent[0], ent[1]
+        wait = _L().pdf_stream_wait
+        wait(side_raw, ctypes.c_void_p(cur_raw))
         for p in self.params:
             if p is not None:
                 last = getattr(p, '_pdf_wg_last', None)
-                if last is not None and last is not side:
-                    side.wait_stream(last)
-                p._pdf_wg_last = side
+                if last is not None and last is not ent:
+                    wait(side_raw, last[1])
+                p._pdf_wg_last = ent
         for t in self.tensors:                      # produced / owned by the main stream, read on the side stream
             if t is not None:
                 t.record_stream(side)
@@ -239,21 +246,22 @@ class wgrad_stream:
                 if s16 is not None:
                     s16.record_stream(side)
         _wg_used.add(key)
-        self._ctx = torch.cuda.stream(side)
-        self._ctx.__enter__()
+        self._prev = torch._C._cuda_getCurrentStream(dev)
+        torch._C._cuda_setStream(stream_id=ent[2], device_index=ent[3], device_type=ent[4])
         return self
 
     def __exit__(self, *exc):
         if self.enabled:
-            self._ctx.__exit__(*exc)
+            p = self._prev
+            torch._C._cuda_setStream(stream_id=p[0], device_index=p[1], device_type=p[2])
         return False
 
 
 def join_wgrad():
     """Make the current stream wait for every outstanding side-stream weight-gradient kernel."""
-    cur = torch.cuda.current_stream()
+    cur = hip.stream()
     for key in list(_wg_used):
-        cur.wait_stream(_wg_streams[key])
+        _L().pdf_stream_wait(cur, _wg_streams[key][1])
     _wg_used.clear()
 
 
