@@ -879,3 +879,38 @@ def test_limits_and_empty_inputs(F):
     # a batch whose hands are all invalid: every per-sample term is weighted by 0, the loss stays finite
     got = F.rowloss(dev(rnd(2, 3, 5)), dev(rnd(2, 3, 5, seed=1)), 2, 'l1') * dev(torch.zeros(2, 3))
     assert torch.isfinite(got).all() and float(got.abs().sum()) == 0.0
+
+
+def test_stream_wait_orders_two_streams(F):
+    """pdf_stream_wait(waiter, signaler): work issued on `waiter` afterwards sees everything `signaler` was given before --
+    the fork / join the host layer uses around the weight-gradient side stream (functional.wgrad_stream / join_wgrad)."""
+    import ctypes
+    from pdfnet_amd import hip
+    L = hip.lib()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    ra, rb = ctypes.c_void_p(a.cuda_stream), ctypes.c_void_p(b.cuda_stream)
+    assert L.pdf_stream_wait(ra, ra) == 0                                  # a stream never waits for itself
+    x = dev(rnd(512, 2048))
+    w = dev(rnd(2048, 2048, seed=1))
+    torch.cuda.synchronize()
+    for rep in range(2000 // 100):                                         # > the 1,024-slot event ring in total: slots are reused
+        with torch.cuda.stream(a):
+            y = x
+            for _ in range(6):                                             # a dependent chain that keeps stream a busy
+                y = F.linear(y, w) * 1e-1
+        for _ in range(100):
+            L.pdf_stream_wait(rb, ra)
+        with torch.cuda.stream(b):
+            z = y.sum()                                                    # would read a half-written y without the wait
+        y.record_stream(b)
+        L.pdf_stream_wait(ra, rb)
+        torch.cuda.synchronize()
+        assert float(z) == float(y.sum()), rep
+    # the context manager built on it leaves the current stream as it found it, and its kernels land on the side stream
+    cur = torch.cuda.current_stream().cuda_stream
+    with F.wgrad_stream(True, x):
+        side = torch.cuda.current_stream().cuda_stream
+        assert side != cur or not F.ASYNC_WGRAD
+    assert torch.cuda.current_stream().cuda_stream == cur
+    F.join_wgrad()
+    torch.cuda.synchronize()
