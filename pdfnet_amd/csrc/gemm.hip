@@ -757,10 +757,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -908,6 +908,10 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     // (a 256x128 tile -- 128 accumulator registers, one wave per SIMD -- was measured: 104 vs 123 TFLOP/s on the largest conv)
     // (also measured for this tile: 8 waves per block with K-step 32 -- <128,128,4,2,..,32>, 4 waves/SIMD, half the barriers
     // per flop: +1 % alone (125.5 vs 124.2 TFLOP/s on the largest conv), -0.3 % inside the step)
+    // 1x1 layers with a short reduction (2-16 K-steps per tile) are all prologue and epilogue: the 64x64 kernel's 4x block count hides
+    // them better (r02: ResNet 128->512 @32x32 49.7 -> 70.5 TFLOP/s, 64->256 @64x64 45.4 -> 53.5, 512->256 backward-data 61.6 -> 88.7);
+    // the million-row PointNet++ linears keep the wide tile (54.5 vs 50.5)
+    const bool short_k = g.T == 1 && ((g.K <= 256 && g.M <= 262144) || (g.K <= 512 && g.M <= 32768)) && env_int(ENV_IG_SHORTK, 1);
     bool halo = fast && groups == 1 && g.T == 9 && !g.plain_in && g.plain_out && g.ps_cout == 0 && g.sy == 1 && g.sx == 1 && g.QW == g.W && g.QH == g.H &&
                 (g.W == 64 || g.W == 32 || g.W == 16) && (g.H * g.W) % 128 == 0 && g.M % 128 == 0 && g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) &&
                 g.Cin >= env_int(ENV_IG_HALO_MINC, 256) &&      // measured: 128-channel layers lose (94 vs 107 TFLOP/s forward), 256+ gain 2-3 %
@@ -919,7 +923,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
         else hipLaunchKernelGGL(igemm_halo3x3<false>, grid, dim3(256), 0, s, g);
         g_last_tile = 128128;
     }
-    else if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600))
+    else if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) && !short_k)
         launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s), g_last_tile = 128128;
     else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int(ENV_IG_T128, 600))
         launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s), g_last_tile = 128064;   // (K-step 32: no gain here)
