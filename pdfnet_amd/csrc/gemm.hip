@@ -757,10 +757,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1272,6 +1272,10 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     // write-through slab stores would need 16-byte stores from a re-laid-out accumulator (4-byte sc1 stores are ~6x slower).
     // BatchNorm's in-launch finalisation (norm.hip) publishes 32 bytes per block and does use the write-through form.
     g.counters = (splits > 1 && env_int(ENV_WG_INLAUNCH, 0)) ? pdf_ticket_counters((int)tiles * groups) : nullptr;
+    // Accumulating launches (the trainer's flat gradient buffer, zeroed once per step) add their partial tiles with fp32 atomics:
+    // no slab round trip through HBM and no reduce_slabs launch (174 launches, 2.6 ms per step).  Overwriting launches keep the
+    // slabs (fixed summation order).
+    g.atomic = (splits > 1 && accumulate && g.counters == nullptr && env_int(ENV_WG_ATOMIC, 1)) ? 1 : 0;
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     int brc = 0;
     if (bf16) {
@@ -1293,7 +1297,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         else hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, false>), grid, dim3(256), 0, s, g);
     }
     PDF_LAUNCH_CHECK();
-    if (splits > 1 && g.counters == nullptr) {
+    if (splits > 1 && g.counters == nullptr && !g.atomic) {
         Reduce r = {ws, out, out1, per, bws, db, db1, (int)perb, splits, accumulate};
         if (splits >= 16 && per <= (1L << 20)) {
             const int mb = (int)((per + 63) / 64);

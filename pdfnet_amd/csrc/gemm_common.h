@@ -60,6 +60,9 @@ struct WGemm {
     // in-launch reduction of the split slabs (pdf_last_block_arrives): the last block of every output tile sums the slabs in split
     // order into out / out1 (+= when accumulate) and the bias partials into bout / bout1; counters == NULL: reduce_slabs launch
     float* out; float* out1; float* bout; float* bout1; int accumulate; int* counters;
+    // atomic != 0 (several splits, accumulate): every block adds its partial tile straight into out / out1 (bout / bout1) with
+    // global_atomic_add_f32 -- no slabs, no reduction pass; the summation order then varies from run to run
+    int atomic;
     const void* P16; const void* Q16;         // bf16 shadows of P / Q (see IGemm::A16)
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
@@ -75,6 +78,25 @@ __device__ __forceinline__ void wgemm_finish(const WGemm& g, const f32x16 (&acc)
     float* slabp = grp ? g.slab1 : g.slab;
     float* bslabp = grp ? g.bslab1 : g.bslab;
     const int NJ = g.T * g.Cq;
+    if (g.atomic) {
+        if (bias_thread) atomicAdd((grp ? g.bout1 : g.bout) + i0 + threadIdx.x, bval);
+        float* dst = grp ? g.out1 : g.out;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
+            if (col >= NJ) continue;
+            const int t = col / g.Cq;
+            const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < g.NI) atomicAdd(dst + (long)row * g.ldw + wcol, acc[i][j][r]);
+                }
+        }
+        return;
+    }
     if (bias_thread) {
         float* bo = bslabp + (long)split * g.NI + i0 + threadIdx.x;
         *bo = g.beta ? *bo + bval : bval;

@@ -1,0 +1,96 @@
+"""Phase timeline of the EAGER step from HIP events recorded on the main stream at a dozen host points (no profiler: rocprofv3
+slows the host enough to make the traced step launch-bound, which hides what the untraced step waits for).
+Usage: phase_events.py [batch] [bf16]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+if len(sys.argv) > 2 and sys.argv[2] == 'bf16':
+    os.environ['PDFNET_GEMM'] = 'bf16'
+from bench import make_opt
+from pdfnet_amd import functional as F
+from pdfnet_amd.networks.intaghand_model import load_model_intag
+from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch, to_device
+from pdfnet_amd.trains.simplified import CtdetLoss
+from pdfnet_amd.trains.base_trainer import Trainer
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev = torch.device('cuda')
+opt = make_opt(256)
+torch.manual_seed(0)
+model = load_model_intag(opt).to(dev)
+consts = synthetic_loss_constants()
+trainer = Trainer(opt, model, CtdetLoss(opt, consts).to(dev), lr=1e-4)
+if os.environ.get('PDFNET_GEMM') == 'bf16':
+    F._L().pdf_set_gemm_precision(1)
+batch = to_device(synthetic_train_batch(B, 256, consts=consts), dev)
+marks = []
+
+
+def mark(name):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    marks.append((name, e))
+
+
+enc, dec, mwl = model.encoder, model.decoder, trainer.model_with_loss
+trunk0 = enc.trunk
+def trunk(*a, **k):
+    r = trunk0(*a, **k)
+    mark('fwd: trunk + PointNet++ + fusion issued')
+    r['img_fmaps'][0].register_hook(lambda g: mark('bwd: mesh decoder done (grad of fused feature)'))
+    return r
+enc.trunk = trunk
+enc.on_trunk_output_grad_prev = enc.on_trunk_output_grad
+def x1_grad():
+    mark('bwd: everything above the ResNet output done (grad of x1)')
+    if enc.on_trunk_output_grad_prev is not None:
+        enc.on_trunk_output_grad_prev()
+enc.on_trunk_output_grad = x1_grad
+dec_fwd = dec.forward
+def dforward(*a, **k):
+    r = dec_fwd(*a, **k)
+    mark('fwd: mesh decoder')
+    return r
+dec.forward = dforward
+model_fwd = model.forward
+def mforward(*a, **k):
+    r = model_fwd(*a, **k)
+    mark('fwd: dense branches joined, mid_model')
+    return r
+model.forward = mforward
+join0 = F.join_wgrad
+opt_step = trainer.optimizer.step
+
+
+def step():
+    marks.clear()
+    mark('start')
+    trainer.reducer.reset()
+    trainer.optimizer.zero_grad()
+    loss, stats, _, _ = mwl(batch, 'train', 0)
+    loss = loss.mean()
+    mark('fwd: loss')
+    loss.backward()
+    mark('bwd: main chain + forked streams done')
+    join0()
+    mark('bwd: weight-gradient side streams joined')
+    F.step_counter(loss.device).add_(1)
+    opt_step(grad_scale=1.0)
+    mark('Adam')
+
+
+for _ in range(6):
+    trainer.train_step(batch)
+res = []
+for _ in range(6):                       # no sync between steps: the host runs ahead as in the bench loop
+    step()
+    res.append(list(marks))
+torch.cuda.synchronize()
+for r in res[-3:]:
+    t0 = r[0][1]
+    print("---- step (ms since its start on the main stream)")
+    prev = 0.0
+    for name, e in r[1:]:
+        t = t0.elapsed_time(e)
+        print("  %8.2f  (+%6.2f)  %s" % (t, t - prev, name))
+        prev = t
