@@ -40,6 +40,22 @@ def trunk(*a, **k):
     r['img_fmaps'][0].register_hook(lambda g: mark('bwd: mesh decoder done (grad of fused feature)'))
     return r
 enc.trunk = trunk
+l4 = enc.resnet.layer4
+l4_fwd = l4.forward
+def l4forward(*a, **k):
+    r = l4_fwd(*a, **k)
+    mark('fwd: ResNet layers 1-4 (x1)')
+    return r
+l4.forward = l4forward
+fb = enc.feat_bn
+fb_fwd = fb.forward
+def fbforward(*a, **k):
+    r = fb_fwd(*a, **k)
+    mark('fwd: pyramid + feat + feat_bn (x0)')
+    if r.requires_grad:
+        r.register_hook(lambda g: mark('bwd: PointNet++ / centre features / hm head done (grad of x0)'))
+    return r
+fb.forward = fbforward
 enc.on_trunk_output_grad_prev = enc.on_trunk_output_grad
 def x1_grad():
     mark('bwd: everything above the ResNet output done (grad of x1)')
