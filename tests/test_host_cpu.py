@@ -121,3 +121,11 @@ def test_bf16_shadow_bookkeeping_ignores_stale_or_relaid_out_copies():
     assert F.shadow_of(t) is None
     u = t.clone()
     assert F.shadow_of(u) is None                          # attributes do not travel to new tensors
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/pdfnet_hip.h compiles as C99 with -Wall -Werror and a client without Python / torch links against the library
+    (tests/c_abi/c_client.c; the GPU suite runs it)."""
+    from tests.util import build_c_client
+    exe = build_c_client(tmp_path)
+    assert os.path.exists(exe)

@@ -914,3 +914,13 @@ def test_stream_wait_orders_two_streams(F):
     assert torch.cuda.current_stream().cuda_stream == cur
     F.join_wgrad()
     torch.cuda.synchronize()
+
+
+def test_plain_c_client_of_the_c_abi(F, tmp_path):
+    """The boundary without Python or torch: a C99 program (gcc) allocates with the HIP runtime, calls pdf_linear_fwd /
+    pdf_stream_wait / pdf_linear_bwd_weight through include/pdfnet_hip.h and checks them against host loops."""
+    import subprocess
+    from tests.util import build_c_client
+    r = subprocess.run([build_c_client(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c_client: ok" in r.stdout, r.stdout

@@ -156,3 +156,18 @@ def pack_demo(res):
         o[k + "_abs_sum"] = t.double().abs().sum().reshape(1)
         o[k + "_crop"] = t[:, :, 8:24, 8:24]
     return o
+
+
+def build_c_client(out_dir):
+    """Compile tests/c_abi/c_client.c (plain C, gcc) against include/pdfnet_hip.h and libpdfnet_hip.so -> path of the binary."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "pdfnet_amd")
+    exe = os.path.join(str(out_dir), "c_client")
+    cmd = ["gcc", "-O1", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+           os.path.join(root, "tests", "c_abi", "c_client.c"), "-o", exe, "-L", lib, "-lpdfnet_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
