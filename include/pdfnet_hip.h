@@ -184,7 +184,9 @@ int pdf_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, int F,
  *   z = x + dropout_p(add)   (add == NULL: z = x, nothing written to z)
  *   y = act(LayerNorm(z) * gamma_g + beta_g),  act 0 none / 1 relu,  g = 0 for rows < R_split else 1 (R_split >= R: one set).
  * Backward: dz = LN-backward(dy * act'(y)) + dz_in (dz_in may be NULL) is the gradient of x; dadd = dropout mask applied to dz
- * (NULL when there was no add); dgamma / dbeta of both sets are ACCUMULATED (atomics; zero-fill or pre-load them). */
+ * (NULL when there was no add); dgamma / dbeta of both sets are ACCUMULATED (atomics; zero-fill or pre-load them).
+ * The two halves may be launched separately: all four parameter-gradient pointers NULL = data gradient only (no atomics -- the
+ * half that sits on the dependent chain); dz == NULL (then dz_in and dadd NULL too) = parameter gradients only. */
 int pdf_layernorm_fused_fwd(const float* x, int ldx, const float* add, int ldadd, float p, unsigned long long seed,
                             const unsigned long long* step, int F, long R, long R_split,
                             const float* gamma0, const float* beta0, const float* gamma1, const float* beta1, float eps, int act,

@@ -816,6 +816,10 @@ PDF_API int pdf_layernorm_fused_fwd(const float* x, int ldx, const float* add, i
 // dz = rstd * (g - mean(g) - xhat * mean(g*xhat)) [+ dz_in], g = dy * act'(y) * gamma; dgamma += sum dy' * xhat; dbeta += sum dy'
 // dadd = dropout-mask(dz) (the gradient of the dropped operand); dz itself is the gradient of x (the residual operand).
 // (dgamma/dbeta accumulated with one atomic per channel per block; caller zero-fills or accumulates)
+// DZ: write dz / dadd (the data gradient, on the dependent chain); PARAMS: accumulate dgamma / dbeta.  The two halves can be
+// launched separately: the parameter half then runs on the weight-gradient side stream, and the chain's half has no atomics
+// (512 blocks adding into the same 2 F addresses were most of the one-shot kernel's 28 us).
+template <bool DZ, bool PARAMS>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int act,
                                                             const float* __restrict__ zin, int ldz, int F, long R, long R_split,
                                                             const float* __restrict__ gamma0, const float* __restrict__ gamma1,
@@ -825,9 +829,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const unsigned long long* __restrict__ step,
                                                             float* __restrict__ dgamma0, float* __restrict__ dbeta0,
                                                             float* __restrict__ dgamma1, float* __restrict__ dbeta1) {
-    __shared__ float sg[64 * LN_MAXV], sb[64 * LN_MAXV];
-    for (int i = threadIdx.x; i < F; i += 256) { sg[i] = 0.f; sb[i] = 0.f; }
-    __syncthreads();
+    __shared__ float sg[PARAMS ? 64 * LN_MAXV : 1], sb[PARAMS ? 64 * LN_MAXV : 1];
+    if constexpr (PARAMS) {
+        for (int i = threadIdx.x; i < F; i += 256) { sg[i] = 0.f; sb[i] = 0.f; }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const long rb = blockIdx.y ? R_split : 0, re = blockIdx.y ? R : min(R, R_split);
     const float* __restrict__ gamma = blockIdx.y ? gamma1 : gamma0;
@@ -852,12 +858,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 d = dy[r * lddy + c];
                 if (act == 1 && !(y[r * ldy + c] > 0.f)) d = 0.f;
                 h = (zin[r * ldz + c] - mu) * rs;
-                ag[i] += d * h; ab[i] += d;
+                if constexpr (PARAMS) { ag[i] += d * h; ab[i] += d; }
                 d *= gamma[c];
             }
             g[i] = d; xh[i] = h;
             s1 += d; s2 += d * h;
         }
+        if constexpr (!DZ) continue;
         s1 = wave_sum(s1) / (float)F;
         s2 = wave_sum(s2) / (float)F;
 #pragma unroll
@@ -874,15 +881,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
+    if constexpr (PARAMS) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        int c = lane + 64 * i;
-        if (c < F) { atomicAdd(&sg[c], ag[i]); atomicAdd(&sb[c], ab[i]); }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < F; i += 256) {
-        if (dgamma != nullptr) atomicAdd(&dgamma[i], sg[i]);
-        if (dbeta != nullptr) atomicAdd(&dbeta[i], sb[i]);
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = lane + 64 * i;
+            if (c < F) { atomicAdd(&sg[c], ag[i]); atomicAdd(&sb[c], ab[i]); }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < F; i += 256) {
+            if (dgamma != nullptr) atomicAdd(&dgamma[i], sg[i]);
+            if (dbeta != nullptr) atomicAdd(&dbeta[i], sb[i]);
+        }
     }
 }
 
@@ -894,9 +903,15 @@ static int ln_bwd_launch(const float* dy, int lddy, const float* y, int ldy, int
     if (R <= 0) return 0;
     const unsigned groups = R_split < R ? 2 : 1;
     const long rows = groups == 2 ? max(R_split, R - R_split) : R;
-    int grid = grid_for(rows * 64, 256, 512);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid, groups), dim3(256), 0, s, dy, lddy, y, ldy, act, z, ldz, F, R, R_split, g0, g1, mean, rstd,
-                       dz_in, lddzin, dz, lddz, dadd, lddadd, p, seed, step, dg0, db0, dg1, db1);
+    const bool params = dg0 != nullptr || db0 != nullptr || dg1 != nullptr || db1 != nullptr;
+    if (dz == nullptr && !params) return 0;
+    if (dz == nullptr && (dadd != nullptr || dz_in != nullptr)) return PDF_E_BADARG;
+    // one-shot / parameter half: few blocks (every block ends with 2 F same-address atomics); data half: one row per wave
+    const int grid = grid_for(rows * 64, 256, dz == nullptr ? 128 : params ? 512 : 4096);
+#define LN_BWD(DZ_, PA_) hipLaunchKernelGGL((layernorm_bwd_kernel<DZ_, PA_>), dim3(grid, groups), dim3(256), 0, s, dy, lddy, y, ldy, act, z, ldz, F, R, \
+                       R_split, g0, g1, mean, rstd, dz_in, lddzin, dz, lddz, dadd, lddadd, p, seed, step, dg0, db0, dg1, db1)
+    if (dz == nullptr) LN_BWD(false, true); else if (params) LN_BWD(true, true); else LN_BWD(true, false);
+#undef LN_BWD
     PDF_LAUNCH_CHECK();
     return 0;
 }

@@ -924,9 +924,22 @@ class _LayerNormFused(Function):
         dadd = torch.empty_like(zin) if has_add else None
         d0, e0 = outs[0], outs[1]
         d1, e1 = (outs[2], outs[3]) if pair else (d0, e0)
-        _L().pdf_layernorm_fused_bwd(ptr(dy.contiguous()), Fd, ptr(y), Fd, act, ptr(zin), Fd, Fd, R, split, ptr(g0), ptr(g1 if pair else g0),
-                                     ptr(mean), ptr(rstd), ptr(dz_in.contiguous() if dz_in is not None else None), Fd, ptr(dz), Fd,
-                                     ptr(dadd), Fd, p, seed, ptr(step_counter(zin.device)), ptr(d0), ptr(e0), ptr(d1), ptr(e1), stream())
+        dy = dy.contiguous()
+        dz_in = dz_in.contiguous() if dz_in is not None else None
+        gb = ptr(g1 if pair else g0)
+        if direct and ASYNC_WGRAD and USE_SIDE_STREAMS:
+            # data gradient on the dependent chain (no atomics), parameter gradients into the flat buffer on the weight-gradient
+            # side stream: the one-shot kernel's same-address atomics were most of its 28 us, 37 times on the decoder's chain
+            _L().pdf_layernorm_fused_bwd(ptr(dy), Fd, ptr(y), Fd, act, ptr(zin), Fd, Fd, R, split, ptr(g0), gb, ptr(mean), ptr(rstd),
+                                         ptr(dz_in), Fd, ptr(dz), Fd, ptr(dadd), Fd, p, seed, ptr(step_counter(zin.device)),
+                                         None, None, None, None, stream())
+            with wgrad_stream(True, dy, y, zin, mean, rstd, params=pars):
+                _L().pdf_layernorm_fused_bwd(ptr(dy), Fd, ptr(y), Fd, act, ptr(zin), Fd, Fd, R, split, ptr(g0), gb, ptr(mean), ptr(rstd),
+                                             None, Fd, None, Fd, None, Fd, 0.0, 0, None, ptr(d0), ptr(e0), ptr(d1), ptr(e1), stream())
+        else:
+            _L().pdf_layernorm_fused_bwd(ptr(dy), Fd, ptr(y), Fd, act, ptr(zin), Fd, Fd, R, split, ptr(g0), gb,
+                                         ptr(mean), ptr(rstd), ptr(dz_in), Fd, ptr(dz), Fd,
+                                         ptr(dadd), Fd, p, seed, ptr(step_counter(zin.device)), ptr(d0), ptr(e0), ptr(d1), ptr(e1), stream())
         if direct:
             outs = [None] * 4
         return dz, dadd, outs[0], outs[1], outs[2], outs[3], None, None, None, None
