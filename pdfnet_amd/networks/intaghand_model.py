@@ -5,6 +5,7 @@ it drops into `ModleWithLoss` (lib/trains/base_trainer.py:24-78) / demo.py:202 u
 import torch
 import torch.nn as nn
 
+from .. import functional as F
 from .intaghand_decoder import load_decoder
 from .intaghand_encoder import load_encoder
 from .layers import BatchNorm
@@ -19,6 +20,8 @@ class HandNET_GCN(nn.Module):
         # mid_model's fmaps are dead downstream but its BatchNorm running statistics are
         # state the reference updates every step; keep it on by default for state parity.
         self.run_mid_model = run_mid_model
+        self.defer_mid_model = False       # set by ModleWithLoss: mid_model on a side stream, joined after the loss
+        self._deferred = []
 
     def forward(self, img, choose, cloud, depth, ind, K_new, valid):
         st = self.encoder.trunk(img, ind, choose, cloud, depth, K_new, valid)
@@ -34,8 +37,15 @@ class HandNET_GCN(nn.Module):
         result, paramsDict, handDictList, otherInfo = self.decoder(gl, gr)
         hms, mask, ret, hms_fmaps, dp_fmaps = join_dense()
         if self.run_mid_model:
-            with torch.no_grad():
-                self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)          # live state: its BN running statistics only
+            def run_mid():
+                with torch.no_grad():
+                    self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)      # live state: its BN running statistics only
+            if self.defer_mid_model and self.training:
+                # nothing reads its outputs: 0.9 ms of convolutions that need not sit between the mesh decoder and the loss.
+                # The caller that set `defer_mid_model` calls `join_deferred()` once the loss has been issued.
+                self._deferred.append(F.fork(run_mid))
+            else:
+                run_mid()
         BatchNorm.flush_counters()
         otherInfo['hms'] = hms
         otherInfo['mask'] = mask
@@ -44,6 +54,12 @@ class HandNET_GCN(nn.Module):
         otherInfo['converter_left'] = self.decoder.converter['left']
         otherInfo['converter_right'] = self.decoder.converter['right']
         return result, paramsDict, handDictList, otherInfo
+
+    def join_deferred(self):
+        """Make the current stream wait for the work `forward` left on side streams (see `defer_mid_model`)."""
+        for f in self._deferred:
+            f.join()
+        self._deferred.clear()
 
 
 def load_model_intag(opt):

@@ -26,12 +26,17 @@ class ModleWithLoss(torch.nn.Module):
         super().__init__()
         self.model = model
         self.loss = loss
+        if hasattr(model, 'join_deferred') and os.environ.get('PDFNET_DEFER_MID', '1') != '0':
+            model.defer_mid_model = True                       # joined below, right after the loss has been issued
 
     def forward(self, batch, mode, epoch):
         ind = batch['ind'] if mode == 'train' else None
         result, paramsDict, handDictList, otherInfo = self.model(
             batch['input'], batch['choose'], batch['cloud'], batch.get('depth'), ind, batch['K_new'], batch['valid'])
-        return self.loss(result, paramsDict, handDictList, otherInfo, batch, mode, epoch)
+        out = self.loss(result, paramsDict, handDictList, otherInfo, batch, mode, epoch)
+        if hasattr(self.model, 'join_deferred'):
+            self.model.join_deferred()
+        return out
 
 
 class FlatAdam:
