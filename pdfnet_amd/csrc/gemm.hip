@@ -1272,10 +1272,12 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     // write-through slab stores would need 16-byte stores from a re-laid-out accumulator (4-byte sc1 stores are ~6x slower).
     // BatchNorm's in-launch finalisation (norm.hip) publishes 32 bytes per block and does use the write-through form.
     g.counters = (splits > 1 && env_int(ENV_WG_INLAUNCH, 0)) ? pdf_ticket_counters((int)tiles * groups) : nullptr;
-    // Accumulating launches (the trainer's flat gradient buffer, zeroed once per step) add their partial tiles with fp32 atomics:
-    // no slab round trip through HBM and no reduce_slabs launch (174 launches, 2.6 ms per step).  Overwriting launches keep the
-    // slabs (fixed summation order).
-    g.atomic = (splits > 1 && accumulate && g.counters == nullptr && env_int(ENV_WG_ATOMIC, 1)) ? 1 : 0;
+    // Optional (PDF_WG_ATOMIC = minimum split count; default: never): accumulating launches add their partial tiles with fp32
+    // atomics instead of writing slabs -- no slab round trip, no reduce_slabs launch (-133 launches, -2.1 ms of side-stream work
+    // per step).  Measured: fp32 B=32 420.4 / 421.3 without vs 417.9 / 420.5 with, RGB-only encoder B=8 483 vs 473, bf16 B=64
+    // 862 vs 865 -- the reductions run on the side stream beside MFMA-bound kernels and cost nothing there, the atomic
+    // read-modify-writes cost the weight-gradient kernels' epilogues more than plain stores.
+    g.atomic = (splits >= env_int(ENV_WG_ATOMIC, 1 << 30) && splits > 1 && accumulate && g.counters == nullptr) ? 1 : 0;
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     int brc = 0;
     if (bf16) {
