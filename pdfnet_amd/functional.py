@@ -229,10 +229,10 @@ class wgrad_stream:
         ent = _wg_streams.get(key)
         if ent is None:
             s = torch.cuda.Stream()
-            ent = _wg_streams[key] = (s, ctypes.c_void_p(s.cuda_stream), s.stream_id, s.device_index, s.device_type)
+            ent = _wg_streams[key] = (s, s.cuda_stream, s.stream_id, s.device_index, s.device_type)
         side, side_raw = ent[0], ent[1]
         wait = _L().pdf_stream_wait
-        wait(side_raw, ctypes.c_void_p(cur_raw))
+        wait(side_raw, cur_raw)
         for p in self.params:
             if p is not None:
                 last = getattr(p, '_pdf_wg_last', None)

@@ -88,17 +88,18 @@ def stream():
     `torch.cuda.current_stream()` builds a Stream object through the device-index helpers (~9 us, a fifth of the step's
     host time)."""
     if _raw_stream is not None and _raw_device is not None:
-        return ctypes.c_void_p(_raw_stream(_raw_device()))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    """Device address as a plain int (ctypes converts ints and None for `void*` parameters itself; ~7,000 pointers a step)."""
+    return t.data_ptr() if t is not None else None
 
 
 def ptr_at(t, elements):
     """Device pointer `elements` elements into `t` (a channel offset inside an NHWC row)."""
-    return ctypes.c_void_p(t.data_ptr() + elements * t.element_size())
+    return t.data_ptr() + elements * t.element_size()
 
 
 def require_gpu(*tensors):
