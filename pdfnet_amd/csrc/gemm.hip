@@ -757,10 +757,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1350,6 +1350,88 @@ PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* d
 }
 
 // dW[Cout][KH][KW][Cin] (+)= sum over output pixels dy[m][co] * x[pos(m,tap)][ci]
+
+// Weight gradient of the ResNet stem (7x7, stride 2, pad 3, 3 -> 64 channels): dW[co][ky][kx][ci] = sum over output pixels of
+// dy[p][co] * x[2 oy - 3 + ky][2 ox - 3 + kx][ci].  The generic kernel walks its 3-channel taps element by element (18 TFLOP/s,
+// 0.54 ms at B = 32, and it is the LAST weight gradient of the step -- the tail after the main chain).  Here a block stages, per
+// chunk of 64 output pixels of one row, the 7 x 133 x 3 input patch and the 64 x 64 gradient tile in LDS and runs the 64 x 147
+// (padded to 160) contraction on the matrix pipe: A = dy as it lies ([pixel][co]), B = the im2col row gathered from the patch
+// through a per-lane offset; each wave takes 16 of the 64 pixels, the four partial tiles are summed in LDS at the end, one
+// partial matrix per block goes to the workspace (reduce_slabs_2d sums them in a fixed order).
+__global__ __launch_bounds__(256) void stem7x7_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                            int N, int H, int W, int ldx, int OH, int OW, int lddy, int cpb) {
+    constexpr int CH = 64, XW = 2 * CH + 5, XF = 7 * XW * 3, ZB = 2800, DYB = 3200, NJ = 147, NJP = 160;
+    __shared__ __attribute__((aligned(16))) float sm[64 * NJP];     // [0, XF): patch, [XF, DYB): zeros, [DYB, DYB + 4096): dy tile; at the end [64][160]
+    float* Xs = sm;
+    float* dYs = sm + DYB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = XF + tid; i < DYB; i += 256) sm[i] = 0.f;
+    int boff[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int j = 32 * t + (lane & 31);
+        const int tap = j / 3, ci = j - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+        boff[t] = j < NJ ? (ky * XW + kx) * 3 + ci : ZB;           // columns 147..159 read zeros (ZB + 6 * 63 < DYB)
+    }
+    f32x16 acc[2][5];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+    const int cpr = OW / CH;
+    const long total = (long)N * OH * cpr;
+    const long c0 = (long)blockIdx.x * cpb, c1 = min(total, c0 + cpb);
+    for (long c = c0; c < c1; ++c) {
+        const int n = (int)(c / ((long)OH * cpr));
+        const int rem = (int)(c - (long)n * OH * cpr);
+        const int oy = rem / cpr, ox0 = (rem - oy * cpr) * CH;
+        __syncthreads();                                            // the previous chunk's fragments have been read
+        for (int e = tid; e < XF; e += 256) {
+            const int r = e / (XW * 3), q = e - r * (XW * 3), col = q / 3, ci = q - col * 3;
+            const int iy = 2 * oy - 3 + r, ix = 2 * ox0 - 3 + col;
+            Xs[e] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((long)(n * H + iy) * W + ix) * ldx + ci] : 0.f;
+        }
+        for (int e = tid; e < CH * 16; e += 256) {
+            const int px = e >> 4, c4 = (e & 15) * 4;
+            *reinterpret_cast<float4*>(&dYs[px * 64 + c4]) =
+                *reinterpret_cast<const float4*>(&dy[((long)(n * OH + oy) * OW + ox0 + px) * lddy + c4]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int px = 16 * wave + 2 * ks + (lane >> 5);
+            const float a0 = dYs[px * 64 + (lane & 31)], a1 = dYs[px * 64 + 32 + (lane & 31)];
+            float b[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) b[t] = Xs[boff[t] + px * 6];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[t], acc[1][t], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * NJP; i += 256) sm[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = 32 * t + (lane & 31);
+                atomicAdd(&sm[co * NJP + j], acc[a][t][r]);
+            }
+    __syncthreads();
+    for (int i = tid; i < 64 * NJ; i += 256) {
+        const int co = i / NJ, j = i - co * NJ;
+        part[(long)blockIdx.x * (64 * NJ) + i] = sm[co * NJP + j];
+    }
+}
+
 PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                                   int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
@@ -1360,6 +1442,19 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
         hipLaunchKernelGGL((tiny_conv_wgrad_kernel<3, 3, 3, 3>), dim3(nblk), dim3(256), 0, s, x, dy, ws, N, H, W, ldx, pad, OH, OW, lddy);
         Reduce r = {ws, dw, nullptr, 81, nullptr, nullptr, nullptr, 0, nblk, accumulate};
         hipLaunchKernelGGL(reduce_slabs_2d, dim3(2, 1), dim3(256), 0, s, r, 2);
+        PDF_LAUNCH_CHECK();
+        return 0;
+    }
+    if (Cin == 3 && Cout == 64 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && db == nullptr && OW % 64 == 0 && OH * 2 == H && OW * 2 == W &&
+        lddy % 4 == 0 && aligned16(dy) && ws_floats >= 64L * 147 * 64 && env_int(ENV_WG_STEM, 1)) {
+        const long total = (long)N * OH * (OW / 64);
+        int nblk = (int)min(min((long)512, ws_floats / (64 * 147)), total);
+        const int cpb = (int)cdiv(total, nblk);
+        nblk = (int)cdiv(total, cpb);
+        hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, ws, N, H, W, ldx, OH, OW, lddy, cpb);
+        Reduce r = {ws, dw, nullptr, 64L * 147, nullptr, nullptr, nullptr, 0, nblk, accumulate};
+        const int mb = (64 * 147 + 63) / 64;
+        hipLaunchKernelGGL(reduce_slabs_2d, dim3(mb, 1), dim3(256), 0, s, r, mb);
         PDF_LAUNCH_CHECK();
         return 0;
     }

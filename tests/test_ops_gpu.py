@@ -72,7 +72,9 @@ CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, act, bias
     (5, 256, 64, 64, 512, 3, 1, 1, 0, True), (5, 512, 64, 64, 256, 3, 1, 1, 0, False), (20, 272, 32, 32, 512, 3, 1, 1, 0, False),
     (20, 512, 32, 32, 256, 3, 1, 1, 0, True), (80, 256, 16, 16, 512, 3, 1, 1, 0, True), (80, 512, 16, 16, 256, 3, 1, 1, 0, False),
     # valid 3x3 on the 5x5 / 3x3 centre windows (few rows, long reduction: 32x32 tiles)
-    (64, 256, 5, 5, 512, 3, 1, 0, 0, False), (64, 512, 3, 3, 1024, 3, 1, 0, 0, False)]
+    (64, 256, 5, 5, 512, 3, 1, 0, 0, False), (64, 512, 3, 3, 1024, 3, 1, 0, 0, False),
+    # the ResNet stem at output widths that are multiples of 64: its dedicated MFMA weight-gradient kernel (image borders on all sides)
+    (3, 3, 128, 128, 64, 7, 2, 3, 0, False), (2, 3, 64, 256, 64, 7, 2, 3, 1, False)]
 
 
 @pytest.mark.parametrize("cfg", CONVS)
