@@ -1133,6 +1133,83 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const float* __restri
 
 // Conv2d forward on NHWC.  w is [Cout][KH][KW][Cin] (the channels_last storage of an OIHW weight).
 // Replaces nn.Conv2d.forward at intaghand_encoder.py:711-772,790-791 and resnet.py:202-218.
+
+// Forward of the ResNet stem (7x7, stride 2, pad 3, 3 -> 64 channels) on the matrix pipe: the generic implicit GEMM gathers its
+// 3-channel taps element by element (43 TFLOP/s, 0.22 ms at B = 32, the first kernel of every step).  A block keeps the weights
+// in LDS as [j = (ky, kx, ci)][co] (148 rows, the last one zero), stages per chunk of 64 output pixels of one row the 7 x 133 x 3
+// input patch, and each of its four waves computes one 32 pixel x 32 channel tile over the 74 K-steps: A = the im2col row
+// gathered from the patch (offset of column j is a compile-time constant, selected per half-wave), B = a weight row.
+__host__ __device__ constexpr int stem_off(int j) { return j < 147 ? ((j / 3 / 7) * 133 + (j / 3) % 7) * 3 + j % 3 : 2800; }
+template <int KS>
+__device__ __forceinline__ void stem_fwd_steps(const float* Xs, const float* Ws, int pxo, int hi, int bcol, f32x16& acc) {
+    if constexpr (KS < 74) {
+        const int off = hi ? stem_off(2 * KS + 1) : stem_off(2 * KS);
+        const float a = Xs[off + pxo];
+        const float b = Ws[(2 * KS) * 64 + bcol];                  // bcol already holds hi * 64 + column
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        stem_fwd_steps<KS + 1>(Xs, Ws, pxo, hi, bcol, acc);
+    }
+}
+__global__ __launch_bounds__(256) void stem7x7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                          int N, int H, int W, int OH, int OW, int ldy, int act, int cpb) {
+    constexpr int CH = 64, XW = 2 * CH + 5, RW = XW * 3, XF = 7 * RW, DYB = 3200;
+    __shared__ __attribute__((aligned(16))) float Xs[DYB];          // [0, XF): patch, [XF, DYB): zeros
+    __shared__ __attribute__((aligned(16))) float Ws[148 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = XF + tid; i < DYB; i += 256) Xs[i] = 0.f;
+    for (int i = tid; i < 148 * 64; i += 256) {
+        const int j = i >> 6, co = i & 63;
+        Ws[i] = j < 147 ? w[co * 147 + j] : 0.f;
+    }
+    const int pt = wave >> 1, ct = wave & 1, hi = lane >> 5;
+    const int pxo = (32 * pt + (lane & 31)) * 6, bcol = hi * 64 + 32 * ct + (lane & 31);
+    const int cpr = OW / CH;
+    const long total = (long)N * OH * cpr;
+    const long c0 = (long)blockIdx.x * cpb, c1 = min(total, c0 + cpb);
+    float xr[14];
+    auto gload = [&](long c) {                                     // see stem7x7_wgrad_kernel
+        const int n = (int)(c / ((long)OH * cpr));
+        const int rem = (int)(c - (long)n * OH * cpr);
+        const int oy = rem / cpr, ox0 = (rem - oy * cpr) * CH;
+        const int lin0 = (2 * ox0 - 3) * 3;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int iy = 2 * oy - 3 + r;
+            const float* row = x + ((long)(n * H + iy) * W) * 3;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = tid + 256 * h, lin = lin0 + e;
+                const bool ok = iy >= 0 && iy < H && e < RW && lin >= 0 && lin < 3 * W;
+                xr[r * 2 + h] = ok ? row[lin] : 0.f;
+            }
+        }
+    };
+    if (c0 < c1) gload(c0);
+    for (long c = c0; c < c1; ++c) {
+        const int n = (int)(c / ((long)OH * cpr));
+        const int rem = (int)(c - (long)n * OH * cpr);
+        const int oy = rem / cpr, ox0 = (rem - oy * cpr) * CH;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { const int e = tid + 256 * h; if (e < RW) Xs[r * RW + e] = xr[r * 2 + h]; }
+        __syncthreads();
+        if (c + 1 < c1) gload(c + 1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        stem_fwd_steps<0>(Xs, Ws, pxo, hi, bcol, acc);
+        float* yp = y + ((long)(n * OH + oy) * OW + ox0 + 32 * pt) * ldy + 32 * ct + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+            if (act == 1) v = fmaxf(v, 0.f); else if (act == 2) v = v > 0.f ? v : 0.1f * v;
+            yp[(long)((r & 3) + 8 * (r >> 2) + 4 * hi) * ldy] = v;
+        }
+    }
+}
+
 PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                            int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                            int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s) {
@@ -1140,6 +1217,17 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && (long)N * OH * OW >= (1L << 16)) {
         hipLaunchKernelGGL((tiny_conv_fwd_kernel<3, 3, 3, 3>), dim3(grid_for((long)N * OH * OW)), dim3(256), 0, s, x, w, bias, y, N, H, W, ldx, pad, OH, OW, ldy, act);
+        PDF_LAUNCH_CHECK();
+        return 0;
+    }
+    if (Cin == 3 && ldx == 3 && Cout == 64 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && bias == nullptr && OW % 64 == 0 && OH * 2 == H && OW * 2 == W &&
+        env_int(ENV_WG_STEM, 1)) {
+        const long total = (long)N * OH * (OW / 64);
+        int nblk = (int)min((long)512, total);
+        const int cpb = (int)cdiv(total, nblk);
+        nblk = (int)cdiv(total, cpb);
+        hipLaunchKernelGGL(stem7x7_fwd_kernel, dim3(nblk), dim3(256), 0, s, x, w, y, N, H, W, OH, OW, ldy, act, cpb);
+        g_last_tile = 0;
         PDF_LAUNCH_CHECK();
         return 0;
     }
@@ -1356,11 +1444,11 @@ PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* d
 // 0.54 ms at B = 32, and it is the LAST weight gradient of the step -- the tail after the main chain).  Here a block stages, per
 // chunk of 64 output pixels of one row, the 7 x 133 x 3 input patch and the 64 x 64 gradient tile in LDS and runs the 64 x 147
 // (padded to 160) contraction on the matrix pipe: A = dy as it lies ([pixel][co]), B = the im2col row gathered from the patch
-// through a per-lane offset; each wave takes 16 of the 64 pixels, the four partial tiles are summed in LDS at the end, one
+// through a per-lane offset; each wave takes half the channels and half the pixels, the partial tiles are summed in LDS at the end, one
 // partial matrix per block goes to the workspace (reduce_slabs_2d sums them in a fixed order).
 __global__ __launch_bounds__(256) void stem7x7_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
-                                                            int N, int H, int W, int ldx, int OH, int OW, int lddy, int cpb) {
-    constexpr int CH = 64, XW = 2 * CH + 5, XF = 7 * XW * 3, ZB = 2800, DYB = 3200, NJ = 147, NJP = 160;
+                                                            int N, int H, int W, int OH, int OW, int lddy, int cpb) {
+    constexpr int CH = 64, XW = 2 * CH + 5, RW = XW * 3, XF = 7 * RW, ZB = 2800, DYB = 3200, NJ = 147, NJP = 160;
     __shared__ __attribute__((aligned(16))) float sm[64 * NJP];     // [0, XF): patch, [XF, DYB): zeros, [DYB, DYB + 4096): dy tile; at the end [64][160]
     float* Xs = sm;
     float* dYs = sm + DYB;
@@ -1373,58 +1461,75 @@ __global__ __launch_bounds__(256) void stem7x7_wgrad_kernel(const float* __restr
         const int tap = j / 3, ci = j - tap * 3, ky = tap / 7, kx = tap - ky * 7;
         boff[t] = j < NJ ? (ky * XW + kx) * 3 + ci : ZB;           // columns 147..159 read zeros (ZB + 6 * 63 < DYB)
     }
-    f32x16 acc[2][5];
+    // wave = (channel half a, pixel half kh): 32 channels x 160 columns over 32 of the chunk's 64 pixels -- 80 accumulator registers
+    // (all 64 channels per wave, 160 registers, spilled once the prefetch registers were added)
+    const int wa = wave & 1, kh = wave >> 1;
+    f32x16 acc[5];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int t = 0; t < 5; ++t)
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int cpr = OW / CH;
     const long total = (long)N * OH * cpr;
     const long c0 = (long)blockIdx.x * cpb, c1 = min(total, c0 + cpb);
-    for (long c = c0; c < c1; ++c) {
+    // the next chunk's patch rows (contiguous in NHWC with 3 channels: 399 floats each) and dy tile travel through registers while
+    // the current chunk is on the matrix pipe
+    typedef float v4f __attribute__((ext_vector_type(4)));          // (an array of HIP's float4 struct lands in scratch)
+    float xr[14]; v4f dr[4];
+    auto gload = [&](long c) {
         const int n = (int)(c / ((long)OH * cpr));
         const int rem = (int)(c - (long)n * OH * cpr);
         const int oy = rem / cpr, ox0 = (rem - oy * cpr) * CH;
-        __syncthreads();                                            // the previous chunk's fragments have been read
-        for (int e = tid; e < XF; e += 256) {
-            const int r = e / (XW * 3), q = e - r * (XW * 3), col = q / 3, ci = q - col * 3;
-            const int iy = 2 * oy - 3 + r, ix = 2 * ox0 - 3 + col;
-            Xs[e] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((long)(n * H + iy) * W + ix) * ldx + ci] : 0.f;
-        }
-        for (int e = tid; e < CH * 16; e += 256) {
-            const int px = e >> 4, c4 = (e & 15) * 4;
-            *reinterpret_cast<float4*>(&dYs[px * 64 + c4]) =
-                *reinterpret_cast<const float4*>(&dy[((long)(n * OH + oy) * OW + ox0 + px) * lddy + c4]);
-        }
-        __syncthreads();
+        const int lin0 = (2 * ox0 - 3) * 3;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int px = 16 * wave + 2 * ks + (lane >> 5);
-            const float a0 = dYs[px * 64 + (lane & 31)], a1 = dYs[px * 64 + 32 + (lane & 31)];
+        for (int r = 0; r < 7; ++r) {
+            const int iy = 2 * oy - 3 + r;
+            const float* row = x + ((long)(n * H + iy) * W) * 3;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = tid + 256 * h, lin = lin0 + e;
+                const bool ok = iy >= 0 && iy < H && e < RW && lin >= 0 && lin < 3 * W;
+                xr[r * 2 + h] = ok ? row[lin] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, px = e >> 4, c4 = (e & 15) * 4;
+            dr[q] = *reinterpret_cast<const v4f*>(&dy[((long)(n * OH + oy) * OW + ox0 + px) * lddy + c4]);
+        }
+    };
+    if (c0 < c1) gload(c0);
+    for (long c = c0; c < c1; ++c) {
+        __syncthreads();                                            // the previous chunk's fragments have been read
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { const int e = tid + 256 * h; if (e < RW) Xs[r * RW + e] = xr[r * 2 + h]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = tid + 256 * q; *reinterpret_cast<v4f*>(&dYs[(e >> 4) * 64 + (e & 15) * 4]) = dr[q]; }
+        __syncthreads();
+        if (c + 1 < c1) gload(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int px = 32 * kh + 2 * ks + (lane >> 5);
+            const float a0 = dYs[px * 64 + 32 * wa + (lane & 31)];
             float b[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) b[t] = Xs[boff[t] + px * 6];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[t], acc[1][t], 0, 0, 0);
-            }
+            for (int t = 0; t < 5; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[t], acc[t], 0, 0, 0);
         }
     }
     __syncthreads();
     for (int i = tid; i < 64 * NJP; i += 256) sm[i] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int t = 0; t < 5; ++t)
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = 32 * t + (lane & 31);
-                atomicAdd(&sm[co * NJP + j], acc[a][t][r]);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int co = 32 * wa + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = 32 * t + (lane & 31);
+            atomicAdd(&sm[co * NJP + j], acc[t][r]);
+        }
     __syncthreads();
     for (int i = tid; i < 64 * NJ; i += 256) {
         const int co = i / NJ, j = i - co * NJ;
@@ -1445,13 +1550,13 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
         PDF_LAUNCH_CHECK();
         return 0;
     }
-    if (Cin == 3 && Cout == 64 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && db == nullptr && OW % 64 == 0 && OH * 2 == H && OW * 2 == W &&
+    if (Cin == 3 && ldx == 3 && Cout == 64 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && db == nullptr && OW % 64 == 0 && OH * 2 == H && OW * 2 == W &&
         lddy % 4 == 0 && aligned16(dy) && ws_floats >= 64L * 147 * 64 && env_int(ENV_WG_STEM, 1)) {
         const long total = (long)N * OH * (OW / 64);
         int nblk = (int)min(min((long)512, ws_floats / (64 * 147)), total);
         const int cpb = (int)cdiv(total, nblk);
         nblk = (int)cdiv(total, cpb);
-        hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, ws, N, H, W, ldx, OH, OW, lddy, cpb);
+        hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, ws, N, H, W, OH, OW, lddy, cpb);
         Reduce r = {ws, dw, nullptr, 64L * 147, nullptr, nullptr, nullptr, 0, nblk, accumulate};
         const int mb = (64 * 147 + 63) / 64;
         hipLaunchKernelGGL(reduce_slabs_2d, dim3(mb, 1), dim3(256), 0, s, r, mb);
