@@ -76,13 +76,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = (g.K + BK - 1) / BK;
-    int kt0 = 0, kt1 = nk;                               // split-K launch: this block's K-steps (T == 1 only)
+    int kt0 = 0, kt1 = nk;                               // split-K launch: this block's K-steps
     if (g.ksteps > 0) { kt0 = blockIdx.z * g.ksteps; kt1 = min(nk, kt0 + g.ksteps); }
 
     float4 ra[RA], rb[RB];
     // tap state of the NEXT tile to load (tiles are loaded strictly in order): no per-tile division and the
     // tap table (scalar loads that share lgkmcnt with the LDS traffic) is read only when the tap changes
-    int nt_tap = 0, nt_ci = kt0 * BK, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * (KN ? g.btap : g.Cin);
+    int nt_tap = 0, nt_ci = kt0 * BK;
+    if (g.ksteps > 0 && g.T > 1) { nt_tap = nt_ci / g.Cin; nt_ci -= nt_tap * g.Cin; }      // split-K over taps: Cin % BK == 0 (launch_igemm)
+    int ddy = g.dy[nt_tap], ddx = g.dx[nt_tap], wbase = g.wt[nt_tap] * (KN ? g.btap : g.Cin);
     auto gload = [&](int kt) {
         if (FAST) {
             const int ci0 = nt_ci + kq;
@@ -880,7 +882,9 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     // up-projections): a handful of CUs would walk K step by step at load latency.  Split K over blockIdx.z so that ~320 blocks
     // run, partial tiles through the scratch ring, bias / activation in splitk_finish.
     const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
-    if (groups == 1 && g.T == 1 && g.plain_in && g.plain_out && g.ps_cout == 0 && !g.accum && t64 <= 128 && g.K >= 512 && env_int(ENV_IG_SPLITK, 1)) {
+    // (also the valid 3x3 convolutions on the 5x5 / 3x3 centre windows: taps are walked in K order, a split may start inside any tap)
+    const bool sk_plain = g.T == 1 && g.plain_in, sk_taps = g.T > 1 && !g.plain_in && fast && g.Cin % 32 == 0 && g.K == g.T * g.Cin;
+    if (groups == 1 && (sk_plain || sk_taps) && g.plain_out && g.ps_cout == 0 && !g.accum && t64 <= 128 && g.K >= 512 && env_int(ENV_IG_SPLITK, 1)) {
         const bool bk32 = fast && g.Cin % 32 == 0;
         const int bk = bk32 ? 32 : 16, nk = cdiv(g.K, bk);
         int splits = (int)min((long)cdiv(320, (int)t64), (long)(g.K / 128));
