@@ -32,9 +32,10 @@ class Bottleneck(nn.Module):
             self.downsample = nn.Sequential(Conv2d(cin, width * 4, 1, stride, 0, bias=False), BatchNorm(width * 4))
 
     def forward(self, x):
-        if self.downsample is None and x.requires_grad:
-            # identity block: conv1 hands the input back as the shortcut so both gradients of x meet in conv1's backward,
-            # which accumulates onto the shortcut's gradient in the GEMM epilogue (no separate add pass)
+        if x.requires_grad:
+            # conv1 hands the input back as the shortcut's source so both gradients of x meet in conv1's backward, which
+            # accumulates onto the shortcut's gradient (identity, or the projection's backward-data) in the GEMM epilogue
+            # -- no separate add pass over the block input's gradient
             y, sc = F.conv2d_with_skip(x, self.conv1.weight, None, 1, 0)
         else:
             y, sc = self.conv1(x), x
@@ -42,7 +43,7 @@ class Bottleneck(nn.Module):
         y = self.bn2(self.conv2(y), relu=True)
         y = self.conv3(y)
         if self.downsample is not None:
-            sc = self.downsample[1](self.downsample[0](x))
+            sc = self.downsample[1](self.downsample[0](sc))
         return self.bn3(y, relu=True, res=sc)          # relu(bn3(y) + shortcut) in one pass
 
 
