@@ -253,6 +253,8 @@ int pdf_dropout_add(const float* x, const float* res, float* y, long n, float p,
  * (gather over the <= 4 windows of an input element); otherwise dx must be zero-filled by the caller (atomic scatter). */
 int pdf_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, unsigned char* arg, void* stream);
 int pdf_maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, void* stream);
+/* dx += (dx holds the gradient of the pooled tensor's other consumers; autograd's add pass folded into this one) */
+int pdf_maxpool3s2_bwd_add(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, void* stream);
 /* nn.Upsample(scale_factor=2, bilinear, align_corners=True) (intaghand_encoder.py:287-302) */
 int pdf_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);
 int pdf_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream);

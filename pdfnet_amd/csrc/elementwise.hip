@@ -305,13 +305,13 @@ __global__ void maxpool3s2_bwd_kernel(const float* __restrict__ dy, const unsign
 // gather form: every INPUT element looks at the <= 4 windows that contain it and takes the gradient of those whose arg-max it
 // is -- writes every dx element exactly once (no zero fill, no atomics: 134 MB of memset + 8.4 M atomic adds at B = 32 before)
 __global__ __launch_bounds__(256) void maxpool3s2_bwd_gather_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, int N, int H, int W, int C,
-                                                                     int OH, int OW, float* __restrict__ dx, long total4) {
+                                                                     int OH, int OW, float* __restrict__ dx, long total4, int accumulate) {
     const int C4 = C >> 2;
     GRID_STRIDE(i, total4) {
         const int c = (int)(i % C4) * 4; long p = i / C4;
         const int ix = (int)(p % W); p /= W;
         const int iy = (int)(p % H); const int n = (int)(p / H);
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g = accumulate ? *reinterpret_cast<const float4*>(dx + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         // windows with oy * 2 - 1 + ky = iy, ky in 0..2:  oy in [ceil((iy - 1) / 2), floor((iy + 1) / 2)] = [iy / 2, (iy + 1) / 2]
         for (int oy = iy / 2; oy <= min(OH - 1, (iy + 1) / 2); ++oy) {
             const int ky = iy + 1 - 2 * oy;
@@ -332,19 +332,27 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_gather_kernel(const float*
         *reinterpret_cast<float4*>(dx + i * 4) = g;
     }
 }
-PDF_API int pdf_maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, hipStream_t s) {
+static int maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, int accumulate, hipStream_t s) {
     int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     long total = (long)N * OH * OW * C;
     if (total <= 0) return 0;
     if (C % 4 == 0 && !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) && !(reinterpret_cast<uintptr_t>(arg) & 3)) {
         const long tin4 = (long)N * H * W * C / 4;          // (dx need not be zero-filled on this path; the caller's fill is harmless)
-        hipLaunchKernelGGL(maxpool3s2_bwd_gather_kernel, dim3(grid_for(tin4)), dim3(256), 0, s, dy, arg, N, H, W, C, OH, OW, dx, tin4);
+        hipLaunchKernelGGL(maxpool3s2_bwd_gather_kernel, dim3(grid_for(tin4)), dim3(256), 0, s, dy, arg, N, H, W, C, OH, OW, dx, tin4, accumulate);
         PDF_LAUNCH_CHECK();
         return 0;
     }
     hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, arg, N, H, W, C, OH, OW, dx, total);
     PDF_LAUNCH_CHECK();
     return 0;
+}
+PDF_API int pdf_maxpool3s2_bwd(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, hipStream_t s) {
+    return maxpool3s2_bwd(dy, arg, N, H, W, C, dx, 0, s);
+}
+// dx += the same: dx already holds the gradient of the input's other consumers (the stem output also feeds the PointNet++ row
+// gathers) -- one pass instead of a separate add over both tensors.  (The atomic fallback accumulates by construction.)
+PDF_API int pdf_maxpool3s2_bwd_add(const float* dy, const unsigned char* arg, int N, int H, int W, int C, float* dx, hipStream_t s) {
+    return maxpool3s2_bwd(dy, arg, N, H, W, C, dx, 1, s);
 }
 
 // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) on NHWC (intaghand_encoder.py:281-302)

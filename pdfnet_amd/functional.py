@@ -703,8 +703,12 @@ def relu(x):
 
 
 class _MaxPool3s2(Function):
+    """skip=True: also returns the input as a second output for its other consumers (see _Conv2d): their gradient arrives here
+    and the pooling gradient is added onto it in the same pass (pdf_maxpool3s2_bwd_add)."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, skip=False):
+        x_in = x
         x = cl(x)
         N, C, H, W = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -713,20 +717,30 @@ class _MaxPool3s2(Function):
         _L().pdf_maxpool3s2_fwd(ptr(x), N, H, W, C, ptr(y), ptr(arg), stream())
         ctx.save_for_backward(arg)
         ctx.shape = (N, C, H, W)
+        ctx.set_materialize_grads(False)
+        if skip:
+            return y, x_in.view_as(x_in)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         (arg,) = ctx.saved_tensors
         N, C, H, W = ctx.shape
+        if dy is None:
+            return dskip, None
+        if dskip is not None and dskip.shape == (N, C, H, W) and dskip.is_contiguous(memory_format=CL) and dskip.dtype == torch.float32:
+            _L().pdf_maxpool3s2_bwd_add(ptr(cl(dy)), ptr(arg), N, H, W, C, ptr(dskip), stream())
+            return dskip, None
         # (C % 4 == 0: the gather kernel writes every element once; otherwise the atomic scatter needs a zero-filled dx)
         dx = torch.empty((N, C, H, W), device=dy.device, memory_format=CL) if C % 4 == 0 else _zeros_cl((N, C, H, W), dy.device)
         _L().pdf_maxpool3s2_bwd(ptr(cl(dy)), ptr(arg), N, H, W, C, ptr(dx), stream())
-        return dx
+        if dskip is not None:
+            dx = dx + dskip
+        return dx, None
 
 
-def maxpool3s2(x):
-    return _MaxPool3s2.apply(x)
+def maxpool3s2(x, skip=False):
+    return _MaxPool3s2.apply(x, skip)
 
 
 class _Up2(Function):
@@ -1103,8 +1117,9 @@ class _GatherRows(Function):
     """feat 4-D channels_last [B,C,H,W]; ind int64 [B,M] -> [B,M,ldo] (channels >= C zero)."""
 
     @staticmethod
-    def forward(ctx, feat, ind, R, shift, ldo):
+    def forward(ctx, feat, ind, R, shift, ldo, chain=False):
         hip.require_gpu(feat, ind)
+        feat_in = feat
         feat = cl(feat)
         B, C, H, W = feat.shape
         M = ind.shape[1]
@@ -1113,27 +1128,48 @@ class _GatherRows(Function):
         _L().pdf_gather_rows(ptr(feat), C, C, H * W, ptr(ind), ind.stride(0), B, M, R, shift, ptr(out), ldo, stream())
         ctx.save_for_backward(ind)
         ctx.cfg = (B, C, H, W, M, R, shift, ldo)
+        ctx.set_materialize_grads(False)                     # an unused alias arrives as None, not as an NCHW-strided zero tensor
+        if chain:
+            return out, feat_in.view_as(feat_in)
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, dalias=None):
         (ind,) = ctx.saved_tensors
         B, C, H, W, M, R, shift, ldo = ctx.cfg
-        dfeat = _zeros_cl((B, C, H, W), g.device)
+        if g is None:
+            return dalias, None, None, None, None, None
+        dfeat, extra = _chain_target(dalias, (B, C, H, W), g.device)
         _L().pdf_scatter_rows_add(ptr(g.contiguous()), ldo, C, H * W, ptr(ind), ind.stride(0), B, M, R, shift, ptr(dfeat), C, stream())
-        return dfeat, None, None, None, None
+        if extra is not None:
+            dfeat = dfeat + extra
+        return dfeat, None, None, None, None, None
 
 
-def gather_rows(feat, ind, R=1, shift=0, ldo=None):
-    return _GatherRows.apply(feat, ind, R, shift, ldo or feat.shape[1])
+def _chain_target(dalias, shape, dev):
+    """Where a scatter-type backward accumulates: `dalias` itself -- the gradient of the feature map's later consumers, handed
+    over through the alias output of a `chain=True` gather (a zero tensor from autograd when there are none) -- so that the
+    consumers of one map fill ONE gradient tensor instead of a zero-filled tensor each plus an add pass per pair.
+    -> (target, tensor still to be added or None)."""
+    if dalias is None:
+        return _zeros_cl(shape, dev), None
+    if tuple(dalias.shape) == tuple(shape) and dalias.dtype == torch.float32 and dalias.is_contiguous(memory_format=CL):
+        return dalias, None
+    return _zeros_cl(shape, dev), dalias
+
+
+def gather_rows(feat, ind, R=1, shift=0, ldo=None, chain=False):
+    """chain=True -> (rows, feat): pass the second output to the map's NEXT consumer (see _chain_target)."""
+    return _GatherRows.apply(feat, ind, R, shift, ldo or feat.shape[1], chain)
 
 
 class _WindowGather(Function):
     """feat [B,C,H,W] channels_last, ind [B,M] -> windows [B*M, C, win, win] (channels_last), zero outside."""
 
     @staticmethod
-    def forward(ctx, feat, ind, r):
+    def forward(ctx, feat, ind, r, chain=False):
         hip.require_gpu(feat, ind)
+        feat_in = feat
         feat = cl(feat)
         B, C, H, W = feat.shape
         M, win = ind.shape[1], 2 * r + 1
@@ -1141,15 +1177,22 @@ class _WindowGather(Function):
         _L().pdf_window_op(ptr(feat), C, C, H, W, ptr(ind), ind.stride(0), B, M, r, ptr(out), None, 0, stream())
         ctx.save_for_backward(ind)
         ctx.cfg = (B, C, H, W, M, r)
+        ctx.set_materialize_grads(False)
+        if chain:
+            return out, feat_in.view_as(feat_in)
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, dalias=None):
         (ind,) = ctx.saved_tensors
         B, C, H, W, M, r = ctx.cfg
-        dfeat = _zeros_cl((B, C, H, W), g.device)
+        if g is None:
+            return dalias, None, None, None
+        dfeat, extra = _chain_target(dalias, (B, C, H, W), g.device)
         _L().pdf_window_op(ptr(dfeat), C, C, H, W, ptr(ind), ind.stride(0), B, M, r, ptr(cl(g)), None, 1, stream())
-        return dfeat, None, None
+        if extra is not None:
+            dfeat = dfeat + extra
+        return dfeat, None, None, None
 
 
 class _WindowMask(Function):
@@ -1173,8 +1216,8 @@ class _WindowMask(Function):
         return _WindowMask.apply(g, ind, H, W, r), None, None, None, None
 
 
-def window_gather(feat, ind, r):
-    return _WindowGather.apply(feat, ind, r)
+def window_gather(feat, ind, r, chain=False):
+    return _WindowGather.apply(feat, ind, r, chain)
 
 
 def window_mask(x, ind, H, W, r):

@@ -145,32 +145,41 @@ class PointNet_Plus(nn.Module):
     def forward(self, cloud, emb, choose):
         return self.stage_b(*self.stage_a(cloud, emb[0], emb[1], choose), emb[2], choose)
 
-    def stage_a(self, cloud, emb0, emb1, choose):
+    def stage_a(self, cloud, emb0, emb1, choose, chain=False):
         """Set-abstraction levels 1 and 2 (:120-145).  They read only the two shallow embeddings (e_conv1 and the stem), so
         the encoder starts them on a side stream next to the ResNet trunk: HBM-bound point kernels under MFMA-bound convs."""
         o = self.opt
         R, S1, S2, K = o.default_resolution, o.sample_num_level1, o.sample_num_level2, o.knn_K
         B = cloud.shape[0]
-        pts = self.sft0(cloud, F.gather_rows(emb0, choose))                                # [B,1024,3]   (:120-122)
+        # chain=True: also returns emb0 / emb1 for the NEXT consumer of these maps (the other hand): the scatter-type backward
+        # passes of all consumers then fill one gradient tensor per map (F.gather_rows)
+        e0 = F.gather_rows(emb0, choose, chain=chain)
+        if chain:
+            e0, emb0 = e0
+        pts = self.sft0(cloud, e0)                                                         # [B,1024,3]   (:120-122)
         y1 = self._group_conv(self.netR_1[0], torch.nn.functional.pad(pts, (0, _pad16(3) - 3)), S1, K, o.ball_radius)   # (:123,:49)
         x = self._mlp_max(self.netR_1, y1, K)                                               # [B*S1,128]   (:132)
-        e1 = F.gather_rows(emb1, choose[:, :S1], R, 1)                                     # [B,S1,64]    (:125-127)
+        e1 = F.gather_rows(emb1, choose[:, :S1], R, 1, chain=chain)                        # [B,S1,64]    (:125-127)
+        if chain:
+            e1, emb1 = e1
         x = torch.cat((pts[:, :S1], x.view(B, S1, 128), x.new_zeros(B, S1, _pad16(131) - 131)), 2)   # [B,S1,131 | 0]   (:134)
         x = self.sft1(x, e1)                                                               #              (:137)
         y1 = self._group_conv(self.netR_2[0], x, S2, K, o.ball_radius2)                    # (:139,:68)
         y = self._mlp_max(self.netR_2, y1, K)                                               # [B*S2,256]
-        return x, y
+        return (x, y, emb0, emb1) if chain else (x, y)
 
-    def stage_b(self, x, y, emb2, choose):
+    def stage_b(self, x, y, emb2, choose, chain=False):
         """Level 3 (:146-152): needs the fused pyramid feature map x0."""
         o = self.opt
         R, S2 = o.default_resolution, o.sample_num_level2
         B = x.shape[0]
-        e2 = F.gather_rows(emb2, choose[:, :S2], R, 2)                                     # [B,S2,256]   (:126,128)
+        e2 = F.gather_rows(emb2, choose[:, :S2], R, 2, chain=chain)                        # [B,S2,256]   (:126,128)
+        if chain:
+            e2, emb2 = e2
         y = torch.cat((x[:, :S2, :3], y.view(B, S2, 256), y.new_zeros(B, S2, _pad16(259) - 259)), 2)   # [B,S2,259 | 0]
         y = self.sft2(y, e2)                                                               #              (:147)
         y = self._mlp_max(self.netR_3, self.netR_3[0](y), S2)                               # [B,1024]     (:152)
-        return y.view(B, 1, 1024)
+        return (y.view(B, 1, 1024), emb2) if chain else y.view(B, 1, 1024)
 
 
 class ResNetSimple_decoder(nn.Module):
@@ -244,23 +253,26 @@ class ResNetSimple(nn.Module):
         self.dp_decoder = ResNetSimple_decoder(2, True)
         self.dense_center = False
 
-    def center_features(self, x0, ind):
+    def center_features(self, x0, ind, chain=False):
         """center_feat_up0 -> center_feat_up1 -> gather at the 2 centre pixels (:790-792).
         sparse (default): exact evaluation on the 5x5 window of x0 around each centre -- up0 on the 3x3
         neighbourhood (zeroed where it leaves the map, because up1's padding pads up0 with zeros), then up1
         at the centre: 0.06 instead of 48.3 GFLOP/img, same values.
         dense: the reference formulation (two full 3x3 convolutions, then keep 2 pixels)."""
         if self.dense_center:
-            return F.gather_rows(self.center_feat_up1(self.center_feat_up0(x0)), ind)
+            out = F.gather_rows(self.center_feat_up1(self.center_feat_up0(x0)), ind)
+            return (out, x0) if chain else out
         B, _, H, W = x0.shape
         up0, up1 = self.center_feat_up0, self.center_feat_up1
-        win = F.window_gather(x0, ind, 2)                                                  # [B*2,256,5,5]
+        win = F.window_gather(x0, ind, 2, chain)                                           # [B*2,256,5,5]
+        if chain:
+            win, x0_next = win
         u0 = F.conv2d(win, up0.weight, None, 1, 0)                                         # [B*2,512,3,3] (valid conv)
         u0 = F.window_mask(u0, ind, H, W, 1)
         # a valid 3x3 convolution of a 3x3 map is one full contraction: a plain [B*2, 9*512] x [1024, 9*512]^T GEMM on the NHWC
         # rows (as a convolution the backward-data pass walks 9 taps of which 8 are masked per position)
         u1 = F.linear(u0.permute(0, 2, 3, 1).reshape(B * 2, -1), F.as_matrix(up1.weight))  # [B*2,1024]
-        return u1.reshape(B, 2, 1024)
+        return (u1.reshape(B, 2, 1024), x0_next) if chain else u1.reshape(B, 2, 1024)
 
     def forward(self, img, ind, choose, cloud, depth=None, K_new=None, valid=None):
         """The reference's encoder call (intaghand_encoder.py:706-811): trunk and dense branches in one go."""
@@ -293,10 +305,25 @@ class ResNetSimple(nn.Module):
         emb1 = r.bn1(r.conv1(img), relu=True)                                             # :712-715
         have_clouds = choose is not None and cloud is not None
         f_pn = None
+        # Feature maps with several scatter-type consumers (emb0 / emb1: both hands' row gathers, emb1 also the max pool; x0: the
+        # centre windows and both hands' gathers) are handed from consumer to consumer (`chain`): their backward passes then fill
+        # ONE gradient tensor per map -- no zero-filled 134 MB tensor per consumer, no add pass per pair (0.27 ms per step)
+        chain = have_clouds and emb1.requires_grad
+        pooled = F.maxpool3s2(emb1, skip=chain)
+        emb1c = emb1
+        if chain:
+            pooled, emb1c = pooled
         if have_clouds:                                                                    # measured: 374 vs 348 img/s
             pn = self.pointnet_plus                                                        # left first: BN update order (:805-806)
-            f_pn = F.fork(lambda: (pn.stage_a(cloud[:, 0], emb0, emb1, choose[:, 0]), pn.stage_a(cloud[:, 1], emb0, emb1, choose[:, 1])))
-        x4 = r.layer1(F.maxpool3s2(emb1))
+
+            def both_hands():
+                if not chain:
+                    return pn.stage_a(cloud[:, 0], emb0, emb1, choose[:, 0]), pn.stage_a(cloud[:, 1], emb0, emb1, choose[:, 1])
+                xl, yl, e0, e1 = pn.stage_a(cloud[:, 0], emb0, emb1c, choose[:, 0], True)
+                xr, yr, _, _ = pn.stage_a(cloud[:, 1], e0, e1, choose[:, 1], True)
+                return (xl, yl), (xr, yr)
+            f_pn = F.fork(both_hands)
+        x4 = r.layer1(pooled)
         x3 = r.layer2(x4)
         x2 = r.layer3(x3)
         x1 = r.layer4(x2)
@@ -313,7 +340,9 @@ class ResNetSimple(nn.Module):
         st['ret']['hm'] = hm_fc[2](hm_fc[0](x0, F.ACT_RELU))                               # 'hm' is first in opt.heads (:291)
         if ind is None:                                                                    # :750-758
             ind = nms_top1_centers(st['ret']['hm'])
-        f_center = F.fork(lambda: self.center_features(x0, ind))                           # [B,2,1024]  (:790-792)
+        chain0 = f_pn is not None and x0.requires_grad and not self.dense_center
+        f_center = F.fork(lambda: self.center_features(x0, ind, chain0))                   # [B,2,1024]  (:790-792)
+        x0c = f_center.out[1] if chain0 else x0                                            # (a view of x0: usable before the join)
         emb = [emb0, emb1, x0]
         if choose is None or cloud is None:
             # test/demo path (:779-784): clouds from the depth map and the PREDICTED hand masks -- on the GPU, any batch
@@ -327,12 +356,18 @@ class ResNetSimple(nn.Module):
             choose, cloud, _ = F.depth2pcl(depth, st['dp'][0], K_new, valid)
         if f_pn is not None:
             al, ar = f_pn.join()
-            fl = self.pointnet_plus.stage_b(*al, x0, choose[:, 0])
-            fr = self.pointnet_plus.stage_b(*ar, x0, choose[:, 1])
+            if chain0:
+                fl, x0c = self.pointnet_plus.stage_b(*al, x0c, choose[:, 0], True)
+                fr, _ = self.pointnet_plus.stage_b(*ar, x0c, choose[:, 1], True)
+            else:
+                fl = self.pointnet_plus.stage_b(*al, x0, choose[:, 0])
+                fr = self.pointnet_plus.stage_b(*ar, x0, choose[:, 1])
         else:
             fl = self.pointnet_plus(cloud[:, 0], emb, choose[:, 0])                        # :805
             fr = self.pointnet_plus(cloud[:, 1], emb, choose[:, 1])                        # :806 (same module: left BN update first)
         center = f_center.join()
+        if chain0:
+            center = center[0]
         fuse = self.sft(torch.cat((fl, fr), 1), center)                                    # [B,2,1024]  (:807-809)
         st['img_fmaps'] = [fuse, x2, x3, x4]
         st['ind'] = ind
