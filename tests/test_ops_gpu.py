@@ -926,3 +926,39 @@ def test_plain_c_client_of_the_c_abi(F, tmp_path):
     r = subprocess.run([build_c_client(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "c_client: ok" in r.stdout, r.stdout
+
+
+def test_gradient_chain_of_a_map_with_several_consumers(F):
+    """max pool (skip) -> row gather (chain) -> row gather (chain) -> window gather (chain) on ONE feature map: the backward
+    passes fill one gradient tensor; the result equals the sum autograd forms from independent consumers."""
+    B, C, H, W = 2, 64, 32, 32
+    x = rnd(B, C, H, W, seed=1)
+    ind1 = torch.randint(0, H * W, (B, 40), generator=torch.Generator().manual_seed(2))
+    ind2 = torch.randint(0, H * W, (B, 24), generator=torch.Generator().manual_seed(3))
+    ind3 = torch.tensor([[0, H * W - 1], [W + 1, 5 * W + 7]])                 # windows that leave the map / overlap
+    gp, g1, g2, g3 = rnd(B, C, 16, 16, seed=4), rnd(B, 40, C, seed=5), rnd(B, 24, C, seed=6), rnd(B * 2, C, 5, 5, seed=7)
+
+    def run(chained):
+        xd = dev(x).contiguous(memory_format=torch.channels_last).requires_grad_()
+        if chained:
+            p, a = F.maxpool3s2(xd, skip=True)
+            r1, a = F.gather_rows(a, dev(ind1), chain=True)
+            r2, a = F.gather_rows(a, dev(ind2), chain=True)
+            w, a = F.window_gather(a, dev(ind3), 2, True)                      # the last alias stays unused
+        else:
+            p, r1, r2, w = F.maxpool3s2(xd), F.gather_rows(xd, dev(ind1)), F.gather_rows(xd, dev(ind2)), F.window_gather(xd, dev(ind3), 2)
+        gw = dev(g3).contiguous(memory_format=torch.channels_last)
+        torch.autograd.backward([p, r1, r2, w], [dev(gp).contiguous(memory_format=torch.channels_last), dev(g1), dev(g2), gw])
+        return [t.detach().cpu() for t in (p, r1, r2, w)], xd.grad.detach().cpu()
+    (oc, gc), (ou, gu) = run(True), run(False)
+    for a, b in zip(oc, ou):
+        assert torch.equal(a, b)
+    close(gc, gu, 1e-5, rtol=1e-6, what="chained gradient of the shared map")
+    # a chain whose first outputs are unused still delivers the later consumers' gradients
+    xd = dev(x).contiguous(memory_format=torch.channels_last).requires_grad_()
+    r1, a = F.gather_rows(xd, dev(ind1), chain=True)
+    r2, a = F.gather_rows(a, dev(ind2), chain=True)
+    r2.backward(dev(g2))
+    xr = dev(x).contiguous(memory_format=torch.channels_last).requires_grad_()
+    F.gather_rows(xr, dev(ind2)).backward(dev(g2))
+    close(xd.grad, xr.grad, 1e-6, what="chain with an unused consumer")
