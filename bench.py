@@ -123,6 +123,53 @@ class GemmProfiler:
         return sorted(sh.items(), key=lambda kv: -kv[1][2])
 
 
+class KernelTimer:
+    """The library's own per-kernel timing (pdf_debug_kernel_timing, csrc/gemm.hip KTimer): every GEMM-family kernel launch is
+    bracketed by two HIP events on the stream it is launched on and recorded under its symbol name with the algorithmic FLOPs
+    and bytes (every operand once) of that launch -- one record per kernel launch, not per entry-point call."""
+
+    def __init__(self):
+        from pdfnet_amd import hip
+        self.lib = hip.lib()
+
+    def __enter__(self):
+        self.lib.pdf_debug_kernel_timing(1)
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.pdf_debug_kernel_timing(0)
+
+    def by_symbol(self):
+        """kernel symbol -> [launches, flops, bytes, seconds]"""
+        import ctypes
+        torch.cuda.synchronize()
+        out = {}
+        name = ctypes.create_string_buffer(128)
+        fl, by, ms = ctypes.c_double(), ctypes.c_double(), ctypes.c_float()
+        for i in range(self.lib.pdf_debug_kernel_record_count()):
+            self.lib.pdf_debug_kernel_record(i, name, 128, ctypes.byref(fl), ctypes.byref(by), ctypes.byref(ms))
+            d = out.setdefault(name.value.decode(), [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += fl.value
+            d[2] += by.value
+            d[3] += ms.value * 1e-3
+        return out
+
+
+def symbol_roofline(sym, peak, traffic_by_symbol=None, traffic_src=None):
+    """-> (`roofline` fields of the symbol with the most time, per-symbol table)."""
+    table = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[3] * 1e3, 3), "tflops": round(v[1] / max(v[3], 1e-9) / 1e12, 1),
+                 "algorithmic_MB_per_launch": round(v[2] / max(v[0], 1) / 1e6, 1)} for k, v in sorted(sym.items(), key=lambda kv: -kv[1][3])}
+    mfma = {k: v for k, v in sym.items() if v[1] > 0}
+    name, dom = max(mfma.items(), key=lambda kv: kv[1][3]) if mfma else ("none", [0, 0.0, 0.0, 1e-9])
+    tr = (traffic_by_symbol or {}).get(name)
+    head = {"kernel": name, "achieved": round(dom[1] / dom[3] / 1e12, 2), "frac": round(dom[1] / dom[3] / 1e12 / peak, 4),
+            "launches_per_step": dom[0], "ms_per_step": round(dom[3] * 1e3, 3),
+            "algorithmic_gflop_per_launch": round(dom[1] / max(dom[0], 1) / 1e9, 2), "avg_launch_ms": round(dom[3] / max(dom[0], 1) * 1e3, 4),
+            "algorithmic_bytes_per_launch": round(dom[2] / max(dom[0], 1)), "traffic": tr, "traffic_source": traffic_src}
+    return head, table
+
+
 def _isnull(v):
     return v is None or getattr(v, 'value', 1) in (None, 0)
 
@@ -241,7 +288,7 @@ def _flush_c_stdout():
 
 
 def pmc_traffic():
-    """-> (HBM bytes per launch of igemm_nt<128,128>, of the whole GEMM family, source tag).  PMC counters cannot be read
+    """-> ({kernel symbol: HBM bytes per launch}, bytes per launch of the whole GEMM family, source tag).  PMC counters cannot be read
     from inside this process: the figures come from the last committed profile (tools/profile_step.sh -> profiles/*_pmc_traffic.json,
     separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950).  The profile records the sha256 of csrc/gemm.hip it
     was taken with; if the kernel source has changed since, the numbers are withheld (null) instead of going stale."""
@@ -256,7 +303,8 @@ def pmc_traffic():
         cur = hashlib.sha256(open(os.path.join(ROOT, "pdfnet_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
         if d.get("gemm_hip_sha256") != cur:
             return None, None, "%s is older than csrc/gemm.hip (withheld)" % os.path.basename(p)
-        return (round(d["kernels"]["igemm_nt<128,128>"]["bytes_per_launch"]), round(d["gemm_family"]["bytes_per_launch"]),
+        per_symbol = {k: round(v["bytes_per_launch"]) for k, v in d.get("symbols", {}).items()}
+        return (per_symbol, round(d["gemm_family"]["bytes_per_launch"]),
                 "%s (rocprofv3 --pmc, %s)" % (os.path.basename(p), d.get("tag", "")))
     except Exception as e:                                     # noqa: BLE001
         return None, None, "unreadable profile: %s" % e
@@ -404,6 +452,54 @@ def rgb_encoder_bench(args, dev, rank, world):
     print(json.dumps(out), flush=True)
 
 
+def bf16_leg(opt, R, B, dev, consts, steps, warmup):
+    """BASELINE configs[3] / configs[4] as their per-GPU step (B = 32 / 64 per rank): bf16-input MFMA GEMMs
+    with fp32 accumulation, bf16 shadows, fp32 master weights / statistics / loss, the trainer configured for bf16 gradient
+    transport.  A fresh model and trainer, timed like the headline (warm-up, K steps between synchronisations), then one
+    instrumented step for the dominant kernel symbol."""
+    from pdfnet_amd import functional as F
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_train_batch, to_device
+    from pdfnet_amd.trains.base_trainer import Trainer
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    F.set_gemm_precision('bf16')
+    try:
+        torch.manual_seed(0)
+        F.manual_seed(4321)
+        model = load_model_intag(opt).to(dev)
+        tr = Trainer(opt, model, CtdetLoss(opt, consts).to(dev), lr=1e-4, grad_comm_dtype=torch.bfloat16)
+        batch = to_device(synthetic_train_batch(B, R, seed=1, consts=consts), dev)
+        for _ in range(warmup):
+            tr.train_step(batch)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(steps):
+            last = tr.train_step(batch)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        loss_val = float(last)
+        assert loss_val == loss_val, "bf16 leg: loss is NaN"
+        tr.collectives = False
+        F.USE_SIDE_STREAMS = False
+        with KernelTimer() as kt:
+            tr.train_step(batch)
+        sym = kt.by_symbol()
+        F.USE_SIDE_STREAMS = True
+        head, _ = symbol_roofline(sym, PEAK_BF16_MFMA_TFLOPS)
+        fl, sec = sum(v[1] for v in sym.values()), sum(v[3] for v in sym.values())
+        out = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "batch": B, "steps": steps, "warmup": warmup,
+               "final_loss": round(loss_val, 4),
+               "dominant_kernel": {k: head[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "ms_per_step")},
+               "all_gemm_kernels_tflops": round(fl / max(sec, 1e-9) / 1e12, 1), "gemm_ms_per_step_exclusive": round(sec * 1e3, 2),
+               "step_level_frac_of_bf16_mfma_peak": round(fl / B * (B * steps / dt) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+        del tr, model, batch
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        F.USE_SIDE_STREAMS = True
+        F.set_gemm_precision('fp32')
+
+
 def check_grads(trainer, batch, world, dev):
     """--check-grads (N > 1): the gradient the trainer's overlapped all-reduce leaves in the flat buffer must equal the
     sum over ranks of the rank-local gradients, gathered with a plain all_gather.  Two extra steps after the timed region
@@ -447,7 +543,9 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-mpjpe', action='store_true')
     ap.add_argument('--broadcast-buffers', action='store_true', help="DDP's per-iteration BN-buffer broadcast (base_trainer.py:94-95)")
-    ap.add_argument('--check-grads', action='store_true', help='N>1: verify the reduced gradient against an all_gather of the rank-local ones')
+    ap.add_argument('--check-grads', action='store_true', help='(default for --gpus > 1) verify the reduced gradient against an all_gather of the rank-local ones')
+    ap.add_argument('--no-check-grads', action='store_true')
+    ap.add_argument('--no-bf16-legs', action='store_true', help='skip the bf16 B=32 / B=64 per-GPU legs (bf16_per_gpu) of the default fp32 run')
     ap.add_argument('--gemm-shapes', default=None, help='write the per-shape table of the instrumented step to this file')
     args = ap.parse_args()
     if args.batch is None:
@@ -524,15 +622,16 @@ def main():
     mp_batch = None
     if not args.no_mpjpe:
         out["mpjpe"], mp_batch = mpjpe_report(trainer, consts, R, min(B, 8), dev)      # every rank takes part (all-reduced sums)
-    if world > 1 and args.check_grads:
+    if world > 1 and not args.no_check_grads:
         out["check_grads"] = check_grads(trainer, batch, world, dev)
     if rank == 0 and not args.no_roofline:
         # instrumented eager step: events around every implicit-GEMM entry point on the launch stream
         trainer.use_graph = False
         trainer.collectives = False        # rank-local step: the other ranks are already past their last collective
         F.USE_SIDE_STREAMS = False         # exclusive per-launch durations (no overlapped branches)
-        with GemmProfiler() as prof, HbmProfiler() as hprof:
+        with GemmProfiler() as prof, HbmProfiler() as hprof, KernelTimer() as ktimer:
             trainer.train_step(batch)
+        sym = ktimer.by_symbol()
         per = prof.summary()
         hper = hprof.summary()
         if args.gemm_shapes:
@@ -542,26 +641,18 @@ def main():
         calls = sum(v[0] for v in per.values())
         flops = sum(v[1] for v in per.values())
         secs = sum(v[2] for v in per.values())
-        tiles = prof.by_tile()
-        tname = {128128: "igemm_nt<128,128>", 128064: "igemm_nt<128,64>", 64064: "igemm_nt<64,64>", 32032: "igemm_nt<32,32>", 0: "small_k_gemm", -1: "wgemm_*", 16: "igemm_bf16_kernel"}
-        dom = tiles.get(16 if bf16 else 128128, [0, 0.0, 1e-9])          # the kernel with the most time per step
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         traffic, traffic_all, traffic_src = pmc_traffic() if not bf16 else (None, None, 'no PMC profile of the bf16 kernels')
+        # the rocprofv3 symbol with the most time per step, timed per kernel launch by the library itself (events on the launch
+        # stream): name, launches and ms are one row of profiles/*_kernel_stats_exclusive.csv
+        head, table = symbol_roofline(sym, peak, traffic, traffic_src)
         out["roofline"] = {
-            "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
-            "kernel": ("igemm_bf16_kernel (csrc/gemm_bf16.hip: bf16 MFMA implicit GEMM, all forward / backward-data passes)" if bf16 else
-                       "igemm_nt<128,128,2,2> (csrc/gemm.hip: fp32 MFMA implicit GEMM, forward / backward-data / transposed-conv passes "
-                       "of the large layers; the kernel with the most time per step)"),
-            "achieved": round(dom[1] / dom[2] / 1e12, 2), "frac": round(dom[1] / dom[2] / 1e12 / peak, 4),
-            "launches_per_step": dom[0], "ms_per_step": round(dom[2] * 1e3, 2),
-            "algorithmic_gflop_per_launch": round(dom[1] / max(dom[0], 1) / 1e9, 1), "avg_launch_ms": round(dom[2] / max(dom[0], 1) * 1e3, 4),
-            "traffic": traffic, "traffic_source": traffic_src,
+            "bound": "mfma", "peak": peak, "unit": "TFLOP/s", **head,
+            "per_symbol": table,
             "all_gemm_kernels": {
                 "achieved": round(flops / secs / 1e12, 2), "frac": round(flops / secs / 1e12 / peak, 4),
                 "launches_per_step": calls, "algorithmic_gflop_per_step": round(flops / 1e9, 1), "gemm_ms_per_step": round(secs * 1e3, 2),
                 "traffic": traffic_all,
-                "per_tile": {tname.get(k, str(k)): {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
-                                                    "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(tiles.items())},
                 "per_entry_point": {k: {"calls": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
                                         "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(per.items())}},
             "formulation": "executed contraction = exact sparse centre features (SURVEY 8a6): ~214 GFLOP/img/step; "
@@ -590,6 +681,11 @@ def main():
             "fps": fps_hbm(dev),
         }
         F.USE_SIDE_STREAMS = True
+    if rank == 0 and world == 1 and not bf16 and not args.no_bf16_legs and args.batch == 32:
+        # BASELINE configs[3] / [4] per GPU, driver-timed in the same run: short legs after the fp32 headline
+        out["bf16_per_gpu"] = {"note": "per-rank step of configs[3] (B=32/GPU) and configs[4] (B=64/GPU): bf16 MFMA GEMMs + bf16 shadows, fp32 "
+                                       "accumulate / master weights / statistics / loss; eager, one GPU, no collective",
+                               "B32": bf16_leg(opt, R, 32, dev, consts, 12, 4), "B64": bf16_leg(opt, R, 64, dev, consts, 8, 3)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = max(1, (os.cpu_count() or 2) // 2)
         out["cpu_baseline"] = cpu_baseline(R, threads)

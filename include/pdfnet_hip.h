@@ -43,6 +43,16 @@ long pdf_wgrad_workspace_floats(int M, int NI, int NJ);
  * statistics and weight-gradient slabs).  Called once per process after the device is selected, outside any stream capture;
  * the entry points call it lazily otherwise. */
 int pdf_init(void);
+/* The device the rings were created on (-1 before pdf_init).  One process drives one GPU: pdf_init from another current
+ * device returns PDF_E_WORKSPACE. */
+int pdf_debug_init_device(void);
+/* Per-kernel timing for bench.py's roofline object: while on, every GEMM-family kernel launch is bracketed by two events on
+ * its launch stream and recorded under its symbol name (as rocprofv3 prints it, without the `void` / argument list) together
+ * with the algorithmic FLOPs and bytes (every operand once) of that launch.  on != 0 clears the records and starts, 0 stops.
+ * pdf_debug_kernel_record reads record i once the device is idle. */
+int pdf_debug_kernel_timing(int on);
+int pdf_debug_kernel_record_count(void);
+int pdf_debug_kernel_record(int i, char* name, int cap, double* flops, double* bytes, float* ms);
 /* Stream fork / join for the host layer: everything issued on `signaler` so far completes before anything issued on
  * `waiter` afterwards (hipEventRecord + hipStreamWaitEvent on a ring of timing-disabled events created by pdf_init; valid
  * inside a stream capture).  The reference has no counterpart -- it runs on one stream. */

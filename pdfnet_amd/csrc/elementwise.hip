@@ -598,7 +598,16 @@ PDF_API int pdf_stream_wait(hipStream_t waiter, hipStream_t signaler) {
     return 0;
 }
 
+// The rings (ticket counters, split-K scratch, events) are process-wide and live on the device that was current at the first
+// call: one process drives one GPU (one rank per GPU).  A later call from another current device is refused instead of handing
+// kernels on GPU n the memory and events of GPU m.
+static std::atomic<int> g_init_device{-1};
+PDF_API int pdf_debug_init_device(void) { return g_init_device.load(); }
 PDF_API int pdf_init(void) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return PDF_E_WORKSPACE;
+    int expected = -1;
+    if (!g_init_device.compare_exchange_strong(expected, dev) && expected != dev) return PDF_E_WORKSPACE;
     if (int rc = pdf_event_ring()) return rc;
     return (pdf_ticket_counters(1) != nullptr && pdf_scratch(64) != nullptr) ? 0 : PDF_E_WORKSPACE;
 }

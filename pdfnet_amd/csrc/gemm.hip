@@ -774,6 +774,59 @@ static int env_int(int which, int dflt) {
     return vals[which] == INT_MIN ? dflt : vals[which];
 }
 
+// ---- per-kernel timing (KTimer, gemm_common.h)
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+struct KRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
+static std::vector<KRec> g_krecs;
+static std::mutex g_krec_mu;
+static int g_ktiming = 0;
+KTimer::KTimer(const char* name, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_ktiming) return;
+    KRec r; r.name = name; r.flops = flops; r.bytes = bytes;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, s);
+    std::lock_guard<std::mutex> lk(g_krec_mu);
+    slot = (int)g_krecs.size();
+    g_krecs.push_back(r);
+}
+KTimer::~KTimer() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_krec_mu);
+    (void)hipEventRecord(g_krecs[slot].e1, stream);
+}
+// on != 0: drop the old records and start recording; 0: stop (the records stay readable)
+PDF_API int pdf_debug_kernel_timing(int on) {
+    std::lock_guard<std::mutex> lk(g_krec_mu);
+    if (on) {
+        for (auto& r : g_krecs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        g_krecs.clear();
+    }
+    g_ktiming = on ? 1 : 0;
+    return 0;
+}
+PDF_API int pdf_debug_kernel_record_count(void) { std::lock_guard<std::mutex> lk(g_krec_mu); return (int)g_krecs.size(); }
+// record i -> kernel symbol, algorithmic FLOPs and bytes (operands once) of that launch, its duration (the device must be idle)
+PDF_API int pdf_debug_kernel_record(int i, char* name, int cap, double* flops, double* bytes, float* ms) {
+    std::lock_guard<std::mutex> lk(g_krec_mu);
+    if (i < 0 || i >= (int)g_krecs.size() || cap < 2) return PDF_E_BADARG;
+    const KRec& r = g_krecs[i];
+    snprintf(name, cap, "%s", r.name.c_str());
+    *flops = r.flops; *bytes = r.bytes;
+    if (hipError_t e = hipEventElapsedTime(ms, r.e0, r.e1)) return (int)e;
+    return 0;
+}
+static double igemm_bytes(const IGemm& g, int groups) {
+    const double a = g.plain_in ? (double)g.M * g.Cin : (double)(g.M / max(1, g.QH * g.QW)) * g.H * g.W * g.Cin;
+    return 4.0 * groups * (a + (double)g.N * g.K + (double)g.M * g.N * (g.accum ? 2 : 1));
+}
+static double wgemm_bytes(const WGemm& g, int groups) {
+    const double q = g.plain_q ? (double)g.M * g.Cq : (double)(g.M / max(1, g.QH * g.QW)) * g.H * g.W * g.Cq;
+    return 4.0 * groups * ((double)g.M * g.NI + q + (double)g.NI * g.T * g.Cq);
+}
+
 // C[m][n] = act(sum_k A[m][k] B[n][k] + bias[n]) for K <= 48, plain rows in / out: HBM-bound streaming (the backward-data
 // of the 2- / 42-channel output convs: dy has 2 or 42 channels, dx 128-256).  B^T lives in LDS; one thread per (m, 4 n).
 #define SMALLK_MAX 48
@@ -834,6 +887,9 @@ __global__ __launch_bounds__(256) void splitk_finish(const float* __restrict__ p
 template <int BM, int BN, int WM, int WN, int BKF = 16>
 static void launch_igemm_tile(const IGemm& g, bool fast, dim3 grid, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
+    char nm[96] = "";
+    if (g_ktiming) snprintf(nm, sizeof nm, "igemm_nt<%d, %d, %d, %d, %s, %s, %d>", BM, BN, WM, WN, fast ? "true" : "false", g.b_kn ? "true" : "false", fast ? BKF : 16);
+    KTimer kt(nm, 2.0 * g.M * g.N * g.K * grid.y, igemm_bytes(g, grid.y), s);
     if (fast && g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, true, BKF>), grid, dim3(NT), 0, s, g);
     else if (fast) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, false, BKF>), grid, dim3(NT), 0, s, g);
     else if (g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, true>), grid, dim3(NT), 0, s, g);
@@ -864,6 +920,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     if (!fast && groups == 1 && !g.accum && (!g.b_kn || (g.T == 1 && g.wt[0] == 0)) && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
         (long)g.M * g.N >= (1L << 20)) {
         dim3 grid(grid_for((long)g.M * ((min(g.N, 256) + 3) / 4)), cdiv(g.N, 256));
+        KTimer kt("small_k_gemm", 2.0 * g.M * g.N * g.K, igemm_bytes(g, 1), s);
         hipLaunchKernelGGL(small_k_gemm, grid, dim3(256), 0, s, g);
         g_last_tile = 0;
         PDF_LAUNCH_CHECK();
@@ -899,6 +956,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
                 const dim3 grid((unsigned)t64, 1, (unsigned)splits);
                 if (bk32) launch_igemm_tile<64, 64, 2, 2, 32>(gs, fast, grid, s);
                 else launch_igemm_tile<64, 64, 2, 2>(gs, fast, grid, s);
+                KTimer kt("splitk_finish", 0.0, 4.0 * (splits + 1) * g.M * g.N, s);
                 hipLaunchKernelGGL(splitk_finish, dim3(grid_for((long)g.M * g.N)), dim3(256), 0, s, part, splits, g.M, g.N, g.bias, g.act, g.C, g.ldc);
                 g_last_tile = 64064;
                 PDF_LAUNCH_CHECK();
@@ -923,6 +981,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     for (int t = 0; halo && t < 9; ++t) halo = g.dy[t] >= -1 && g.dy[t] <= 1 && g.dx[t] >= -1 && g.dx[t] <= 1;
     if (halo) {
         const dim3 grid((g.M / 128) * cdiv(g.N, 128));
+        KTimer kt(g.b_kn ? "igemm_halo3x3<true>" : "igemm_halo3x3<false>", 2.0 * g.M * g.N * g.K, igemm_bytes(g, 1), s);
         if (g.b_kn) hipLaunchKernelGGL(igemm_halo3x3<true>, grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL(igemm_halo3x3<false>, grid, dim3(256), 0, s, g);
         g_last_tile = 128128;
@@ -1220,7 +1279,9 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
     const Shadows sh = take_shadows();
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && (long)N * OH * OW >= (1L << 16)) {
+        KTimer kt("tiny_conv_fwd_kernel<3, 3, 3, 3>", 2.0 * N * OH * OW * 81, 4.0 * N * (H * W + OH * OW) * 3, s);
         hipLaunchKernelGGL((tiny_conv_fwd_kernel<3, 3, 3, 3>), dim3(grid_for((long)N * OH * OW)), dim3(256), 0, s, x, w, bias, y, N, H, W, ldx, pad, OH, OW, ldy, act);
+        g_last_tile = 0;
         PDF_LAUNCH_CHECK();
         return 0;
     }
@@ -1230,6 +1291,7 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
         int nblk = (int)min((long)512, total);
         const int cpb = (int)cdiv(total, nblk);
         nblk = (int)cdiv(total, cpb);
+        KTimer kt("stem7x7_fwd_kernel", 2.0 * N * OH * OW * 64 * 147, 4.0 * N * ((double)H * W * 3 + (double)OH * OW * 64), s);
         hipLaunchKernelGGL(stem7x7_fwd_kernel, dim3(nblk), dim3(256), 0, s, x, w, y, N, H, W, OH, OW, ldy, act, cpb);
         g_last_tile = 0;
         PDF_LAUNCH_CHECK();
@@ -1372,6 +1434,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     g.atomic = (splits >= env_int(ENV_WG_ATOMIC, 1 << 30) && splits > 1 && accumulate && g.counters == nullptr) ? 1 : 0;
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     int brc = 0;
+    const double wflops = 2.0 * groups * g.M * g.NI * NJ, wbytes = wgemm_bytes(g, groups);
     if (bf16) {
         g_shadow_operands += (g.P16 != nullptr) + (g.Q16 != nullptr);
         brc = launch_wgemm_bf16(g, splits, groups, small ? 1 : 0, s);
@@ -1379,12 +1442,16 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     }
     if (brc == 1) {
     } else if (small) {
-        if (fast && env_int(ENV_WG_BK32, 1)) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
+        const bool bk32 = fast && env_int(ENV_WG_BK32, 1);
+        KTimer kt(bk32 ? "wgemm_tn<64, 64, 2, 2, true, 32>" : fast ? "wgemm_tn<64, 64, 2, 2, true, 16>" : "wgemm_tn<64, 64, 2, 2, false, 16>", wflops, wbytes, s);
+        if (bk32) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);
     } else {
         const int dma = env_int(ENV_WG_DMA, 3);
         const int pad = env_int(ENV_WG_LDSPAD, 0) * 1024;
+        KTimer kt(fast && dma == 4 ? "wgemm_tn_dma<4>" : fast && dma == 3 ? "wgemm_tn_dma<3>" : fast ? "wgemm_tn<128, 128, 2, 2, true, 16>" : "wgemm_tn<128, 128, 2, 2, false, 16>",
+                  wflops, wbytes, s);
         if (fast && dma == 4) hipLaunchKernelGGL(wgemm_tn_dma<4>, grid, dim3(256), pad, s, g);
         else if (fast && dma == 3) hipLaunchKernelGGL(wgemm_tn_dma<3>, grid, dim3(256), pad, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, true>), grid, dim3(256), 0, s, g);
@@ -1393,7 +1460,9 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     PDF_LAUNCH_CHECK();
     if (splits > 1 && g.counters == nullptr && !g.atomic) {
         Reduce r = {ws, out, out1, per, bws, db, db1, (int)perb, splits, accumulate};
-        if (splits >= 16 && per <= (1L << 20)) {
+        const bool two_d = splits >= 16 && per <= (1L << 20);
+        KTimer kt(two_d ? "reduce_slabs_2d" : "reduce_slabs", 0.0, 4.0 * groups * (splits + 1 + (accumulate ? 1 : 0)) * (per + perb), s);
+        if (two_d) {
             const int mb = (int)((per + 63) / 64);
             hipLaunchKernelGGL(reduce_slabs_2d, dim3(mb + (int)((perb + 63) / 64), groups), dim3(256), 0, s, r, mb);
         } else {
@@ -1548,6 +1617,7 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && db == nullptr && (long)N * OH * OW >= (1L << 16) && ws_floats >= 81L * 64) {
         const int nblk = (int)min((long)1024, ws_floats / 81);
+        KTimer kt("tiny_conv_wgrad_kernel<3, 3, 3, 3> + reduce_slabs_2d", 2.0 * N * OH * OW * 81, 4.0 * N * (H * W + OH * OW) * 3, s);
         hipLaunchKernelGGL((tiny_conv_wgrad_kernel<3, 3, 3, 3>), dim3(nblk), dim3(256), 0, s, x, dy, ws, N, H, W, ldx, pad, OH, OW, lddy);
         Reduce r = {ws, dw, nullptr, 81, nullptr, nullptr, nullptr, 0, nblk, accumulate};
         hipLaunchKernelGGL(reduce_slabs_2d, dim3(2, 1), dim3(256), 0, s, r, 2);
@@ -1560,6 +1630,7 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
         int nblk = (int)min(min((long)512, ws_floats / (64 * 147)), total);
         const int cpb = (int)cdiv(total, nblk);
         nblk = (int)cdiv(total, cpb);
+        KTimer kt("stem7x7_wgrad_kernel + reduce_slabs_2d", 2.0 * N * OH * OW * 64 * 147, 4.0 * N * ((double)H * W * 3 + (double)OH * OW * 64), s);
         hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, ws, N, H, W, OH, OW, lddy, cpb);
         Reduce r = {ws, dw, nullptr, 64L * 147, nullptr, nullptr, nullptr, 0, nblk, accumulate};
         const int mb = (64 * 147 + 63) / 64;
@@ -1575,6 +1646,7 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
             const int rpb = cdiv(M, nblk);
             nblk = cdiv(M, rpb);
             float* bws = ws + (long)nblk * per;
+            KTimer kt("narrow_wgrad_kernel + reduce_slabs_2d", 2.0 * M * Cout * Cin, 4.0 * M * (Cout + Cin), s);
             hipLaunchKernelGGL(narrow_wgrad_kernel, dim3(nblk), dim3(256), 0, s, dy, x, ws, db ? bws : nullptr, M, Cout, Cin, lddy, ldx, rpb);
             Reduce r = {ws, dw, nullptr, per, bws, db, nullptr, (int)perb, nblk, accumulate};
             const int mb = (int)((per + 63) / 64);

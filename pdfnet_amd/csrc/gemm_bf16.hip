@@ -14,6 +14,7 @@
 //       (A first version transposed in registers and wrote tile[row][k] with ds_write_b64: 16-way bank conflicts -- the
 //       weight-gradient kernel ran at 54-80 TFLOP/s, below the fp32 kernel.)
 #include "gemm_common.h"
+#include <cstdio>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -288,6 +289,10 @@ static void launch_tile_bf16_s(const IGemm& g, dim3 grid, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 static void launch_tile_bf16(const IGemm& g, dim3 grid, hipStream_t s) {
     const bool sa = g.A16 != nullptr, sb = g.B16 != nullptr;
+    char nm[96];
+    snprintf(nm, sizeof nm, "igemm_bf16_kernel<%d, %d, %d, %d, %s, %s, %s>", BM, BN, WM, WN, g.b_kn ? "true" : "false", sa ? "true" : "false", sb ? "true" : "false");
+    const double a = g.plain_in ? (double)g.M * g.Cin : (double)(g.M / max(1, g.QH * g.QW)) * g.H * g.W * g.Cin;
+    KTimer kt(nm, 2.0 * g.M * g.N * g.K * grid.y, grid.y * ((sa ? 2.0 : 4.0) * a + (sb ? 2.0 : 4.0) * g.N * g.K + 4.0 * g.M * g.N * (g.accum ? 2 : 1)), s);
     if (sa && sb) launch_tile_bf16_s<BM, BN, WM, WN, true, true>(g, grid, s);
     else if (sa) launch_tile_bf16_s<BM, BN, WM, WN, true, false>(g, grid, s);
     else if (sb) launch_tile_bf16_s<BM, BN, WM, WN, false, true>(g, grid, s);
@@ -473,6 +478,10 @@ int launch_wgemm_bf16(const WGemm& g, int splits, int groups, int small, hipStre
     const int NJ = g.T * g.Cq;
     if (g.NI % 4 != 0 || g.Cq % 4 != 0 || g.ldp % 4 != 0 || g.ldq % 4 != 0 || g.rows_per_split % BK16 != 0) return 0;
     const bool sp = g.P16 != nullptr, sq = g.Q16 != nullptr;
+    char nm[96];
+    snprintf(nm, sizeof nm, "wgemm_bf16_kernel<%d, %d, %s, %s>", small ? 64 : 128, small ? 64 : 128, sp ? "true" : "false", sq ? "true" : "false");
+    const double qel = g.plain_q ? (double)g.M * g.Cq : (double)(g.M / max(1, g.QH * g.QW)) * g.H * g.W * g.Cq;
+    KTimer kt(nm, 2.0 * groups * g.M * g.NI * NJ, groups * ((sp ? 2.0 : 4.0) * g.M * g.NI + (sq ? 2.0 : 4.0) * qel + 4.0 * g.NI * NJ), s);
     if (small) {
         dim3 grid((unsigned)(cdiv(g.NI, 64) * cdiv(NJ, 64)), (unsigned)splits, (unsigned)groups);
         if (sp && sq) hipLaunchKernelGGL((wgemm_bf16_kernel<64, 64, true, true>), grid, dim3(256), 0, s, g);

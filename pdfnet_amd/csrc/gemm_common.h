@@ -150,6 +150,15 @@ __device__ __forceinline__ void wgemm_finish(const WGemm& g, const f32x16 (&acc)
     }
 }
 
+// Per-kernel timing for bench.py's roofline (pdf_debug_kernel_timing, gemm.hip): while enabled, every GEMM-family kernel launch
+// is bracketed by two events on ITS launch stream and recorded under its symbol name with the algorithmic FLOPs / bytes of
+// that launch.  Disabled (the default) it costs one branch per launch.
+struct KTimer {
+    KTimer(const char* name, double flops, double bytes, hipStream_t s);
+    ~KTimer();
+    int slot; hipStream_t stream;
+};
+
 // bf16-input MFMA path (gemm_bf16.hip): same descriptors, operands rounded to bf16 while they are staged into LDS,
 // fp32 accumulation.  Return 1 if the launch was issued, 0 if the shape is not supported there (the caller then uses the
 // fp32 kernel), negative / hipError on failure.

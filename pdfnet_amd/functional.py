@@ -130,7 +130,7 @@ def attach_shadow(t, s16):
 
 def shadow_of(t):
     """The bf16 copy of `t` if it has a valid one with the same layout, else None."""
-    if t is None:
+    if t is None or not (BF16_SHADOWS and _GEMM_BF16):
         return None
     s16 = getattr(t, '_pdf_bf16', None)
     if s16 is None or t._version != getattr(t, '_pdf_bf16_ver', -1) or s16.shape != t.shape or s16.stride() != t.stride():
@@ -523,12 +523,19 @@ def as_matrix(weight):
     view (no copy) for `linear`, carrying the same view of the trainer's flat gradient so that the weight gradient is still
     accumulated in place."""
     w2 = weight.permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+    if w2.data_ptr() != weight.data_ptr():
+        return w2                          # not channels_last storage: `reshape` copied; autograd carries dw back through it
     w16 = shadow_of(weight)
     if w16 is not None:
-        attach_shadow(w2, w16.permute(0, 2, 3, 1).reshape(weight.shape[0], -1))
+        s2 = w16.permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+        if s2.data_ptr() == w16.data_ptr():
+            attach_shadow(w2, s2)
     if getattr(weight, '_pdf_main_grad', False) and weight.grad is not None:
-        w2._pdf_main_grad = True
-        w2._pdf_grad_alias = weight.grad.permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+        # only when the re-shaped gradient is a VIEW of the flat gradient buffer: a copy would swallow the accumulation
+        g2 = weight.grad.permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+        if g2.data_ptr() == weight.grad.data_ptr():
+            w2._pdf_main_grad = True
+            w2._pdf_grad_alias = g2
     return w2
 
 

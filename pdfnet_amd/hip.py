@@ -74,8 +74,25 @@ def lib():
     if _lib is None:
         _lib = _Lib()
         if torch.cuda.is_available():
+            # The library's rings live on the device that is current NOW (one process = one GPU).  Under a multi-GPU
+            # launcher the rank must have selected its GPU first: binding the library before
+            # torch.cuda.set_device(LOCAL_RANK) would put every rank's rings on GPU 0.
+            lr = os.environ.get("LOCAL_RANK")
+            if lr is not None and torch.cuda.device_count() > 1 and int(lr) != torch.cuda.current_device():
+                _lib = None
+                raise RuntimeError("pdfnet_amd: LOCAL_RANK=%s but the current device is cuda:%d -- call torch.cuda.set_device(LOCAL_RANK) "
+                                   "(trains.base_trainer.init_distributed) before the first pdfnet_amd call" % (lr, torch.cuda.current_device()))
             _lib.pdf_init()                # device-side ticket counters: allocate now, never inside a stream capture
     return _lib
+
+
+def check_device(dev):
+    """Raise if tensors on `dev` would be handed to a library whose rings live on another GPU."""
+    L = lib()
+    have = L.pdf_debug_init_device()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if have >= 0 and have != idx:
+        raise RuntimeError("pdfnet_amd: libpdfnet_hip was initialised on cuda:%d, the model lives on cuda:%d (one process per GPU)" % (have, idx))
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

@@ -24,6 +24,9 @@ class HandNET_GCN(nn.Module):
         self._deferred = []
 
     def forward(self, img, choose, cloud, depth, ind, K_new, valid):
+        # a previous train-mode call that nobody joined (a direct `model(...)` outside ModleWithLoss): its mid_model pass still
+        # owns a fork stream and writes BatchNorm running statistics this call is about to read / update
+        self.join_deferred()
         st = self.encoder.trunk(img, ind, choose, cloud, depth, K_new, valid)
         img_fmaps, ind = st['img_fmaps'], st['ind']
         # The dense branches are issued BEFORE the launch-bound mesh decoder.  Issuing them after it (so that their heavy
@@ -60,6 +63,15 @@ class HandNET_GCN(nn.Module):
         for f in self._deferred:
             f.join()
         self._deferred.clear()
+
+    # readers of the module's state first wait for the deferred mid_model pass (it writes BatchNorm running statistics)
+    def state_dict(self, *args, **kwargs):
+        self.join_deferred()
+        return super().state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        self.join_deferred()
+        return super().train(mode)
 
 
 def load_model_intag(opt):

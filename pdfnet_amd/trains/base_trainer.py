@@ -80,6 +80,7 @@ class FlatAdam:
         assert len(order) == len(self.params) and all(id(p) in pos for p in order), "FlatAdam: ckpt_order must be a permutation of params"
         self.ckpt_index = [pos[id(p)] for p in order]                        # checkpoint index -> position in the flat order
         self.step_t = torch.zeros(1, device=dev)                             # device-side step count (graph-safe)
+        self._p16_synced = False
         self.corr = torch.ones(2, device=dev)
         self._b = torch.tensor(betas, device=dev)
 
@@ -113,6 +114,12 @@ class FlatAdam:
         for p, v, o in zip(self.params, self._p16_views, self.offsets):
             if p.data_ptr() == base + 4 * o:                  # still the view into the flat buffer
                 F.attach_shadow(p, v)
+        self._p16_synced = True
+
+    def params_changed(self):
+        """Something other than `step()` wrote the parameters (checkpoint load, replica broadcast, user code): the next train
+        step re-casts and re-attaches the bf16 shadows."""
+        self._p16_synced = False
 
     def reattach_grads(self):
         """The HIP backward kernels accumulate into `p.grad` only while it is the view into the flat gradient buffer.
@@ -133,6 +140,11 @@ class FlatAdam:
         hip.lib().pdf_adam_step(hip.ptr(self.flat_p), hip.ptr(self.flat_g), hip.ptr(self.flat_m), hip.ptr(self.flat_v),
                                 self.n_live, float(self.lr), self.betas[0], self.betas[1], self.eps, hip.ptr(self.corr),
                                 float(grad_scale), hip.stream())
+        if getattr(self, 'flat_p16', None) is not None and F.shadows_on():
+            # The update went through raw pointers (no version bump on the parameters), so the attached shadows -- views into
+            # flat_p16 -- would go on serving the PREVIOUS weights to whatever runs next (evaluation, a plain model call):
+            # re-cast in place right here; the views stay attached and are current again.
+            hip.lib().pdf_cast_bf16(hip.ptr(self.flat_p), hip.ptr(self.flat_p16), self.n_live, hip.stream())
 
     def _view(self, flat, i):
         p, o = self.params[i], self.offsets[i]
@@ -284,6 +296,7 @@ class Trainer:
         self.n_early = self.optimizer.offsets[len(early)] if late else self.optimizer.n_live
         self.n_live = self.optimizer.n_live
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
         self.reducer = GradReducer(self.optimizer.flat_g, self.n_early, self.n_live, grad_comm_dtype)
         self.force_collectives = False                         # tests: run the all-reduces on a one-rank group as well
         self.collectives = True                                # False: a rank-local step (bench.py's instrumented step on rank 0)
@@ -295,12 +308,16 @@ class Trainer:
             model.encoder.on_trunk_output_grad = self._early_grads_ready
         self.use_graph = use_graph
         self._graphs = {}
+        self._graph_pool = None
+        hip.check_device(self.optimizer.flat_p.device)
+        model.register_load_state_dict_post_hook(lambda *_: self.optimizer.params_changed())
         if self.world > 1:
             self.sync_replicas()
 
     def sync_replicas(self):
         """What DistributedDataParallel's constructor does: every rank starts from rank 0's parameters and buffers."""
         dist.broadcast(self.optimizer.flat_p, 0)
+        self.optimizer.params_changed()
         for b in self._float_buffers():
             dist.broadcast(b, 0)
 
@@ -332,8 +349,8 @@ class Trainer:
     def train_step(self, batch, epoch=0):
         """batch: dict of device tensors. Returns the (device) scalar loss; no host sync."""
         self.model_with_loss.train()
-        if F.shadows_on():
-            self.optimizer.refresh_bf16_shadows()
+        if F.shadows_on() and not self.optimizer._p16_synced:
+            self.optimizer.refresh_bf16_shadows()              # (after a step() the shadows are re-cast in place: nothing to do)
         if self.broadcast_buffers and self.world > 1 and self.collectives:
             for b in self._float_buffers():
                 dist.broadcast(b, 0)
@@ -356,14 +373,29 @@ class Trainer:
         entry = self._graphs.get(key)
         if entry is None:
             static = {k: v.clone() for k, v in tens.items()}
+            # The two un-captured warm-up passes (allocator, lazy init) run the model in train mode: each would apply one
+            # more BatchNorm running-statistics update, bump num_batches_tracked and advance the dropout step counter without
+            # an optimizer step -- state the reference advances exactly once per batch.  Snapshot and restore it.
+            from ..networks.layers import BatchNorm
+            BatchNorm.flush_counters()
+            bufs = [b for b in self.model.buffers()]
+            saved = [b.clone() for b in bufs]
+            ctr = F.step_counter(self.optimizer.flat_p.device)
+            ctr_saved = ctr.clone()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):                         # warm-up on a side stream (allocator, lazy init)
+            with torch.cuda.stream(s):                         # warm-up on a side stream
                 for _ in range(2):
                     self._fwd_bwd(static, epoch)
+                BatchNorm.flush_counters()
             torch.cuda.current_stream().wait_stream(s)
+            for b, v in zip(bufs, saved):
+                b.copy_(v)
+            ctr.copy_(ctr_saved)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()     # one private pool for every key (not one multi-GB pool per key)
+            with torch.cuda.graph(graph, pool=self._graph_pool):
                 loss_out, _ = self._fwd_bwd(static, epoch)
             entry = self._graphs[key] = (graph, static, loss_out)
         graph, static, loss_out = entry
@@ -374,6 +406,8 @@ class Trainer:
 
     def train(self, epoch, loader, device):
         tot, n = 0.0, 0
+        if hasattr(loader, 'set_epoch'):
+            loader.set_epoch(epoch)                            # main.py:108 (`ShardedLoader`: this rank's shard of this epoch)
         for batch in loader:
             # the reference loader also yields non-tensor entries ('meta', base_trainer.py:134-136 skips them)
             batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -382,26 +416,57 @@ class Trainer:
         return tot / max(n, 1)
 
 
-    def evaluation(self, loader, device=None):
+    def evaluation(self, loader, device=None, score_path=None, json_path=None):
         """Counterpart of `BaseTrainer.evaluation` (lib/trains/base_trainer.py:207-429, H2O branch): the test-mode pass
         (centres from the predicted heat-map, root from the predicted depth) and the mean Euclidean errors per hand --
         absolute and root-relative joints / vertices in mm, 2-D landmarks in pixels.  The reference evaluates on rank 0
         with batch size 1 and pulls every error to the host; here any batch size, every rank takes the batches its
         loader yields, the sums stay on the device (`F.point_dist_sum`) and are all-reduced once at the end.
-        Returns a dict of floats (one host sync)."""
+        Returns a dict of floats (one host sync).
+
+        score_path: rank 0 appends the reference's `H2O-val.txt` block (base_trainer.py:420-429).
+        json_path:  rank 0 writes the reference's `hand_poses.json` submission file (base_trainer.py:328-335,432-433,486-489):
+                    {"modality": "RGBD", "<action id>": {"<frame:06d>.txt": [2 x 21 x 3 absolute joints, left hand first]}};
+                    needs the dataset's `id` / `frame_num` entries in every batch; the predictions of all ranks are gathered."""
         mwl = self.model_with_loss
         was_training = mwl.training
         mwl.eval()
         dev = device or self.optimizer.flat_p.device
         acc = torch.zeros(11, dtype=torch.float64, device=dev)        # 5 metrics x 2 hands + sample count
+        poses = []
         with torch.no_grad():
             for batch in loader:
                 batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
-                acc += evaluation_sums(mwl(batch, 'test', None), batch)
+                tup = mwl(batch, 'test', None)
+                acc += evaluation_sums(tup, batch)
+                if json_path is not None:
+                    if 'id' not in batch or 'frame_num' not in batch:
+                        raise KeyError("Trainer.evaluation: hand_poses.json needs batch['id'] and batch['frame_num'] (interhand.py H2O entries)")
+                    jp = tup[1]
+                    key = torch.stack((torch.as_tensor(batch['id'], device=dev).reshape(-1).double(),
+                                       torch.as_tensor(batch['frame_num'], device=dev).reshape(-1).double()), 1)
+                    poses.append(torch.cat((key, jp.reshape(jp.shape[0], -1).double()), 1))          # [B, 2 + 126]
         if self.world > 1:
             dist.all_reduce(acc)
+        out = finish_evaluation(acc.cpu())
+        if json_path is not None:
+            rows = torch.cat(poses) if poses else torch.zeros((0, 128), dtype=torch.float64, device=dev)
+            if self.world > 1:                                 # ragged gather: pad every rank's block to the longest
+                n = torch.tensor([rows.shape[0]], device=dev)
+                ns = [torch.zeros_like(n) for _ in range(self.world)]
+                dist.all_gather(ns, n)
+                m = max(int(x) for x in ns)
+                pad = torch.zeros((m, rows.shape[1]), dtype=rows.dtype, device=dev)
+                pad[:rows.shape[0]] = rows
+                parts = [torch.empty_like(pad) for _ in range(self.world)]
+                dist.all_gather(parts, pad)
+                rows = torch.cat([p[:int(k)] for p, k in zip(parts, ns)])
+            if self.rank == 0:
+                write_hand_poses_json(json_path, rows.cpu())
+        if score_path is not None and self.rank == 0:
+            write_h2o_scores(score_path, out)
         mwl.train(was_training)
-        return finish_evaluation(acc.cpu())
+        return out
 
 
 EVAL_KEYS = ('abs_joints', 'abs_verts', 'off_joints', 'off_verts', 'lms_px')
@@ -438,6 +503,30 @@ def finish_evaluation(acc):
     out['mpjpe_off_mm'] = (out['off_left_joints'] + out['off_right_joints']) / 2
     out['mpvpe_off_mm'] = (out['off_left_verts'] + out['off_right_verts']) / 2
     return out
+
+
+def write_h2o_scores(path, ev):
+    """Append the block `BaseTrainer.evaluation` writes to `H2O-val.txt` (base_trainer.py:420-429; same keys, order, %.2f mm)."""
+    with open(path, 'a') as fo:
+        fo.write('eval \n')
+        for kind in ('abs', 'off'):
+            for what in ('joints', 'verts'):
+                for hand in ('left', 'right'):
+                    fo.write('%s_%s_%s_loss_all: %.2f\n' % (kind, hand, what, ev['%s_%s_%s' % (kind, hand, what)]))
+
+
+def write_hand_poses_json(path, rows):
+    """rows [n, 2 + 126] = (action id, frame number, absolute joints of both hands) -> the H2O submission file the reference
+    dumps at base_trainer.py:486-489: actions in ascending id, frames in the order they were evaluated."""
+    import json
+    out = {"modality": "RGBD"}
+    for r in rows.tolist():
+        out.setdefault('%d' % int(r[0]), {})['%06d.txt' % int(r[1])] = [float(x) for x in r[2:]]
+    ordered = {"modality": "RGBD"}
+    for k in sorted((k for k in out if k != "modality"), key=int):
+        ordered[k] = out[k]
+    with open(path, 'w') as fo:
+        json.dump(ordered, fo)
 
 
 def init_distributed():

@@ -118,3 +118,46 @@ def test_trainer_reduction_object_world2_bf16_transport():
     res = _run_reducer('bf16')
     assert all(e < 1e-2 for _, e, _ in res), res             # bf16 rounding of the summands: 2^-8 relative
     assert all(b == 44032 * 2 for _, _, b in res)
+
+
+def _shard_worker(rank, world, port, q):
+    """Two ranks draw their shard of one epoch the way Trainer.train does (ShardedLoader.set_epoch, main.py:79,88,108)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pdfnet_amd.trains.sampler import ShardedLoader
+    n, B = 37, 4                                             # odd dataset: the permutation is padded to 38 by repeating its head
+    data = {'idx': torch.arange(n), 'x': torch.arange(n, dtype=torch.float32) * 2}
+    ld = ShardedLoader(data, batch_size=B, rank=dist.get_rank(), world=dist.get_world_size(), seed=0)
+    per_epoch = []
+    for epoch in (1, 2):
+        ld.set_epoch(epoch)
+        picks = torch.cat([b['idx'] for b in ld])
+        assert len(ld) == 19 // B and picks.numel() == (19 // B) * B          # the rank's 19 picks -> 4 full batches, the rest dropped
+        every = torch.tensor(ld.indices())
+        gathered = [torch.empty_like(every) for _ in range(world)]
+        dist.all_gather(gathered, every)
+        per_epoch.append((picks.tolist(), [g.tolist() for g in gathered]))
+    q.put((rank, per_epoch))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_draw_disjoint_padded_shards_that_change_with_the_epoch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for e in range(2):
+        a, b = res[0][e][1]                                  # both ranks' full index streams, as rank 0 gathered them
+        assert res[1][e][1] == [a, b]                        # ... and rank 1 saw the same
+        assert len(a) == len(b) == 19
+        union = a + b
+        assert set(union) == set(range(37)) and len(union) == 38          # every sample once, one repeated (the padding)
+        assert len(set(a) & set(b)) <= 1                     # disjoint up to the padded element
+        assert res[0][e][0] == a[:16] and res[1][e][0] == b[:16]           # batches = the shard in order, last partial batch dropped
+    assert res[0][0][1] != res[0][1][1]                      # set_epoch reshuffles

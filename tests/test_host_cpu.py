@@ -114,13 +114,90 @@ def test_bf16_shadow_bookkeeping_ignores_stale_or_relaid_out_copies():
     assert F.shadow_of(t) is None and F.shadow_of(None) is None
     s = t.to(torch.bfloat16)
     F.attach_shadow(t, s)
-    assert F.shadow_of(t) is s
-    t.add_(1.0)                                            # modified in place: the copy is stale
-    assert F.shadow_of(t) is None
-    F.attach_shadow(t, s.contiguous())                     # NCHW-contiguous copy of a channels_last tensor: other strides
-    assert F.shadow_of(t) is None
-    u = t.clone()
-    assert F.shadow_of(u) is None                          # attributes do not travel to new tensors
+    assert F.shadow_of(t) is None                          # fp32 mode: shadows are never handed out
+    old = F._GEMM_BF16
+    F._GEMM_BF16 = True                                    # (what set_gemm_precision('bf16') caches)
+    try:
+        assert F.shadow_of(t) is s
+        t.add_(1.0)                                        # modified in place: the copy is stale
+        assert F.shadow_of(t) is None
+        F.attach_shadow(t, s.contiguous())                 # NCHW-contiguous copy of a channels_last tensor: other strides
+        assert F.shadow_of(t) is None
+        u = t.clone()
+        assert F.shadow_of(u) is None                      # attributes do not travel to new tensors
+        # as_matrix: the [Cout, KH*KW*Cin] view of a channels_last weight carries the gradient alias only when it IS a view
+        w = torch.nn.Parameter(torch.randn(8, 4, 3, 3).contiguous(memory_format=torch.channels_last))
+        w.grad = torch.zeros(8, 4, 3, 3).contiguous(memory_format=torch.channels_last)
+        w._pdf_main_grad = True
+        w2 = F.as_matrix(w)
+        assert w2.data_ptr() == w.data_ptr() and w2._pdf_grad_alias.data_ptr() == w.grad.data_ptr()
+        w.grad = torch.zeros(8, 4, 3, 3)                   # an NCHW-contiguous gradient: reshape would copy -> no alias, no tag
+        assert not getattr(F.as_matrix(w), '_pdf_main_grad', False)
+        wn = torch.nn.Parameter(torch.randn(8, 4, 3, 3))   # an NCHW-contiguous weight: as_matrix is a copy, autograd carries dw
+        wn._pdf_main_grad = True
+        wn.grad = torch.zeros(8, 4, 3, 3)
+        assert not getattr(F.as_matrix(wn), '_pdf_main_grad', False)
+    finally:
+        F._GEMM_BF16 = old
+
+
+def test_distributed_shard_is_the_reference_samplers_index_stream():
+    """main.py:79,108: DistributedSampler(train_dataset) + set_epoch -- `distributed_shard` must draw the same indices, for
+    ragged sizes, both drop_last modes, with and without shuffling; `ShardedLoader` then cuts batches with the loader's
+    drop_last=True (main.py:88)."""
+    from torch.utils.data.distributed import DistributedSampler
+    from pdfnet_amd.trains.sampler import ShardedLoader, distributed_shard
+    for n in (1, 7, 64, 101):
+        ds = list(range(n))
+        for world in (1, 2, 3, 8):
+            for drop in (False, True):
+                for shuffle in (True, False):
+                    for epoch in (0, 3):
+                        for rank in range(world):
+                            ref = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=0, drop_last=drop)
+                            ref.set_epoch(epoch)
+                            assert list(ref) == distributed_shard(n, rank, world, epoch, 0, shuffle, drop), (n, world, drop, shuffle, epoch, rank)
+    data = {'x': torch.arange(101.0).reshape(101, 1), 'meta': [str(i) for i in range(101)]}
+    seen = []
+    for rank in range(2):
+        ld = ShardedLoader(data, batch_size=8, rank=rank, world=2, seed=0)
+        ld.set_epoch(5)
+        assert len(ld) == 51 // 8                            # 102 padded picks -> 51 per rank -> 6 full batches, the 7th (3 picks) dropped
+        for b in ld:
+            assert b['x'].shape == (8, 1) and len(b['meta']) == 8 and [int(v) for v in b['x'][:, 0]] == [int(m) for m in b['meta']]
+            seen.append((rank, [int(v) for v in b['x'][:, 0]]))
+    a = sum((v for r, v in seen if r == 0), [])
+    b = sum((v for r, v in seen if r == 1), [])
+    assert len(a) == len(b) == 48 and not set(a) & set(b)
+
+
+def test_evaluation_writers_use_the_reference_formats(tmp_path):
+    """H2O-val.txt block (base_trainer.py:420-429) and hand_poses.json (:328-335,486-489)."""
+    import json
+    from pdfnet_amd.trains.base_trainer import finish_evaluation, write_h2o_scores, write_hand_poses_json
+    acc = torch.arange(1.0, 12.0, dtype=torch.float64) / 1000
+    acc[10] = 4.0
+    ev = finish_evaluation(acc)
+    p = str(tmp_path / "H2O-val.txt")
+    write_h2o_scores(p, ev)
+    write_h2o_scores(p, ev)                                  # appended, like the reference's open(..., 'a')
+    lines = open(p).read().splitlines()
+    assert len(lines) == 18 and lines[0] == 'eval ' and lines[9] == 'eval '
+    assert [l.split(':')[0] for l in lines[1:9]] == ['abs_left_joints_loss_all', 'abs_right_joints_loss_all', 'abs_left_verts_loss_all',
+                                                     'abs_right_verts_loss_all', 'off_left_joints_loss_all', 'off_right_joints_loss_all',
+                                                     'off_left_verts_loss_all', 'off_right_verts_loss_all']
+    assert lines[1] == 'abs_left_joints_loss_all: %.2f' % (1.0 / 4) and lines[4] == 'abs_right_verts_loss_all: %.2f' % (4.0 / 4)
+    rows = torch.zeros(3, 128, dtype=torch.float64)
+    rows[0, :2] = torch.tensor([2.0, 7.0])
+    rows[1, :2] = torch.tensor([1.0, 0.0])
+    rows[2, :2] = torch.tensor([1.0, 12.0])
+    rows[:, 2:] = torch.arange(3 * 126, dtype=torch.float64).reshape(3, 126)
+    q = str(tmp_path / "hand_poses.json")
+    write_hand_poses_json(q, rows)
+    d = json.load(open(q))
+    assert list(d) == ['modality', '1', '2'] and d['modality'] == 'RGBD'
+    assert list(d['1']) == ['000000.txt', '000012.txt'] and list(d['2']) == ['000007.txt']
+    assert d['2']['000007.txt'] == [float(i) for i in range(126)] and len(d['1']['000012.txt']) == 126
 
 
 def test_header_is_plain_c_and_a_c_client_links(tmp_path):

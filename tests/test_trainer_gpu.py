@@ -104,9 +104,10 @@ def test_graph_replay_follows_the_loss_schedule_across_epoch_20():
     four steps of the two modes see the same function (train-mode BatchNorm uses batch statistics)."""
     from pdfnet_amd import functional as F
     from pdfnet_amd.trains.base_trainer import Trainer
-    res = {}
+    res, state = {}, {}
     for mode in ('eager', 'graph'):
         opt, m, crit, batch = _setup()
+        ctr0 = int(F.step_counter(torch.device('cuda')))
         tr = Trainer(opt, m, crit, lr=0.0, use_graph=(mode == 'graph'))
         old, F.ASYNC_WGRAD = F.ASYNC_WGRAD, (mode != 'graph')
         try:
@@ -118,12 +119,22 @@ def test_graph_replay_follows_the_loss_schedule_across_epoch_20():
         finally:
             F.ASYNC_WGRAD = old
         res[mode] = out
+        # state the reference advances once per batch: BatchNorm running statistics, their counters, the dropout step counter.
+        # The un-captured warm-up passes of a new graph key must not advance them.
+        from pdfnet_amd.networks.layers import BatchNorm
+        BatchNorm.flush_counters()
+        state[mode] = (m.encoder.feat_bn.running_mean.clone(), m.encoder.resnet.bn1.running_var.clone(),
+                       int(m.encoder.feat_bn.num_batches_tracked), int(m.mid_model.convs[2][2].num_batches_tracked),
+                       int(F.step_counter(torch.device('cuda'))) - ctr0)
         if mode == 'graph':
             assert len(tr._graphs) == 2
     for i in range(4):
         (le, ge), (lg, gg) = res['eager'][i], res['graph'][i]
         assert abs(le - lg) <= 1e-5 * abs(le), (i, le, lg)
         assert float((ge - gg).abs().max()) <= 1e-4 * float(ge.abs().max()), i
+    assert state['eager'][2:] == state['graph'][2:] == (4, 4, 4), (state['eager'][2:], state['graph'][2:])
+    for a, b in zip(state['eager'][:2], state['graph'][:2]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-7
     for mode in ('eager', 'graph'):
         r = res[mode]
         assert r[2][0] > r[1][0] * 1.0001, mode                                   # alpha = 1 adds 2000*edge + 1000*joints2d
@@ -181,3 +192,29 @@ def test_headline_batch_32_properties():
     # besides the structurally dead tensors only the wh / params heads (no loss term, simplified.py:397-399) stay at zero
     assert all(DEAD_PATTERN.match(n) or n.startswith(('encoder.wh.', 'encoder.params.')) for n in live_zero), \
         [n for n in live_zero if not DEAD_PATTERN.match(n) and not n.startswith(('encoder.wh.', 'encoder.params.'))][:5]
+
+
+def test_evaluation_writes_the_reference_score_and_submission_files(tmp_path):
+    """Trainer.evaluation(score_path=, json_path=): the `H2O-val.txt` block and `hand_poses.json` of base_trainer.py:420-429,
+    :328-335,486-489 -- the json holds, per action id and frame, the 2 x 21 x 3 absolute joints the test-mode pass predicted."""
+    import json
+    from pdfnet_amd.trains.base_trainer import Trainer
+    opt, m, crit, batch = _setup(B=4)
+    tr = Trainer(opt, m, crit, lr=1e-4)
+    b1 = dict(batch)
+    b1['id'] = torch.tensor([1, 1, 2, 2])
+    b1['frame_num'] = torch.tensor([0, 1, 0, 5])
+    sp, jp = str(tmp_path / "H2O-val.txt"), str(tmp_path / "hand_poses.json")
+    ev = tr.evaluation([b1], score_path=sp, json_path=jp)
+    lines = open(sp).read().splitlines()
+    assert lines[0] == 'eval ' and lines[1] == 'abs_left_joints_loss_all: %.2f' % ev['abs_left_joints'] and len(lines) == 9
+    d = json.load(open(jp))
+    assert list(d) == ['modality', '1', '2'] and list(d['2']) == ['000000.txt', '000005.txt']
+    m.eval()
+    with torch.no_grad():
+        tup = tr.model_with_loss(b1, 'test', None)
+    want = tup[1][3].reshape(-1).cpu().tolist()                       # joints_pred of sample 3 = action 2, frame 5
+    got = d['2']['000005.txt']
+    assert len(got) == 126 and max(abs(a - b) for a, b in zip(got, want)) <= 1e-6
+    with pytest.raises(KeyError):
+        tr.evaluation([batch], json_path=jp)                          # no id / frame_num in the batch
