@@ -464,6 +464,7 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
     from pdfnet_amd.trains.simplified import CtdetLoss
     F.set_gemm_precision('bf16')
     try:
+        torch.cuda.empty_cache()                             # the fp32 run's cached blocks have other sizes: start from a clean pool
         torch.manual_seed(0)
         F.manual_seed(4321)
         model = load_model_intag(opt).to(dev)
@@ -685,7 +686,7 @@ def main():
         # BASELINE configs[3] / [4] per GPU, driver-timed in the same run: short legs after the fp32 headline
         out["bf16_per_gpu"] = {"note": "per-rank step of configs[3] (B=32/GPU) and configs[4] (B=64/GPU): bf16 MFMA GEMMs + bf16 shadows, fp32 "
                                        "accumulate / master weights / statistics / loss; eager, one GPU, no collective",
-                               "B32": bf16_leg(opt, R, 32, dev, consts, 12, 4), "B64": bf16_leg(opt, R, 64, dev, consts, 8, 3)}
+                               "B32": bf16_leg(opt, R, 32, dev, consts, 12, 6), "B64": bf16_leg(opt, R, 64, dev, consts, 10, 6)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = max(1, (os.cpu_count() or 2) // 2)
         out["cpu_baseline"] = cpu_baseline(R, threads)

@@ -51,6 +51,16 @@ int pdf_debug_init_device(void);
  * with the algorithmic FLOPs and bytes (every operand once) of that launch.  on != 0 clears the records and starts, 0 stops.
  * pdf_debug_kernel_record reads record i once the device is idle. */
 int pdf_debug_kernel_timing(int on);
+/* BatchNorm statistics out of the producing GEMM's epilogue (reference: nn.Conv2d -> nn.BatchNorm2d pairs, resnet.py:102-122,
+ * intaghand_encoder.py:48-103,742-743): pdf_set_stats_output hands the NEXT pdf_conv2d_fwd / pdf_linear_fwd call of this thread
+ * a buffer for per-row-block (mean, sum of squared deviations) pairs of its output columns, part[(t * N + c) * 2 + {0,1}];
+ * afterwards pdf_stats_result_tiles() / pdf_stats_result_rows() give the number of row blocks and rows per block it wrote
+ * (0 tiles: the kernel it chose has no statistics epilogue, or cap_floats < tiles * N * 2).  pdf_set_bn_tile_stats hands
+ * such partials to the NEXT pdf_bn_train_fwd / pdf_bn_relu_maxk_fwd call, which then skips its own statistics pass. */
+int pdf_set_stats_output(float* part, long cap_floats);
+long pdf_stats_result_tiles(void);
+long pdf_stats_result_rows(void);
+int pdf_set_bn_tile_stats(const float* part, long tiles, long rows_per_tile);
 int pdf_debug_kernel_record_count(void);
 int pdf_debug_kernel_record(int i, char* name, int cap, double* flops, double* bytes, float* ms);
 /* Stream fork / join for the host layer: everything issued on `signaler` so far completes before anything issued on

@@ -207,6 +207,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
         return;
     }
     // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+    StatAcc st[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) st[j] = StatAcc{0.f, 0.f, 0.f, 0.f};
+    const bool do_stat = g.stat != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -239,10 +243,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
                     }
                     if (g.accum) v += Cp[o];
                     Cp[o] = v;
+                    if (do_stat) stat_add(st[j], v);
                 }
             }
         }
     }
+    if (do_stat) stat_finish<TN, WM, WN, BN>(st, &As[0][0], g.stat, tmi, n0, g.N, wm, wn, lane, tid);     // (As: the loop's last barrier is behind us)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -365,6 +371,10 @@ __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
         if (tap == 8) abuf ^= 1;
         tap = ntap; chunk = nchunk;
     }
+    StatAcc st[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) st[j] = StatAcc{0.f, 0.f, 0.f, 0.f};
+    const bool do_stat = g.stat != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -381,9 +391,11 @@ __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
                     else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
                     if (g.accum) v += Cp[(long)row * g.ldc + col];
                     Cp[(long)row * g.ldc + col] = v;
+                    if (do_stat) stat_add(st[j], v);
                 }
             }
     }
+    if (do_stat) stat_finish<TN, 2, WN, BN>(st, &As[0][0], g.stat, tmi, n0, g.N, wm, wn, lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -759,10 +771,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -910,10 +922,32 @@ PDF_API int pdf_debug_shadow_operands() { return g_shadow_operands; }       // i
 PDF_API int pdf_debug_last_tile() { return g_last_tile; }
 PDF_API int pdf_debug_igemm_launches() { return g_igemm_launches; }
 
+// BatchNorm statistics out of a forward GEMM's epilogue (IGemm::stat): the request of the NEXT conv2d / linear forward call of
+// this thread (pdf_set_stats_output) and what that call produced (pdf_stats_result_tiles / _rows; 0 tiles: the launch it chose
+// has no statistics epilogue -- the caller then runs the ordinary statistics pass).
+static thread_local float* tl_stat_req = nullptr;
+static thread_local long tl_stat_cap = 0;
+static thread_local long tl_stat_tiles = 0, tl_stat_rows = 0;
+PDF_API int pdf_set_stats_output(float* part, long cap_floats) { tl_stat_req = part; tl_stat_cap = cap_floats; return 0; }
+PDF_API long pdf_stats_result_tiles(void) { return tl_stat_tiles; }
+PDF_API long pdf_stats_result_rows(void) { return tl_stat_rows; }
+struct StatReq { float* part; long cap; };
+static StatReq take_stat_request() { StatReq r = {tl_stat_req, tl_stat_cap}; tl_stat_req = nullptr; tl_stat_cap = 0; tl_stat_tiles = tl_stat_rows = 0; return r; }
+// the launch about to be issued uses row blocks of BM rows: keep the request if the partials fit, and publish the layout
+static void stat_plan(IGemm& g, long cap, int BM) {
+    if (g.stat == nullptr) return;
+    const long tiles = cdiv(g.M, BM);
+    if (!g.plain_out || g.ps_cout > 0 || g.accum || tiles * g.N * 2 > cap) { g.stat = nullptr; return; }
+    tl_stat_tiles = tiles; tl_stat_rows = BM;
+}
+
 // groups == 2: paired launch (see IGemm::B1), blockIdx.y selects the group
-static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
+static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap = 0) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
     ++g_igemm_launches;
+    if (groups > 1) g.stat = nullptr;
+    float* const stat_req = g.stat;
+    g.stat = nullptr;                                   // (the streaming / bf16 / split-K launches below have no statistics epilogue)
     bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
     if (g.b_kn) fast = fast && (g.N % 4 == 0) && (g.btap % 4 == 0);
     if (groups > 1) fast = fast && aligned16(g.B1) && (g.gsA % 4 == 0);
@@ -941,10 +975,10 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
     const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
     // (also the valid 3x3 convolutions on the 5x5 / 3x3 centre windows: taps are walked in K order, a split may start inside any tap)
     const bool sk_plain = g.T == 1 && g.plain_in, sk_taps = g.T > 1 && !g.plain_in && fast && g.Cin % 32 == 0 && g.K == g.T * g.Cin;
-    if (groups == 1 && (sk_plain || sk_taps) && g.plain_out && g.ps_cout == 0 && !g.accum && t64 <= 128 && g.K >= 512 && env_int(ENV_IG_SPLITK, 1)) {
+    if (groups == 1 && (sk_plain || sk_taps) && g.plain_out && g.ps_cout == 0 && !g.accum && t64 <= env_int(ENV_IG_SPLITK_MAXT, 128) && g.K >= 512 && env_int(ENV_IG_SPLITK, 1)) {
         const bool bk32 = fast && g.Cin % 32 == 0;
         const int bk = bk32 ? 32 : 16, nk = cdiv(g.K, bk);
-        int splits = (int)min((long)cdiv(320, (int)t64), (long)(g.K / 128));
+        int splits = (int)min((long)cdiv(env_int(ENV_IG_SPLITK_TARGET, 320), (int)t64), (long)(g.K / 128));
         while (splits > 1 && (long)splits * g.M * g.N > PDF_SCRATCH_MAX) --splits;
         if (splits >= 2) {
             const int ksteps = cdiv(nk, splits);
@@ -979,7 +1013,9 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
                 g.Cin >= env_int(ENV_IG_HALO_MINC, 256) &&      // measured: 128-channel layers lose (94 vs 107 TFLOP/s forward), 256+ gain 2-3 %
                 env_int(ENV_IG_HALO, 1);
     for (int t = 0; halo && t < 9; ++t) halo = g.dy[t] >= -1 && g.dy[t] <= 1 && g.dx[t] >= -1 && g.dx[t] <= 1;
+    g.stat = stat_req;
     if (halo) {
+        stat_plan(g, stat_cap, 128);
         const dim3 grid((g.M / 128) * cdiv(g.N, 128));
         KTimer kt(g.b_kn ? "igemm_halo3x3<true>" : "igemm_halo3x3<false>", 2.0 * g.M * g.N * g.K, igemm_bytes(g, 1), s);
         if (g.b_kn) hipLaunchKernelGGL(igemm_halo3x3<true>, grid, dim3(256), 0, s, g);
@@ -987,16 +1023,18 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1) {
         g_last_tile = 128128;
     }
     else if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) && !short_k)
-        launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s), g_last_tile = 128128;
+        stat_plan(g, stat_cap, 128), launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s), g_last_tile = 128128;
     else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int(ENV_IG_T128, 600))
-        launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s), g_last_tile = 128064;   // (K-step 32: no gain here)
+        stat_plan(g, stat_cap, 128), launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s), g_last_tile = 128064;   // (K-step 32: no gain here)
     else if (fast && (long)cdiv(g.M, 64) * cdiv(g.N, 64) * groups < 96 && g.K >= 512 && env_int(ENV_IG_T32, 1)) {
         // a handful of 64x64 tiles with a long reduction (M = 64 centre windows, the mesh decoder's 1024-wide layers): latency
         // bound on a few CUs -- 32x32 tiles put 4x as many blocks on the chip (one wave each)
+        stat_plan(g, stat_cap, 32);
         launch_igemm_tile<32, 32, 1, 1>(g, fast, dim3(cdiv(g.M, 32) * cdiv(g.N, 32), groups), s), g_last_tile = 32032;
     }
     else
     {
+        stat_plan(g, stat_cap, 64);
         const dim3 grid(cdiv(g.M, 64) * cdiv(g.N, 64), groups);
         // K-step 32 for the small tile: its 8 MFMAs per wave and 16-wide step leave the barrier exposed (l4 3x3: 62 -> 72 TFLOP/s)
         if (fast && g.Cin % 32 == 0 && env_int(ENV_IG_BK32, 1)) launch_igemm_tile<64, 64, 2, 2, 32>(g, fast, grid, s);
@@ -1033,9 +1071,11 @@ static IGemm linear_desc(const float* x, const float* w, const float* bias, floa
 PDF_API int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
                            int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) {
     const Shadows sh = take_shadows();
+    const StatReq sr = take_stat_request();
     IGemm g = linear_desc(x, w, bias, y, M, N, K, ldx, ldw, ldy, act);
     g.A16 = sh.op0; g.B16 = sh.op1;
-    return launch_igemm(g, s);
+    g.stat = sr.part;
+    return launch_igemm(g, s, 1, sr.cap);
 }
 // Two same-shaped layers with their own parameters in ONE launch (the left / right hand branches of the mesh decoder,
 // DualGraph.py:83-84, inter_attn.py:66-67): rows [0, M) of x / y belong to (w0, b0), rows [M, 2M) to (w1, b1).
@@ -1214,7 +1254,7 @@ __device__ __forceinline__ void stem_fwd_steps(const float* Xs, const float* Ws,
     }
 }
 __global__ __launch_bounds__(256) void stem7x7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                                          int N, int H, int W, int OH, int OW, int ldy, int act, int cpb) {
+                                                          int N, int H, int W, int OH, int OW, int ldy, int act, int cpb, float* __restrict__ stat) {
     constexpr int CH = 64, XW = 2 * CH + 5, RW = XW * 3, XF = 7 * RW, DYB = 3200;
     __shared__ __attribute__((aligned(16))) float Xs[DYB];          // [0, XF): patch, [XF, DYB): zeros
     __shared__ __attribute__((aligned(16))) float Ws[148 * 64];
@@ -1247,6 +1287,7 @@ __global__ __launch_bounds__(256) void stem7x7_fwd_kernel(const float* __restric
             }
         }
     };
+    StatAcc st[1] = {StatAcc{0.f, 0.f, 0.f, 0.f}};             // BatchNorm statistics of this block's rows (IGemm::stat form: one row block per BLOCK)
     if (c0 < c1) gload(c0);
     for (long c = c0; c < c1; ++c) {
         const int n = (int)(c / ((long)OH * cpr));
@@ -1269,7 +1310,12 @@ __global__ __launch_bounds__(256) void stem7x7_fwd_kernel(const float* __restric
             float v = acc[r];
             if (act == 1) v = fmaxf(v, 0.f); else if (act == 2) v = v > 0.f ? v : 0.1f * v;
             yp[(long)((r & 3) + 8 * (r >> 2) + 4 * hi) * ldy] = v;
+            if (stat != nullptr) stat_add(st[0], v);
         }
+    }
+    if (stat != nullptr) {
+        __syncthreads();                                            // the patch is no longer read: its LDS carries the wave partials
+        stat_finish<1, 2, 2, 64>(st, Xs, stat, blockIdx.x, 0, 64, pt, ct, lane, tid);
     }
 }
 
@@ -1277,6 +1323,7 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
                            int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
                            int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s) {
     const Shadows sh = take_shadows();
+    const StatReq sr = take_stat_request();
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && (long)N * OH * OW >= (1L << 16)) {
         KTimer kt("tiny_conv_fwd_kernel<3, 3, 3, 3>", 2.0 * N * OH * OW * 81, 4.0 * N * (H * W + OH * OW) * 3, s);
@@ -1292,7 +1339,9 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
         const int cpb = (int)cdiv(total, nblk);
         nblk = (int)cdiv(total, cpb);
         KTimer kt("stem7x7_fwd_kernel", 2.0 * N * OH * OW * 64 * 147, 4.0 * N * ((double)H * W * 3 + (double)OH * OW * 64), s);
-        hipLaunchKernelGGL(stem7x7_fwd_kernel, dim3(nblk), dim3(256), 0, s, x, w, y, N, H, W, OH, OW, ldy, act, cpb);
+        float* stat = (sr.part != nullptr && (long)nblk * 64 * 2 <= sr.cap) ? sr.part : nullptr;
+        if (stat != nullptr) { tl_stat_tiles = nblk; tl_stat_rows = (long)cpb * 64; }
+        hipLaunchKernelGGL(stem7x7_fwd_kernel, dim3(nblk), dim3(256), 0, s, x, w, y, N, H, W, OH, OW, ldy, act, cpb, stat);
         g_last_tile = 0;
         PDF_LAUNCH_CHECK();
         return 0;
@@ -1305,7 +1354,8 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
     g.plain_in = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
     g.plain_out = 1; g.act = act;
     g.A16 = sh.op0; g.B16 = sh.op1;
-    return launch_igemm(g, s);
+    g.stat = sr.part;
+    return launch_igemm(g, s, 1, sr.cap);
 }
 
 // Conv2d backward-data: dx[N,H,W,Cin] from dy[N,OH,OW,Cout] and the FORWARD weight w = [Cout][KH][KW][Cin], read as

@@ -28,6 +28,11 @@ struct IGemm {
     // straight into LDS (half the L2 -> LDS bytes, no conversion); results are bit-identical to rounding while staging
     const void* A16; const void* B16; const void* B116;
     int accum;                                // C += result (after bias / activation): a gradient accumulated into an existing one
+    // BatchNorm statistics of the OUTPUT out of the accumulator registers (forward of a conv / linear layer that feeds a
+    // BatchNorm): per output tile row-block t and column c, stat[(t * N + c) * 2 + {0, 1}] = (mean, sum of squared deviations)
+    // of the stored values C[m][c] over the block's rows m in [t BM, min(M, (t+1) BM)).  Chan-combined per lane -> half-wave
+    // pair -> waves in a fixed order (deterministic); pdf_bn_train_fwd combines the row-blocks in fp64 (norm.hip).
+    float* stat;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
@@ -41,6 +46,49 @@ __device__ __forceinline__ void xcd_tile(int bid, int nblk, int ntn, int& tm, in
     int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
     tn = lin % ntn;
     tm = lin / ntn;
+}
+
+// Statistics epilogue shared by igemm_nt / igemm_halo3x3 (see IGemm::stat).  A lane holds, per column tile j, TM*16 values of
+// ONE column; `StatAcc` collects them as shifted sums around the lane's first value.
+struct StatAcc { float n, s, a, b; };
+__device__ __forceinline__ void stat_add(StatAcc& t, float v) {
+    if (t.n == 0.f) t.s = v;
+    const float d = v - t.s;
+    t.n += 1.f; t.a += d; t.b = fmaf(d, d, t.b);
+}
+// (n, mean, M2) of two disjoint row sets of one column -> of their union
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float n2, float mean2, float m22) {
+    const float nt = n + n2;
+    if (nt > 0.f) {
+        const float d = mean2 - mean, f = n2 / nt;
+        mean = fmaf(d, f, mean);
+        m2 = m2 + m22 + d * d * n * f;
+    }
+    n = nt;
+}
+// sm: >= WM * BN * 3 floats of LDS nobody reads any more; every thread of the block must call this (it has a barrier)
+template <int TN, int WM, int WN, int BN>
+__device__ __forceinline__ void stat_finish(const StatAcc (&acc)[TN], float* sm, float* __restrict__ stat, int tile_row, int n0, int N,
+                                            int wm, int wn, int lane, int tid) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float n = acc[j].n;
+        float mean = n > 0.f ? acc[j].s + acc[j].a / n : 0.f;
+        float m2 = n > 0.f ? fmaxf(acc[j].b - acc[j].a * acc[j].a / n, 0.f) : 0.f;
+        chan_merge(n, mean, m2, __shfl_xor(n, 32, 64), __shfl_xor(mean, 32, 64), __shfl_xor(m2, 32, 64));     // the other 16*TM rows of this column
+        if (lane < 32) {
+            float* o = sm + ((wm * BN) + wn * TN * 32 + j * 32 + lane) * 3;
+            o[0] = n; o[1] = mean; o[2] = m2;
+        }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+        float n = sm[tid * 3], mean = sm[tid * 3 + 1], m2 = sm[tid * 3 + 2];
+#pragma unroll
+        for (int w = 1; w < WM; ++w) chan_merge(n, mean, m2, sm[(w * BN + tid) * 3], sm[(w * BN + tid) * 3 + 1], sm[(w * BN + tid) * 3 + 2]);
+        float* o = stat + ((long)tile_row * N + n0 + tid) * 2;
+        o[0] = mean; o[1] = m2;
+    }
 }
 
 struct WGemm {

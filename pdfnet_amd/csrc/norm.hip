@@ -146,6 +146,55 @@ __global__ __launch_bounds__(FIN_TX * FIN_TY) void bn_finalize_kernel(const floa
     shift[c] = beta[c] - (float)mean * sc;
 }
 
+// Statistics that arrive as per-row-block (mean, M2) pairs out of the producing GEMM's epilogue (IGemm::stat, gemm_common.h):
+// part[(t * C + c) * 2 + {0, 1}], block t covers rows [t rpt, min(R, (t + 1) rpt)).  Combined in fp64 in block order
+// (deterministic): mean = sum n_t mean_t / R, M2 = sum (M2_t + n_t mean_t^2) - R mean^2.
+__global__ __launch_bounds__(FIN_TX * FIN_TY) void bn_finalize_tiles_kernel(const float* __restrict__ part, int tiles, long rpt, int C, long R,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                   float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double s1[FIN_TY][FIN_TX], s2[FIN_TY][FIN_TX];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c = blockIdx.x * FIN_TX + tx;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        const float2* p2 = reinterpret_cast<const float2*>(part) + c;
+#pragma unroll 4
+        for (int t = ty; t < tiles; t += FIN_TY) {
+            const float2 v = p2[(long)t * C];
+            const double n = (double)min(rpt, R - (long)t * rpt), m = (double)v.x;
+            a += n * m; b += (double)v.y + n * m * m;
+        }
+    }
+    s1[ty][tx] = a; s2[ty][tx] = b;
+    __syncthreads();
+    if (c >= C || ty != 0) return;
+    a = 0.0; b = 0.0;
+    for (int j = 0; j < FIN_TY; ++j) { a += s1[j][tx]; b += s2[j][tx]; }
+    const double n = (double)R;
+    const double mean = a / n;
+    double var = b / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_rstd[c] = rstd;
+    if (running_mean != nullptr) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        const double unb = R > 1 ? var * n / (n - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+}
+// handed over for the NEXT pdf_bn_train_fwd / pdf_bn_relu_maxk_fwd call of this thread (like pdf_set_bf16_output)
+static thread_local const float* tl_tile_part = nullptr;
+static thread_local long tl_tile_n = 0, tl_tile_rows = 0;
+PDF_API int pdf_set_bn_tile_stats(const float* part, long tiles, long rows_per_tile) { tl_tile_part = part; tl_tile_n = tiles; tl_tile_rows = rows_per_tile; return 0; }
+struct TileStats { const float* part; long tiles, rows; };
+static TileStats take_tile_stats() { TileStats t = {tl_tile_part, tl_tile_n, tl_tile_rows}; tl_tile_part = nullptr; tl_tile_n = tl_tile_rows = 0; return t; }
+
 __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
                                      float* __restrict__ scale, float* __restrict__ shift) {
@@ -395,12 +444,18 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
                              const float* res, int ldr, int relu, float* y, int ldy,
                              float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, hipStream_t s) {
     void* y16 = pdf_tls_take_output();                       // bf16 shadow of y (pdf_set_bf16_output), vectorised path only
+    const TileStats ts = take_tile_stats();
     if (R <= 0 || C <= 0) return 0;
     long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
     BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, nullptr};
-    if (v4_ok(C, {ldx}, {x})) {
+    if (ts.part != nullptr) {                                // statistics came out of the producing GEMM's epilogue: no pass over x
+        if (ts.tiles * ts.rows < R || (ts.tiles - 1) * ts.rows >= R) return PDF_E_BADARG;
+        hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ts.part, (int)ts.tiles, ts.rows, C, R, gamma, beta,
+                           running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+        fin.counters = reinterpret_cast<int*>(1);            // (marks "finalised" for the branch below)
+    } else if (v4_ok(C, {ldx}, {x})) {
         fin.counters = bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr;          // finalize in the last block of each channel tile
         hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws, fin);
     } else
@@ -635,7 +690,12 @@ PDF_API int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, 
     if (R <= 0 || C <= 0 || K <= 0) return 0;
     if (!v4_ok(C, {ldy, ldo}, {y, out, arg, scale, shift})) return PDF_E_BADARG;
     const long rows = R * K;
-    if (training) {
+    const TileStats ts = take_tile_stats();
+    if (training && ts.part != nullptr) {
+        if (ts.tiles * ts.rows < rows || (ts.tiles - 1) * ts.rows >= rows) return PDF_E_BADARG;
+        hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ts.part, (int)ts.tiles, ts.rows, C, rows, gamma, beta,
+                           running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+    } else if (training) {
         long chunks = bn_chunks(C, rows);
         long rpc = (rows + chunks - 1) / chunks;
         chunks = (rows + rpc - 1) / rpc;

@@ -148,6 +148,46 @@ def _set_ops(a, b):
         _L().pdf_set_bf16_operands(ptr(a), ptr(b))
 
 
+# ---- BatchNorm statistics out of the producing GEMM's epilogue (fp32 kernels): a conv / linear forward called with stats=True
+# asks the library for per-row-block (mean, M2) pairs of its output columns (pdf_set_stats_output); they travel as an attribute
+# of the output tensor and the BatchNorm that consumes it skips its own statistics pass over the tensor (pdf_set_bn_tile_stats).
+BN_EPILOGUE_STATS = _os.environ.get("PDFNET_BN_EPILOGUE_STATS", "1") != "0"
+
+
+def _stats_request(stats, rows, cols, dev):
+    """-> the partials buffer for the next conv / linear forward launch, or None."""
+    if not (stats and BN_EPILOGUE_STATS) or _GEMM_BF16:
+        return None
+    cap = ((rows + 31) // 32) * cols * 2
+    part = torch.empty(cap, dtype=torch.float32, device=dev)
+    _L().pdf_set_stats_output(ptr(part), cap)
+    return part
+
+
+def _stats_attach(y, part):
+    if part is None:
+        return
+    L = _L()
+    tiles = L.pdf_stats_result_tiles()
+    if tiles > 0:
+        y._pdf_bn_tiles = (part, tiles, L.pdf_stats_result_rows(), y._version)
+
+
+def tile_stats_of(x):
+    t = getattr(x, '_pdf_bn_tiles', None)
+    if t is None or t[3] != x._version:
+        return None
+    return t
+
+
+def carry_stats(src, dst):
+    """`dst` is a re-shaped VIEW of `src` with the same rows x channels: it keeps the statistics partials."""
+    t = getattr(src, '_pdf_bn_tiles', None)
+    if t is not None and dst.data_ptr() == src.data_ptr():
+        dst._pdf_bn_tiles = t
+    return dst
+
+
 class _forced_fp32:
     """Launches issued inside run on the fp32 kernels even in bf16 mode (the precision flag is read on the host at launch)."""
 
@@ -339,7 +379,7 @@ class _Conv2d(Function):
     its epilogue (pdf_conv2d_bwd_data_add) -- instead of autograd's separate add pass over both tensors."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, skip=False):
+    def forward(ctx, x, w, b, stride, pad, act, skip=False, stats=False):
         hip.require_gpu(x, w)
         w_in = w
         x_in = x
@@ -351,7 +391,9 @@ class _Conv2d(Function):
         y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
         x16, w16 = shadow_of(x), shadow_of(w)
         _set_ops(x16, w16)
+        part = _stats_request(stats, N * OH * OW, Cout, x.device)
         _L().pdf_conv2d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream())
+        _stats_attach(y, part)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.s16 = (x16, w16)
         ctx.cfg = (stride, pad, act, b is not None)
@@ -393,16 +435,18 @@ class _Conv2d(Function):
             L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
                                     stride, pad, OH, OW, Cout, acc, stream())
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True, shadows=(x16, g16))
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE):
-    return _Conv2d.apply(x, w, b, stride, pad, act)
+def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, stats=False):
+    """stats=True: the output feeds a training-mode BatchNorm -- its statistics are taken in the GEMM epilogue (see
+    _stats_request); harmless when the launch has no statistics epilogue (the BatchNorm then runs its own pass)."""
+    return _Conv2d.apply(x, w, b, stride, pad, act, False, stats)
 
 
-def conv2d_with_skip(x, w, b=None, stride=1, pad=0, act=ACT_NONE):
+def conv2d_with_skip(x, w, b=None, stride=1, pad=0, act=ACT_NONE, stats=False):
     """-> (conv2d(x), x): use the second output as the block's identity shortcut (see _Conv2d)."""
-    return _Conv2d.apply(x, w, b, stride, pad, act, True)
+    return _Conv2d.apply(x, w, b, stride, pad, act, True, stats)
 
 
 class _Deconv2d(Function):
@@ -463,7 +507,7 @@ class _Linear(Function):
     """y[..., N] = act(x[..., K] w[N, K]^T + b)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, fp32=False):
+    def forward(ctx, x, w, b, act, fp32=False, stats=False):
         hip.require_gpu(x, w)
         w_in = w
         x, w = x.contiguous(), w.contiguous()
@@ -474,7 +518,9 @@ class _Linear(Function):
         x16, w16 = (None, None) if fp32 else (shadow_of(x), shadow_of(w))
         with _forced_fp32(fp32):
             _set_ops(x16, w16)
+            part = _stats_request(stats, M, Nn, x.device)
             _L().pdf_linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), M, Nn, K, K, K, Nn, act, stream())
+            _stats_attach(y, part)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.s16 = (x16, w16)
         ctx.fp32 = fp32
@@ -509,13 +555,13 @@ class _Linear(Function):
                 _set_ops(x16, g16)
                 L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K, fused_bias=True, shadows=(x16, g16))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE, fp32=False):
+def linear(x, w, b=None, act=ACT_NONE, fp32=False, stats=False):
     """fp32=True: keep this layer on the exact fp32 kernels when the library runs in bf16 mode (layers whose INPUT must not
-    be rounded -- absolute point coordinates that are only meaningful as differences)."""
-    return _Linear.apply(x, w, b, act, fp32)
+    be rounded -- absolute point coordinates that are only meaningful as differences).  stats: see conv2d."""
+    return _Linear.apply(x, w, b, act, fp32, stats)
 
 
 def as_matrix(weight):
@@ -631,7 +677,12 @@ class _BatchNorm(Function):
         if training:
             mean = torch.empty(C, device=dev)
             rstd = torch.empty(C, device=dev)
-            ws = _ws(L.pdf_bn_workspace_floats(C, R), dev)
+            tiles = tile_stats_of(x)
+            if tiles is not None:                           # statistics came out of the producing GEMM's epilogue
+                ws = None
+                L.pdf_set_bn_tile_stats(ptr(tiles[0]), tiles[1], tiles[2])
+            else:
+                ws = _ws(L.pdf_bn_workspace_floats(C, R), dev)
             y16 = new_shadow(y) if C % 4 == 0 else None
             if y16 is not None:
                 L.pdf_set_bf16_output(ptr(y16))
@@ -1353,7 +1404,12 @@ class _BnReluMaxK(Function):
         arg = torch.empty((R, C), dtype=torch.int32, device=dev)
         mean, rstd, scale, shift = (torch.empty(C, device=dev) for _ in range(4))
         L = _L()
-        ws = _ws(L.pdf_bn_workspace_floats(C, R * K), dev)
+        tiles = tile_stats_of(x) if training else None
+        if tiles is not None:
+            ws = None
+            L.pdf_set_bn_tile_stats(ptr(tiles[0]), tiles[1], tiles[2])
+        else:
+            ws = _ws(L.pdf_bn_workspace_floats(C, R * K), dev)
         L.pdf_bn_relu_maxk_fwd(ptr(x), C, C, R, K, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps, int(training),
                                ptr(out), C, ptr(arg), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
         ctx.save_for_backward(x, gamma, arg, mean, rstd, scale, shift)

@@ -32,18 +32,19 @@ class Bottleneck(nn.Module):
             self.downsample = nn.Sequential(Conv2d(cin, width * 4, 1, stride, 0, bias=False), BatchNorm(width * 4))
 
     def forward(self, x):
+        tr = self.training                             # every convolution feeds a BatchNorm: statistics in the GEMM epilogue
         if x.requires_grad:
             # conv1 hands the input back as the shortcut's source so both gradients of x meet in conv1's backward, which
             # accumulates onto the shortcut's gradient (identity, or the projection's backward-data) in the GEMM epilogue
             # -- no separate add pass over the block input's gradient
-            y, sc = F.conv2d_with_skip(x, self.conv1.weight, None, 1, 0)
+            y, sc = F.conv2d_with_skip(x, self.conv1.weight, None, 1, 0, stats=tr)
         else:
-            y, sc = self.conv1(x), x
+            y, sc = self.conv1(x, stats=tr), x
         y = self.bn1(y, relu=True)
-        y = self.bn2(self.conv2(y), relu=True)
-        y = self.conv3(y)
+        y = self.bn2(self.conv2(y, stats=tr), relu=True)
+        y = self.conv3(y, stats=tr)
         if self.downsample is not None:
-            sc = self.downsample[1](self.downsample[0](sc))
+            sc = self.downsample[1](self.downsample[0](sc, stats=tr))
         return self.bn3(y, relu=True, res=sc)          # relu(bn3(y) + shortcut) in one pass
 
 
@@ -124,9 +125,10 @@ class PointNet_Plus(nn.Module):
         """Rest of a set-abstraction MLP after its first 1x1 convolution (:48-65,67-103): BN -> ReLU, 2 x (conv -> BN -> ReLU),
         MaxPool over the K neighbours.  y1: rows [cloud*centroid*neighbour, channel].  The last BatchNorm, its ReLU and the
         pooling are one pass over the last convolution's output (F.bn_relu_max_over_k)."""
-        x = seq[1](y1.reshape(-1, y1.shape[-1]), relu=True)
-        x = seq[4](seq[3](x), relu=True)
-        return seq[7].relu_max_over_k(seq[6](x), K)
+        tr = seq[1].training
+        x = seq[1](F.carry_stats(y1, y1.reshape(-1, y1.shape[-1])), relu=True)
+        x = seq[4](seq[3](x, stats=tr), relu=True)
+        return seq[7].relu_max_over_k(seq[6](x, stats=tr), K)
 
     @staticmethod
     def _group_conv(conv, rows, S, K, r2):
@@ -178,7 +180,7 @@ class PointNet_Plus(nn.Module):
             e2, emb2 = e2
         y = torch.cat((x[:, :S2, :3], y.view(B, S2, 256), y.new_zeros(B, S2, _pad16(259) - 259)), 2)   # [B,S2,259 | 0]
         y = self.sft2(y, e2)                                                               #              (:147)
-        y = self._mlp_max(self.netR_3, self.netR_3[0](y), S2)                               # [B,1024]     (:152)
+        y = self._mlp_max(self.netR_3, self.netR_3[0](y, stats=self.training), S2)           # [B,1024]     (:152)
         return (y.view(B, 1, 1024), emb2) if chain else y.view(B, 1, 1024)
 
 
@@ -199,10 +201,11 @@ class ResNetSimple_decoder(nn.Module):
 
     def forward(self, x):
         fmaps = []
-        x = self.models[0][2](self.models[0][0](x, F.ACT_RELU))
+        tr = self.training
+        x = self.models[0][2](self.models[0][0](x, F.ACT_RELU, stats=tr))
         fmaps.append(x)
         for m in list(self.models)[1:]:
-            x = m[3](m[1](F.upsample2x(x), F.ACT_RELU))
+            x = m[3](m[1](F.upsample2x(x), F.ACT_RELU, stats=tr))
             fmaps.append(x)
         if self.up_scale:
             x = F.upsample2x(self.final_layer[1](F.upsample2x(x)))
@@ -287,14 +290,14 @@ class ResNetSimple(nn.Module):
         r = self.resnet
         img = F.cl(img)
         emb0 = self.e_conv1(img, F.ACT_RELU)                                              # :711
-        emb1 = r.bn1(r.conv1(img), relu=True)                                             # :712-715
+        emb1 = r.bn1(r.conv1(img, stats=r.bn1.training), relu=True)                                             # :712-715
         x4 = r.layer1(F.maxpool3s2(emb1))
         x3 = r.layer2(x4)
         x2 = r.layer3(x3)
         x1 = r.layer4(x2)
         pyr = F.l2norm_cat([self.p2(x4), self.p3(x3), self.p4(x2), self.p5(x1)],         # NHWC channel concat, written in place
                            [self.p2_l2.weight, self.p3_l2.weight, self.p4_l2.weight, self.p5_l2.weight])
-        return self.feat_bn(self.feat(pyr), relu=True), emb0, x1                          # :740-744
+        return self.feat_bn(self.feat(pyr, stats=self.training), relu=True), emb0, x1     # :740-744
 
     def trunk(self, img, ind, choose, cloud, depth=None, K_new=None, valid=None):
         """Everything the mesh decoder waits on: ResNet, pyramid, `feat`, the centre heat-map head, centre features,
@@ -302,7 +305,7 @@ class ResNetSimple(nn.Module):
         r = self.resnet
         img = F.cl(img)
         emb0 = self.e_conv1(img, F.ACT_RELU)                                              # :711
-        emb1 = r.bn1(r.conv1(img), relu=True)                                             # :712-715
+        emb1 = r.bn1(r.conv1(img, stats=r.bn1.training), relu=True)                                             # :712-715
         have_clouds = choose is not None and cloud is not None
         f_pn = None
         # Feature maps with several scatter-type consumers (emb0 / emb1: both hands' row gathers, emb1 also the max pool; x0: the
@@ -334,7 +337,7 @@ class ResNetSimple(nn.Module):
         st = {'x1': x1, 'ret': {}}
         pyr = F.l2norm_cat([self.p2(x4), self.p3(x3), self.p4(x2), self.p5(x1)],         # NHWC channel concat, written in place
                            [self.p2_l2.weight, self.p3_l2.weight, self.p4_l2.weight, self.p5_l2.weight])
-        x0 = self.feat_bn(self.feat(pyr), relu=True)                                      # :740-744
+        x0 = self.feat_bn(self.feat(pyr, stats=self.training), relu=True)                 # :740-744
         st['x0'] = x0
         hm_fc = self.hm
         st['ret']['hm'] = hm_fc[2](hm_fc[0](x0, F.ACT_RELU))                               # 'hm' is first in opt.heads (:291)
@@ -423,7 +426,7 @@ class resnet_mid(nn.Module):
         fmaps = []
         for i, conv in enumerate(self.convs):
             parts = [hms_f[i], dp_f[i]] + ([img_f[i]] if i > 0 else [])
-            fmaps.append(conv[2](conv[0](torch.cat(parts, 1), F.ACT_RELU)))
+            fmaps.append(conv[2](conv[0](torch.cat(parts, 1), F.ACT_RELU, stats=self.training)))
         return img_f[0][:, 0], img_f[0][:, 1], fmaps
 
 

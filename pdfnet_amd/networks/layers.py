@@ -25,8 +25,9 @@ class Conv2d(nn.Module):
         else:
             self.register_parameter('bias', None)
 
-    def forward(self, x, act=F.ACT_NONE):
-        return F.conv2d(x, self.weight, self.bias, self.stride, self.pad, act)
+    def forward(self, x, act=F.ACT_NONE, stats=False):
+        """stats: the output goes straight into a training-mode BatchNorm (F.conv2d)."""
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.pad, act, stats)
 
 
 class ConvTranspose2d(nn.Module):
@@ -80,14 +81,15 @@ class PointConv(nn.Module):
             w = torch.nn.functional.pad(w, (0, kpad - w.shape[1]))
         return w
 
-    def forward(self, x, act=F.ACT_NONE, npad=None):
+    def forward(self, x, act=F.ACT_NONE, npad=None, stats=False):
         """npad: also pad the OUTPUT channels (zero weight rows, zero bias) -- a 131- / 259-wide output has rows that are not
-        16-byte aligned, which sends its backward-data and weight-gradient GEMMs down the per-element path."""
+        16-byte aligned, which sends its backward-data and weight-gradient GEMMs down the per-element path.
+        stats: the output goes straight into a training-mode BatchNorm (F.linear)."""
         w, b = self.matrix(x.shape[-1]), self.bias
         if npad is not None and npad != w.shape[0]:
             w = torch.nn.functional.pad(w, (0, 0, 0, npad - w.shape[0]))
             b = torch.nn.functional.pad(b, (0, npad - b.shape[0]))
-        return F.linear(x, w, b, act)
+        return F.linear(x, w, b, act, stats=stats)
 
 
 class BatchNorm(nn.Module):

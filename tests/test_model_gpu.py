@@ -488,6 +488,22 @@ def test_rgb_only_encoder_config2_forward_and_gradients(setup, R):
     go = {n: p.grad for n, p in o.encoder.named_parameters() if p.grad is not None}
     gm = {n: p.grad for n, p in m.encoder.named_parameters() if p.grad is not None}
     assert set(go) == set(gm) and len(go) > 160
+    # Noise floor of fp32 arithmetic itself at this size: the SAME oracle evaluated in float32 against its
+    # float64 run.  At 256x256 the stem's gradients pass through 4x the pixels of the 128x128 case and fp32 round-off
+    # (in ANY implementation) moves them by more than the fixed bar; a tensor may then deviate by twice what plain PyTorch
+    # fp32 deviates -- never more than 1e-2 / cosine 0.999.
+    floor = {}
+    if R > 128:
+        o32 = O.load_model_cpu(make_opt(R))
+        o32.load_state_dict(sd)
+        o32.train()
+        outs32 = o32.encoder.rgb_encoder(img)
+        sum((a * b).sum() for a, b in zip(outs32, w)).backward()
+        for n, p in o32.encoder.named_parameters():
+            if p.grad is not None and n in go:
+                a, b = go[n], p.grad.double()
+                na, nb = float(a.norm()), float(b.norm())
+                floor[n] = (abs(na - nb) / (na + 1e-300), 1.0 - float((a * b).sum()) / (na * nb + 1e-300))
     bad = []
     for n, a in go.items():
         b = gm[n].detach().cpu().double()
@@ -495,8 +511,10 @@ def test_rgb_only_encoder_config2_forward_and_gradients(setup, R):
         if na < 1e-12:
             continue
         cos = float((a * b).sum()) / (na * nb + 1e-300)
+        fn, fc = floor.get(n, (0.0, 0.0))
+        tol_n, tol_c = min(1.5e-3 + 2.0 * fn, 1e-2), min(1e-4 + 2.0 * max(fc, 0.0), 1e-3)
         # conv biases / weights directly in front of a BatchNorm have an exactly-zero gradient: rounding noise only
-        if abs(na - nb) > 1.5e-3 * na + 1e-9 or cos < 0.9999:
+        if abs(na - nb) > tol_n * na + 1e-9 or cos < 1.0 - tol_c:
             ref = float(go[n[:-4] + 'weight'].norm()) if n.endswith('.bias') and (n[:-4] + 'weight') in go else 0.0
             if not (n.endswith('.bias') and na < 1e-4 * ref):
                 bad.append((n, na, nb, cos))

@@ -962,3 +962,67 @@ def test_gradient_chain_of_a_map_with_several_consumers(F):
     xr = dev(x).contiguous(memory_format=torch.channels_last).requires_grad_()
     F.gather_rows(xr, dev(ind2)).backward(dev(g2))
     close(xd.grad, xr.grad, 1e-6, what="chain with an unused consumer")
+
+
+# (N, Cin, H, W, Cout, k, stride, pad, act): one per statistics-capable launch -- the LDS-halo 128x128 tile, igemm_nt 128x128,
+# 128x64 (narrow output), 64x64 with K-step 32 and 16, the one-wave 32x32 tile, ragged M / N, the per-element (non-FAST) form
+# the last entry (few tiles under a long reduction) takes the split-K launch, which has none: the BatchNorm must fall back
+STAT_CONVS = [(10, 256, 64, 64, 256, 3, 1, 1, 0, True), (10, 128, 64, 64, 256, 3, 1, 1, 0, True), (40, 64, 64, 64, 64, 3, 1, 1, 0, True),
+              (8, 128, 32, 32, 128, 3, 1, 1, 1, True), (40, 64, 64, 64, 256, 1, 1, 0, 0, True), (4, 48, 16, 16, 96, 3, 1, 1, 0, True),
+              (2, 80, 4, 4, 64, 3, 1, 1, 0, True), (3, 48, 17, 15, 72, 3, 2, 1, 0, True), (2, 6, 9, 9, 20, 3, 1, 1, 1, True),
+              (4, 3, 256, 256, 64, 7, 2, 3, 0, True),          # the ResNet stem's own kernel (stem7x7_fwd_kernel)
+              (2, 512, 4, 4, 64, 3, 1, 1, 0, False)]
+
+
+@pytest.mark.parametrize("cfg", STAT_CONVS)
+def test_batchnorm_statistics_from_the_gemm_epilogue(F, cfg):
+    """conv -> training BatchNorm with the statistics taken out of the GEMM accumulators (IGemm::stat, per-row-block Chan
+    partials, fp64 combination in pdf_bn_train_fwd): same output, saved statistics, running statistics and gradients as the
+    BatchNorm's own statistics pass over the stored tensor, and both agree with a float64 evaluation."""
+    N, Cin, H, W, Cout, k, st, pad, act, has_epilogue = cfg
+    x = (rnd(N, Cin, H, W, seed=3) * 1.5 + 0.4)
+    w = rnd(Cout, Cin, k, k, seed=4) / (Cin * k * k) ** 0.5
+    g, b = torch.rand(Cout) + 0.5, rnd(Cout, seed=2)
+    rm0, rv0 = rnd(Cout, seed=5), torch.rand(Cout) + 0.5
+    res = {}
+    for mode in ('epilogue', 'pass'):
+        xd = dev(x).contiguous(memory_format=torch.channels_last).requires_grad_()
+        wd = dev(w).contiguous(memory_format=torch.channels_last).requires_grad_()
+        gd, bd = dev(g).requires_grad_(), dev(b).requires_grad_()
+        rm, rv = dev(rm0.clone()), dev(rv0.clone())
+        y = F.conv2d(xd, wd, None, st, pad, act, stats=(mode == 'epilogue'))
+        if mode == 'epilogue':
+            assert (F.tile_stats_of(y) is not None) == has_epilogue, "statistics epilogue expected: %s" % has_epilogue
+        else:
+            assert F.tile_stats_of(y) is None
+        out = F.batch_norm(y, gd, bd, rm, rv, True, 0.1, 1e-5, True)
+        out.backward(dev(rnd(*out.shape, seed=6)).contiguous(memory_format=torch.channels_last))
+        F.join_wgrad()
+        torch.cuda.synchronize()
+        res[mode] = (out.detach(), rm, rv, xd.grad, wd.grad, gd.grad, bd.grad, y.detach())
+    for a, c, what in zip(res['epilogue'], res['pass'], ('out', 'running_mean', 'running_var', 'dx', 'dw', 'dgamma', 'dbeta', 'y')):
+        close(a, c.cpu(), 2e-5, rtol=2e-5, what=what)
+    y64 = res['pass'][7].cpu().double().permute(0, 2, 3, 1).reshape(-1, Cout)
+    mean, var = y64.mean(0), y64.var(0, unbiased=True)
+    close(res['epilogue'][1], (0.9 * rm0.double() + 0.1 * mean).float(), 1e-5, rtol=1e-5, what="running_mean vs float64")
+    close(res['epilogue'][2], (0.9 * rv0.double() + 0.1 * var).float(), 1e-5, rtol=2e-5, what="running_var vs float64")
+
+
+def test_statistics_epilogue_survives_a_large_common_offset(F):
+    """mean >> std: sums of x and x^2 would cancel catastrophically in fp32; the epilogue's shifted / Chan-combined partials do
+    not (1x1 convolution with a large bias-like input channel: every output sits at ~1000 +- 1)."""
+    N, Cin, H, W, Cout = 4, 64, 32, 32, 128
+    x = rnd(N, Cin, H, W, seed=1)
+    x[:, 0] = 1000.0
+    w = rnd(Cout, Cin, 1, 1, seed=2) * 0.1
+    w[:, 0] = 1.0
+    xd, wd = dev(x).contiguous(memory_format=torch.channels_last), dev(w).contiguous(memory_format=torch.channels_last)
+    y = F.conv2d(xd, wd, None, 1, 0, 0, stats=True)
+    assert F.tile_stats_of(y) is not None
+    rm, rv = dev(torch.zeros(Cout)), dev(torch.ones(Cout))
+    out = F.batch_norm(y, dev(torch.ones(Cout)), dev(torch.zeros(Cout)), rm, rv, True, 1.0, 1e-5, False)
+    y64 = y.cpu().double().permute(0, 2, 3, 1).reshape(-1, Cout)
+    close(rm, y64.mean(0).float(), 1e-6, rtol=1e-6, what="mean")
+    close(rv, y64.var(0, unbiased=True).float(), 1e-6, rtol=1e-4, what="var")
+    ref = ((y64 - y64.mean(0)) / (y64.var(0, unbiased=False) + 1e-5).sqrt()).float()
+    close(out.permute(0, 2, 3, 1).reshape(-1, Cout), ref, 2e-3, what="normalised")          # (fp32 spacing at 1000 is 6e-5: y itself carries it)

@@ -107,7 +107,7 @@ def test_graph_replay_follows_the_loss_schedule_across_epoch_20():
     res, state = {}, {}
     for mode in ('eager', 'graph'):
         opt, m, crit, batch = _setup()
-        ctr0 = int(F.step_counter(torch.device('cuda')))
+        ctr0 = int(F.step_counter(torch.device('cuda', 0)))
         tr = Trainer(opt, m, crit, lr=0.0, use_graph=(mode == 'graph'))
         old, F.ASYNC_WGRAD = F.ASYNC_WGRAD, (mode != 'graph')
         try:
@@ -125,7 +125,7 @@ def test_graph_replay_follows_the_loss_schedule_across_epoch_20():
         BatchNorm.flush_counters()
         state[mode] = (m.encoder.feat_bn.running_mean.clone(), m.encoder.resnet.bn1.running_var.clone(),
                        int(m.encoder.feat_bn.num_batches_tracked), int(m.mid_model.convs[2][2].num_batches_tracked),
-                       int(F.step_counter(torch.device('cuda'))) - ctr0)
+                       int(F.step_counter(torch.device('cuda', 0))) - ctr0)
         if mode == 'graph':
             assert len(tr._graphs) == 2
     for i in range(4):
