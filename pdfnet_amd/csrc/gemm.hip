@@ -399,7 +399,11 @@ __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int BI, int BJ, int WM, int WN, bool FAST, int BKT = 16>
+// BUF (FAST only): operands through buffer descriptors -- a masked element (row past the split, padded tap, column past the
+// matrix) is an out-of-range 32-bit offset that the hardware returns as zeros; `if (ok) v = load` compiles to an exec-mask branch
+// with an s_waitcnt vmcnt(0) per load, which serialises the tile's loads (see wgemm_tn_dma).
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+template <int BI, int BJ, int WM, int WN, bool FAST, int BKT = 16, bool BUF = false>
 __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     constexpr int BK = BKT;
     constexpr int TM = BI / WM / 32, TN = BJ / WN / 32;
@@ -468,7 +472,37 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
         q_y[i] = rem / g.QW;
         q_x[i] = rem - q_y[i] * g.QW;
     }
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)Pp, 0, BUF ? g.pbytes : 0, 0x00020000);
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qp, 0, BUF ? g.qbytes : 0, 0x00020000);
     auto gload = [&](int mb) {
+        if constexpr (BUF) {
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                const int m = mb + pr + i * (256 / TPR_P);
+                const unsigned op = (m < me && i0 + pc < g.NI) ? (unsigned)(m * g.ldp + i0 + pc) * 4u : 0xffffffffu;
+                const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rsP, op, 0, 0);
+                rp[i] = *reinterpret_cast<const float4*>(&v);
+            }
+#pragma unroll
+            for (int i = 0; i < RQ; ++i) {
+                const int m = mb + qr + i * (256 / TPR_Q);
+                unsigned oq;
+                if (g.plain_q) oq = (m < me && qok[0]) ? (unsigned)(m * g.ldq + qch[0]) * 4u : 0xffffffffu;
+                else {
+                    const int iy = q_y[i] * g.sy + g.dy[qt[0]], ix = q_x[i] * g.sx + g.dx[qt[0]];
+                    const bool ok = m < me && qok[0] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                    oq = ok ? (unsigned)(((q_ni[i] * g.H + iy) * g.W + ix) * g.ldq + qch[0]) * 4u : 0xffffffffu;
+                }
+                const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, oq, 0, 0);
+                rq[i] = *reinterpret_cast<const float4*>(&v);
+                q_x[i] += BK;
+                while (q_x[i] >= g.QW) {
+                    q_x[i] -= g.QW;
+                    if (++q_y[i] == g.QH) { q_y[i] = 0; ++q_ni[i]; }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
             int m = mb + pr + i * (256 / TPR_P);
@@ -586,7 +620,13 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
 #define GLDS16(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                                           (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int ST>
+// BUF: both operands are addressed through buffer descriptors (buffer_load_dwordx4 ... offen lds): a 32-bit byte offset per lane,
+// and a masked lane (row past the split, padded tap, column past the matrix) takes the offset 0xffffffff, which the hardware's
+// range check turns into zeros -- no select between two 64-bit addresses.  The flat form computes each lane's address with
+// 64-bit multiply-adds under exec-mask branches and re-loads the zero word's address from the GOT four times per K-step, each
+// behind an s_waitcnt lgkmcnt(0) that also drains the wave's LDS reads (see the .s): ~150 scalar / vector instructions per K-step.
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+template <int ST, bool BUF>
 __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     constexpr int BI = 128, BJ = 128, BK = 16, WN = 2, TM = 2, TN = 2;
     __shared__ __attribute__((aligned(16))) float smem[ST * 2 * BK * 128];     // [stage][P|Q][k][128]  (48 KB, ONE array)
@@ -632,6 +672,8 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
         q_x[i] = rem - q_y[i] * g.QW;
     }
     const int wbase = __builtin_amdgcn_readfirstlane(wave) * 2 * 128;      // wave-uniform LDS row base (floats)
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)Pp, 0, BUF ? g.pbytes : 0, 0x00020000);
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qp, 0, BUF ? g.qbytes : 0, 0x00020000);
 
     auto issue = [&](int t, int st) {                       // tile t (rows ms + 16t ...) -> ring stage st
         float* sp = smem + (st * 2 + 0) * BK * 128 + wbase;
@@ -641,16 +683,29 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
         for (int i = 0; i < 2; ++i) {
             const int m = mb + pr + i * 8;
             const bool rowok = m < me;
-            const float* srcp = (rowok && pcol_ok) ? Pp + (long)m * g.ldp + i0 + pc : g_zero16;
-            const float* srcq;
-            if (g.plain_q) srcq = (rowok && qcol_ok) ? Qp + (long)m * g.ldq + qch : g_zero16;
-            else {
-                const int iy = q_y[i] * g.sy + tdy, ix = q_x[i] * g.sx + tdx;
-                const bool ok = rowok && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-                srcq = ok ? Qp + ((long)q_ni[i] * g.H * g.W + (long)iy * g.W + ix) * g.ldq + qch : g_zero16;
+            if constexpr (BUF) {
+                const unsigned op = (rowok && pcol_ok) ? (unsigned)(m * g.ldp + i0 + pc) * 4u : 0xffffffffu;
+                unsigned oq;
+                if (g.plain_q) oq = (rowok && qcol_ok) ? (unsigned)(m * g.ldq + qch) * 4u : 0xffffffffu;
+                else {
+                    const int iy = q_y[i] * g.sy + tdy, ix = q_x[i] * g.sx + tdx;
+                    const bool ok = rowok && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                    oq = ok ? (unsigned)(((q_ni[i] * g.H + iy) * g.W + ix) * g.ldq + qch) * 4u : 0xffffffffu;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, LDS_PTR(sp + i * 8 * 128), 16, op, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, LDS_PTR(sq + i * 8 * 128), 16, oq, 0, 0, 0);
+            } else {
+                const float* srcp = (rowok && pcol_ok) ? Pp + (long)m * g.ldp + i0 + pc : g_zero16;
+                const float* srcq;
+                if (g.plain_q) srcq = (rowok && qcol_ok) ? Qp + (long)m * g.ldq + qch : g_zero16;
+                else {
+                    const int iy = q_y[i] * g.sy + tdy, ix = q_x[i] * g.sx + tdx;
+                    const bool ok = rowok && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                    srcq = ok ? Qp + ((long)q_ni[i] * g.H * g.W + (long)iy * g.W + ix) * g.ldq + qch : g_zero16;
+                }
+                GLDS16(srcp, sp + i * 8 * 128);
+                GLDS16(srcq, sq + i * 8 * 128);
             }
-            GLDS16(srcp, sp + i * 8 * 128);
-            GLDS16(srcq, sq + i * 8 * 128);
         }
         if (g.QW * 2 >= BK) {
 #pragma unroll
@@ -771,10 +826,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1485,6 +1540,8 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     dim3 grid((unsigned)tiles, (unsigned)splits, (unsigned)groups);
     int brc = 0;
     const double wflops = 2.0 * groups * g.M * g.NI * NJ, wbytes = wgemm_bytes(g, groups);
+    // operand extents for the buffer-descriptor kernels (from the group's base pointer; every element the kernel may address)
+    const double pext = 4.0 * g.M * g.ldp, qext = 4.0 * (g.plain_q ? (double)g.M * g.ldq : (double)cdiv(g.M, g.QH * g.QW) * g.H * g.W * g.ldq);
     if (bf16) {
         g_shadow_operands += (g.P16 != nullptr) + (g.Q16 != nullptr);
         brc = launch_wgemm_bf16(g, splits, groups, small ? 1 : 0, s);
@@ -1493,17 +1550,23 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     if (brc == 1) {
     } else if (small) {
         const bool bk32 = fast && env_int(ENV_WG_BK32, 1);
-        KTimer kt(bk32 ? "wgemm_tn<64, 64, 2, 2, true, 32>" : fast ? "wgemm_tn<64, 64, 2, 2, true, 16>" : "wgemm_tn<64, 64, 2, 2, false, 16>", wflops, wbytes, s);
-        if (bk32) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
+        const bool buf = bk32 && pext < 4294967000.0 && qext < 4294967000.0 && env_int(ENV_WG_BUF, 1);
+        g.pbytes = buf ? (unsigned)pext : 0; g.qbytes = buf ? (unsigned)qext : 0;
+        KTimer kt(buf ? "wgemm_tn<64, 64, 2, 2, true, 32, true>" : bk32 ? "wgemm_tn<64, 64, 2, 2, true, 32, false>" : fast ? "wgemm_tn<64, 64, 2, 2, true, 16, false>" : "wgemm_tn<64, 64, 2, 2, false, 16, false>", wflops, wbytes, s);
+        if (buf) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32, true>), grid, dim3(256), 0, s, g);
+        else if (bk32) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);
     } else {
         const int dma = env_int(ENV_WG_DMA, 3);
         const int pad = env_int(ENV_WG_LDSPAD, 0) * 1024;
-        KTimer kt(fast && dma == 4 ? "wgemm_tn_dma<4>" : fast && dma == 3 ? "wgemm_tn_dma<3>" : fast ? "wgemm_tn<128, 128, 2, 2, true, 16>" : "wgemm_tn<128, 128, 2, 2, false, 16>",
+        const bool buf = fast && dma == 3 && pext < 4294967000.0 && qext < 4294967000.0 && env_int(ENV_WG_BUF, 1);
+        g.pbytes = buf ? (unsigned)pext : 0; g.qbytes = buf ? (unsigned)qext : 0;
+        KTimer kt(buf ? "wgemm_tn_dma<3, true>" : fast && dma == 4 ? "wgemm_tn_dma<4, false>" : fast && dma == 3 ? "wgemm_tn_dma<3, false>" : fast ? "wgemm_tn<128, 128, 2, 2, true, 16>" : "wgemm_tn<128, 128, 2, 2, false, 16>",
                   wflops, wbytes, s);
-        if (fast && dma == 4) hipLaunchKernelGGL(wgemm_tn_dma<4>, grid, dim3(256), pad, s, g);
-        else if (fast && dma == 3) hipLaunchKernelGGL(wgemm_tn_dma<3>, grid, dim3(256), pad, s, g);
+        if (buf) hipLaunchKernelGGL((wgemm_tn_dma<3, true>), grid, dim3(256), pad, s, g);
+        else if (fast && dma == 4) hipLaunchKernelGGL((wgemm_tn_dma<4, false>), grid, dim3(256), pad, s, g);
+        else if (fast && dma == 3) hipLaunchKernelGGL((wgemm_tn_dma<3, false>), grid, dim3(256), pad, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, false>), grid, dim3(256), 0, s, g);
     }

@@ -15,6 +15,7 @@
 //       weight-gradient kernel ran at 54-80 TFLOP/s, below the fp32 kernel.)
 #include "gemm_common.h"
 #include <cstdio>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -68,7 +69,7 @@ __device__ __forceinline__ void st_col4(unsigned char* dst, const float4& v) {
 // SA / SB: the A / B operand comes as a bf16 shadow (IGemm::A16 / B16) -- compile-time, because a run-time branch around the
 // operand loads makes the compiler drain them one by one (measured: 672 -> 376 img/s with `if (A16 != nullptr)` in the loop)
 template <int BM, int BN, int WM, int WN, bool KN, bool SHA, bool SHB>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
+__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IGemm g) {
     constexpr int BK = BK16;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int CPR = BK / 8;                          // 8-float chunks per ROW tile row
@@ -134,14 +135,21 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
 
     const int spt = (g.Cin + BK - 1) / BK;               // K-steps per tap
     const int nk = g.T * spt;
+    // DEEP (both operands are bf16 shadows: 8 x 16-byte loads per thread and K-step): TWO register sets, tiles are loaded two
+    // K-steps ahead.  A K-step is only 16 MFMAs (512 cycles) per wave and two waves share a SIMD, so a one-step prefetch leaves
+    // most of the ~2-4k cycle L2 / HBM latency exposed (the kernel ran at 12 % of the bf16 MFMA peak).  fp32 sources need 16
+    // float4 per set: two sets would not fit beside the accumulators.
+    constexpr bool DEEP = SHA && SHB;
+    constexpr int NS = DEEP ? 2 : 1;
     float4 ra[SHA ? 1 : RA][2];
     float4 rb[(KN || SHB) ? 1 : (RB > 0 ? RB : 1)][2];
     float4 rc[(KN && !SHB) ? NCB : 1];
-    u32x4 ra16[SHA ? RA : 1];                            // shadow operands: raw bf16 bits, 8 (ROW) / 4 (COL) elements per load
-    u32x4 rb16[(!KN && SHB) ? (RB > 0 ? RB : 1) : 1];
-    u32x2 rc16[(KN && SHB) ? NCB : 1];
+    u32x4 ra16[NS][SHA ? RA : 1];                        // shadow operands: raw bf16 bits, 8 (ROW) / 4 (COL) elements per load
+    u32x4 rb16[NS][(!KN && SHB) ? (RB > 0 ? RB : 1) : 1];
+    u32x2 rc16[NS][(KN && SHB) ? NCB : 1];
     int nt_tap = 0, nt_ci = 0, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * (KN ? g.btap : g.Cin);
-    auto gload = [&]() {
+    auto gload = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
         const int ci0 = nt_ci + ach;
         const bool kin = ci0 < g.Cin;                     // Cin % 8 == 0: a chunk is inside or outside as a whole
 #pragma unroll
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
             }
             if constexpr (SHA) {                            // 8 bf16 = one 16-byte load, stored to LDS as it is
                 const unsigned short* src = ok ? A16 + off : z16;
-                ra16[i] = *reinterpret_cast<const u32x4*>(src);
+                ra16[S][i] = *reinterpret_cast<const u32x4*>(src);
             } else {
                 const float* src = ok ? Ap + off : g_zero32;
                 ra[i][0] = *reinterpret_cast<const float4*>(src);
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
                 const bool ok = bval[i] && kin;
                 if constexpr (SHB) {
                     const unsigned short* src = ok ? B16 + bbase[i] + wbase + ci0 : z16;
-                    rb16[i] = *reinterpret_cast<const u32x4*>(src);
+                    rb16[S][i] = *reinterpret_cast<const u32x4*>(src);
                 } else {
                     const float* src = ok ? Bp + bbase[i] + wbase + ci0 : g_zero32;
                     rb[i][0] = *reinterpret_cast<const float4*>(src);
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
                 const bool ok = bcol_ok && ci < g.Cin;
                 if constexpr (SHB) {                        // 4 bf16 = 8 bytes
                     const unsigned short* src = ok ? B16 + (long)ci * g.ldb + wbase + n0 + bcg : z16;
-                    rc16[u] = *reinterpret_cast<const u32x2*>(src);
+                    rc16[S][u] = *reinterpret_cast<const u32x2*>(src);
                 } else rc[u] = *reinterpret_cast<const float4*>(ok ? Bp + (long)ci * g.ldb + wbase + n0 + bcg : g_zero32);
             }
         }
@@ -193,37 +201,32 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
             ddy = g.dy[nt_tap]; ddx = g.dx[nt_tap]; wbase = g.wt[nt_tap] * (KN ? g.btap : g.Cin);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto SET) {
+        constexpr int S = decltype(SET)::value;
         unsigned char* as = smem + buf * TILE;
         unsigned char* bs = as + ABYTES;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             unsigned char* d = as + (arow + i * (256 / CPR)) * LROW + ach * 2;
-            if constexpr (SHA) *reinterpret_cast<u32x4*>(d) = ra16[i]; else st_row8(d, ra[i][0], ra[i][1]);
+            if constexpr (SHA) *reinterpret_cast<u32x4*>(d) = ra16[S][i]; else st_row8(d, ra[i][0], ra[i][1]);
         }
         if (!KN) {
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 unsigned char* d = bs + (arow + i * (256 / CPR)) * LROW + ach * 2;
-                if constexpr (SHB) *reinterpret_cast<u32x4*>(d) = rb16[i]; else st_row8(d, rb[i][0], rb[i][1]);
+                if constexpr (SHB) *reinterpret_cast<u32x4*>(d) = rb16[S][i]; else st_row8(d, rb[i][0], rb[i][1]);
             }
         } else {
 #pragma unroll
             for (int u = 0; u < NCB; ++u) {
                 unsigned char* d = bs + (bk0 + u * KPP) * SB + bcg * 2;
-                if constexpr (SHB) *reinterpret_cast<u32x2*>(d) = rc16[u];
+                if constexpr (SHB) *reinterpret_cast<u32x2*>(d) = rc16[S][u];
                 else st_col4(d, rc[u]);
             }
         }
     };
-
-    gload();
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload();
-        const unsigned char* as = smem + cur * TILE;
+    auto compute = [&](int buf) {
+        const unsigned char* as = smem + buf * TILE;
         const unsigned char* bs = as + ABYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -237,9 +240,42 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemm g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NS - 1>;
+    if constexpr (DEEP) {
+        // tile t lives in register set t & 1 until it is written to LDS buffer t & 1 at the end of iteration t - 1;
+        // iteration t issues the loads of tile t + 2 into the set tile t has just left
+        // (the loads are issued UNCONDITIONALLY -- past the last tile every lane reads the zero word: a load under `if (more)`
+        // makes the compiler's s_waitcnt pass assume it may not have been issued and wait vmcnt(7..0) for the older set, which
+        // drains the set just issued as well)
+        gload(S0{});
+        gload(S1{});
+        lstore(0, S0{});
         __syncthreads();
-        cur ^= 1;
+        for (int kt = 0; kt < nk; kt += 2) {
+            gload(S0{});
+            compute(0);
+            lstore(1, S1{});
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            gload(S1{});
+            compute(1);
+            lstore(0, S0{});
+            __syncthreads();
+        }
+    } else {
+        gload(S0{});
+        lstore(0, S0{});
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) gload(S0{});
+            compute(cur);
+            if (kt + 1 < nk) lstore(cur ^ 1, S0{});
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // epilogue (same as igemm_nt): lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -315,7 +351,7 @@ int launch_igemm_bf16(const IGemm& g, hipStream_t s, int groups) {
 // the slow axis of both operands in HBM, so both are COL operands (tile[m][i], tile[m][j]) read with transposing loads.
 // BI x BJ tile, K-step 64 pixels, M split over blockIdx.y into slabs (summed by reduce_slabs of gemm.hip).
 template <int BI, int BJ, bool SP16, bool SQ16>
-__global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
+__global__ __launch_bounds__(256, 2) void wgemm_bf16_kernel(const WGemm g) {
     constexpr int BK = BK16;
     constexpr int WN = 2, TM = BI / 2 / 32, TN = BJ / 2 / 32;
     constexpr int GP = SP16 ? 8 : 4, GQ = SQ16 ? 8 : 4;  // columns per 16-byte load: 4 fp32 or 8 bf16 (shadow operand)
@@ -381,16 +417,19 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    constexpr bool DEEP = SP16 && SQ16;                    // two register sets, loads two K-steps ahead (see igemm_bf16_kernel)
+    constexpr int NS = DEEP ? 2 : 1;
     float4 rp[SP16 ? 1 : NP], rq[SQ16 ? 1 : NQ];
-    u32x4 rp16[SP16 ? NP : 1], rq16[SQ16 ? NQ : 1];        // 8 bf16 each
-    auto gload = [&](int mb) {
+    u32x4 rp16[NS][SP16 ? NP : 1], rq16[NS][SQ16 ? NQ : 1];        // 8 bf16 each
+    auto gload = [&](int mb, auto SET) {
+        constexpr int S = decltype(SET)::value;
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int m = mb + pk0 + u * KPP_P;
             const bool ok = m < me && pcol_ok;
             if constexpr (SP16) {                          // 4 bf16 = 8 bytes (the host never combines this with the bias partials)
                 const unsigned short* src = ok ? P16 + (long)m * g.ldp + i0 + pcg : z16;
-                rp16[u] = *reinterpret_cast<const u32x4*>(src);
+                rp16[S][u] = *reinterpret_cast<const u32x4*>(src);
             } else rp[u] = *reinterpret_cast<const float4*>(ok ? Pp + (long)m * g.ldp + i0 + pcg : g_zero32);
         }
 #pragma unroll
@@ -410,21 +449,22 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
             }
             if constexpr (SQ16) {
                 const unsigned short* src = ok ? Q16 + off : z16;
-                rq16[u] = *reinterpret_cast<const u32x4*>(src);
+                rq16[S][u] = *reinterpret_cast<const u32x4*>(src);
             } else {
                 const float* src = ok ? Qp + off : g_zero32;
                 rq[u] = *reinterpret_cast<const float4*>(src);
             }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto SET) {
+        constexpr int S = decltype(SET)::value;
         unsigned char* ps = smem + buf * TILE;
         unsigned char* qs = ps + PBYTES;
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             unsigned char* d = ps + (pk0 + u * KPP_P) * SP + pcg * 2;
             if constexpr (SP16) {
-                *reinterpret_cast<u32x4*>(d) = rp16[u];      // (never together with the bias partials: launch_wgemm drops P16 then)
+                *reinterpret_cast<u32x4*>(d) = rp16[S][u];   // (never together with the bias partials: launch_wgemm drops P16 then)
             } else {
                 st_col4(d, rp[u]);
                 if (do_bias) { bsum[0] += rp[u].x; bsum[1] += rp[u].y; bsum[2] += rp[u].z; bsum[3] += rp[u].w; }
@@ -433,18 +473,13 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             unsigned char* d = qs + (qk0 + u * KPP_Q) * SQ + qcg * 2;
-            if constexpr (SQ16) *reinterpret_cast<u32x4*>(d) = rq16[u];
+            if constexpr (SQ16) *reinterpret_cast<u32x4*>(d) = rq16[S][u];
             else st_col4(d, rq[u]);
         }
     };
 
-    if (ms < me) { gload(ms); lstore(0); }
-    __syncthreads();
-    int cur = 0;
-    for (int mb = ms; mb < me; mb += BK) {
-        const bool more = mb + BK < me;
-        if (more) gload(mb + BK);
-        const unsigned char* ps = smem + cur * TILE;
+    auto compute = [&](int buf) {
+        const unsigned char* ps = smem + buf * TILE;
         const unsigned char* qs = ps + PBYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -458,9 +493,37 @@ __global__ __launch_bounds__(256) void wgemm_bf16_kernel(const WGemm g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) lstore(cur ^ 1);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NS - 1>;
+    if constexpr (DEEP) {
+        gload(ms, S0{});                                    // (unconditional: rows past `me` read the zero word; see igemm_bf16_kernel)
+        gload(ms + BK, S1{});
+        lstore(0, S0{});
         __syncthreads();
-        cur ^= 1;
+        for (int mb = ms; mb < me; mb += 2 * BK) {
+            gload(mb + 2 * BK, S0{});
+            compute(0);
+            lstore(1, S1{});
+            __syncthreads();
+            if (mb + BK >= me) break;
+            gload(mb + 3 * BK, S1{});
+            compute(1);
+            lstore(0, S0{});
+            __syncthreads();
+        }
+    } else {
+        if (ms < me) { gload(ms, S0{}); lstore(0, S0{}); }
+        __syncthreads();
+        int cur = 0;
+        for (int mb = ms; mb < me; mb += BK) {
+            const bool more = mb + BK < me;
+            if (more) gload(mb + BK, S0{});
+            compute(cur);
+            if (more) lstore(cur ^ 1, S0{});
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     float bval = 0.f;

@@ -112,6 +112,9 @@ struct WGemm {
     // global_atomic_add_f32 -- no slabs, no reduction pass; the summation order then varies from run to run
     int atomic;
     const void* P16; const void* Q16;         // bf16 shadows of P / Q (see IGemm::A16)
+    // byte extents of P / Q as seen from their (group-adjusted) base pointers, for the buffer descriptors of wgemm_tn_dma<.., true>
+    // (0: an operand is >= 4 GiB - 32 and the flat-address form of the kernel is used)
+    unsigned int pbytes, qbytes;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
