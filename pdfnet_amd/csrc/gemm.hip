@@ -13,7 +13,15 @@
 
 #include "gemm_common.h"
 
-template <int BM, int BN, int WM, int WN, bool FAST, bool KN, int BKT = 16>
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 as_f4(const u32x4v& v) { return *reinterpret_cast<const float4*>(&v); }
+
+// BUF (FAST only): both operands are fetched through buffer descriptors with 32-bit byte offsets; a masked element (row past M,
+// padded tap, column past N) is the offset 0xffffffff, which the hardware's range check returns as zeros.  Per K-step and load
+// that is one add, one select and the load.  The flat-address form costs ~25 instructions per load -- 64-bit multiply-adds under
+// exec-mask branches, the zero word's address re-read from the GOT behind an s_waitcnt lgkmcnt(0) -- ~240 instructions per
+// K-step of the 64x64 tile against 16 MFMAs: with four waves per SIMD the VALU, not the matrix pipe, was the bound.
+template <int BM, int BN, int WM, int WN, bool FAST, bool KN, int BKT = 16, bool BUF = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
     constexpr int NT = WM * WN * 64;                     // threads: one wave per (BM/WM) x (BN/WN) sub-tile
     constexpr int BK = BKT, LD = BK + 1;                 // K-step: 16, or 32 for the small tile (half the barriers per flop)
@@ -85,8 +93,41 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
     int nt_tap = 0, nt_ci = kt0 * BK;
     if (g.ksteps > 0 && g.T > 1) { nt_tap = nt_ci / g.Cin; nt_ci -= nt_tap * g.Cin; }      // split-K over taps: Cin % BK == 0 (launch_igemm)
     int ddy = g.dy[nt_tap], ddx = g.dx[nt_tap], wbase = g.wt[nt_tap] * (KN ? g.btap : g.Cin);
+    // ---- BUF state: per-row byte offsets (fixed for the whole kernel), per-row validity under the current tap
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, BUF ? g.abytes : 0, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, BUF ? g.bbytes : 0, 0x00020000);
+    unsigned aoffB[RA], boffB[RB]; bool aok[RA];
+    int tapoffB = 0;
+    auto tap_valid = [&]() {
+        tapoffB = g.plain_in ? 0 : (ddy * g.W + ddx) * g.lda * 4;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
+            aok[i] = aval[i] && (g.plain_in || (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W));
+        }
+    };
+    if constexpr (BUF) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) aoffB[i] = (unsigned)(abase[i] + ((long)iy0[i] * g.W + ix0[i]) * g.lda + kq) * 4u;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) boffB[i] = (unsigned)(bbase[i] + (KN ? 0 : kq)) * 4u;
+        tap_valid();
+    }
     auto gload = [&](int kt) {
-        if (FAST) {
+        if constexpr (FAST && BUF) {
+            const unsigned sa = (unsigned)(tapoffB + nt_ci * 4);
+            const unsigned sb = KN ? (unsigned)((nt_ci * g.ldb + wbase) * 4) : (unsigned)((wbase + nt_ci) * 4);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, aok[i] ? aoffB[i] + sa : 0xffffffffu, 0, 0));
+#pragma unroll
+            for (int i = 0; i < RB; ++i) rb[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsB, bval[i] ? boffB[i] + sb : 0xffffffffu, 0, 0));
+            nt_ci += BK;
+            if (nt_ci >= g.Cin && nt_tap + 1 < g.T) {
+                ++nt_tap; nt_ci = 0;
+                ddy = g.dy[nt_tap]; ddx = g.dx[nt_tap]; wbase = g.wt[nt_tap] * (KN ? g.btap : g.Cin);
+                tap_valid();
+            }
+        } else if (FAST) {
             const int ci0 = nt_ci + kq;
             const long wofs = KN ? (long)nt_ci * g.ldb + wbase : (long)(wbase + ci0);
             nt_ci += BK;
@@ -262,7 +303,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
 // K order: channel chunk outer, tap inner (B tile = 128 x 16 weights per (chunk, tap) as before).
 // LDS: A halo [2][264][17] + B [2][128][17] floats = 53 KB -> 3 blocks / CU like igemm_nt<128,128>.
 #define HALO_MAX_PIX 264
-template <bool KN>
+template <bool KN, bool BUF = false>
 __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
     constexpr int BM = 128, BN = 128, WN = 2, BK = 16, LD = 17, TM = 2, TN = 2;
     constexpr int NH = (HALO_MAX_PIX * 4 + 255) / 256;                    // float4 halo loads per thread and chunk (5)
@@ -307,9 +348,22 @@ __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float4 ra[NH], rb[2];
+    // BUF: see igemm_nt -- 32-bit byte offsets through buffer descriptors, a masked element is the out-of-range offset 0xffffffff
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, BUF ? g.abytes : 0, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, BUF ? g.bbytes : 0, 0x00020000);
+    unsigned hoffB[NH], boffB[2];
+    if constexpr (BUF) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) hoffB[i] = (unsigned)hsrc[i] * 4u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) boffB[i] = (unsigned)(bbase[i] + (KN ? 0 : kq)) * 4u;
+    }
     auto hload = [&](int ci0) {
 #pragma unroll
-        for (int i = 0; i < NH; ++i) ra[i] = *reinterpret_cast<const float4*>(hok[i] ? Ap + hsrc[i] + ci0 : g_zero16);
+        for (int i = 0; i < NH; ++i) {
+            if constexpr (BUF) ra[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, hok[i] ? hoffB[i] + (unsigned)ci0 * 4u : 0xffffffffu, 0, 0));
+            else ra[i] = *reinterpret_cast<const float4*>(hok[i] ? Ap + hsrc[i] + ci0 : g_zero16);
+        }
     };
     auto hstore = [&](int buf) {
 #pragma unroll
@@ -318,9 +372,15 @@ __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
     };
     auto bload = [&](int ci0, int tap) {
         const int wb = g.wt[tap] * (KN ? g.btap : g.Cin);
-        const long wofs = KN ? (long)ci0 * g.ldb + wb : (long)(wb + ci0 + kq);
+        if constexpr (BUF) {
+            const unsigned sb = KN ? (unsigned)(ci0 * g.ldb + wb) * 4u : (unsigned)(wb + ci0) * 4u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const float4*>(bval[i] ? Bp + bbase[i] + wofs : g_zero16);
+            for (int i = 0; i < 2; ++i) rb[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsB, bval[i] ? boffB[i] + sb : 0xffffffffu, 0, 0));
+        } else {
+            const long wofs = KN ? (long)ci0 * g.ldb + wb : (long)(wb + ci0 + kq);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const float4*>(bval[i] ? Bp + bbase[i] + wofs : g_zero16);
+        }
     };
     auto bstore = [&](int buf) {
 #pragma unroll
@@ -402,7 +462,6 @@ __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
 // BUF (FAST only): operands through buffer descriptors -- a masked element (row past the split, padded tap, column past the
 // matrix) is an out-of-range 32-bit offset that the hardware returns as zeros; `if (ok) v = load` compiles to an exec-mask branch
 // with an s_waitcnt vmcnt(0) per load, which serialises the tile's loads (see wgemm_tn_dma).
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 template <int BI, int BJ, int WM, int WN, bool FAST, int BKT = 16, bool BUF = false>
 __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     constexpr int BK = BKT;
@@ -826,10 +885,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -955,9 +1014,12 @@ template <int BM, int BN, int WM, int WN, int BKF = 16>
 static void launch_igemm_tile(const IGemm& g, bool fast, dim3 grid, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     char nm[96] = "";
-    if (g_ktiming) snprintf(nm, sizeof nm, "igemm_nt<%d, %d, %d, %d, %s, %s, %d>", BM, BN, WM, WN, fast ? "true" : "false", g.b_kn ? "true" : "false", fast ? BKF : 16);
+    const bool buf = fast && g.abytes != 0 && env_int(ENV_IG_BUF, 1);
+    if (g_ktiming) snprintf(nm, sizeof nm, "igemm_nt<%d, %d, %d, %d, %s, %s, %d, %s>", BM, BN, WM, WN, fast ? "true" : "false", g.b_kn ? "true" : "false", fast ? BKF : 16, buf ? "true" : "false");
     KTimer kt(nm, 2.0 * g.M * g.N * g.K * grid.y, igemm_bytes(g, grid.y), s);
-    if (fast && g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, true, BKF>), grid, dim3(NT), 0, s, g);
+    if (buf && g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, true, BKF, true>), grid, dim3(NT), 0, s, g);
+    else if (buf) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, false, BKF, true>), grid, dim3(NT), 0, s, g);
+    else if (fast && g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, true, BKF>), grid, dim3(NT), 0, s, g);
     else if (fast) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, false, BKF>), grid, dim3(NT), 0, s, g);
     else if (g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, true>), grid, dim3(NT), 0, s, g);
     else hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, false, false>), grid, dim3(NT), 0, s, g);
@@ -1006,6 +1068,12 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
     if (g.b_kn) fast = fast && (g.N % 4 == 0) && (g.btap % 4 == 0);
     if (groups > 1) fast = fast && aligned16(g.B1) && (g.gsA % 4 == 0);
+    g.abytes = g.bbytes = 0;
+    if (fast) {                                          // operand extents for the buffer-descriptor form (per group, from the base pointers)
+        const double aext = 4.0 * (g.plain_in ? (double)g.M * g.lda : (double)cdiv(g.M, g.QH * g.QW) * g.H * g.W * g.lda);
+        const double bext = 4.0 * (double)(g.b_kn ? g.Cin : g.N) * g.ldb;
+        if (aext < 4294967000.0 && bext < 4294967000.0) { g.abytes = (unsigned)aext; g.bbytes = (unsigned)bext; }
+    }
     if (!fast && groups == 1 && !g.accum && (!g.b_kn || (g.T == 1 && g.wt[0] == 0)) && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
         (long)g.M * g.N >= (1L << 20)) {
         dim3 grid(grid_for((long)g.M * ((min(g.N, 256) + 3) / 4)), cdiv(g.N, 256));
@@ -1072,9 +1140,13 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     if (halo) {
         stat_plan(g, stat_cap, 128);
         const dim3 grid((g.M / 128) * cdiv(g.N, 128));
-        KTimer kt(g.b_kn ? "igemm_halo3x3<true>" : "igemm_halo3x3<false>", 2.0 * g.M * g.N * g.K, igemm_bytes(g, 1), s);
-        if (g.b_kn) hipLaunchKernelGGL(igemm_halo3x3<true>, grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL(igemm_halo3x3<false>, grid, dim3(256), 0, s, g);
+        const bool buf = g.abytes != 0 && env_int(ENV_IG_BUF, 1);
+        KTimer kt(g.b_kn ? (buf ? "igemm_halo3x3<true, true>" : "igemm_halo3x3<true, false>") : (buf ? "igemm_halo3x3<false, true>" : "igemm_halo3x3<false, false>"),
+                  2.0 * g.M * g.N * g.K, igemm_bytes(g, 1), s);
+        if (buf && g.b_kn) hipLaunchKernelGGL((igemm_halo3x3<true, true>), grid, dim3(256), 0, s, g);
+        else if (buf) hipLaunchKernelGGL((igemm_halo3x3<false, true>), grid, dim3(256), 0, s, g);
+        else if (g.b_kn) hipLaunchKernelGGL((igemm_halo3x3<true, false>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((igemm_halo3x3<false, false>), grid, dim3(256), 0, s, g);
         g_last_tile = 128128;
     }
     else if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) && !short_k)
@@ -1544,6 +1616,8 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     const double pext = 4.0 * g.M * g.ldp, qext = 4.0 * (g.plain_q ? (double)g.M * g.ldq : (double)cdiv(g.M, g.QH * g.QW) * g.H * g.W * g.ldq);
     if (bf16) {
         g_shadow_operands += (g.P16 != nullptr) + (g.Q16 != nullptr);
+        const bool fits = pext < 4294967000.0 && qext < 4294967000.0;
+        g.pbytes = fits ? (unsigned)pext : 0; g.qbytes = fits ? (unsigned)qext : 0;
         brc = launch_wgemm_bf16(g, splits, groups, small ? 1 : 0, s);
         if (brc < 0) return -brc;
     }

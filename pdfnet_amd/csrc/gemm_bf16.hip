@@ -27,6 +27,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static __device__ __attribute__((aligned(32))) float g_zero32[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+__device__ __forceinline__ float4 as_f4(const u32x4& v) { return *reinterpret_cast<const float4*>(&v); }
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     f32x2 f = {a, b};
     bf16x2 v = __builtin_convertvector(f, bf16x2);
@@ -148,57 +149,73 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IGemm g) {
     u32x4 rb16[NS][(!KN && SHB) ? (RB > 0 ? RB : 1) : 1];
     u32x2 rc16[NS][(KN && SHB) ? NCB : 1];
     int nt_tap = 0, nt_ci = 0, ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * (KN ? g.btap : g.Cin);
-    auto gload = [&](auto SET) {
-        constexpr int S = decltype(SET)::value;
-        const int ci0 = nt_ci + ach;
-        const bool kin = ci0 < g.Cin;                     // Cin % 8 == 0: a chunk is inside or outside as a whole
+    // Operands through buffer descriptors (see gemm.hip igemm_nt BUF): per-row byte offsets fixed for the whole kernel, a masked
+    // element = the out-of-range offset 0xffffffff (the hardware returns zeros); per K-step and load: one add, one select, the load.
+    // (The flat form -- 64-bit multiply-adds under exec-mask branches, the zero word's address re-read from the GOT -- cost ~250
+    // instructions per K-step against 16 MFMAs of 32 cycles: the kernels were issue-bound at ~12 % of the bf16 MFMA peak.)
+    constexpr unsigned EA = SHA ? 2u : 4u, EB = SHB ? 2u : 4u;          // element sizes of the A / B sources
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(SHA ? (void*)A16 : (void*)Ap, 0, SHA ? g.abytes / 2 : g.abytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(SHB ? (void*)B16 : (void*)Bp, 0, SHB ? g.bbytes / 2 : g.bbytes, 0x00020000);
+    unsigned aoffB[RA], boffB[RB > 0 ? RB : 1], coffB[NCB]; bool aok[RA];
+    int tapoff = 0;
+    auto tap_valid = [&]() {
+        tapoff = g.plain_in ? 0 : (ddy * g.W + ddx) * g.lda;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            // branch-free: the element offset is computed for every lane, a masked lane SELECTS the zero word's address
-            bool ok; long off;
-            if (g.plain_in) { ok = aval[i] && kin; off = abase[i] + ci0; }
+            const int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
+            aok[i] = aval[i] && (g.plain_in || (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W));
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < RA; ++i) aoffB[i] = (unsigned)(abase[i] + ((long)iy0[i] * g.W + ix0[i]) * g.lda + ach) * EA;
+    if (!KN) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) boffB[i] = (unsigned)(bbase[i] + ach) * EB;
+    } else {
+#pragma unroll
+        for (int u = 0; u < NCB; ++u) coffB[u] = (unsigned)((long)(bk0 + u * KPP) * g.ldb + n0 + bcg) * EB;
+    }
+    tap_valid();
+    auto gload = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
+        const bool kin = nt_ci + ach < g.Cin;             // Cin % 8 == 0: a chunk is inside or outside as a whole
+        const unsigned sa = (unsigned)(tapoff + nt_ci) * EA;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            // (masked: 0xffffffe0, so that the second half's offset + 16 is out of range as well -- extents are < 0xfffffed8)
+            const unsigned vo = (aok[i] && kin) ? aoffB[i] + sa : 0xffffffe0u;
+            if constexpr (SHA) ra16[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0);      // 8 bf16, stored to LDS as they are
             else {
-                const int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
-                ok = aval[i] && kin && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-                off = abase[i] + ((long)iy * g.W + ix) * g.lda + ci0;
-            }
-            if constexpr (SHA) {                            // 8 bf16 = one 16-byte load, stored to LDS as it is
-                const unsigned short* src = ok ? A16 + off : z16;
-                ra16[S][i] = *reinterpret_cast<const u32x4*>(src);
-            } else {
-                const float* src = ok ? Ap + off : g_zero32;
-                ra[i][0] = *reinterpret_cast<const float4*>(src);
-                ra[i][1] = *reinterpret_cast<const float4*>(src + 4);
+                ra[i][0] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
+                ra[i][1] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, vo + 16u, 0, 0));
             }
         }
         if (!KN) {
+            const unsigned sb = (unsigned)(wbase + nt_ci) * EB;
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                const bool ok = bval[i] && kin;
-                if constexpr (SHB) {
-                    const unsigned short* src = ok ? B16 + bbase[i] + wbase + ci0 : z16;
-                    rb16[S][i] = *reinterpret_cast<const u32x4*>(src);
-                } else {
-                    const float* src = ok ? Bp + bbase[i] + wbase + ci0 : g_zero32;
-                    rb[i][0] = *reinterpret_cast<const float4*>(src);
-                    rb[i][1] = *reinterpret_cast<const float4*>(src + 4);
+                const unsigned vo = (bval[i] && kin) ? boffB[i] + sb : 0xffffffe0u;
+                if constexpr (SHB) rb16[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, vo, 0, 0);
+                else {
+                    rb[i][0] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsB, vo, 0, 0));
+                    rb[i][1] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsB, vo + 16u, 0, 0));
                 }
             }
         } else {
+            const unsigned sb = (unsigned)(nt_ci * g.ldb + wbase) * EB;
 #pragma unroll
             for (int u = 0; u < NCB; ++u) {
-                const int ci = nt_ci + bk0 + u * KPP;
-                const bool ok = bcol_ok && ci < g.Cin;
-                if constexpr (SHB) {                        // 4 bf16 = 8 bytes
-                    const unsigned short* src = ok ? B16 + (long)ci * g.ldb + wbase + n0 + bcg : z16;
-                    rc16[S][u] = *reinterpret_cast<const u32x2*>(src);
-                } else rc[u] = *reinterpret_cast<const float4*>(ok ? Bp + (long)ci * g.ldb + wbase + n0 + bcg : g_zero32);
+                const bool ok = bcol_ok && nt_ci + bk0 + u * KPP < g.Cin;
+                const unsigned vo = ok ? coffB[u] + sb : 0xffffffffu;
+                if constexpr (SHB) rc16[S][u] = __builtin_amdgcn_raw_buffer_load_b64(rsB, vo, 0, 0);   // 4 bf16
+                else rc[u] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsB, vo, 0, 0));
             }
         }
         nt_ci += BK;
         if (nt_ci >= g.Cin && nt_tap + 1 < g.T) {
             ++nt_tap; nt_ci = 0;
             ddy = g.dy[nt_tap]; ddx = g.dx[nt_tap]; wbase = g.wt[nt_tap] * (KN ? g.btap : g.Cin);
+            tap_valid();
         }
     };
     auto lstore = [&](int buf, auto SET) {
@@ -337,6 +354,7 @@ static void launch_tile_bf16(const IGemm& g, dim3 grid, hipStream_t s) {
 
 int launch_igemm_bf16(const IGemm& g, hipStream_t s, int groups) {
     if (g.Cin % 8 != 0 || g.lda % 4 != 0 || g.ldb % 4 != 0) return 0;
+    if (g.abytes == 0 || g.bbytes == 0) return 0;        // an operand of 4 GiB or more: the fp32 kernels' flat-address form takes it
     if (g.b_kn && (g.N % 4 != 0 || g.btap % 4 != 0)) return 0;
     const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;
     if (g.N > 64 && t128 >= 192) launch_tile_bf16<128, 128, 2, 2>(g, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
@@ -421,39 +439,36 @@ __global__ __launch_bounds__(256, 2) void wgemm_bf16_kernel(const WGemm g) {
     constexpr int NS = DEEP ? 2 : 1;
     float4 rp[SP16 ? 1 : NP], rq[SQ16 ? 1 : NQ];
     u32x4 rp16[NS][SP16 ? NP : 1], rq16[NS][SQ16 ? NQ : 1];        // 8 bf16 each
+    // operands through buffer descriptors: 32-bit byte offsets, a masked element = the out-of-range offset (see igemm_bf16_kernel)
+    constexpr unsigned EP = SP16 ? 2u : 4u, EQ = SQ16 ? 2u : 4u;
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc(SP16 ? (void*)P16 : (void*)Pp, 0, SP16 ? g.pbytes / 2 : g.pbytes, 0x00020000);
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(SQ16 ? (void*)Q16 : (void*)Qp, 0, SQ16 ? g.qbytes / 2 : g.qbytes, 0x00020000);
     auto gload = [&](int mb, auto SET) {
         constexpr int S = decltype(SET)::value;
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int m = mb + pk0 + u * KPP_P;
-            const bool ok = m < me && pcol_ok;
-            if constexpr (SP16) {                          // 4 bf16 = 8 bytes (the host never combines this with the bias partials)
-                const unsigned short* src = ok ? P16 + (long)m * g.ldp + i0 + pcg : z16;
-                rp16[S][u] = *reinterpret_cast<const u32x4*>(src);
-            } else rp[u] = *reinterpret_cast<const float4*>(ok ? Pp + (long)m * g.ldp + i0 + pcg : g_zero32);
+            const unsigned vo = (m < me && pcol_ok) ? (unsigned)(m * g.ldp + i0 + pcg) * EP : 0xffffffffu;
+            if constexpr (SP16) rp16[S][u] = __builtin_amdgcn_raw_buffer_load_b128(rsP, vo, 0, 0);       // 8 bf16
+            else rp[u] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsP, vo, 0, 0));
         }
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int m = mb + qk0 + u * KPP_Q;
-            bool ok; long off;
-            if (g.plain_q) { ok = m < me && qcol_ok; off = (long)m * g.ldq + qch; }
+            unsigned vo;
+            if (g.plain_q) vo = (m < me && qcol_ok) ? (unsigned)(m * g.ldq + qch) * EQ : 0xffffffffu;
             else {
                 const int iy = q_y[u] * g.sy + tdy, ix = q_x[u] * g.sx + tdx;
-                ok = m < me && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-                off = ((long)q_ni[u] * g.H * g.W + (long)iy * g.W + ix) * g.ldq + qch;
+                const bool ok = m < me && qcol_ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                vo = ok ? (unsigned)(((q_ni[u] * g.H + iy) * g.W + ix) * g.ldq + qch) * EQ : 0xffffffffu;
                 q_x[u] += BK;
                 while (q_x[u] >= g.QW) {
                     q_x[u] -= g.QW;
                     if (++q_y[u] == g.QH) { q_y[u] = 0; ++q_ni[u]; }
                 }
             }
-            if constexpr (SQ16) {
-                const unsigned short* src = ok ? Q16 + off : z16;
-                rq16[S][u] = *reinterpret_cast<const u32x4*>(src);
-            } else {
-                const float* src = ok ? Qp + off : g_zero32;
-                rq[u] = *reinterpret_cast<const float4*>(src);
-            }
+            if constexpr (SQ16) rq16[S][u] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, vo, 0, 0);
+            else rq[u] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsQ, vo, 0, 0));
         }
     };
     auto lstore = [&](int buf, auto SET) {
@@ -540,6 +555,7 @@ __global__ __launch_bounds__(256, 2) void wgemm_bf16_kernel(const WGemm g) {
 int launch_wgemm_bf16(const WGemm& g, int splits, int groups, int small, hipStream_t s) {
     const int NJ = g.T * g.Cq;
     if (g.NI % 4 != 0 || g.Cq % 4 != 0 || g.ldp % 4 != 0 || g.ldq % 4 != 0 || g.rows_per_split % BK16 != 0) return 0;
+    if (g.pbytes == 0 || g.qbytes == 0) return 0;        // an operand of 4 GiB or more: the fp32 kernels take it
     const bool sp = g.P16 != nullptr, sq = g.Q16 != nullptr;
     char nm[96];
     snprintf(nm, sizeof nm, "wgemm_bf16_kernel<%d, %d, %s, %s>", small ? 64 : 128, small ? 64 : 128, sp ? "true" : "false", sq ? "true" : "false");

@@ -33,6 +33,8 @@ struct IGemm {
     // of the stored values C[m][c] over the block's rows m in [t BM, min(M, (t+1) BM)).  Chan-combined per lane -> half-wave
     // pair -> waves in a fixed order (deterministic); pdf_bn_train_fwd combines the row-blocks in fp64 (norm.hip).
     float* stat;
+    // byte extents of A / B from their (group-adjusted) base pointers for the buffer-descriptor form of the kernels (0: not used)
+    unsigned int abytes, bbytes;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
