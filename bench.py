@@ -192,6 +192,9 @@ class HbmProfiler:
         if name == 'pdf_gather_sub_bwd':                 # dy, lddy, idx, du, ldu, dv, ldv, Bc, N, S, K, C
             Bc, N, S, K, C = a[7:12]
             return Bc * (S * K * C * f + S * K * 4 + N * C * f + S * C * f)
+        if name == 'pdf_gather_sub_bwd_sorted':          # dy, lddy, start, list, du, ldu, dv, ldv, Bc, N, S, K, C
+            Bc, N, S, K, C = a[8:13]
+            return Bc * (S * K * C * f + S * K * 4 + N * C * f + S * C * f)
         if name == 'pdf_bn_relu_maxk_fwd':               # y, ldy, C, R, K, ..., training at 11
             C, R, K = a[2:5]
             return R * K * C * f * (2 if a[11] else 1) + R * C * 8
@@ -220,7 +223,7 @@ class HbmProfiler:
             return a[4] * f * 7
         return 0
 
-    NAMES = ('pdf_knn_ball_group', 'pdf_gather_sub_fwd', 'pdf_gather_sub_bwd', 'pdf_bn_relu_maxk_fwd', 'pdf_bn_relu_maxk_bwd',
+    NAMES = ('pdf_knn_ball_group', 'pdf_gather_sub_fwd', 'pdf_gather_sub_bwd', 'pdf_gather_sub_bwd_sorted', 'pdf_bn_relu_maxk_fwd', 'pdf_bn_relu_maxk_bwd',
              'pdf_bn_train_fwd', 'pdf_bn_train_bwd', 'pdf_gather_rows', 'pdf_scatter_rows_add', 'pdf_l2norm_fwd', 'pdf_l2norm_bwd',
              'pdf_upsample2x_fwd', 'pdf_upsample2x_bwd', 'pdf_adam_step')
 
@@ -665,7 +668,7 @@ def main():
                            "frac_of_mfma_peak": round(flops / 1e9 / B * out["value"] / world / 1e3 / peak, 4)},
         }
         hb, hs = sum(v[1] for v in hper.values()), sum(v[2] for v in hper.values())
-        pn = ('pdf_knn_ball_group', 'pdf_gather_sub_fwd', 'pdf_gather_sub_bwd', 'pdf_bn_relu_maxk_fwd', 'pdf_bn_relu_maxk_bwd', 'pdf_gather_rows', 'pdf_scatter_rows_add')
+        pn = ('pdf_knn_ball_group', 'pdf_gather_sub_fwd', 'pdf_gather_sub_bwd', 'pdf_gather_sub_bwd_sorted', 'pdf_bn_relu_maxk_fwd', 'pdf_bn_relu_maxk_bwd', 'pdf_gather_rows', 'pdf_scatter_rows_add')
         pb, ps = sum(hper[k][1] for k in pn if k in hper), sum(hper[k][2] for k in pn if k in hper)
         htraffic, htraffic_src = pmc_traffic_hbm()
         out["roofline_hbm"] = {

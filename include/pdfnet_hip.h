@@ -141,6 +141,12 @@ int pdf_gather_sub_fwd(const float* u, int ldu, const float* v, int ldv, const i
                        float* y, int ldy, void* stream);
 int pdf_gather_sub_bwd(const float* dy, int lddy, const int* idx, float* du, int ldu, float* dv, int ldv,
                        int Bc, int N, int S, int K, int C, void* stream);
+/* Deterministic form of the same backward (no float atomics; du needs no zero fill): pdf_invert_index turns idx [Bc][E = S*K]
+ * (values in [0, N)) into per-point slot lists -- start [Bc][N + 1], list [Bc][E] ascending within a point's segment, tmp [Bc][E]
+ * scratch -- once per forward; pdf_gather_sub_bwd_sorted sums each point's rows of dy in list order.  N <= 8191. */
+int pdf_invert_index(const int* idx, int Bc, int N, int E, int* start, int* list, int* tmp, void* stream);
+int pdf_gather_sub_bwd_sorted(const float* dy, int lddy, const int* start, const int* list, float* du, int ldu, float* dv, int ldv,
+                              int Bc, int N, int S, int K, int C, void* stream);
 /* _tranpose_and_gather_feat (lib/models/utils.py:22-26) on an NHWC map: out[b][m][:] = feat[b][ind'[b][m]][:],
  * ind' = pyramid index of intaghand_encoder.py:125-126 when shift > 0.  ind is int64 [B][>=M] with batch stride. */
 int pdf_gather_rows(const float* feat, int ldf, int C, long HW, const long* ind, long ind_bstride,

@@ -13,6 +13,11 @@
 
 #include "gemm_common.h"
 
+// Read the LDS fragments of the next k-pair while the MFMAs of the current one run (see igemm_nt).  Compile-time switch for A/B runs.
+#ifndef PDF_FRAG_PIPE
+#define PDF_FRAG_PIPE 1
+#endif
+constexpr bool FRAG_PIPE = PDF_FRAG_PIPE != 0;
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 as_f4(const u32x4v& v) { return *reinterpret_cast<const float4*>(&v); }
 
@@ -214,18 +219,25 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
         if (kt + 1 < kt1) gload(kt + 1);
         const float* as = As[cur];
         const float* bs = Bs[cur];
+        // fragments of k-pair kk + 1 are read while the MFMAs of pair kk run (two register sets, FRAG_PIPE)
+        float a[2][TM], b[2][TN];
+        auto frag = [&](int set, int kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[set][i] = as[arow + i * 32 * LD + kk * 2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[set][j] = bs[brow + j * 32 * LD + kk * 2];
+        };
+        if (FRAG_PIPE) frag(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[arow + i * 32 * LD + kk * 2];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[brow + j * 32 * LD + kk * 2];
+            const int set = FRAG_PIPE ? (kk & 1) : 0;
+            if (FRAG_PIPE) { if (kk + 1 < BK / 2) frag(set ^ 1, kk + 1); }
+            else frag(0, kk);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < kt1) lstore(cur ^ 1);
         __syncthreads();
@@ -412,17 +424,23 @@ __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
         const int toff = (g.dy[tap] * HC + g.dx[tap]) * LD;
         const float* as = As[abuf] + toff;
         const float* bs = Bs[bbuf];
+        float a[2][TM], b[2][TN];
+        auto frag = [&](int set, int kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[set][i] = as[arow[i] + kk * 2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[set][j] = bs[brow + j * 32 * LD + kk * 2];
+        };
+        if (FRAG_PIPE) frag(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[arow[i] + kk * 2];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[brow + j * 32 * LD + kk * 2];
+            const int set = FRAG_PIPE ? (kk & 1) : 0;
+            if (FRAG_PIPE) { if (kk + 1 < BK / 2) frag(set ^ 1, kk + 1); }
+            else frag(0, kk);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
         }
         if (more) bstore(bbuf ^ 1);
         if (stage_a) hstore(abuf ^ 1);
@@ -816,18 +834,24 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
 #pragma unroll
             for (int kb = 0; kb < BK; ++kb) bsum += ps[kb * 128 + tid];
         }
+        float a[2][TM], b[2][TN];
+        auto frag = [&](int set, int kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[set][i] = ps[aoff + kk * 2 * 128 + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[set][j] = qs[boff + kk * 2 * 128 + j * 32];
+        };
+        if (FRAG_PIPE) frag(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ps[aoff + kk * 2 * 128 + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = qs[boff + kk * 2 * 128 + j * 32];
+            const int set = FRAG_PIPE ? (kk & 1) : 0;
+            if (FRAG_PIPE) { if (kk + 1 < BK / 2) frag(set ^ 1, kk + 1); }
+            else frag(0, kk);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
         }
         st = st == ST - 1 ? 0 : st + 1;
         stn = stn == ST - 1 ? 0 : stn + 1;
@@ -1559,8 +1583,15 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     long tiles = (long)cdiv(g.NI, BI) * cdiv(NJ, BJ);
     // split policy (measured, tools/gemm_bench.py): big gradient matrices want ~1024 blocks; few-tile / huge-M
     // (HBM-bound) ones ~512 longer-running blocks; small M may go down to 128 rows per split to fill the chip
-    const int target = env_int(ENV_WG_TARGET, tiles >= 8 ? 1024 : 512);
-    int splits = (int)((target + tiles * groups - 1) / (tiles * groups));
+    // Split count.  Every block runs equally long and a CU holds `occ` of them (128x128 LDS-DMA kernel: 48 KB of LDS and 144
+    // VGPRs -> 3; 64x64 kernel: 4), so the chip takes blocks in passes of 256 * occ: a block count just above a pass (r02: 1008 =
+    // 768 + 240 for `feat`) leaves a second pass that runs at a third of the occupancy.  Fill ONE pass: splits = slots / tiles
+    // (measured on MI355X, tools/sweep_wg.sh: feat 104.8 -> 106.2, l3 3x3 70.8 -> 76.7, l4 3x3 71.7 -> 77.3 TFLOP/s; three full passes
+    // of smaller blocks are slower again: 99.9).  PDF_WG_TARGET=<blocks> restores the r02 rule (ceil(target / tiles)).
+    const bool bf16_mode = g_gemm_bf16 && fast;              // (the bf16 kernels: 80 KB / 48 KB of LDS -> 2 / 3 blocks per CU)
+    const int slots = env_int(ENV_WG_SLOTS, bf16_mode ? (small ? 768 : 512) : (small ? 1024 : 768));
+    const int target = env_int(ENV_WG_TARGET, 0);
+    int splits = target > 0 ? (int)((target + tiles * groups - 1) / (tiles * groups)) : (int)max(1L, slots / (tiles * groups));
     int max_by_rows = cdiv(g.M, env_int(ENV_WG_MINROWS, g.M >= 16384 ? 512 : 128));
     if (splits > max_by_rows) splits = max_by_rows;
     long per = (long)g.NI * g.ldw;
@@ -1577,7 +1608,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     // The blocks all run equally long and the chip retires them CU by CU: 1044 blocks on 256 CUs leave most CUs idle for the
     // fifth pass (82 % busy).  Among split counts down to 3/4 of the target, take the one whose block count fills whole
     // passes best (never more splits than the workspace was sized for).
-    if (splits > 1 && env_int(ENV_WG_QUANT, 1)) {
+    if (splits > 1 && target > 0 && env_int(ENV_WG_QUANT, 1)) {
         int best = splits; double beste = -1.0;
         for (int sp = splits; sp >= 1 && sp * 4 >= splits * 3; --sp) {
             const int r = cdiv(cdiv(g.M, sp), rq) * rq;

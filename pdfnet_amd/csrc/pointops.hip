@@ -220,6 +220,126 @@ __global__ __launch_bounds__(256) void gather_sub_bwd_kernel(const float* __rest
         }
     }
 }
+// ---- deterministic backward of the gather: the index is inverted ONCE per forward (per cloud: for every point the list of
+// (centroid, neighbour) slots e = s*K + k that picked it, ascending), and the backward sums each point's rows of dy in list order
+// -- no float atomics, bit-reproducible, every du row written exactly once (no zero fill).
+//   start [Bc][N + 1] : list segment of point n = [start[n], start[n + 1])      list [Bc][E] : slots, ascending within a segment
+// One block per cloud.  Counting sort: histogram (LDS atomics: integer, order-free), exclusive scan, fill through LDS cursors in
+// arbitrary order into `tmp`, then every segment is rank-sorted into `list` (segments are short: E / N = 16-32 on average).
+__global__ __launch_bounds__(256) void invert_index_kernel(const int* __restrict__ idx, int N, int E, int* __restrict__ start,
+                                                            int* __restrict__ list, int* __restrict__ tmp) {
+    extern __shared__ int sm[];                              // [N] counts / cursors, [N + 1] starts
+    int* cnt = sm;
+    int* st = sm + N;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* id = idx + (long)b * E;
+    int* lst = list + (long)b * E;
+    int* tm = tmp + (long)b * E;
+    for (int n = tid; n < N; n += 256) cnt[n] = 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) atomicAdd(&cnt[id[e]], 1);
+    __syncthreads();
+    if (wave == 0) {                                         // exclusive scan of the counts by one wave, 64 points per round
+        int run = 0;
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            const int n = n0 + lane;
+            const int c = n < N ? cnt[n] : 0;
+            int inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            if (n < N) st[n] = run + inc - c;
+            run += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) st[N] = run;
+    }
+    __syncthreads();
+    for (int n = tid; n <= N; n += 256) start[(long)b * (N + 1) + n] = st[n];
+    for (int n = tid; n < N; n += 256) cnt[n] = st[n];     // cursors
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) tm[atomicAdd(&cnt[id[e]], 1)] = e;
+    __syncthreads();                                         // (block-scope: the same block reads tmp back; global writes made visible by the barrier's fence)
+    __threadfence_block();
+    for (int n = wave; n < N; n += 4) {                      // rank sort of segment n by one wave
+        const int s0 = st[n], L = st[n + 1] - s0;
+        for (int i = lane; i < L; i += 64) {
+            const int v = tm[s0 + i];
+            int r = 0;
+            for (int j = 0; j < L; ++j) r += tm[s0 + j] < v;
+            lst[s0 + r] = v;
+        }
+    }
+}
+PDF_API int pdf_invert_index(const int* idx, int Bc, int N, int E, int* start, int* list, int* tmp, hipStream_t s) {
+    if (Bc <= 0 || E <= 0) return 0;
+    if (N <= 0 || (2L * N + 1) * 4 > 64 * 1024) return PDF_E_BADARG;
+    hipLaunchKernelGGL(invert_index_kernel, dim3(Bc), dim3(256), (2 * N + 1) * sizeof(int), s, idx, N, E, start, list, tmp);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+// du[b, n, :] = sum over the slots of point n, in list order, of dy[b, slot, :]      (one wave per point; lanes over channels)
+__global__ __launch_bounds__(256) void gather_sub_bwd_du_kernel(const float* __restrict__ dy, int lddy, const int* __restrict__ start,
+                                                                const int* __restrict__ list, float* __restrict__ du, int ldu,
+                                                                int N, int E, int C, long total_points) {
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    const int c4 = lane * 4;                                 // C <= 256: one float4 per lane
+    for (long pt = w0; pt < total_points; pt += nw) {
+        const long b = pt / N;
+        const int n = (int)(pt - b * N);
+        const int* st = start + b * (N + 1);
+        const int s0 = st[n], s1 = st[n + 1];
+        const int* lst = list + b * E;
+        const float* g = dy + b * E * lddy;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < C) {
+            int j = s0;
+            for (; j + 4 <= s1; j += 4) {                    // four rows in flight; summed in list order
+                const float4 x0 = *reinterpret_cast<const float4*>(g + (long)lst[j] * lddy + c4);
+                const float4 x1 = *reinterpret_cast<const float4*>(g + (long)lst[j + 1] * lddy + c4);
+                const float4 x2 = *reinterpret_cast<const float4*>(g + (long)lst[j + 2] * lddy + c4);
+                const float4 x3 = *reinterpret_cast<const float4*>(g + (long)lst[j + 3] * lddy + c4);
+                acc.x = ((((acc.x + x0.x) + x1.x) + x2.x) + x3.x); acc.y = ((((acc.y + x0.y) + x1.y) + x2.y) + x3.y);
+                acc.z = ((((acc.z + x0.z) + x1.z) + x2.z) + x3.z); acc.w = ((((acc.w + x0.w) + x1.w) + x2.w) + x3.w);
+            }
+            for (; j < s1; ++j) {
+                const float4 x = *reinterpret_cast<const float4*>(g + (long)lst[j] * lddy + c4);
+                acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+            }
+            *reinterpret_cast<float4*>(du + pt * ldu + c4) = acc;
+        }
+    }
+}
+// dv[b, s, :] = -sum_k dy[b, s, k, :]   (one wave per centroid, k in order)
+__global__ __launch_bounds__(256) void gather_sub_bwd_dv_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dv, int ldv,
+                                                                int K, int C, long total_rows) {
+    const int lane = threadIdx.x & 63;
+    const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    const int c4 = lane * 4;
+    for (long row = w0; row < total_rows; row += nw) {
+        if (c4 >= C) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* g = dy + row * K * lddy + c4;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float4 x = *reinterpret_cast<const float4*>(g + (long)k * lddy);
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        *reinterpret_cast<float4*>(dv + row * ldv + c4) = make_float4(-acc.x, -acc.y, -acc.z, -acc.w);
+    }
+}
+PDF_API int pdf_gather_sub_bwd_sorted(const float* dy, int lddy, const int* start, const int* list, float* du, int ldu, float* dv, int ldv,
+                                      int Bc, int N, int S, int K, int C, hipStream_t s) {
+    if (C > 256 || C % 4 != 0 || lddy % 4 != 0 || ldu % 4 != 0 || ldv % 4 != 0) return PDF_E_BADARG;
+    const long pts = (long)Bc * N, rows = (long)Bc * S;
+    if (pts == 0 || rows == 0) return 0;
+    hipLaunchKernelGGL(gather_sub_bwd_du_kernel, dim3(grid_for(pts * 64)), dim3(256), 0, s, dy, lddy, start, list, du, ldu, N, S * K, C, pts);
+    hipLaunchKernelGGL(gather_sub_bwd_dv_kernel, dim3(grid_for(rows * 64)), dim3(256), 0, s, dy, lddy, dv, ldv, K, C, rows);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
 PDF_API int pdf_gather_sub_bwd(const float* dy, int lddy, const int* idx, float* du, int ldu, float* dv, int ldv,
                                int Bc, int N, int S, int K, int C, hipStream_t s) {
     if (C > 256) return PDF_E_BADARG;

@@ -1331,19 +1331,35 @@ class _GatherSub(Function):
         Bc, N, C = u.shape
         S, K = idx.shape[1], idx.shape[2]
         y = torch.empty((Bc, S, K, C), device=u.device)
-        _L().pdf_gather_sub_fwd(ptr(u), C, ptr(v), C, ptr(idx), Bc, N, S, K, C, ptr(y), C, stream())
-        ctx.save_for_backward(idx)
+        L = _L()
+        L.pdf_gather_sub_fwd(ptr(u), C, ptr(v), C, ptr(idx), Bc, N, S, K, C, ptr(y), C, stream())
+        inv = None
+        if GATHER_SORTED and (u.requires_grad or v.requires_grad) and N <= 8191:
+            # the index inverted now, beside the forward (it is launch-bound filler there), for a backward without float atomics
+            start = torch.empty((Bc, N + 1), dtype=torch.int32, device=u.device)
+            lst = torch.empty((Bc, S * K), dtype=torch.int32, device=u.device)
+            L.pdf_invert_index(ptr(idx), Bc, N, S * K, ptr(start), ptr(lst), ptr(torch.empty_like(lst)), stream())
+            inv = (start, lst)
+        ctx.save_for_backward(idx, *(inv or ()))
         ctx.cfg = (Bc, N, S, K, C)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (idx,) = ctx.saved_tensors
+        idx = ctx.saved_tensors[0]
         Bc, N, S, K, C = ctx.cfg
-        du = torch.zeros((Bc, N, C), device=dy.device)
         dv = torch.empty((Bc, S, C), device=dy.device)
-        _L().pdf_gather_sub_bwd(ptr(dy.contiguous()), C, ptr(idx), ptr(du), C, ptr(dv), C, Bc, N, S, K, C, stream())
+        if len(ctx.saved_tensors) == 3:                      # deterministic: every point sums its rows of dy in a fixed order
+            start, lst = ctx.saved_tensors[1:]
+            du = torch.empty((Bc, N, C), device=dy.device)
+            _L().pdf_gather_sub_bwd_sorted(ptr(dy.contiguous()), C, ptr(start), ptr(lst), ptr(du), C, ptr(dv), C, Bc, N, S, K, C, stream())
+        else:
+            du = torch.zeros((Bc, N, C), device=dy.device)
+            _L().pdf_gather_sub_bwd(ptr(dy.contiguous()), C, ptr(idx), ptr(du), C, ptr(dv), C, Bc, N, S, K, C, stream())
         return du, dv, None
+
+
+GATHER_SORTED = _os.environ.get("PDFNET_GATHER_SORTED", "1") != "0"
 
 
 def gather_sub(u, v, idx):

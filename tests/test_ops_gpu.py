@@ -225,6 +225,47 @@ def test_group_then_conv_equals_conv_then_gather(F, N, S, K, Cin, Cout):
     close(bd.grad, br.grad.float(), 2e-3, rtol=1e-4, what="d bias")
 
 
+def test_gather_sub_backward_is_deterministic_and_needs_no_atomics(F):
+    """pdf_invert_index + pdf_gather_sub_bwd_sorted: every point's slot list is the ascending list of (centroid, neighbour) slots
+    that picked it; the backward is bit-identical from run to run and equals the atomic form to summation-order accuracy -- incl.
+    points nobody picked (zero rows) and a hub point picked by every centroid."""
+    B, N, S, K, C = 3, 512, 128, 64, 128
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, N, (B, S, K), generator=g, dtype=torch.int32)
+    idx[0, :, 0] = 7                                          # a hub: 128 slots
+    idx[1][idx[1] == 11] = 12                                 # point 11 of cloud 1 is picked by nobody
+    u, v = dev(torch.randn(B, N, C, generator=g)).requires_grad_(), dev(torch.randn(B, S, C, generator=g)).requires_grad_()
+    gy = dev(torch.randn(B, S, K, C, generator=g))
+    idd = dev(idx)
+    L = F._L()
+    start = torch.empty((B, N + 1), dtype=torch.int32, device='cuda')
+    lst = torch.empty((B, S * K), dtype=torch.int32, device='cuda')
+    L.pdf_invert_index(idd.data_ptr(), B, N, S * K, start.data_ptr(), lst.data_ptr(), torch.empty_like(lst).data_ptr(), None)
+    torch.cuda.synchronize()
+    flat = idx.reshape(B, -1).long()
+    for b in range(B):
+        order = torch.sort(flat[b], stable=True)[1].int()      # slots grouped by point, ascending inside a group
+        assert torch.equal(lst[b].cpu(), order)
+        assert torch.equal(start[b].cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(flat[b], minlength=N).cumsum(0)]))
+    outs = []
+    for mode in (True, True, False):
+        F.GATHER_SORTED = mode
+        try:
+            uu, vv = u.detach().clone().requires_grad_(), v.detach().clone().requires_grad_()
+            F.gather_sub(uu, vv, idd).backward(gy)
+            torch.cuda.synchronize()
+            outs.append((uu.grad.clone(), vv.grad.clone()))
+        finally:
+            F.GATHER_SORTED = True
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])          # run to run: identical bits
+    close(outs[0][0], outs[2][0], 1e-4, rtol=1e-5, what="du sorted vs atomic")
+    close(outs[0][1], outs[2][1], 1e-4, rtol=1e-5, what="dv")
+    assert float(outs[0][0][1, 11].abs().max()) == 0.0
+    ref = torch.zeros(B, N, C, dtype=torch.float64).index_put_((torch.arange(B)[:, None].expand(B, S * K).reshape(-1), flat.reshape(-1)),
+                                                                gy.cpu().double().reshape(-1, C), accumulate=True)
+    close(outs[0][0], ref.float(), 1e-4, rtol=1e-5, what="du vs float64")
+
+
 def test_pool_upsample_relu(F):
     x = rnd(2, 16, 13, 14, seed=1)
     xr = x.clone().requires_grad_()
