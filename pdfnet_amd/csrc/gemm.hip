@@ -15,7 +15,7 @@
 
 // Read the LDS fragments of the next k-pair while the MFMAs of the current one run (see igemm_nt).  Compile-time switch for A/B runs.
 #ifndef PDF_FRAG_PIPE
-#define PDF_FRAG_PIPE 1
+#define PDF_FRAG_PIPE 0
 #endif
 constexpr bool FRAG_PIPE = PDF_FRAG_PIPE != 0;
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -810,6 +810,50 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
         }
     };
 
+    // ---- uniform form of `issue` (WGemm::uniform; BUF only): positions of rows mb and mb + 8 in scalar registers
+    const bool uni = BUF && g.uniform != 0;
+    const int utap = __builtin_amdgcn_readfirstlane(j0 < NJ ? j0 / g.Cq : 0);
+    const int udy = g.dy[utap], udx = g.dx[utap];
+    int s_ni[2], s_y[2], s_x[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = __builtin_amdgcn_readfirstlane(ms + i * 8), hw = g.QH * g.QW;
+        s_ni[i] = m / hw;
+        const int rem = m - s_ni[i] * hw;
+        s_y[i] = rem / g.QW;
+        s_x[i] = rem - s_y[i] * g.QW;
+    }
+    const int cx = pr * g.sx + udx;                                                       // this thread's x = s_x * sx + cx
+    const unsigned kP = (unsigned)(pr * g.ldp + i0 + pc) * 4u;                            // per-thread constants of the byte offsets
+    const unsigned kQ = g.plain_q ? (unsigned)(pr * g.ldq + qch) * 4u : (unsigned)(cx * g.ldq + (jcol - utap * g.Cq)) * 4u;
+    auto issue_uni = [&](int t, int st) {
+        float* sp = smem + (st * 2 + 0) * BK * 128 + wbase;
+        float* sq = smem + (st * 2 + 1) * BK * 128 + wbase;
+        const int mb = ms + t * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m0 = mb + i * 8;                       // scalar
+            const bool rowok = m0 + pr < me;
+            unsigned sQ; bool yok = true, xok = true;
+            if (g.plain_q) sQ = (unsigned)(m0 * g.ldq) * 4u;
+            else {
+                const int iy = s_y[i] * g.sy + udy, x0 = s_x[i] * g.sx;
+                yok = iy >= 0 && iy < g.H;
+                sQ = (unsigned)(((s_ni[i] * g.H + iy) * g.W + x0) * g.ldq) * 4u;
+                xok = x0 + cx >= 0 && x0 + cx < g.W;
+                s_x[i] += BK;                                // advance to the next K-step (uniform: scalar unit)
+                while (s_x[i] >= g.QW) {
+                    s_x[i] -= g.QW;
+                    if (++s_y[i] == g.QH) { s_y[i] = 0; ++s_ni[i]; }
+                }
+            }
+            const unsigned op = (rowok && pcol_ok) ? kP + (unsigned)(m0 * g.ldp) * 4u : 0xffffffffu;
+            const unsigned oq = (rowok && qcol_ok && yok && xok) ? kQ + sQ : 0xffffffffu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, LDS_PTR(sp + i * 8 * 128), 16, op, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, LDS_PTR(sq + i * 8 * 128), 16, oq, 0, 0, 0);
+        }
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -821,13 +865,13 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     const int aoff = (lane >> 5) * 128 + wm * TM * 32 + (lane & 31);
     const int boff = (lane >> 5) * 128 + wn * TN * 32 + (lane & 31);
 #pragma unroll
-    for (int p = 0; p < ST - 1; ++p) issue(p, p);
+    for (int p = 0; p < ST - 1; ++p) { if (uni) issue_uni(p, p); else issue(p, p); }
     int st = 0, stn = ST - 1;
     for (int t = 0; t < nt; ++t) {
         // this wave's 4 DMAs of tile t have landed (the ST-2 younger tiles may still fly) ...
         if (ST == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // ... and everybody's; everybody also finished reading tile t-1
-        issue(t + ST - 1, stn);                             // refill the stage tile t-1 used (rows past the end read zeros)
+        if (uni) issue_uni(t + ST - 1, stn); else issue(t + ST - 1, stn);      // refill the stage tile t-1 used (rows past the end read zeros)
         const float* ps = smem + (st * 2 + 0) * BK * 128;
         const float* qs = smem + (st * 2 + 1) * BK * 128;
         if (do_bias) {
@@ -909,10 +953,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1667,6 +1711,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         const int pad = env_int(ENV_WG_LDSPAD, 0) * 1024;
         const bool buf = fast && dma == 3 && pext < 4294967000.0 && qext < 4294967000.0 && env_int(ENV_WG_BUF, 1);
         g.pbytes = buf ? (unsigned)pext : 0; g.qbytes = buf ? (unsigned)qext : 0;
+        g.uniform = (buf && (g.plain_q || (g.QW % 8 == 0 && g.Cq % 128 == 0)) && env_int(ENV_WG_UNIFORM, 1)) ? 1 : 0;
         KTimer kt(buf ? "wgemm_tn_dma<3, true>" : fast && dma == 4 ? "wgemm_tn_dma<4, false>" : fast && dma == 3 ? "wgemm_tn_dma<3, false>" : fast ? "wgemm_tn<128, 128, 2, 2, true, 16>" : "wgemm_tn<128, 128, 2, 2, false, 16>",
                   wflops, wbytes, s);
         if (buf) hipLaunchKernelGGL((wgemm_tn_dma<3, true>), grid, dim3(256), pad, s, g);

@@ -117,6 +117,10 @@ struct WGemm {
     // byte extents of P / Q as seen from their (group-adjusted) base pointers, for the buffer descriptors of wgemm_tn_dma<.., true>
     // (0: an operand is >= 4 GiB - 32 and the flat-address form of the kernel is used)
     unsigned int pbytes, qbytes;
+    // wgemm_tn_dma<.., true>: the 16 rows of a K-step are two runs of 8 consecutive pixels of ONE image row each (QW % 8 == 0)
+    // and the tile's 128 columns belong to one tap (Cq % 128 == 0), or Q is plain rows: the pixel position, the tap and all
+    // offsets except a per-thread constant are block-uniform, i.e. scalar-unit work
+    int uniform;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 

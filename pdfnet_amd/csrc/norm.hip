@@ -149,19 +149,23 @@ __global__ __launch_bounds__(FIN_TX * FIN_TY) void bn_finalize_kernel(const floa
 // Statistics that arrive as per-row-block (mean, M2) pairs out of the producing GEMM's epilogue (IGemm::stat, gemm_common.h):
 // part[(t * C + c) * 2 + {0, 1}], block t covers rows [t rpt, min(R, (t + 1) rpt)).  Combined in fp64 in block order
 // (deterministic): mean = sum n_t mean_t / R, M2 = sum (M2_t + n_t mean_t^2) - R mean^2.
-__global__ __launch_bounds__(FIN_TX * FIN_TY) void bn_finalize_tiles_kernel(const float* __restrict__ part, int tiles, long rpt, int C, long R,
+#define FT_C 16                                              // channels per block
+#define FT_L 64                                              // tile lanes per channel
+__global__ __launch_bounds__(FT_C * FT_L) void bn_finalize_tiles_kernel(const float* __restrict__ part, int tiles, long rpt, int C, long R,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
                                    float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                    float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double s1[FIN_TY][FIN_TX], s2[FIN_TY][FIN_TX];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int c = blockIdx.x * FIN_TX + tx;
+    // 16 channels x 64 tile lanes per block (C / 16 blocks): with 64 channels per block a 64-channel layer was ONE block walking
+    // 1,024 row blocks 16 at a time -- 15 us per call of pure latency, 78 calls per step
+    __shared__ double s1[FT_L][FT_C], s2[FT_L][FT_C];
+    const int tx = threadIdx.x & (FT_C - 1), ty = threadIdx.x / FT_C;
+    const int c = blockIdx.x * FT_C + tx;
     double a = 0.0, b = 0.0;
     if (c < C) {
         const float2* p2 = reinterpret_cast<const float2*>(part) + c;
 #pragma unroll 4
-        for (int t = ty; t < tiles; t += FIN_TY) {
+        for (int t = ty; t < tiles; t += FT_L) {
             const float2 v = p2[(long)t * C];
             const double n = (double)min(rpt, R - (long)t * rpt), m = (double)v.x;
             a += n * m; b += (double)v.y + n * m * m;
@@ -169,9 +173,12 @@ __global__ __launch_bounds__(FIN_TX * FIN_TY) void bn_finalize_tiles_kernel(cons
     }
     s1[ty][tx] = a; s2[ty][tx] = b;
     __syncthreads();
+    for (int h = FT_L / 2; h >= 1; h >>= 1) {                // fixed tree: deterministic
+        if (ty < h) { s1[ty][tx] += s1[ty + h][tx]; s2[ty][tx] += s2[ty + h][tx]; }
+        __syncthreads();
+    }
     if (c >= C || ty != 0) return;
-    a = 0.0; b = 0.0;
-    for (int j = 0; j < FIN_TY; ++j) { a += s1[j][tx]; b += s2[j][tx]; }
+    a = s1[0][tx]; b = s2[0][tx];
     const double n = (double)R;
     const double mean = a / n;
     double var = b / n - mean * mean;
@@ -452,7 +459,7 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
     BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, nullptr};
     if (ts.part != nullptr) {                                // statistics came out of the producing GEMM's epilogue: no pass over x
         if (ts.tiles * ts.rows < R || (ts.tiles - 1) * ts.rows >= R) return PDF_E_BADARG;
-        hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ts.part, (int)ts.tiles, ts.rows, C, R, gamma, beta,
+        hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(C, FT_C)), dim3(FT_C * FT_L), 0, s, ts.part, (int)ts.tiles, ts.rows, C, R, gamma, beta,
                            running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
         fin.counters = reinterpret_cast<int*>(1);            // (marks "finalised" for the branch below)
     } else if (v4_ok(C, {ldx}, {x})) {
@@ -693,7 +700,7 @@ PDF_API int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, 
     const TileStats ts = take_tile_stats();
     if (training && ts.part != nullptr) {
         if (ts.tiles * ts.rows < rows || (ts.tiles - 1) * ts.rows >= rows) return PDF_E_BADARG;
-        hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ts.part, (int)ts.tiles, ts.rows, C, rows, gamma, beta,
+        hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(C, FT_C)), dim3(FT_C * FT_L), 0, s, ts.part, (int)ts.tiles, ts.rows, C, rows, gamma, beta,
                            running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
     } else if (training) {
         long chunks = bn_chunks(C, rows);

@@ -2,6 +2,7 @@
 // row gathers/scatters on NHWC maps, and the max-over-neighbours pool.  All HBM-bound: coalesced
 // row reads, the cloud staged once per 16 centroids in LDS, wavefront ballots for the selection.
 #include "common.h"
+#include <mutex>
 
 // ---------------------------------------------------------------------------------------------
 // knn_ball_group: replaces group_points / group_points_2 (reference lib/utils/utils.py:134-188):
@@ -226,18 +227,19 @@ __global__ __launch_bounds__(256) void gather_sub_bwd_kernel(const float* __rest
 //   start [Bc][N + 1] : list segment of point n = [start[n], start[n + 1])      list [Bc][E] : slots, ascending within a segment
 // One block per cloud.  Counting sort: histogram (LDS atomics: integer, order-free), exclusive scan, fill through LDS cursors in
 // arbitrary order into `tmp`, then every segment is rank-sorted into `list` (segments are short: E / N = 16-32 on average).
-__global__ __launch_bounds__(256) void invert_index_kernel(const int* __restrict__ idx, int N, int E, int* __restrict__ start,
-                                                            int* __restrict__ list, int* __restrict__ tmp) {
-    extern __shared__ int sm[];                              // [N] counts / cursors, [N + 1] starts
+#define INV_NT 1024
+__global__ __launch_bounds__(INV_NT) void invert_index_kernel(const int* __restrict__ idx, int N, int E, int* __restrict__ start,
+                                                              int* __restrict__ list) {
+    extern __shared__ int sm[];                              // [N] counts / cursors, [N + 1] starts, [E] unsorted slots (u16 pairs when E <= 65536)
     int* cnt = sm;
     int* st = sm + N;
+    unsigned short* tm = reinterpret_cast<unsigned short*>(sm + 2 * N + 1);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* id = idx + (long)b * E;
     int* lst = list + (long)b * E;
-    int* tm = tmp + (long)b * E;
-    for (int n = tid; n < N; n += 256) cnt[n] = 0;
+    for (int n = tid; n < N; n += INV_NT) cnt[n] = 0;
     __syncthreads();
-    for (int e = tid; e < E; e += 256) atomicAdd(&cnt[id[e]], 1);
+    for (int e = tid; e < E; e += INV_NT) atomicAdd(&cnt[id[e]], 1);
     __syncthreads();
     if (wave == 0) {                                         // exclusive scan of the counts by one wave, 64 points per round
         int run = 0;
@@ -253,13 +255,12 @@ __global__ __launch_bounds__(256) void invert_index_kernel(const int* __restrict
         if (lane == 0) st[N] = run;
     }
     __syncthreads();
-    for (int n = tid; n <= N; n += 256) start[(long)b * (N + 1) + n] = st[n];
-    for (int n = tid; n < N; n += 256) cnt[n] = st[n];     // cursors
+    for (int n = tid; n <= N; n += INV_NT) start[(long)b * (N + 1) + n] = st[n];
+    for (int n = tid; n < N; n += INV_NT) cnt[n] = st[n];  // cursors
     __syncthreads();
-    for (int e = tid; e < E; e += 256) tm[atomicAdd(&cnt[id[e]], 1)] = e;
-    __syncthreads();                                         // (block-scope: the same block reads tmp back; global writes made visible by the barrier's fence)
-    __threadfence_block();
-    for (int n = wave; n < N; n += 4) {                      // rank sort of segment n by one wave
+    for (int e = tid; e < E; e += INV_NT) tm[atomicAdd(&cnt[id[e]], 1)] = (unsigned short)e;      // arbitrary order inside a segment ...
+    __syncthreads();
+    for (int n = wave; n < N; n += INV_NT / 64) {            // ... then every segment is rank-sorted by one wave (slots are distinct), all in LDS
         const int s0 = st[n], L = st[n + 1] - s0;
         for (int i = lane; i < L; i += 64) {
             const int v = tm[s0 + i];
@@ -270,9 +271,13 @@ __global__ __launch_bounds__(256) void invert_index_kernel(const int* __restrict
     }
 }
 PDF_API int pdf_invert_index(const int* idx, int Bc, int N, int E, int* start, int* list, int* tmp, hipStream_t s) {
+    (void)tmp;                                               // (the unsorted slots live in LDS)
     if (Bc <= 0 || E <= 0) return 0;
-    if (N <= 0 || (2L * N + 1) * 4 > 64 * 1024) return PDF_E_BADARG;
-    hipLaunchKernelGGL(invert_index_kernel, dim3(Bc), dim3(256), (2 * N + 1) * sizeof(int), s, idx, N, E, start, list, tmp);
+    const size_t lds = (2 * (size_t)N + 1) * 4 + (size_t)E * 2;
+    if (N <= 0 || E > 65536 || lds > 160 * 1024) return PDF_E_BADARG;
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(invert_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    hipLaunchKernelGGL(invert_index_kernel, dim3(Bc), dim3(INV_NT), lds, s, idx, N, E, start, list);
     PDF_LAUNCH_CHECK();
     return 0;
 }

@@ -240,7 +240,7 @@ def test_gather_sub_backward_is_deterministic_and_needs_no_atomics(F):
     L = F._L()
     start = torch.empty((B, N + 1), dtype=torch.int32, device='cuda')
     lst = torch.empty((B, S * K), dtype=torch.int32, device='cuda')
-    L.pdf_invert_index(idd.data_ptr(), B, N, S * K, start.data_ptr(), lst.data_ptr(), torch.empty_like(lst).data_ptr(), None)
+    L.pdf_invert_index(idd.data_ptr(), B, N, S * K, start.data_ptr(), lst.data_ptr(), None, None)
     torch.cuda.synchronize()
     flat = idx.reshape(B, -1).long()
     for b in range(B):
@@ -1036,7 +1036,10 @@ def test_batchnorm_statistics_from_the_gemm_epilogue(F, cfg):
             assert (F.tile_stats_of(y) is not None) == has_epilogue, "statistics epilogue expected: %s" % has_epilogue
         else:
             assert F.tile_stats_of(y) is None
-        out = F.batch_norm(y, gd, bd, rm, rv, True, 0.1, 1e-5, True)
+        # (no ReLU here: the two paths' (scale, shift) differ in the last bit, which would flip the mask of the odd element whose
+        # normalised value is within 1e-7 of zero -- an O(1) change of that element's gradient in either valid evaluation, about
+        # once per 10^7 elements, i.e. a flaky element-wise comparison.  The mask logic itself is test_batchnorm's subject.)
+        out = F.batch_norm(y, gd, bd, rm, rv, True, 0.1, 1e-5, False)
         out.backward(dev(rnd(*out.shape, seed=6)).contiguous(memory_format=torch.channels_last))
         F.join_wgrad()
         torch.cuda.synchronize()

@@ -37,9 +37,20 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+BF16 = os.environ.get("PDF_BENCH_BF16", "0") != "0"      # bf16 kernels with bf16 shadows of every operand
+
+
+def sh(*ts):
+    """bf16 mode: hand the library the bf16 copies of the next call's two operands."""
+    if BF16:
+        L.pdf_set_bf16_operands(ptr(ts[0]), ptr(ts[1]))
+
+
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     dev = 'cuda'
+    if BF16:
+        L.pdf_set_gemm_precision(1)
     tot = {}
     for name, Cin, H, Cout, k, s, p in CONVS:
         if flt not in name:
@@ -54,9 +65,10 @@ def main():
         n = L.pdf_wgrad_workspace_floats(B * OH * OH, Cout, k * k * Cin)
         ws = torch.empty(max(n, 1), device=dev)
         fl = 2.0 * B * OH * OH * Cout * Cin * k * k
-        t_f = timeit(lambda: L.pdf_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream()))
-        t_d = timeit(lambda: L.pdf_conv2d_bwd_data(ptr(dy), ptr(w), ptr(dx), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, stream()))
-        t_w = timeit(lambda: L.pdf_conv2d_bwd_weight(ptr(x), ptr(dy), ptr(dw), None, ptr(ws), n, B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream()))
+        x16, w16, dy16 = (t.to(torch.bfloat16) for t in (x, w, dy))
+        t_f = timeit(lambda: (sh(x16, w16), L.pdf_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream())))
+        t_d = timeit(lambda: (sh(dy16, w16), L.pdf_conv2d_bwd_data(ptr(dy), ptr(w), ptr(dx), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, stream())))
+        t_w = timeit(lambda: (sh(x16, dy16), L.pdf_conv2d_bwd_weight(ptr(x), ptr(dy), ptr(dw), None, ptr(ws), n, B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream())))
         print("%-16s M=%7d N=%5d K=%5d  %7.1f GF | fwd %6.3f ms %6.1f TF | bwd_data %6.3f ms %6.1f TF | bwd_w %6.3f ms %6.1f TF" %
               (name, B * OH * OH, Cout, Cin * k * k, fl / 1e9, t_f * 1e3, fl / t_f / 1e12, t_d * 1e3, fl / t_d / 1e12, t_w * 1e3, fl / t_w / 1e12), flush=True)
     for name, M, K, N in LINS:

@@ -51,11 +51,11 @@ def load(d, counter, by_tile=False):
     return agg
 
 
-HBM_KERNELS = ("knn_ball_group_kernel", "gather_sub_fwd_kernel", "gather_sub_bwd_kernel", "bn_relu_maxk_fwd_kernel", "bn_maxk_bwd_partial_kernel",
+HBM_KERNELS = ("knn_ball_group_kernel", "gather_sub_fwd_kernel", "gather_sub_bwd_kernel", "gather_sub_bwd_du_kernel", "gather_sub_bwd_dv_kernel", "invert_index_kernel", "bn_relu_maxk_fwd_kernel", "bn_maxk_bwd_partial_kernel",
                "bn_maxk_bwd_apply_kernel", "gather_rows_kernel", "scatter_rows_kernel", "bn_partial_v4_kernel", "affine_apply_v4_kernel",
                "bn_bwd_partial_v4_kernel", "bn_bwd_apply_v4_kernel", "l2norm_fwd_kernel", "l2norm_bwd_kernel", "l2norm_cat_fwd_kernel", "l2norm_cat_bwd_kernel", "up2_fwd_v4_kernel", "up2_bwd_v4_kernel",
                "adam_kernel", "fps_kernel", "maxk_fwd_kernel", "maxk_bwd_kernel", "group_bwd_kernel")
-POINTNET = HBM_KERNELS[:8]
+POINTNET = HBM_KERNELS[:11]
 
 
 def hbm_family(fdir, wdir, steps):
@@ -114,6 +114,25 @@ def main():
         n = fk[k][0] or wk[k][0]
         b = fk[k][1] * 1024 * 2 + wk[k][1] * 1024
         res["kernels"][k] = {"launches_per_step": n / steps, "hbm_GB_per_step": b / steps / 1e9, "bytes_per_launch": b / max(n, 1)}
+    # per rocprofv3 SYMBOL (as bench.py's roofline.kernel names it: 'void ' and the argument list stripped): the bench line looks its
+    # dominant symbol up here for `roofline.traffic`
+    def by_symbol(d, counter):
+        f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter or not re.search(r"gemm|reduce_slabs|splitk|stem7x7|tiny_conv|narrow_wgrad", r["Kernel_Name"]):
+                continue
+            k = re.sub(r"^void |\(.*$", "", r["Kernel_Name"])
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+        return agg
+    fs, ws = by_symbol(fdir, "FETCH_SIZE"), by_symbol(wdir, "WRITE_SIZE")
+    res["symbols"] = {}
+    for k in sorted(set(fs) | set(ws)):
+        n = fs[k][0] or ws[k][0]
+        rb, wb = fs[k][1] * 1024 * 2, ws[k][1] * 1024
+        res["symbols"][k] = {"launches_per_step": n / steps, "read_MB_per_launch": rb / max(n, 1) / 1e6, "write_MB_per_launch": wb / max(n, 1) / 1e6,
+                             "bytes_per_launch": (rb + wb) / max(n, 1)}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res["tag"] = sys.argv[5] if len(sys.argv) > 5 else ""
     res["gemm_hip_sha256"] = hashlib.sha256(open(os.path.join(root, "pdfnet_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
