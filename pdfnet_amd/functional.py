@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from . import hip
-from .hip import ptr, stream
+from .hip import ptr, ptr_at, stream
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 import os as _os
@@ -1721,6 +1721,42 @@ class _RegressJointsPair(Function):
 
 def regress_joints_pair(reg0, reg1, verts):
     return _RegressJointsPair.apply(reg0, reg1, verts)
+
+
+class _ProjectPoints(Function):
+    """p[..., b, n, :] = pts[..., b, n, :] @ K[b]^T  (pts [G..., B, n, 3], K [B, 3, 3], no gradient to K): the pinhole matrix
+    product of get_Landmarks_new (Mano_render.py:203-209) -- a HIP kernel instead of an aten (rocBLAS) batched matmul."""
+
+    @staticmethod
+    def forward(ctx, pts, K):
+        hip.require_gpu(pts, K)
+        pts, K = pts.contiguous(), K.detach().float().reshape(-1, 3, 3).contiguous()
+        B, n = pts.shape[-3], pts.shape[-2]
+        if pts.shape[-1] != 3 or K.shape[0] != B:
+            raise ValueError("pdfnet_amd: project_points wants pts [..., B, n, 3] and K [B, 3, 3]")
+        out = torch.empty_like(pts)
+        G = pts.numel() // (B * n * 3)
+        for h in range(G):
+            _L().pdf_bmm_strided(ptr_at(pts, h * B * n * 3), ptr(K), ptr_at(out, h * B * n * 3), B, n, 3, 3, 1,
+                                 n * 3, 0, 3, 1, 9, 0, 1, 3, n * 3, 3, 1, 0, stream())
+        ctx.save_for_backward(K)
+        ctx.cfg = (G, B, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (K,) = ctx.saved_tensors
+        G, B, n = ctx.cfg
+        g = g.contiguous()
+        d = torch.empty_like(g)
+        for h in range(G):
+            _L().pdf_bmm_strided(ptr_at(g, h * B * n * 3), ptr(K), ptr_at(d, h * B * n * 3), B, n, 3, 3, 1,
+                                 n * 3, 0, 3, 1, 9, 0, 3, 1, n * 3, 3, 1, 0, stream())
+        return d, None
+
+
+def project_points(pts, K):
+    return _ProjectPoints.apply(pts, K)
 
 
 class _RowLoss(Function):

@@ -34,7 +34,7 @@ def bone_direction_loss(j2d, gt2d, a, c):
 
 def perspective(pts, K):
     """Mano_render.py:203-209 `get_Landmarks_new`."""
-    p = pts @ K.reshape(-1, 3, 3).transpose(2, 1)                        # pts [..., B, n, 3]
+    p = F.project_points(pts, K)                                          # pts [..., B, n, 3] @ K[b]^T
     return p[..., :2] / (p[..., 2:] + 1e-7)
 
 
