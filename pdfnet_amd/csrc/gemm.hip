@@ -975,14 +975,18 @@ static int env_int(int which, int dflt) {
 #include <cstring>
 struct KRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 static std::vector<KRec> g_krecs;
+static std::vector<hipEvent_t> g_kpool;                      // events are created when timing is switched on, not inside the timed step
+static size_t g_kpool_next = 0;
 static std::mutex g_krec_mu;
 static int g_ktiming = 0;
+#define PDF_KTIMER_POOL 8192
 KTimer::KTimer(const char* name, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
     if (!g_ktiming) return;
-    KRec r; r.name = name; r.flops = flops; r.bytes = bytes;
-    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-    (void)hipEventRecord(r.e0, s);
     std::lock_guard<std::mutex> lk(g_krec_mu);
+    if (g_kpool_next + 2 > g_kpool.size()) return;           // pool exhausted: this launch goes unrecorded
+    KRec r; r.name = name; r.flops = flops; r.bytes = bytes;
+    r.e0 = g_kpool[g_kpool_next++]; r.e1 = g_kpool[g_kpool_next++];
+    (void)hipEventRecord(r.e0, s);
     slot = (int)g_krecs.size();
     g_krecs.push_back(r);
 }
@@ -995,8 +999,13 @@ KTimer::~KTimer() {
 PDF_API int pdf_debug_kernel_timing(int on) {
     std::lock_guard<std::mutex> lk(g_krec_mu);
     if (on) {
-        for (auto& r : g_krecs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         g_krecs.clear();
+        g_kpool_next = 0;
+        while (g_kpool.size() < PDF_KTIMER_POOL) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return PDF_E_WORKSPACE;
+            g_kpool.push_back(e);
+        }
     }
     g_ktiming = on ? 1 : 0;
     return 0;
@@ -1611,6 +1620,31 @@ PDF_API int pdf_conv2d_bwd_data_add(const float* dy, const float* w, float* dx,
     return conv2d_bwd_data(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, 1, s);
 }
 
+// Split count of a weight-gradient launch: the candidate with the smallest modelled time (see launch_wgemm).
+//   tiles: output tiles x groups; occ: blocks a CU holds; cap: most splits allowed (rows, workspace); rq: row quantum of a split;
+//   tile: 64 or 128; slab_bytes: bytes of one split's partial result.
+static int wg_choose_splits(long tiles, int M, int occ, int cap, int rq, int tile, double slab_bytes) {
+    // time for m co-resident blocks on one CU, in units of "one block alone at full pipe efficiency" (measured efficiencies of
+    // 1 / 2 / 3 / 4 resident blocks of these kernels: ~0.5 / 0.72 / 0.83 / 0.85)
+    static const double G[5] = {0.0, 2.0, 2.78, 3.61, 4.7};
+    const double row_ns = (tile == 128 ? 32768.0 : 8192.0) / 614.5;       // one row of a tile at 157.3 TFLOP/s / 256 CUs
+    const double t0_rows = tile == 128 ? 64.0 : 160.0;                    // prologue + epilogue of a block, in rows
+    int best = 1; double best_t = 1e300;
+    for (int sp = 1; sp <= cap; ++sp) {
+        const int r = cdiv(cdiv(M, sp), rq) * rq;
+        const int nsp = cdiv(M, r);
+        if (nsp != sp) continue;                                           // (not a distinct candidate)
+        const long blocks = tiles * nsp;
+        const long busiest = (blocks + 255) / 256;
+        if (busiest > occ && sp > 1) break;                               // stay within one round of `occ` blocks per CU
+        const double rounds = (double)(busiest / occ) * G[occ] + G[busiest % occ];
+        double t = rounds * (r + t0_rows) * row_ns;
+        if (nsp > 1) t += 5000.0 + nsp * slab_bytes / 3000.0;              // the reduction pass: launch + slabs at ~3 TB/s (bytes / (B/ns))
+        if (t < best_t) { best_t = t; best = sp; }
+    }
+    return best;
+}
+
 // out1 != nullptr: paired launch (see WGemm::gsP); ws then holds both groups' slabs
 // db / db1 != nullptr: also the bias gradient (column sums of P), see WGemm::bslab
 static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int accumulate, hipStream_t s, float* out1 = nullptr,
@@ -1627,22 +1661,30 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     long tiles = (long)cdiv(g.NI, BI) * cdiv(NJ, BJ);
     // split policy (measured, tools/gemm_bench.py): big gradient matrices want ~1024 blocks; few-tile / huge-M
     // (HBM-bound) ones ~512 longer-running blocks; small M may go down to 128 rows per split to fill the chip
-    // Split count.  Every block runs equally long and a CU holds `occ` of them (128x128 LDS-DMA kernel: 48 KB of LDS and 144
-    // VGPRs -> 3; 64x64 kernel: 4), so the chip takes blocks in passes of 256 * occ: a block count just above a pass (r02: 1008 =
-    // 768 + 240 for `feat`) leaves a second pass that runs at a third of the occupancy.  Fill ONE pass: splits = slots / tiles
-    // (measured on MI355X, tools/sweep_wg.sh: feat 104.8 -> 106.2, l3 3x3 70.8 -> 76.7, l4 3x3 71.7 -> 77.3 TFLOP/s; three full passes
-    // of smaller blocks are slower again: 99.9).  PDF_WG_TARGET=<blocks> restores the r02 rule (ceil(target / tiles)).
-    const bool bf16_mode = g_gemm_bf16 && fast;              // (the bf16 kernels: 80 KB / 48 KB of LDS -> 2 / 3 blocks per CU)
-    const int slots = env_int(ENV_WG_SLOTS, bf16_mode ? (small ? 768 : 512) : (small ? 1024 : 768));
+    // Split count (round 3).  Every block of the launch runs equally long and a CU holds `occ` of them at once (128x128 LDS-DMA
+    // kernel: 48 KB of LDS, 144 VGPRs -> 3; 64x64 kernel: 4; bf16 kernels: 2 / 3), sharing the CU's matrix pipe -- so what counts
+    // is the busiest CU: how many blocks it gets and in how many rounds of `occ` it runs them.  The r02 rule aimed at ~1,024 blocks
+    // rounded to multiples of 256: `feat` ran 1,008 blocks, i.e. a fourth block on most CUs that ran alone at half the pipe
+    // efficiency.  wg_choose_splits() prices every candidate with a small model (blocks on the busiest CU, efficiency of 1 / 2 /
+    // 3 / 4 co-resident blocks, a fixed cost per block, the slab reduction) and stays within one round.  Measured with it
+    // (tools/gemm_bench.py, TFLOP/s): feat 104.8 -> 112, p2 / hm 102.6 -> 116, decoder 3x3 88.9 -> 101, l3 3x3 70.8 -> 82.6,
+    // l4 3x3 71.7 -> 82.3; PDF_WG_TARGET=<blocks> restores the r02 rule.
+    const bool bf16_mode = g_gemm_bf16 && fast;
+    const int occ = env_int(ENV_WG_SLOTS, 0) > 0 ? env_int(ENV_WG_SLOTS, 0) / 256 : (bf16_mode ? (small ? 3 : 2) : (small ? 4 : 3));
     const int target = env_int(ENV_WG_TARGET, 0);
-    int splits = target > 0 ? (int)((target + tiles * groups - 1) / (tiles * groups)) : (int)max(1L, slots / (tiles * groups));
+    int splits = target > 0 ? (int)((target + tiles * groups - 1) / (tiles * groups)) : 0;
     int max_by_rows = cdiv(g.M, env_int(ENV_WG_MINROWS, g.M >= 16384 ? 512 : 128));
     if (splits > max_by_rows) splits = max_by_rows;
     long per = (long)g.NI * g.ldw;
     const long perb = db ? g.NI : 0;
-    if ((long)splits * (per + perb) * groups > ws_floats) splits = (int)(ws_floats / ((per + perb) * groups));
-    if (splits < 1) splits = 1;
+    if (target > 0 && (long)splits * (per + perb) * groups > ws_floats) splits = (int)(ws_floats / ((per + perb) * groups));
     const bool bf16 = g_gemm_bf16 && fast;
+    if (target <= 0) {
+        int cap = max_by_rows;
+        if ((long)cap * (per + perb) * groups > ws_floats) cap = (int)(ws_floats / ((per + perb) * groups));
+        splits = wg_choose_splits(tiles * groups, g.M, occ, max(cap, 1), bf16 ? 64 : 16, small ? 64 : 128, (double)(per + perb) * 4.0);
+    }
+    if (splits < 1) splits = 1;
     if (!bf16 || groups > 1) { g.P16 = nullptr; g.Q16 = nullptr; }
     if (db != nullptr) g.P16 = nullptr;                     // the fused bias gradient sums the un-rounded rows of P
     // (16-byte groups of 8 bf16 along the operand's columns)
