@@ -133,13 +133,27 @@ class FlatAdam:
         self.reattach_grads()
         self.flat_g[:self.n_live].zero_()
 
-    def step(self, grad_scale=1.0):
-        F.join_wgrad()                                 # side-stream gradient kernels must have landed (no-op when already joined)
+    def begin_step(self):
+        """Advance the step count and the bias corrections (device side) -- once per optimizer step, before any `apply`."""
         self.step_t += 1
         torch.sub(1.0, torch.pow(self._b, self.step_t), out=self.corr)        # [1-b1^t, 1-b2^t]
-        hip.lib().pdf_adam_step(hip.ptr(self.flat_p), hip.ptr(self.flat_g), hip.ptr(self.flat_m), hip.ptr(self.flat_v),
-                                self.n_live, float(self.lr), self.betas[0], self.betas[1], self.eps, hip.ptr(self.corr),
-                                float(grad_scale), hip.stream())
+
+    def apply(self, lo, hi, grad_scale=1.0, stream=None):
+        """The Adam update of the flat range [lo, hi) on `stream` (default: the current one)."""
+        if hi <= lo:
+            return
+        off = 4 * lo
+        hip.lib().pdf_adam_step(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off, self.flat_m.data_ptr() + off,
+                                self.flat_v.data_ptr() + off, hi - lo, float(self.lr), self.betas[0], self.betas[1], self.eps,
+                                hip.ptr(self.corr), float(grad_scale), hip.stream() if stream is None else stream)
+
+    def step(self, grad_scale=1.0, done_upto=0):
+        """done_upto > 0: the range [0, done_upto) has been updated already this step (Trainer: the early slice, on a side stream
+        beside the trunk backward, after `begin_step`)."""
+        F.join_wgrad()                                 # side-stream gradient kernels must have landed (no-op when already joined)
+        if done_upto <= 0:
+            self.begin_step()
+        self.apply(done_upto, self.n_live, grad_scale)
         if getattr(self, 'flat_p16', None) is not None and F.shadows_on():
             # The update went through raw pointers (no version bump on the parameters), so the attached shadows -- views into
             # flat_p16 -- would go on serving the PREVIOUS weights to whatever runs next (evaluation, a plain model call):
@@ -309,6 +323,8 @@ class Trainer:
         self.use_graph = use_graph
         self._graphs = {}
         self._graph_pool = None
+        self.overlap_adam = os.environ.get('PDFNET_OVERLAP_ADAM', '1') != '0'
+        self._adam_stream, self._adam_done, self._in_train_step = None, 0, False
         hip.check_device(self.optimizer.flat_p.device)
         model.register_load_state_dict_post_hook(lambda *_: self.optimizer.params_changed())
         if self.world > 1:
@@ -327,6 +343,24 @@ class Trainer:
     def _early_grads_ready(self):
         """Runs inside the backward, when d loss / d x1 is complete: start the all-reduce of the early part of the flat
         gradient buffer while the trunk's backward (~a third of the step) still runs."""
+        if self.world == 1 and self.early_probe is None and not self.force_collectives and not self.use_graph and self.collectives \
+                and self.overlap_adam and self._adam_done == 0 and self._in_train_step:
+            # One GPU, nothing to reduce: the early two thirds of the parameters have their final gradients now, so their Adam
+            # update (HBM-bound, 0.3 ms) runs on a side stream beside the trunk's backward (MFMA-bound) instead of after it.
+            # The side stream waits for everything issued so far on this stream and on the weight-gradient streams.
+            dev = hip._raw_device()
+            cur = hip._raw_stream(dev)
+            if self._adam_stream is None:
+                self._adam_stream = torch.cuda.Stream()
+            side = self._adam_stream.cuda_stream
+            self.optimizer.begin_step()
+            wait = hip.lib().pdf_stream_wait
+            wait(side, cur)
+            for key in list(F._wg_used):
+                wait(side, F._wg_streams[key][1])
+            self.optimizer.apply(0, self.n_early, 1.0, stream=side)
+            self._adam_done = self.n_early
+            return
         if self.use_graph or self.reducer.early is not None or not self.collectives or \
                 (self.world == 1 and self.early_probe is None and not self.force_collectives):
             return
@@ -354,14 +388,21 @@ class Trainer:
         if self.broadcast_buffers and self.world > 1 and self.collectives:
             for b in self._float_buffers():
                 dist.broadcast(b, 0)
-        if self.use_graph:
-            loss = self._graph_step(batch, epoch)
-        else:
-            loss, _ = self._fwd_bwd(batch, epoch)
+        self._adam_done, self._in_train_step = 0, True
+        try:
+            if self.use_graph:
+                loss = self._graph_step(batch, epoch)
+            else:
+                loss, _ = self._fwd_bwd(batch, epoch)
+        finally:
+            self._in_train_step = False
         if self.collectives:                                   # the never-used tail is not reduced (zero on every rank)
             self.reducer.force = self.force_collectives
             self.reducer.finish()
-        self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0)
+        if self._adam_done:                                    # the early slice was updated beside the trunk backward
+            hip.lib().pdf_stream_wait(hip.stream(), self._adam_stream.cuda_stream)
+        self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0, done_upto=self._adam_done)
+        self._adam_done = 0
         return loss
 
     def _graph_step(self, batch, epoch):
