@@ -476,11 +476,16 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
         for _ in range(warmup):
             tr.train_step(batch)
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.time()
-        for _ in range(steps):
+        marks[0].record()
+        for i in range(steps):
             last = tr.train_step(batch)
+            marks[i + 1].record()                          # (events on the launch stream: per-step times without a host sync)
         torch.cuda.synchronize()
         dt = time.time() - t0
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        median_ms = per_step[steps // 2]
         loss_val = float(last)
         assert loss_val == loss_val, "bf16 leg: loss is NaN"
         tr.collectives = False
@@ -491,7 +496,9 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
         F.USE_SIDE_STREAMS = True
         head, _ = symbol_roofline(sym, PEAK_BF16_MFMA_TFLOPS)
         fl, sec = sum(v[1] for v in sym.values()), sum(v[3] for v in sym.values())
-        out = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "batch": B, "steps": steps, "warmup": warmup,
+        out = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
+               "median_step_ms": round(median_ms, 3), "images_per_s_at_median_step": round(B / median_ms * 1e3, 2),
+               "batch": B, "steps": steps, "warmup": warmup,
                "final_loss": round(loss_val, 4),
                "dominant_kernel": {k: head[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "ms_per_step")},
                "all_gemm_kernels_tflops": round(fl / max(sec, 1e-9) / 1e12, 1), "gemm_ms_per_step_exclusive": round(sec * 1e3, 2),
