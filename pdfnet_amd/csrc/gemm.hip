@@ -1169,16 +1169,18 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
         if (rc < 0) return -rc;
         if (rc == 1) { g_last_tile = 16; return 0; }
     }
-    // Few output tiles under a long reduction (the M = 64 centre-window layers, 8x8-map 1x1 convs, the mesh decoder's vertex
-    // up-projections): a handful of CUs would walk K step by step at load latency.  Split K over blockIdx.z so that ~320 blocks
-    // run, partial tiles through the scratch ring, bias / activation in splitk_finish.
+    // Few output tiles under a long reduction (the M = 64 centre-window layers, 8x8-map 1x1 / 3x3 convs, the mesh decoder's vertex
+    // up-projections): a handful of CUs would walk K step by step at load latency.  Split K over blockIdx.z so that ~512 blocks
+    // run, partial tiles through the scratch ring, bias / activation in splitk_finish.  (round 3: up to 256 tiles instead of 128 and
+    // ~512 blocks instead of ~320 -- ResNet layer-4 3x3: 79 -> 90 TFLOP/s forward and backward-data, its 1x1 backward-data 75 -> 83;
+    // at 512 tiles the layer-3 1x1 layers lose 7 %, tools/run_r3q.sh)
     const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
     // (also the valid 3x3 convolutions on the 5x5 / 3x3 centre windows: taps are walked in K order, a split may start inside any tap)
     const bool sk_plain = g.T == 1 && g.plain_in, sk_taps = g.T > 1 && !g.plain_in && fast && g.Cin % 32 == 0 && g.K == g.T * g.Cin;
-    if (groups == 1 && (sk_plain || sk_taps) && g.plain_out && g.ps_cout == 0 && !g.accum && t64 <= env_int(ENV_IG_SPLITK_MAXT, 128) && g.K >= 512 && env_int(ENV_IG_SPLITK, 1)) {
+    if (groups == 1 && (sk_plain || sk_taps) && g.plain_out && g.ps_cout == 0 && !g.accum && t64 <= env_int(ENV_IG_SPLITK_MAXT, 256) && g.K >= 512 && env_int(ENV_IG_SPLITK, 1)) {
         const bool bk32 = fast && g.Cin % 32 == 0;
         const int bk = bk32 ? 32 : 16, nk = cdiv(g.K, bk);
-        int splits = (int)min((long)cdiv(env_int(ENV_IG_SPLITK_TARGET, 320), (int)t64), (long)(g.K / 128));
+        int splits = (int)min((long)cdiv(env_int(ENV_IG_SPLITK_TARGET, 512), (int)t64), (long)(g.K / 128));
         while (splits > 1 && (long)splits * g.M * g.N > PDF_SCRATCH_MAX) --splits;
         if (splits >= 2) {
             const int ksteps = cdiv(nk, splits);
