@@ -18,6 +18,16 @@
 #define PDF_FRAG_PIPE 0
 #endif
 constexpr bool FRAG_PIPE = PDF_FRAG_PIPE != 0;
+#ifndef PDF_WHATIF
+#define PDF_WHATIF 0
+#endif
+#ifndef PDF_IG_LEAN_MAX
+#define PDF_IG_LEAN_MAX (1 << 30)             // largest tile (BM * BN) with the buffer-store epilogue (measured: every tile gains)
+#endif
+#ifndef PDF_IG_DEEP
+#define PDF_IG_DEEP 1
+#endif
+constexpr bool IG_DEEP = PDF_IG_DEEP != 0;      // igemm_nt, buffer-load form: two K-steps of prefetch in flight
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 as_f4(const u32x4v& v) { return *reinterpret_cast<const float4*>(&v); }
 
@@ -93,6 +103,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
     if (g.ksteps > 0) { kt0 = blockIdx.z * g.ksteps; kt1 = min(nk, kt0 + g.ksteps); }
 
     float4 ra[RA], rb[RB];
+    float4 ra1[RA], rb1[RB];                             // second register set of the two-steps-ahead prefetch (IG_DEEP)
+    int nload = kt0;                                     // K-step the next gload fetches (BUF: a step past kt1 loads zeros, no traffic)
     // tap state of the NEXT tile to load (tiles are loaded strictly in order): no per-tile division and the
     // tap table (scalar loads that share lgkmcnt with the LDS traffic) is read only when the tap changes
     int nt_tap = 0, nt_ci = kt0 * BK;
@@ -118,14 +130,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
         for (int i = 0; i < RB; ++i) boffB[i] = (unsigned)(bbase[i] + (KN ? 0 : kq)) * 4u;
         tap_valid();
     }
-    auto gload = [&](int kt) {
+    auto gload = [&](int kt, float4 (&ra)[RA], float4 (&rb)[RB]) {
         if constexpr (FAST && BUF) {
+#if PDF_WHATIF == 2
+            const bool live = false;
+#else
+            const bool live = nload < kt1;
+#endif
+            ++nload;
             const unsigned sa = (unsigned)(tapoffB + nt_ci * 4);
             const unsigned sb = KN ? (unsigned)((nt_ci * g.ldb + wbase) * 4) : (unsigned)((wbase + nt_ci) * 4);
 #pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, aok[i] ? aoffB[i] + sa : 0xffffffffu, 0, 0));
+            for (int i = 0; i < RA; ++i) ra[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, (aok[i] && live) ? aoffB[i] + sa : 0xffffffffu, 0, 0));
 #pragma unroll
-            for (int i = 0; i < RB; ++i) rb[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsB, bval[i] ? boffB[i] + sb : 0xffffffffu, 0, 0));
+            for (int i = 0; i < RB; ++i) rb[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsB, (bval[i] && live) ? boffB[i] + sb : 0xffffffffu, 0, 0));
             nt_ci += BK;
             if (nt_ci >= g.Cin && nt_tap + 1 < g.T) {
                 ++nt_tap; nt_ci = 0;
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
             for (int i = 0; i < RB; ++i) rb[i] = make_float4(tmpb[i][0], tmpb[i][1], tmpb[i][2], tmpb[i][3]);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const float4 (&ra)[RA], const float4 (&rb)[RB]) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             float* p = &As[buf][(lrow + i * RPP) * LD + kq];
@@ -209,14 +227,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
         }
     };
 
-    gload(kt0);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
     const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5);
     const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5);
-    for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) gload(kt + 1);
+    auto compute = [&](int cur) {
         const float* as = As[cur];
         const float* bs = Bs[cur];
         // fragments of k-pair kk + 1 are read while the MFMAs of pair kk run (two register sets, FRAG_PIPE)
@@ -239,9 +252,40 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < kt1) lstore(cur ^ 1);
+    };
+    if constexpr (FAST && BUF && IG_DEEP && BM * BN <= 64 * 64) {      // (wider tiles: the compiler doubles the accumulator registers across the two phases)
+        // two K-steps in flight: while step kt is computed from LDS, step kt + 1 sits in one register set and the loads of step
+        // kt + 2 have just been issued into the other -- short reductions (1x1 layers, K = 64 ... 256) expose one memory latency
+        // per tile instead of one per step.  All loads are issued unconditionally (a step past the end reads zeros through the
+        // descriptor's range check) so that the waits before an LDS store cover the older register set only.
+        gload(kt0, ra, rb);
+        gload(kt0 + 1, ra1, rb1);
+        lstore(0, ra, rb);
         __syncthreads();
-        cur ^= 1;
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            gload(kt + 2, ra, rb);
+            compute(0);
+            if (kt + 1 >= kt1) break;
+            lstore(1, ra1, rb1);
+            __syncthreads();
+            gload(kt + 3, ra1, rb1);
+            compute(1);
+            if (kt + 2 < kt1) lstore(0, ra, rb);
+            __syncthreads();
+        }
+        if (g.stat != nullptr) __syncthreads();          // (the statistics epilogue re-uses As)
+    } else {
+        gload(kt0, ra, rb);
+        lstore(0, ra, rb);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            if (kt + 1 < kt1) gload(kt + 1, ra, rb);
+            compute(cur);
+            if (kt + 1 < kt1) lstore(cur ^ 1, ra, rb);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     if (g.ksteps > 0) {                                  // split-K: raw partial tile -> part[split][M][N]
@@ -264,6 +308,53 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) st[j] = StatAcc{0.f, 0.f, 0.f, 0.f};
     const bool do_stat = g.stat != nullptr;
+    if constexpr (FAST && BUF && BM * BN <= PDF_IG_LEAN_MAX) {
+        // Whole tiles of a dense row-major output (every 1x1 / 3x3 layer, every linear): stores through a buffer descriptor --
+        // per-lane byte offset once per 32x32 block, the 16 row offsets as scalar operands, columns past N dropped by the range
+        // check -- instead of a 64-bit address, two compares and an exec-mask branch per element.  (The per-tile instruction
+        // overhead, not memory, bounds the short-reduction layers: with all loads or all stores removed a K = 64 layer kept
+        // 80-90 % of its time.)
+        if (g.cbytes != 0 && m0 + BM <= g.M) {
+            const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cp, 0, g.cbytes, 0x00020000);
+            const unsigned ldc4 = (unsigned)g.ldc * 4u;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+                const bool cok = col < g.N;
+                const float bv = (biasp != nullptr && cok) ? biasp[col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned vo = cok ? (unsigned)((m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5)) * g.ldc + col) * 4u : 0xffffffffu;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+                    if (g.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                    } else if (g.act == 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+                    }
+                    if (g.accum) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            v[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, vo, ((r & 3) + 8 * (r >> 2)) * ldc4, 0));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsC, vo, ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
+                    if (do_stat && cok) {                   // stat_add without the row test: same operations in the same order
+                        if (i == 0) st[j].s = v[0];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { const float d = v[r] - st[j].s; st[j].a += d; st[j].b = fmaf(d, d, st[j].b); }
+                        st[j].n += 16.f;
+                    }
+                }
+            }
+            if (do_stat) stat_finish<TN, WM, WN, BN>(st, &As[0][0], g.stat, tmi, n0, g.N, wm, wn, lane, tid);
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -295,6 +386,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
                         o = (((long)ni * g.OH + oy) * g.OW + ox) * g.ldc + co;
                     }
                     if (g.accum) v += Cp[o];
+#if PDF_WHATIF == 1
+                    if (v == 12345.678f)
+#endif
                     Cp[o] = v;
                     if (do_stat) stat_add(st[j], v);
                 }
@@ -953,10 +1047,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_IG_BUFSTORE, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM", "PDF_IG_BUFSTORE"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1151,6 +1245,8 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
         const double bext = 4.0 * (double)(g.b_kn ? g.Cin : g.N) * g.ldb;
         if (aext < 4294967000.0 && bext < 4294967000.0) { g.abytes = (unsigned)aext; g.bbytes = (unsigned)bext; }
     }
+    g.cbytes = 0;
+    if (fast && g.plain_out && g.ps_cout == 0 && 4.0 * g.M * g.ldc < 4294967000.0 && env_int(ENV_IG_BUFSTORE, 1)) g.cbytes = (unsigned)(4.0 * g.M * g.ldc);
     if (!fast && groups == 1 && !g.accum && (!g.b_kn || (g.T == 1 && g.wt[0] == 0)) && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
         (long)g.M * g.N >= (1L << 20)) {
         dim3 grid(grid_for((long)g.M * ((min(g.N, 256) + 3) / 4)), cdiv(g.N, 256));

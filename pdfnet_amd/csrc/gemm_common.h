@@ -35,6 +35,7 @@ struct IGemm {
     float* stat;
     // byte extents of A / B from their (group-adjusted) base pointers for the buffer-descriptor form of the kernels (0: not used)
     unsigned int abytes, bbytes;
+    unsigned int cbytes;                      // extent of a dense row-major C (plain_out, no pixel-shuffle) for buffer stores, else 0
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 

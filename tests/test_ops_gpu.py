@@ -1009,7 +1009,8 @@ def test_gradient_chain_of_a_map_with_several_consumers(F):
 # 128x64 (narrow output), 64x64 with K-step 32 and 16, the one-wave 32x32 tile, ragged M / N, the per-element (non-FAST) form
 # the last entry (few tiles under a long reduction) takes the split-K launch, which has none: the BatchNorm must fall back
 STAT_CONVS = [(10, 256, 64, 64, 256, 3, 1, 1, 0, True), (10, 128, 64, 64, 256, 3, 1, 1, 0, True), (40, 64, 64, 64, 64, 3, 1, 1, 0, True),
-              (8, 128, 32, 32, 128, 3, 1, 1, 1, True), (40, 64, 64, 64, 256, 1, 1, 0, 0, True), (4, 48, 16, 16, 96, 3, 1, 1, 0, True),
+              (24, 128, 32, 32, 128, 3, 1, 1, 1, True), (8, 128, 32, 32, 128, 3, 1, 1, 1, False),      # (the second: 256 tiles, split over K)
+              (40, 64, 64, 64, 256, 1, 1, 0, 0, True), (4, 48, 16, 16, 96, 3, 1, 1, 0, True),
               (2, 80, 4, 4, 64, 3, 1, 1, 0, True), (3, 48, 17, 15, 72, 3, 2, 1, 0, True), (2, 6, 9, 9, 20, 3, 1, 1, 1, True),
               (4, 3, 256, 256, 64, 7, 2, 3, 0, True),          # the ResNet stem's own kernel (stem7x7_fwd_kernel)
               (2, 512, 4, 4, 64, 3, 1, 1, 0, False)]

@@ -9,6 +9,12 @@ rows = list(csv.DictReader(open(path)))
 ks = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '0')) for r in rows))
 # steady part: from the second-to-last adam_kernel to the last one = one full step
 adams = [i for i, k in enumerate(ks) if k[2].startswith('adam_kernel')]
+# an optimizer step may launch Adam more than once (early slice beside the backward): a step ends at an Adam launch that is
+# followed by a long Adam-free stretch (or by nothing)
+if len(adams) >= 2:
+    gaps_a = [ks[adams[i + 1]][0] - ks[adams[i]][0] for i in range(len(adams) - 1)]
+    ends = [adams[i] for i in range(len(adams) - 1) if gaps_a[i] > 0.5 * max(gaps_a)] + [adams[-1]]
+    adams = ends
 if len(adams) < 2:
     print("need >= 2 steps in the trace"); sys.exit(1)
 lo, hi = adams[-2] + 1, adams[-1] + 1

@@ -1,7 +1,7 @@
 """Phase timeline of the EAGER step from HIP events recorded on the main stream at a dozen host points (no profiler: rocprofv3
 slows the host enough to make the traced step launch-bound, which hides what the untraced step waits for).
 Usage: phase_events.py [batch] [bf16]"""
-import os, sys
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 if len(sys.argv) > 2 and sys.argv[2] == 'bf16':
@@ -29,7 +29,7 @@ marks = []
 def mark(name):
     e = torch.cuda.Event(enable_timing=True)
     e.record()
-    marks.append((name, e))
+    marks.append((name, e, time.perf_counter()))
 
 
 enc, dec, mwl = model.encoder, model.decoder, trainer.model_with_loss
@@ -98,6 +98,11 @@ def step():
 for _ in range(6):
     trainer.train_step(batch)
 res = []
+torch.cuda.synchronize()
+base = torch.cuda.Event(enable_timing=True)
+base.record()
+torch.cuda.synchronize()
+base_host = time.perf_counter()          # GPU time of an event ~ base_host + base.elapsed_time(e): `lag` = how far the GPU runs behind the host
 for _ in range(6):                       # no sync between steps: the host runs ahead as in the bench loop
     step()
     res.append(list(marks))
@@ -106,7 +111,8 @@ for r in res[-3:]:
     t0 = r[0][1]
     print("---- step (ms since its start on the main stream)")
     prev = 0.0
-    for name, e in r[1:]:
+    for name, e, th in r[1:]:
         t = t0.elapsed_time(e)
-        print("  %8.2f  (+%6.2f)  %s" % (t, t - prev, name))
+        lag = base.elapsed_time(e) - (th - base_host) * 1e3
+        print("  %8.2f  (+%6.2f)  GPU behind host issue by %7.2f ms  %s" % (t, t - prev, lag, name))
         prev = t

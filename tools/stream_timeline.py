@@ -6,6 +6,12 @@ import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Stream_Id', r.get('Queue_Id', '0'))) for r in rows)
 adams = [i for i, k in enumerate(ks) if k[2].startswith('adam_kernel')]
+# an optimizer step may launch Adam more than once (early slice beside the backward): a step ends at an Adam launch that is
+# followed by a long Adam-free stretch (or by nothing)
+if len(adams) >= 2:
+    gaps_a = [ks[adams[i + 1]][0] - ks[adams[i]][0] for i in range(len(adams) - 1)]
+    ends = [adams[i] for i in range(len(adams) - 1) if gaps_a[i] > 0.5 * max(gaps_a)] + [adams[-1]]
+    adams = ends
 step = ks[adams[-2] + 1:adams[-1] + 1]
 t0, t1 = step[0][0], max(k[1] for k in step)
 print("kernels %d, wall %.2f ms, sum of durations %.2f ms" % (len(step), (t1 - t0) / 1e6, sum(e - s for s, e, _, _ in step) / 1e6))
