@@ -21,9 +21,6 @@ constexpr bool FRAG_PIPE = PDF_FRAG_PIPE != 0;
 #ifndef PDF_WHATIF
 #define PDF_WHATIF 0
 #endif
-#ifndef PDF_IG_LEAN_MAX
-#define PDF_IG_LEAN_MAX (1 << 30)             // largest tile (BM * BN) with the buffer-store epilogue (measured: every tile gains)
-#endif
 #ifndef PDF_IG_DEEP
 #define PDF_IG_DEEP 1
 #endif
@@ -101,6 +98,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
     const int nk = (g.K + BK - 1) / BK;
     int kt0 = 0, kt1 = nk;                               // split-K launch: this block's K-steps
     if (g.ksteps > 0) { kt0 = blockIdx.z * g.ksteps; kt1 = min(nk, kt0 + g.ksteps); }
+#if PDF_WHATIF >= 3
+    kt1 = kt0;
+#endif
 
     float4 ra[RA], rb[RB];
     float4 ra1[RA], rb1[RB];                             // second register set of the two-steps-ahead prefetch (IG_DEEP)
@@ -304,54 +304,16 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
         return;
     }
     // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#if PDF_WHATIF == 4
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     StatAcc st[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) st[j] = StatAcc{0.f, 0.f, 0.f, 0.f};
     const bool do_stat = g.stat != nullptr;
-    if constexpr (FAST && BUF && BM * BN <= PDF_IG_LEAN_MAX) {
-        // Whole tiles of a dense row-major output (every 1x1 / 3x3 layer, every linear): stores through a buffer descriptor --
-        // per-lane byte offset once per 32x32 block, the 16 row offsets as scalar operands, columns past N dropped by the range
-        // check -- instead of a 64-bit address, two compares and an exec-mask branch per element.  (The per-tile instruction
-        // overhead, not memory, bounds the short-reduction layers: with all loads or all stores removed a K = 64 layer kept
-        // 80-90 % of its time.)
-        if (g.cbytes != 0 && m0 + BM <= g.M) {
-            const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cp, 0, g.cbytes, 0x00020000);
-            const unsigned ldc4 = (unsigned)g.ldc * 4u;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-                const bool cok = col < g.N;
-                const float bv = (biasp != nullptr && cok) ? biasp[col] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const unsigned vo = cok ? (unsigned)((m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5)) * g.ldc + col) * 4u : 0xffffffffu;
-                    float v[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
-                    if (g.act == 1) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-                    } else if (g.act == 2) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
-                    }
-                    if (g.accum) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            v[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, vo, ((r & 3) + 8 * (r >> 2)) * ldc4, 0));
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsC, vo, ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
-                    if (do_stat && cok) {                   // stat_add without the row test: same operations in the same order
-                        if (i == 0) st[j].s = v[0];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) { const float d = v[r] - st[j].s; st[j].a += d; st[j].b = fmaf(d, d, st[j].b); }
-                        st[j].n += 16.f;
-                    }
-                }
-            }
-            if (do_stat) stat_finish<TN, WM, WN, BN>(st, &As[0][0], g.stat, tmi, n0, g.N, wm, wn, lane, tid);
+    if constexpr (FAST && BUF) {
+        if (g.cbytes != 0 && m0 + BM <= g.M) {             // whole tile of a dense row-major output: the buffer-store epilogue
+            lean_epilogue<TM, TN, WM, WN, BN>(acc, g, Cp, biasp, m0, n0, tmi, wm, wn, lane, tid, &As[0][0]);
             return;
         }
     }
@@ -1047,10 +1009,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_IG_BUFSTORE, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_IG_BUFSTORE, ENV_IG_BF16_STATS, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM", "PDF_IG_BUFSTORE"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM", "PDF_IG_BUFSTORE", "PDF_IG_BF16_STATS"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1235,7 +1197,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     ++g_igemm_launches;
     if (groups > 1) g.stat = nullptr;
     float* const stat_req = g.stat;
-    g.stat = nullptr;                                   // (the streaming / bf16 / split-K launches below have no statistics epilogue)
+    g.stat = nullptr;                                   // (the streaming / split-K launches below have no statistics epilogue; bf16: whole tiles only)
     bool fast = (g.Cin % 16 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && aligned16(g.A) && aligned16(g.B);
     if (g.b_kn) fast = fast && (g.N % 4 == 0) && (g.btap % 4 == 0);
     if (groups > 1) fast = fast && aligned16(g.B1) && (g.gsA % 4 == 0);
@@ -1261,9 +1223,14 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     if (g.B16 != nullptr && ((!g.b_kn && g.ldb % 8 != 0) || (reinterpret_cast<uintptr_t>(g.B16) & 15))) g.B16 = nullptr;
     if (g_gemm_bf16 && fast) {
         g_shadow_operands += (g.A16 != nullptr) + (g.B16 != nullptr);
+        // BatchNorm statistics out of the fp32 accumulators: the bf16 kernels take them in their whole-tile epilogue only
+        const int bm16 = igemm_bf16_tile_rows(g, groups);
+        if (stat_req != nullptr && groups == 1 && g.cbytes != 0 && g.M % bm16 == 0 && env_int(ENV_IG_BF16_STATS, 1)) { g.stat = stat_req; stat_plan(g, stat_cap, bm16); }
         const int rc = launch_igemm_bf16(g, s, groups);
         if (rc < 0) return -rc;
         if (rc == 1) { g_last_tile = 16; return 0; }
+        g.stat = nullptr;
+        tl_stat_tiles = tl_stat_rows = 0;
     }
     // Few output tiles under a long reduction (the M = 64 centre-window layers, 8x8-map 1x1 / 3x3 convs, the mesh decoder's vertex
     // up-projections): a handful of CUs would walk K step by step at load latency.  Split K over blockIdx.z so that ~512 blocks

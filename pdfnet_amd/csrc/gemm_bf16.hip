@@ -295,6 +295,10 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IGemm g) {
         }
     }
 
+    if (g.cbytes != 0 && m0 + BM <= g.M) {                 // whole tile of a dense row-major output: buffer stores + BatchNorm statistics
+        lean_epilogue<TM, TN, WM, WN, BN>(acc, g, Cp, biasp, m0, n0, tmi, wm, wn, lane, tid, reinterpret_cast<float*>(smem));
+        return;
+    }
     // epilogue (same as igemm_nt): lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -350,6 +354,14 @@ static void launch_tile_bf16(const IGemm& g, dim3 grid, hipStream_t s) {
     else if (sa) launch_tile_bf16_s<BM, BN, WM, WN, true, false>(g, grid, s);
     else if (sb) launch_tile_bf16_s<BM, BN, WM, WN, false, true>(g, grid, s);
     else launch_tile_bf16_s<BM, BN, WM, WN, false, false>(g, grid, s);
+}
+
+// rows of the tile launch_igemm_bf16 picks (the caller plans the statistics partials of IGemm::stat with it)
+int igemm_bf16_tile_rows(const IGemm& g, int groups) {
+    const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;
+    if (g.N > 64 && t128 >= 192) return 128;
+    if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= 192) return 128;
+    return 64;
 }
 
 int launch_igemm_bf16(const IGemm& g, hipStream_t s, int groups) {
