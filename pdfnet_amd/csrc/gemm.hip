@@ -18,9 +18,6 @@
 #define PDF_FRAG_PIPE 0
 #endif
 constexpr bool FRAG_PIPE = PDF_FRAG_PIPE != 0;
-#ifndef PDF_WHATIF
-#define PDF_WHATIF 0
-#endif
 #ifndef PDF_IG_DEEP
 #define PDF_IG_DEEP 1
 #endif
@@ -34,7 +31,7 @@ __device__ __forceinline__ float4 as_f4(const u32x4v& v) { return *reinterpret_c
 // exec-mask branches, the zero word's address re-read from the GOT behind an s_waitcnt lgkmcnt(0) -- ~240 instructions per
 // K-step of the 64x64 tile against 16 MFMAs: with four waves per SIMD the VALU, not the matrix pipe, was the bound.
 template <int BM, int BN, int WM, int WN, bool FAST, bool KN, int BKT = 16, bool BUF = false>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
+__global__ __launch_bounds__(WM * WN * 64, (BM * BN >= 128 * 128 ? 3 : 1)) void igemm_nt(const IGemm g) {    // (128x128: 3 waves per SIMD = 3 blocks per CU, as its LDS allows)
     constexpr int NT = WM * WN * 64;                     // threads: one wave per (BM/WM) x (BN/WN) sub-tile
     constexpr int BK = BKT, LD = BK + 1;                 // K-step: 16, or 32 for the small tile (half the barriers per flop)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -98,9 +95,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
     const int nk = (g.K + BK - 1) / BK;
     int kt0 = 0, kt1 = nk;                               // split-K launch: this block's K-steps
     if (g.ksteps > 0) { kt0 = blockIdx.z * g.ksteps; kt1 = min(nk, kt0 + g.ksteps); }
-#if PDF_WHATIF >= 3
-    kt1 = kt0;
-#endif
 
     float4 ra[RA], rb[RB];
     float4 ra1[RA], rb1[RB];                             // second register set of the two-steps-ahead prefetch (IG_DEEP)
@@ -132,11 +126,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
     }
     auto gload = [&](int kt, float4 (&ra)[RA], float4 (&rb)[RB]) {
         if constexpr (FAST && BUF) {
-#if PDF_WHATIF == 2
-            const bool live = false;
-#else
             const bool live = nload < kt1;
-#endif
             ++nload;
             const unsigned sa = (unsigned)(tapoffB + nt_ci * 4);
             const unsigned sb = KN ? (unsigned)((nt_ci * g.ldb + wbase) * 4) : (unsigned)((wbase + nt_ci) * 4);
@@ -304,9 +294,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
         return;
     }
     // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-#if PDF_WHATIF == 4
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
     StatAcc st[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) st[j] = StatAcc{0.f, 0.f, 0.f, 0.f};
@@ -348,9 +335,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
                         o = (((long)ni * g.OH + oy) * g.OW + ox) * g.ldc + co;
                     }
                     if (g.accum) v += Cp[o];
-#if PDF_WHATIF == 1
-                    if (v == 12345.678f)
-#endif
                     Cp[o] = v;
                     if (do_stat) stat_add(st[j], v);
                 }
@@ -372,7 +356,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt(const IGemm g) {
 // LDS: A halo [2][264][17] + B [2][128][17] floats = 53 KB -> 3 blocks / CU like igemm_nt<128,128>.
 #define HALO_MAX_PIX 264
 template <bool KN, bool BUF = false>
-__global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
+__global__ __launch_bounds__(256, 3) void igemm_halo3x3(const IGemm g) {
     constexpr int BM = 128, BN = 128, WN = 2, BK = 16, LD = 17, TM = 2, TN = 2;
     constexpr int NH = (HALO_MAX_PIX * 4 + 255) / 256;                    // float4 halo loads per thread and chunk (5)
     __shared__ float As[2][HALO_MAX_PIX * LD];
@@ -504,6 +488,12 @@ __global__ __launch_bounds__(256) void igemm_halo3x3(const IGemm g) {
         bbuf ^= 1;
         if (tap == 8) abuf ^= 1;
         tap = ntap; chunk = nchunk;
+    }
+    if constexpr (BUF) {
+        if (g.cbytes != 0) {                                 // (M % 128 == 0: every tile is whole)
+            lean_epilogue<TM, TN, 2, WN, BN>(acc, g, Cp, biasp, m0, n0, tmi, wm, wn, lane, tid, &As[0][0]);
+            return;
+        }
     }
     StatAcc st[TN];
 #pragma unroll

@@ -142,6 +142,7 @@ __device__ __forceinline__ void lean_epilogue(const f32x16 (&acc)[TM][TN], const
                 for (int r = 0; r < 16; ++r) { const float d = v[r] - st[j].s; st[j].a += d; st[j].b = fmaf(d, d, st[j].b); }
                 st[j].n += 16.f;
             }
+            __builtin_amdgcn_sched_barrier(0);              // one 32x32 block at a time: 16 live values, not TM * TN * 16 (occupancy of the 128x128 kernels)
         }
     }
     if (do_stat) stat_finish<TN, WM, WN, BN>(st, sm, g.stat, tile_row, n0, g.N, wm, wn, lane, tid);
