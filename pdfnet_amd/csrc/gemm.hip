@@ -280,6 +280,25 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN >= 128 * 128 ? 3 : 1)) void 
 
     if (g.ksteps > 0) {                                  // split-K: raw partial tile -> part[split][M][N]
         float* pp = g.part + (long)blockIdx.z * g.M * g.N;
+        if (m0 + BM <= g.M && (long)g.M * g.N < (1L << 29)) {      // whole rows: buffer stores, columns past N dropped by the range check
+            const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)pp, 0, (unsigned)g.M * (unsigned)g.N * 4u, 0x00020000);
+            const unsigned ldn4 = (unsigned)g.N * 4u;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned vo = col < g.N ? (unsigned)((m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5)) * g.N + col) * 4u : 0xffffffffu;
+                    float v[16];                            // (through a VGPR copy: storing acc[i][j][r] directly wrote row 0's values to every row -- hipcc 7.2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsP, vo, ((r & 3) + 8 * (r >> 2)) * ldn4, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -728,7 +747,7 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     }
 
     // (the ticket flag lives in the staging array: a second __shared__ object can de-pipeline LDS-DMA kernels, guide section 5 item 4a)
-    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && i0 + tid < g.NI, bsum, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(&Ps[0][0]));
+    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && i0 + tid < g.NI, bsum, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(&Ps[0][0]), i0 + BI <= g.NI);
 }
 
 
@@ -948,7 +967,7 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
 
-    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && i0 + tid < g.NI, bsum, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(smem));
+    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && i0 + tid < g.NI, bsum, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(smem), i0 + 128 <= g.NI);
 }
 
 // Slab reducers.  blockIdx.y == 1 is group 1 of a paired launch (slabs after group 0's, own outputs).  A launch may carry a
@@ -1769,6 +1788,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     g.bslab = db ? (splits == 1 ? db : bws) : nullptr;
     g.bslab1 = db ? (splits == 1 ? db1 : bws + (long)splits * perb) : nullptr;
     g.beta = splits == 1 ? accumulate : 0;
+    g.wbytes = (4.0 * g.NI * g.ldw < 4294967000.0 && env_int(ENV_IG_BUFSTORE, 1)) ? (unsigned)(4.0 * g.NI * g.ldw) : 0;
     g.out = out; g.out1 = out1; g.bout = db; g.bout1 = db1; g.accumulate = accumulate;
     // In-launch reduction (PDF_WG_INLAUNCH=1) is OFF by default: measured 245 vs 395 img/s.  Every block's agent-scope release
     // fence (buffer_wbl2) writes back the whole XCD L2, which holds megabytes of slabs and of the main stream's fresh outputs;

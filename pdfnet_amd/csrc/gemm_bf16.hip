@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void wgemm_bf16_kernel(const WGemm g) {
         __syncthreads();
         if (tid < BI) for (int k = 0; k < KPP_P; ++k) bval += bred[k * BI + tid];
     }
-    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && tid < BI && i0 + tid < g.NI, bval, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(smem));
+    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && tid < BI && i0 + tid < g.NI, bval, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(smem), i0 + BI <= g.NI);
 }
 
 // g carries the split / slab plan of launch_wgemm (gemm.hip); `small` = its 64 x 64 tile choice

@@ -172,6 +172,7 @@ struct WGemm {
     // byte extents of P / Q as seen from their (group-adjusted) base pointers, for the buffer descriptors of wgemm_tn_dma<.., true>
     // (0: an operand is >= 4 GiB - 32 and the flat-address form of the kernel is used)
     unsigned int pbytes, qbytes;
+    unsigned int wbytes;                      // bytes of ONE split's result matrix (NI * ldw floats) for buffer stores, 0: flat stores
     // wgemm_tn_dma<.., true>: the 16 rows of a K-step are two runs of 8 consecutive pixels of ONE image row each (QW % 8 == 0)
     // and the tile's 128 columns belong to one tap (Cq % 128 == 0), or Q is plain rows: the pixel position, the tap and all
     // offsets except a per-thread constant are block-uniform, i.e. scalar-unit work
@@ -185,7 +186,7 @@ struct WGemm {
 // bias_thread: this thread carries the bias partial `bval` of output row i0 + threadIdx.x.
 template <int TM, int TN>
 __device__ __forceinline__ void wgemm_finish(const WGemm& g, const f32x16 (&acc)[TM][TN], int i0, int j0, int wm, int wn, int lane,
-                                             bool bias_thread, float bval, int tile_id, int ntiles, int* lds_flag) {
+                                             bool bias_thread, float bval, int tile_id, int ntiles, int* lds_flag, bool rows_whole = false) {
     const int grp = blockIdx.z, split = blockIdx.y, splits = gridDim.y;
     float* slabp = grp ? g.slab1 : g.slab;
     float* bslabp = grp ? g.bslab1 : g.bslab;
@@ -214,6 +215,34 @@ __device__ __forceinline__ void wgemm_finish(const WGemm& g, const f32x16 (&acc)
         *bo = g.beta ? *bo + bval : bval;
     }
     float* out = slabp + (long)split * g.NI * g.ldw;
+    if (g.wbytes != 0 && rows_whole) {
+        // every row of the tile is inside the matrix: buffer stores (per-lane offset once per 32x32 block, row offsets as scalar
+        // operands, columns past NJ dropped by the range check) -- see lean_epilogue
+        const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, g.wbytes, 0x00020000);
+        const unsigned ldw4 = (unsigned)g.ldw * 4u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
+            const bool cok = col < NJ;
+            const int t = cok ? col / g.Cq : 0;
+            const int wcol = g.wt[t] * g.Cq + (col - t * g.Cq);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned vo = cok ? (unsigned)((i0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5)) * g.ldw + wcol) * 4u : 0xffffffffu;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+                if (g.beta) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        v[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW, vo, ((r & 3) + 8 * (r >> 2)) * ldw4, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsW, vo, ((r & 3) + 8 * (r >> 2)) * ldw4, 0);
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = j0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -230,6 +259,7 @@ __device__ __forceinline__ void wgemm_finish(const WGemm& g, const f32x16 (&acc)
                     *o = g.beta ? *o + acc[i][j][r] : acc[i][j][r];
                 }
             }
+    }
     }
     if (g.counters == nullptr || splits == 1) return;
     if (!pdf_last_block_arrives(g.counters + grp * ntiles + tile_id, splits, lds_flag, true)) return;
