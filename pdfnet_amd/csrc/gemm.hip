@@ -919,6 +919,50 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
         }
     };
 
+    // ---- WGemm::uniform == 2: besides the above, a K-step's 16 rows are 16 consecutive pixels of ONE image row (map width and
+    // rows per split multiples of 16) or plain rows.  One scalar position per step, advanced incrementally; the byte offset of a
+    // load = per-thread constant (VGPR, fixed for the whole kernel) + scalar offset operand; the tap's shift sits in the
+    // descriptor's base address, so the constants are non-negative.  Per step and wave: ~10 scalar and ~6 vector instructions
+    // beside the 4 DMA loads (the general forms: 60-90 -- measured on `feat`: 5.55 ms with the loads' issue code, 4.64 without).
+    const bool u16 = BUF && g.uniform == 2;
+    const long qshift = g.plain_q ? 0 : ((long)udy * g.W + udx) * g.ldq;
+    const auto rsQs = __builtin_amdgcn_make_buffer_rsrc((void*)(Qp + qshift), 0, BUF ? 0xfffffff0u : 0, 0x00020000);
+    unsigned vP[2], vQ[2]; int cxl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        vP[i] = pcol_ok ? (unsigned)((pr + 8 * i) * g.ldp + i0 + pc) * 4u : 0xffffffffu;
+        vQ[i] = !qcol_ok ? 0xffffffffu : g.plain_q ? (unsigned)((pr + 8 * i) * g.ldq + qch) * 4u : (unsigned)((pr + 8 * i) * g.sx * g.ldq + (jcol - utap * g.Cq)) * 4u;
+        cxl[i] = (pr + 8 * i) * g.sx + udx;                 // this lane's image x = u_x0 * sx + cxl
+    }
+    int u_x0 = s_x[0], u_y = s_y[0];                        // (row ms: x is a multiple of 16)
+    unsigned u_sp = (unsigned)__builtin_amdgcn_readfirstlane(ms) * (unsigned)g.ldp * 4u;
+    unsigned u_sq = g.plain_q ? (unsigned)__builtin_amdgcn_readfirstlane(ms) * (unsigned)g.ldq * 4u
+                              : (unsigned)(((s_ni[0] * g.H + s_y[0] * g.sy) * g.W + s_x[0] * g.sx) * g.ldq) * 4u;
+    const unsigned stepP = 16u * (unsigned)g.ldp * 4u, stepQ = (g.plain_q ? 16u : 16u * (unsigned)g.sx) * (unsigned)g.ldq * 4u;
+    const unsigned wrapX = (unsigned)((g.sy * g.W - g.QW * g.sx) * g.ldq) * 4u, wrapY = (unsigned)((g.H - g.QH * g.sy) * g.W * g.ldq) * 4u;
+    auto issue_u16 = [&](int t, int st) {
+        float* sp = smem + (st * 2 + 0) * BK * 128 + wbase;
+        float* sq = smem + (st * 2 + 1) * BK * 128 + wbase;
+        const bool live = t < nt;                           // (past the end: zeros, no traffic)
+        const int iy = u_y * g.sy + udy;
+        const bool rowq = live && (g.plain_q || (iy >= 0 && iy < g.H));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ix = u_x0 * g.sx + cxl[i];
+            const bool xok = g.plain_q || (ix >= 0 && ix < g.W);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, LDS_PTR(sp + i * 8 * 128), 16, live ? vP[i] : 0xffffffffu, u_sp, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQs, LDS_PTR(sq + i * 8 * 128), 16, (rowq && xok) ? vQ[i] : 0xffffffffu, u_sq, 0, 0);
+        }
+        u_sp += stepP; u_sq += stepQ;
+        if (!g.plain_q) {
+            u_x0 += 16;
+            if (u_x0 >= g.QW) {
+                u_x0 = 0; u_sq += wrapX;
+                if (++u_y == g.QH) { u_y = 0; u_sq += wrapY; }
+            }
+        }
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -930,13 +974,13 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     const int aoff = (lane >> 5) * 128 + wm * TM * 32 + (lane & 31);
     const int boff = (lane >> 5) * 128 + wn * TN * 32 + (lane & 31);
 #pragma unroll
-    for (int p = 0; p < ST - 1; ++p) { if (uni) issue_uni(p, p); else issue(p, p); }
+    for (int p = 0; p < ST - 1; ++p) { if (u16) issue_u16(p, p); else if (uni) issue_uni(p, p); else issue(p, p); }
     int st = 0, stn = ST - 1;
     for (int t = 0; t < nt; ++t) {
         // this wave's 4 DMAs of tile t have landed (the ST-2 younger tiles may still fly) ...
         if (ST == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // ... and everybody's; everybody also finished reading tile t-1
-        if (uni) issue_uni(t + ST - 1, stn); else issue(t + ST - 1, stn);      // refill the stage tile t-1 used (rows past the end read zeros)
+        if (u16) issue_u16(t + ST - 1, stn); else if (uni) issue_uni(t + ST - 1, stn); else issue(t + ST - 1, stn);      // refill the stage tile t-1 used (rows past the end read zeros)
         const float* ps = smem + (st * 2 + 0) * BK * 128;
         const float* qs = smem + (st * 2 + 1) * BK * 128;
         if (do_bias) {
@@ -1828,7 +1872,8 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         const int pad = env_int(ENV_WG_LDSPAD, 0) * 1024;
         const bool buf = fast && dma == 3 && pext < 4294967000.0 && qext < 4294967000.0 && env_int(ENV_WG_BUF, 1);
         g.pbytes = buf ? (unsigned)pext : 0; g.qbytes = buf ? (unsigned)qext : 0;
-        g.uniform = (buf && (g.plain_q || (g.QW % 8 == 0 && g.Cq % 128 == 0)) && env_int(ENV_WG_UNIFORM, 1)) ? 1 : 0;
+        g.uniform = (buf && (g.plain_q || (g.QW % 8 == 0 && g.Cq % 128 == 0)) && env_int(ENV_WG_UNIFORM, 2)) ? 1 : 0;
+        if (g.uniform && env_int(ENV_WG_UNIFORM, 2) >= 2 && g.rows_per_split % 16 == 0 && g.M % 16 == 0 && (g.plain_q || g.QW % 16 == 0)) g.uniform = 2;
         KTimer kt(buf ? "wgemm_tn_dma<3, true>" : fast && dma == 4 ? "wgemm_tn_dma<4, false>" : fast && dma == 3 ? "wgemm_tn_dma<3, false>" : fast ? "wgemm_tn<128, 128, 2, 2, true, 16>" : "wgemm_tn<128, 128, 2, 2, false, 16>",
                   wflops, wbytes, s);
         if (buf) hipLaunchKernelGGL((wgemm_tn_dma<3, true>), grid, dim3(256), pad, s, g);
