@@ -467,7 +467,9 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
     from pdfnet_amd.trains.simplified import CtdetLoss
     F.set_gemm_precision('bf16')
     try:
-        torch.cuda.empty_cache()                             # the fp32 run's cached blocks have other sizes: start from a clean pool
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()                             # the previous run's cached blocks have other sizes: start from a clean pool
         torch.manual_seed(0)
         F.manual_seed(4321)
         model = load_model_intag(opt).to(dev)
@@ -692,16 +694,22 @@ def main():
             "fps": fps_hbm(dev),
         }
         F.USE_SIDE_STREAMS = True
-    if rank == 0 and world == 1 and not bf16 and not args.no_bf16_legs and args.batch == 32:
-        # BASELINE configs[3] / [4] per GPU, driver-timed in the same run: short legs after the fp32 headline
-        out["bf16_per_gpu"] = {"note": "per-rank step of configs[3] (B=32/GPU) and configs[4] (B=64/GPU): bf16 MFMA GEMMs + bf16 shadows, fp32 "
-                                       "accumulate / master weights / statistics / loss; eager, one GPU, no collective",
-                               "B32": bf16_leg(opt, R, 32, dev, consts, 12, 6), "B64": bf16_leg(opt, R, 64, dev, consts, 10, 6)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = max(1, (os.cpu_count() or 2) // 2)
         out["cpu_baseline"] = cpu_baseline(R, threads)
         if mp_batch is not None:
             out["mpjpe"]["parity_vs_cpu_oracle"] = mpjpe_parity(trainer, consts, R, dev, mp_batch)
+    if rank == 0 and world == 1 and not bf16 and not args.no_bf16_legs and args.batch == 32:
+        # BASELINE configs[3] / [4] per GPU, driver-timed in the same run: short legs after the fp32 headline.
+        # The fp32 model, trainer and batches go first (measured: with them alive the legs ran 8-13 ms per step slower than the
+        # same step in a fresh process -- twice the tracked Python objects for the collector, twice the live allocations)
+        import gc
+        del trainer, model, loss, batch, mp_batch, last
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["bf16_per_gpu"] = {"note": "per-rank step of configs[3] (B=32/GPU) and configs[4] (B=64/GPU): bf16 MFMA GEMMs + bf16 shadows, fp32 "
+                                       "accumulate / master weights / statistics / loss; eager, one GPU, no collective",
+                               "B32": bf16_leg(opt, R, 32, dev, consts, 12, 6), "B64": bf16_leg(opt, R, 64, dev, consts, 10, 6)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
