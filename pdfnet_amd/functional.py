@@ -148,15 +148,18 @@ def _set_ops(a, b):
         _L().pdf_set_bf16_operands(ptr(a), ptr(b))
 
 
-# ---- BatchNorm statistics out of the producing GEMM's epilogue (fp32 kernels): a conv / linear forward called with stats=True
+# ---- BatchNorm statistics out of the producing GEMM's epilogue (fp32 and bf16 kernels): a conv / linear forward called with stats=True
 # asks the library for per-row-block (mean, M2) pairs of its output columns (pdf_set_stats_output); they travel as an attribute
 # of the output tensor and the BatchNorm that consumes it skips its own statistics pass over the tensor (pdf_set_bn_tile_stats).
 BN_EPILOGUE_STATS = _os.environ.get("PDFNET_BN_EPILOGUE_STATS", "1") != "0"
+# bf16 mode: the kernels can do it too (whole tiles), but their MFMA time is so short that the epilogue work costs what the saved
+# pass gains -- measured B=32 850 -> 868 img/s, B=64 1,038 -> 1,013 -- so it is opt-in there
+BN_EPILOGUE_STATS_BF16 = _os.environ.get("PDFNET_BN_EPILOGUE_STATS_BF16", "0") != "0"
 
 
 def _stats_request(stats, rows, cols, dev):
     """-> the partials buffer for the next conv / linear forward launch, or None."""
-    if not (stats and BN_EPILOGUE_STATS) or _GEMM_BF16:
+    if not (stats and BN_EPILOGUE_STATS) or (_GEMM_BF16 and not BN_EPILOGUE_STATS_BF16):
         return None
     cap = ((rows + 31) // 32) * cols * 2
     part = torch.empty(cap, dtype=torch.float32, device=dev)

@@ -36,6 +36,39 @@ CONVS = [  # N, Cin, H, W, Cout, k, stride, pad
     (2, 72, 9, 9, 40, 3, 1, 1), (3, 256, 8, 8, 256, 3, 1, 1), (2, 64, 16, 16, 128, 1, 2, 0), (2, 192, 6, 6, 200, 3, 1, 1)]
 
 
+@pytest.mark.parametrize("cfg", [(8, 64, 32, 32, 128, 3, 1, 1), (16, 128, 16, 16, 64, 1, 1, 0), (4, 64, 64, 64, 256, 1, 1, 0)])
+def test_batchnorm_statistics_from_the_bf16_gemm_epilogue(bf16_mode, cfg, monkeypatch):
+    """Opt-in in bf16 mode (PDFNET_BN_EPILOGUE_STATS_BF16): the bf16 kernels' whole-tile epilogue takes the BatchNorm statistics
+    of the stored fp32 output out of the accumulators; the BatchNorm then produces the same output, saved / running statistics
+    and gradients as with its own pass over the same tensor (only the fp32 summation order differs)."""
+    F = bf16_mode
+    N, Cin, H, W, Cout, k, st, pad = cfg
+    g = torch.Generator().manual_seed(11 + sum(cfg))
+    x = torch.randn(N, Cin, H, W, generator=g) * 1.5 + 0.4
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    gam, bet = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    dy = torch.randn(N, Cout, (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1, generator=g)
+    res = {}
+    for mode in ('epilogue', 'pass'):
+        monkeypatch.setattr(F, 'BN_EPILOGUE_STATS_BF16', mode == 'epilogue')
+        xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        wd = w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        gd, bd = gam.cuda().requires_grad_(), bet.cuda().requires_grad_()
+        rm, rv = torch.zeros(Cout).cuda(), torch.ones(Cout).cuda()
+        y = F.conv2d(xd, wd, None, st, pad, F.ACT_NONE, stats=True)
+        assert (F.tile_stats_of(y) is not None) == (mode == 'epilogue')
+        z = F.batch_norm(y, gd, bd, rm, rv, True, 0.1, 1e-5, relu=False)
+        z.backward(dy.cuda())
+        F.join_wgrad()
+        res[mode] = [t.detach().float().cpu() for t in (y, z, rm, rv, xd.grad, wd.grad, gd.grad, bd.grad)]
+    assert torch.equal(res['epilogue'][0], res['pass'][0])            # the same GEMM, the same stored output
+    for a, b, name in zip(res['epilogue'][1:], res['pass'][1:], ('bn out', 'running mean', 'running var', 'dx', 'dw', 'dgamma', 'dbeta')):
+        err = float((a - b).abs().max()) / (1e-6 + float(b.abs().max()))
+        # (dx / dw: the BatchNorm's input gradient is rounded to bf16 on its way into the backward GEMMs, and values 1e-7 apart
+        # can round to different bf16 neighbours)
+        assert err <= (3e-3 if name in ('dx', 'dw') else 2e-5), (name, err)
+
+
 @pytest.mark.parametrize("cfg", CONVS)
 def test_conv2d_bf16_all_three_passes(bf16_mode, cfg):
     F = bf16_mode
