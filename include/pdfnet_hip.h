@@ -265,9 +265,16 @@ int pdf_sft3_bwd(const float* g, int ldg, const float* fea, int ldf, const float
  *   pdf_set_bf16_operands(op0, op1): shadows of the NEXT conv2d / deconv2d / linear call's operands -- forward: (x, w);
  *     backward-data: (dy, w); backward-weight: (x, dy); NULL = none.  Every GEMM-family entry point clears them.
  *   pdf_set_bf16_output(out): pdf_bn_train_fwd writes the shadow of y, pdf_bn_train_bwd of dx, pdf_l2norm_cat_fwd of y.
- *   pdf_cast_bf16: dst[i] = bf16(src[i]), n % 4 == 0 (weight shadows from the flat fp32 master buffer). */
+ *   pdf_cast_bf16: dst[i] = bf16(src[i]), n % 4 == 0 (weight shadows from the flat fp32 master buffer).
+ * bf16 STORAGE of the conv -> BatchNorm tensors (bf16 mode, optional; reference: the nn.Conv2d -> nn.BatchNorm2d pairs of resnet.py:102-122):
+ *   pdf_set_bf16_output(y16) before pdf_conv2d_fwd: the output is written to y16 (bf16, RNE, same shape / ldy) INSTEAD of y, which
+ *     is not touched (whole 64- / 128-row tiles, even Cout, no fused bias / activation needed; PDF_E_BADARG if the launch cannot);
+ *   pdf_set_bn_input_bf16(x16) before pdf_bn_train_fwd / pdf_bn_train_bwd: x is read from x16 instead of the fp32 pointer;
+ *   pdf_bn_train_bwd with dx == NULL and pdf_set_bf16_output(dx16): only the bf16 input gradient is written -- the backward GEMMs
+ *     of the producing conv take it through pdf_set_bf16_operands and never read an fp32 dy. */
 int pdf_set_bf16_operands(const void* op0_bf16, const void* op1_bf16);
 int pdf_set_bf16_output(void* out_bf16);
+int pdf_set_bn_input_bf16(const void* x16);
 int pdf_cast_bf16(const float* src, void* dst, long n, void* stream);
 int pdf_debug_shadow_operands(void);      /* shadow operands consumed by bf16 GEMM launches so far (tests) */
 /* nn.Dropout(p) with a stateless (seed, index) mask: the same call is its own backward (gcn.py:96, self_attn.py:51-52).

@@ -1262,7 +1262,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     }
     g.cbytes = 0;
     if (fast && g.plain_out && g.ps_cout == 0 && 4.0 * g.M * g.ldc < 4294967000.0 && env_int(ENV_IG_BUFSTORE, 1)) g.cbytes = (unsigned)(4.0 * g.M * g.ldc);
-    if (!fast && groups == 1 && !g.accum && (!g.b_kn || (g.T == 1 && g.wt[0] == 0)) && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
+    if (!fast && g.C16 == nullptr && groups == 1 && !g.accum && (!g.b_kn || (g.T == 1 && g.wt[0] == 0)) && g.plain_in && g.plain_out && g.K <= SMALLK_MAX && g.N >= 32 && g.ps_cout == 0 &&
         (long)g.M * g.N >= (1L << 20)) {
         dim3 grid(grid_for((long)g.M * ((min(g.N, 256) + 3) / 4)), cdiv(g.N, 256));
         KTimer kt("small_k_gemm", 2.0 * g.M * g.N * g.K, igemm_bytes(g, 1), s);
@@ -1274,10 +1274,12 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     if (!(g_gemm_bf16 && fast) || groups > 1) { g.A16 = nullptr; g.B16 = nullptr; }
     if (g.A16 != nullptr && (g.lda % 8 != 0 || (reinterpret_cast<uintptr_t>(g.A16) & 15))) g.A16 = nullptr;      // 16-byte chunks of 8 bf16
     if (g.B16 != nullptr && ((!g.b_kn && g.ldb % 8 != 0) || (reinterpret_cast<uintptr_t>(g.B16) & 15))) g.B16 = nullptr;
+    if (g.A == nullptr && g.A16 == nullptr) return PDF_E_BADARG;          // bf16 storage mode: A exists only as bf16 -- it must be usable
     if (g_gemm_bf16 && fast) {
         g_shadow_operands += (g.A16 != nullptr) + (g.B16 != nullptr);
         // BatchNorm statistics out of the fp32 accumulators: the bf16 kernels take them in their whole-tile epilogue only
         const int bm16 = igemm_bf16_tile_rows(g, groups);
+        if (g.C16 != nullptr && (groups != 1 || g.cbytes == 0 || g.M % bm16 != 0 || g.accum)) return PDF_E_BADARG;      // bf16 output: whole tiles only
         if (stat_req != nullptr && groups == 1 && g.cbytes != 0 && g.M % bm16 == 0 && env_int(ENV_IG_BF16_STATS, 1)) { g.stat = stat_req; stat_plan(g, stat_cap, bm16); }
         const int rc = launch_igemm_bf16(g, s, groups);
         if (rc < 0) return -rc;
@@ -1285,6 +1287,8 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
         g.stat = nullptr;
         tl_stat_tiles = tl_stat_rows = 0;
     }
+    if (g.C16 != nullptr) return PDF_E_BADARG;             // (only the bf16 kernels write a bf16 output)
+    if (g.A == nullptr) return PDF_E_BADARG;               // (... and only they read a bf16-only operand)
     // Few output tiles under a long reduction (the M = 64 centre-window layers, 8x8-map 1x1 / 3x3 convs, the mesh decoder's vertex
     // up-projections): a handful of CUs would walk K step by step at load latency.  Split K over blockIdx.z so that ~512 blocks
     // run, partial tiles through the scratch ring, bias / activation in splitk_finish.  (round 3: up to 256 tiles instead of 128 and
@@ -1646,8 +1650,11 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
                            int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s) {
     const Shadows sh = take_shadows();
     const StatReq sr = take_stat_request();
+    unsigned short* y16 = reinterpret_cast<unsigned short*>(pdf_tls_take_output());      // bf16 storage mode: the output goes here INSTEAD of y
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    if (y16 != nullptr && !(g_gemm_bf16 && Cout % 2 == 0 && ldy % 2 == 0)) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && (long)N * OH * OW >= (1L << 16)) {
+        if (y16 != nullptr) return PDF_E_BADARG;
         KTimer kt("tiny_conv_fwd_kernel<3, 3, 3, 3>", 2.0 * N * OH * OW * 81, 4.0 * N * (H * W + OH * OW) * 3, s);
         hipLaunchKernelGGL((tiny_conv_fwd_kernel<3, 3, 3, 3>), dim3(grid_for((long)N * OH * OW)), dim3(256), 0, s, x, w, bias, y, N, H, W, ldx, pad, OH, OW, ldy, act);
         g_last_tile = 0;
@@ -1656,6 +1663,7 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
     }
     if (Cin == 3 && ldx == 3 && Cout == 64 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && bias == nullptr && OW % 64 == 0 && OH * 2 == H && OW * 2 == W &&
         env_int(ENV_WG_STEM, 1)) {
+        if (y16 != nullptr) return PDF_E_BADARG;
         const long total = (long)N * OH * (OW / 64);
         int nblk = (int)min((long)512, total);
         const int cpb = (int)cdiv(total, nblk);
@@ -1677,6 +1685,7 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
     g.plain_out = 1; g.act = act;
     g.A16 = sh.op0; g.B16 = sh.op1;
     g.stat = sr.part;
+    g.C16 = y16;
     return launch_igemm(g, s, 1, sr.cap);
 }
 
@@ -1857,6 +1866,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         brc = launch_wgemm_bf16(g, splits, groups, small ? 1 : 0, s);
         if (brc < 0) return -brc;
     }
+    if (brc != 1 && (g.P == nullptr || g.Q == nullptr)) return PDF_E_BADARG;      // a bf16-only operand and no bf16 launch
     if (brc == 1) {
     } else if (small) {
         const bool bk32 = fast && env_int(ENV_WG_BK32, 1);
@@ -2040,6 +2050,8 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
                                   int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
     const Shadows sh = take_shadows();                       // op0: x, op1: dy
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    // bf16 storage mode: dy exists only as bf16 (dy == NULL) -- the launch must be one the bf16 kernel takes with a shadow operand
+    if (dy == nullptr && (sh.op1 == nullptr || db != nullptr || !g_gemm_bf16 || Cin % 16 != 0 || Cout % 16 != 0 || lddy % 8 != 0)) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && db == nullptr && (long)N * OH * OW >= (1L << 16) && ws_floats >= 81L * 64) {
         const int nblk = (int)min((long)1024, ws_floats / 81);
         KTimer kt("tiny_conv_wgrad_kernel<3, 3, 3, 3> + reduce_slabs_2d", 2.0 * N * OH * OW * 81, 4.0 * N * (H * W + OH * OW) * 3, s);

@@ -36,6 +36,9 @@ struct IGemm {
     // byte extents of A / B from their (group-adjusted) base pointers for the buffer-descriptor form of the kernels (0: not used)
     unsigned int abytes, bbytes;
     unsigned int cbytes;                      // extent of a dense row-major C (plain_out, no pixel-shuffle) for buffer stores, else 0
+    // bf16 storage mode (gemm_bf16.hip, whole tiles only): the output goes to C16 (same shape, ldc in ELEMENTS) rounded to bf16
+    // (RNE) INSTEAD of C -- a conv output that only a training BatchNorm reads; statistics are taken from the rounded values
+    unsigned short* C16;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
@@ -133,9 +136,28 @@ __device__ __forceinline__ void lean_epilogue(const f32x16 (&acc)[TM][TN], const
                 for (int r = 0; r < 16; ++r)
                     v[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, vo, ((r & 3) + 8 * (r >> 2)) * ldc4, 0));
             }
+            if (g.C16 != nullptr) {
+                // bf16 output.  Lanes l and l ^ 1 hold adjacent columns: they swap one value per row pair so that each lane stores
+                // ONE packed pair -- even lanes the even row of the pair, odd lanes the odd row -- 8 four-byte stores per lane.
+                const auto rsH = __builtin_amdgcn_make_buffer_rsrc((void*)g.C16, 0, g.cbytes >> 1, 0x00020000);
+                const bool odd = lane & 1;
+                const unsigned vh = cok ? ((vo >> 1) - (odd ? 2u : 0u)) : 0xffffffffu;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsC, vo, ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
+                for (int r = 0; r < 16; ++r) v[r] = __uint_as_float(pdf_pk_bf16(v[r], v[r]) << 16);        // the value BatchNorm will read
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r0 = 2 * q, r1 = r0 + 1;
+                    const float other = __shfl_xor(odd ? v[r0] : v[r1], 1, 64);
+                    const unsigned pk = odd ? ((__float_as_uint(other) >> 16) | (__float_as_uint(v[r1]) & 0xffff0000u))
+                                            : ((__float_as_uint(v[r0]) >> 16) | (__float_as_uint(other) & 0xffff0000u));
+                    const unsigned ro = (unsigned)(((odd ? r1 : r0) & 3) + 8 * ((odd ? r1 : r0) >> 2)) * (ldc4 >> 1);
+                    __builtin_amdgcn_raw_buffer_store_b32(pk, rsH, cok ? vh + ro : 0xffffffffu, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsC, vo, ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
+            }
             if (do_stat && cok) {                           // stat_add without the row test: same operations in the same order
                 if (i == 0) st[j].s = v[0];
 #pragma unroll

@@ -83,6 +83,7 @@ __device__ __forceinline__ bool tile_sums(const float* __restrict__ part, int ch
 struct BnFin {                                              // forward finalize arguments
     const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps;
     float* save_mean; float* save_rstd; float* scale; float* shift; int* counters;
+    float* shift0;                                          // X16 input: row 0 of x as floats (written by the partial kernel)
 };
 __device__ __forceinline__ void bn_finalize_tile(const float* __restrict__ part, int chunks, const float* __restrict__ x, int C, long R, const BnFin& f,
                                                  int c_tile, double* red) {
@@ -255,6 +256,19 @@ __device__ __forceinline__ void v4_block_reduce(float4 a, float4 b, float4 (&sa)
     }
 }
 
+
+// bf16 storage mode: the BatchNorm input x (a conv output nobody else reads) may come as bf16 (X16): 4 channels = one 8-byte load
+template <bool X16>
+__device__ __forceinline__ float4 ld_x4(const float* __restrict__ x, long idx) {
+    if constexpr (X16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + idx);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(x + idx);
+    }
+}
+
+template <bool X16 = false>
 __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restrict__ x, int ldx, int C, long R, long rows_per_chunk,
                                                             float* __restrict__ part, const BnFin fin) {
     __shared__ float4 sa[V4_TY][V4_TX], sb[V4_TY][V4_TX];
@@ -263,10 +277,11 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
     const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (c0 < C) {
-        const float4 sh = *reinterpret_cast<const float4*>(x + c0);
+        const float4 sh = ld_x4<X16>(x, c0);
+        if (X16 && blockIdx.y == 0 && ty == 0) *reinterpret_cast<float4*>(fin.shift0 + c0) = sh;      // (the finaliser's `x[c]`: row 0 as floats)
 #pragma unroll 4
         for (long r = r0 + ty; r < r1; r += V4_TY) {
-            float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+            float4 v = ld_x4<X16>(x, r * ldx + c0);
             v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             b.x += v.x * v.x; b.y += v.y * v.y; b.z += v.z * v.z; b.w += v.w * v.w;
@@ -276,12 +291,13 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
     if (fin.counters != nullptr) {
         __shared__ double red[512];
         __shared__ int flag;
-        if (pdf_last_block_arrives(fin.counters + blockIdx.x, gridDim.y, &flag, false)) bn_finalize_tile(part, gridDim.y, x, C, R, fin, blockIdx.x, red);
+        if (pdf_last_block_arrives(fin.counters + blockIdx.x, gridDim.y, &flag, false)) bn_finalize_tile(part, gridDim.y, X16 ? fin.shift0 : x, C, R, fin, blockIdx.x, red);
     }
 }
 
 // relu == 2: no residual went into the ReLU, so its mask is recomputed from x as fmaf(x, scale, shift) > 0 -- the exact
 // expression of the forward -- and y is not read at all
+template <bool X16 = false>
 __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int relu,
                                                                 const float* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ scale,
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
 #pragma unroll 4
         for (long r = r0 + ty; r < r1; r += V4_TY) {
             float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c0);
-            const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+            const float4 xv = ld_x4<X16>(x, r * ldx + c0);
             if (relu) {
                 const float4 yv = relu == 2 ? make_float4(fmaf(xv.x, sc.x, sh.x), fmaf(xv.y, sc.y, sh.y), fmaf(xv.z, sc.z, sh.z), fmaf(xv.w, sc.w, sh.w))
                                             : *reinterpret_cast<const float4*>(y + r * ldy + c0);
@@ -343,6 +359,7 @@ __global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __r
 
 // float4 streaming passes on the same (16 channel-quads x 16 row-lanes) block shape: per-channel coefficients live in
 // registers, no index division, 4 independent 16-byte loads per operand in flight per thread.
+template <bool X16 = false>
 __global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ res, int ldr,
                                                               float* __restrict__ y, int ldy, int C, long R, long rows_per_chunk, int relu,
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __res
     const float4 sc = *reinterpret_cast<const float4*>(scale + c0), sh = *reinterpret_cast<const float4*>(shift + c0);
 #pragma unroll 4
     for (long r = r0 + ty; r < r1; r += V4_TY) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+        const float4 xv = ld_x4<X16>(x, r * ldx + c0);
         float4 v = make_float4(fmaf(xv.x, sc.x, sh.x), fmaf(xv.y, sc.y, sh.y), fmaf(xv.z, sc.z, sh.z), fmaf(xv.w, sc.w, sh.w));
         if (res != nullptr) {
             const float4 rv = *reinterpret_cast<const float4*>(res + r * ldr + c0);
@@ -367,6 +384,7 @@ __global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __res
     }
 }
 
+template <bool X16 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int relu,
                                                               const float* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ coef,
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
 #pragma unroll 4
     for (long r = r0 + ty; r < r1; r += V4_TY) {
         float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c0);
-        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c0);
+        const float4 xv = ld_x4<X16>(x, r * ldx + c0);
         if (relu) {
             const float4 yv = relu == 2 ? make_float4(fmaf(xv.x, sc.x, sh.x), fmaf(xv.y, sc.y, sh.y), fmaf(xv.z, sc.z, sh.z), fmaf(xv.w, sc.w, sh.w))
                                         : *reinterpret_cast<const float4*>(y + r * ldy + c0);
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
         o.y = ka.y * (g.y - k1.y - (xv.y - m.y) * rs.y * k2.y);
         o.z = ka.z * (g.z - k1.z - (xv.z - m.z) * rs.z * k2.z);
         o.w = ka.w * (g.w - k1.w - (xv.w - m.w) * rs.w * k2.w);
-        *reinterpret_cast<float4*>(dx + r * lddx + c0) = o;
+        if (dx != nullptr) *reinterpret_cast<float4*>(dx + r * lddx + c0) = o;
         if (dx16 != nullptr) *reinterpret_cast<uint2*>(dx16 + r * lddx + c0) = uint2{pdf_pk_bf16(o.x, o.y), pdf_pk_bf16(o.z, o.w)};
     }
 }
@@ -422,10 +440,14 @@ static bool v4_ok(int C, std::initializer_list<int> lds, std::initializer_list<c
 }
 
 static void launch_affine_apply(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldr,
-                                float* y, int ldy, int C, long R, int relu, hipStream_t s, void* y16 = nullptr) {
-    if (v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift})) {
+                                float* y, int ldy, int C, long R, int relu, hipStream_t s, void* y16 = nullptr, const void* x16 = nullptr) {
+    if (x16 != nullptr) {                                    // (the caller checked v4_ok)
         const long rpc = apply_rows_per_chunk(C, R);
-        hipLaunchKernelGGL(affine_apply_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)((R + rpc - 1) / rpc)), dim3(256), 0, s,
+        hipLaunchKernelGGL((affine_apply_v4_kernel<true>), dim3(cdiv(C, BN_CT), (unsigned)((R + rpc - 1) / rpc)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(x16), ldx, scale, shift, res, ldr, y, ldy, C, R, rpc, relu, reinterpret_cast<unsigned short*>(y16));
+    } else if (v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift})) {
+        const long rpc = apply_rows_per_chunk(C, R);
+        hipLaunchKernelGGL((affine_apply_v4_kernel<false>), dim3(cdiv(C, BN_CT), (unsigned)((R + rpc - 1) / rpc)), dim3(256), 0, s,
                            x, ldx, scale, shift, res, ldr, y, ldy, C, R, rpc, relu, reinterpret_cast<unsigned short*>(y16));
     } else
         hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
@@ -443,8 +465,13 @@ static long bn_chunks(int C, long R) {
 }
 PDF_API long pdf_bn_workspace_floats(int C, long R) {
     long chunks = bn_chunks(C, R);
-    return chunks * C * 2;
+    return chunks * C * 2 + C;                              // (+ C: row 0 of a bf16 input as floats, BnFin::shift0)
 }
+// bf16 storage mode: the NEXT pdf_bn_train_fwd / pdf_bn_train_bwd call of this thread reads its input x from this bf16 tensor
+// (same shape and leading dimension in elements) instead of the fp32 pointer it is given
+static thread_local const void* tl_bn_x16 = nullptr;
+PDF_API int pdf_set_bn_input_bf16(const void* x16) { tl_bn_x16 = x16; return 0; }
+static const void* take_bn_x16() { const void* p = tl_bn_x16; tl_bn_x16 = nullptr; return p; }
 
 PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps,
@@ -452,29 +479,34 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
                              float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, hipStream_t s) {
     void* y16 = pdf_tls_take_output();                       // bf16 shadow of y (pdf_set_bf16_output), vectorised path only
     const TileStats ts = take_tile_stats();
+    const void* x16 = take_bn_x16();
     if (R <= 0 || C <= 0) return 0;
+    if (x16 != nullptr && !v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x16, y, res, scale, shift})) return PDF_E_BADARG;
     long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
-    BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, nullptr};
+    BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, nullptr, ws + bn_chunks(C, R) * C * 2};
     if (ts.part != nullptr) {                                // statistics came out of the producing GEMM's epilogue: no pass over x
         if (ts.tiles * ts.rows < R || (ts.tiles - 1) * ts.rows >= R) return PDF_E_BADARG;
         hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(C, FT_C)), dim3(FT_C * FT_L), 0, s, ts.part, (int)ts.tiles, ts.rows, C, R, gamma, beta,
                            running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
         fin.counters = reinterpret_cast<int*>(1);            // (marks "finalised" for the branch below)
+    } else if (x16 != nullptr) {
+        fin.counters = bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr;
+        hipLaunchKernelGGL((bn_partial_v4_kernel<true>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, reinterpret_cast<const float*>(x16), ldx, C, R, rpc, ws, fin);
     } else if (v4_ok(C, {ldx}, {x})) {
         fin.counters = bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr;          // finalize in the last block of each channel tile
-        hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws, fin);
+        hipLaunchKernelGGL((bn_partial_v4_kernel<false>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws, fin);
     } else
         hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws);
     PDF_LAUNCH_CHECK();
     if (fin.counters == nullptr) {
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, x, C, R, gamma, beta,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, x16 != nullptr ? fin.shift0 : x, C, R, gamma, beta,
                            running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
         PDF_LAUNCH_CHECK();
     }
-    if (y16 != nullptr && !v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift, y16})) return PDF_E_BADARG;
-    launch_affine_apply(x, ldx, scale, shift, res, ldr, y, ldy, C, R, relu, s, y16);
+    if (x16 == nullptr && y16 != nullptr && !v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift, y16})) return PDF_E_BADARG;
+    launch_affine_apply(x, ldx, scale, shift, res, ldr, y, ldy, C, R, relu, s, y16, x16);
     PDF_LAUNCH_CHECK();
     return 0;
 }
@@ -559,19 +591,27 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
                              float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
                              float* ws, hipStream_t s) {
     void* dx16 = pdf_tls_take_output();                      // bf16 shadow of dx
+    const void* x16 = take_bn_x16();                         // bf16 storage mode: x comes as bf16; dx == NULL: only the bf16 gradient is written
     if (R <= 0 || C <= 0) return 0;
     if ((relu == 1 && y == nullptr) || (relu == 2 && (scale == nullptr || shift == nullptr || dres != nullptr))) return PDF_E_BADARG;
+    if (dx == nullptr && dx16 == nullptr) return PDF_E_BADARG;
     long chunks = bn_chunks(C, R);
     long rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
     float* coef = ws + pdf_bn_workspace_floats(C, R);
+    const float* xin = x16 != nullptr ? reinterpret_cast<const float*>(x16) : x;
     const bool vec = v4_ok(C, {lddy, ldx, lddx, relu == 1 ? ldy : 0, dres ? lddr : 0},
-                           {dy, x, dx, dres, relu == 1 ? y : nullptr, save_mean, save_rstd, coef, relu == 2 ? scale : nullptr, relu == 2 ? shift : nullptr});
+                           {dy, xin, dx, dres, relu == 1 ? y : nullptr, save_mean, save_rstd, coef, relu == 2 ? scale : nullptr, relu == 2 ? shift : nullptr});
+    if ((x16 != nullptr || dx == nullptr) && !vec) return PDF_E_BADARG;
     BnBwdFin fin = {gamma, save_rstd, dgamma, dbeta, accumulate, coef, nullptr};
     if (vec) {
         fin.counters = bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr;
-        hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
-                           save_mean, save_rstd, scale, shift, C, R, rpc, ws, fin);
+        if (x16 != nullptr)
+            hipLaunchKernelGGL((bn_bwd_partial_v4_kernel<true>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, xin, ldx,
+                               save_mean, save_rstd, scale, shift, C, R, rpc, ws, fin);
+        else
+            hipLaunchKernelGGL((bn_bwd_partial_v4_kernel<false>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
+                               save_mean, save_rstd, scale, shift, C, R, rpc, ws, fin);
     } else
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
                            save_mean, save_rstd, scale, shift, C, R, rpc, ws);
@@ -582,8 +622,13 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
     }
     if (vec) {
         const long arpc = apply_rows_per_chunk(C, R);
-        hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)((R + arpc - 1) / arpc)), dim3(256), 0, s, dy, lddy, y, ldy, relu,
-                           x, ldx, save_mean, save_rstd, coef, scale, shift, C, R, arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
+        const dim3 grid(cdiv(C, BN_CT), (unsigned)((R + arpc - 1) / arpc));
+        if (x16 != nullptr)
+            hipLaunchKernelGGL((bn_bwd_apply_v4_kernel<true>), grid, dim3(256), 0, s, dy, lddy, y, ldy, relu,
+                               xin, ldx, save_mean, save_rstd, coef, scale, shift, C, R, arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
+        else
+            hipLaunchKernelGGL((bn_bwd_apply_v4_kernel<false>), grid, dim3(256), 0, s, dy, lddy, y, ldy, relu,
+                               x, ldx, save_mean, save_rstd, coef, scale, shift, C, R, arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
     } else if (dx16 != nullptr) return PDF_E_BADARG;
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef,
@@ -707,7 +752,7 @@ PDF_API int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, 
         long rpc = (rows + chunks - 1) / chunks;
         chunks = (rows + rpc - 1) / rpc;
         BnFin fin = {gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift, bn_inlaunch(C, rows) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr};
-        hipLaunchKernelGGL(bn_partial_v4_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, y, ldy, C, rows, rpc, ws, fin);
+        hipLaunchKernelGGL((bn_partial_v4_kernel<false>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, y, ldy, C, rows, rpc, ws, fin);
         if (fin.counters == nullptr)
             hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_TX)), dim3(FIN_TX, FIN_TY), 0, s, ws, (int)chunks, y, C, rows, gamma, beta,
                                running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);

@@ -142,6 +142,32 @@ def new_shadow(t):
     return torch.empty_like(t, dtype=torch.bfloat16) if shadows_on() else None
 
 
+# ---- bf16 STORAGE of the conv -> BatchNorm tensors (bf16 mode, PDFNET_BF16_STORAGE).  A convolution called with stats=True
+# feeds nothing but a training-mode BatchNorm.  Its output then exists only as bf16 (written by the GEMM epilogue, read by the
+# BatchNorm kernels: 2 instead of 4 bytes in five passes), and so does the gradient the BatchNorm hands back (it already wrote a
+# bf16 shadow of it for the backward GEMMs; now it writes nothing else).  Autograd still sees fp32 tensors of the right shape --
+# allocated, never written ("phantoms"), carrying the bf16 tensor as an attribute; the library gets a NULL fp32 pointer for them
+# and refuses (PDF_E_BADARG) any launch that would have to read it.
+BF16_STORAGE = _os.environ.get("PDFNET_BF16_STORAGE", "0") != "0"
+
+
+def storage_on():
+    return BF16_STORAGE and BF16_SHADOWS and _GEMM_BF16
+
+
+def _stored16(t):
+    """The bf16 tensor that IS the value of phantom `t` (None for an ordinary tensor)."""
+    v = getattr(t, '_pdf_y16', None)
+    if v is None or v[1] != t._version:
+        return None
+    return v[0]
+
+
+def _pp(t):
+    """fp32 pointer for the library: NULL for a phantom."""
+    return None if getattr(t, '_pdf_y16', None) is not None else ptr(t)
+
+
 def _set_ops(a, b):
     """Shadows of the next GEMM-family call's two operands (None = none)."""
     if a is not None or b is not None:
@@ -395,8 +421,15 @@ class _Conv2d(Function):
         x16, w16 = shadow_of(x), shadow_of(w)
         _set_ops(x16, w16)
         part = _stats_request(stats, N * OH * OW, Cout, x.device)
+        y16 = None
+        if (stats and storage_on() and b is None and act == ACT_NONE and Cin % 16 == 0 and Cout % 16 == 0
+                and (N * OH * OW) % 128 == 0):
+            y16 = torch.empty_like(y, dtype=torch.bfloat16)  # the output: y itself stays unwritten (see BF16_STORAGE)
+            _L().pdf_set_bf16_output(ptr(y16))
         _L().pdf_conv2d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream())
         _stats_attach(y, part)
+        if y16 is not None:
+            y._pdf_y16 = (y16, y._version)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.s16 = (x16, w16)
         ctx.cfg = (stride, pad, act, b is not None)
@@ -412,21 +445,25 @@ class _Conv2d(Function):
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = w.shape
         OH, OW = dy.shape[2], dy.shape[3]
-        g = cl(dy)
-        if act:
-            g = _act_bwd(g, y, act)
+        g16 = _stored16(dy)                                  # bf16 storage mode: the gradient exists only as bf16 (dy is a phantom)
+        if g16 is not None:
+            g, gp = dy, None
+        else:
+            g = cl(dy)
+            if act:
+                g = _act_bwd(g, y, act)
+            g16, gp = shadow_of(g), ptr(g)
         x16, w16 = ctx.s16
-        g16 = shadow_of(g)
         dx = dw = db = None
         L = _L()
         if ctx.needs_input_grad[0]:
             _set_ops(g16, w16)
             if dskip is not None and stride == 1 and dskip.shape == x.shape and dskip.is_contiguous(memory_format=CL):
                 dx = dskip                                  # the shortcut's gradient (sole consumer: this node); += in the epilogue
-                L.pdf_conv2d_bwd_data_add(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+                L.pdf_conv2d_bwd_data_add(gp, ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
             else:
                 dx = torch.zeros_like(x) if stride > KH else torch.empty_like(x)
-                L.pdf_conv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+                L.pdf_conv2d_bwd_data(gp, ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
                 if dskip is not None:
                     dx = dx + dskip
         w_par, b_par = ctx.params
@@ -435,7 +472,7 @@ class _Conv2d(Function):
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(R, Cout, KH * KW * Cin, x.device)
             _set_ops(x16, g16)
-            L.pdf_conv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+            L.pdf_conv2d_bwd_weight(ptr(x), gp, ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
                                     stride, pad, OH, OW, Cout, acc, stream())
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True, shadows=(x16, g16))
         return dx, dw, db, None, None, None, None, None
@@ -669,7 +706,9 @@ class _BatchNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, res, training, momentum, eps, relu):
         hip.require_gpu(x)
-        x = _canon(x)
+        x16 = _stored16(x) if training else None            # bf16 storage mode: x is a phantom, its value is this bf16 tensor
+        if x16 is None:
+            x = _canon(x)
         res = _canon(res) if res is not None else None
         R, C = _rows(x)
         y = torch.empty_like(x)
@@ -689,17 +728,21 @@ class _BatchNorm(Function):
             y16 = new_shadow(y) if C % 4 == 0 else None
             if y16 is not None:
                 L.pdf_set_bf16_output(ptr(y16))
-            L.pdf_bn_train_fwd(ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
+            if x16 is not None:
+                L.pdf_set_bn_input_bf16(ptr(x16))
+            L.pdf_bn_train_fwd(None if x16 is not None else ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
                                ptr(res), C, int(relu), ptr(y), C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
             if y16 is not None:
                 attach_shadow(y, y16)
             # ReLU without a residual: the backward recomputes the mask from x with (scale, shift); y is not kept for it
             recompute = relu and res is None
-            ctx.save_for_backward(x, gamma, mean, rstd, (scale if recompute else (y if relu else None)), (shift if recompute else None))
+            ctx.save_for_backward(x16 if x16 is not None else x, gamma, mean, rstd, (scale if recompute else (y if relu else None)), (shift if recompute else None))
+            ctx.x_is_16 = x16 is not None
         else:
             L.pdf_bn_eval_fwd(ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps,
                               ptr(res), C, int(relu), ptr(y), C, ptr(scale), ptr(shift), stream())
             ctx.save_for_backward(x, gamma, None, None, y if relu else None, None)
+            ctx.x_is_16 = False
         ctx.cfg = (training, relu, res is not None, eps)
         ctx.params = (gamma, beta)
         return y
@@ -716,8 +759,9 @@ class _BatchNorm(Function):
             raise RuntimeError("pdfnet_amd: BatchNorm backward in eval mode is not implemented")
         R, C = _rows(x)
         g = _canon(dy)
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if has_res else None
+        x_is_16 = ctx.x_is_16
+        dx = torch.empty_like(x, dtype=torch.float32)       # (storage mode: allocated, not written -- the phantom autograd passes on)
+        dres = torch.empty_like(dx) if has_res else None
         g_par, b_par = ctx.params
         mg_g, mg_b = _main_grad(g_par, g_par), _main_grad(b_par, b_par)
         direct = mg_g is not None and mg_b is not None
@@ -728,9 +772,13 @@ class _BatchNorm(Function):
         dx16 = new_shadow(dx) if C % 4 == 0 else None
         if dx16 is not None:
             L.pdf_set_bf16_output(ptr(dx16))
-        L.pdf_bn_train_bwd(ptr(g), C, ptr(y), C, mode, ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R,
-                           ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream())
-        if dx16 is not None:
+        if x_is_16:
+            L.pdf_set_bn_input_bf16(ptr(x))
+        L.pdf_bn_train_bwd(ptr(g), C, ptr(y), C, mode, None if x_is_16 else ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R,
+                           None if x_is_16 else ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream())
+        if x_is_16:
+            dx._pdf_y16 = (dx16, dx._version)               # the conv's backward takes the bf16 gradient; dx itself was not written
+        elif dx16 is not None:
             attach_shadow(dx, dx16)
         if direct:
             dgamma = dbeta = None
