@@ -163,10 +163,6 @@ def _stored16(t):
     return v[0]
 
 
-def _pp(t):
-    """fp32 pointer for the library: NULL for a phantom."""
-    return None if getattr(t, '_pdf_y16', None) is not None else ptr(t)
-
 
 def _set_ops(a, b):
     """Shadows of the next GEMM-family call's two operands (None = none)."""
