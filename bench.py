@@ -479,13 +479,22 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
             tr.train_step(batch)
         torch.cuda.synchronize()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        t0 = time.time()
-        marks[0].record()
-        for i in range(steps):
-            last = tr.train_step(batch)
-            marks[i + 1].record()                          # (events on the launch stream: per-step times without a host sync)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
+        # the B=32 step is within 10 % of the host's issue time: keep the cyclic collector (everything the fp32 run, the CPU oracle
+        # and the MPJPE passes left behind is tracked) out of the timed region, as a training loop on a busy host would
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+        try:
+            t0 = time.time()
+            marks[0].record()
+            for i in range(steps):
+                last = tr.train_step(batch)
+                marks[i + 1].record()                      # (events on the launch stream: per-step times without a host sync)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+        finally:
+            gc.enable()
+            gc.unfreeze()
         per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
         median_ms = per_step[steps // 2]
         loss_val = float(last)
