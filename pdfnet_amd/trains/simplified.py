@@ -83,6 +83,8 @@ class CtdetLoss(nn.Module):
         self.register_buffer('faces_pair', torch.stack((consts['faces_left'], consts['faces_right'])).long(), persistent=False)
         self.register_buffer('bone_a', torch.tensor([b[0] for b in _BONES]), persistent=False)
         self.register_buffer('bone_c', torch.tensor([b[1] for b in _BONES]), persistent=False)
+        self.register_buffer('_hand_scales', torch.tensor([1.0, 1.0, 1000.0, 1000.0, 1000.0, 1.0, 1.0]).view(7, 1, 1), persistent=False)
+        self._coef_cache = {}
 
     def forward(self, result, paramsDict, handDictList, otherInfo, batch, mode, epoch):
         test = mode in ('val', 'test')
@@ -119,20 +121,29 @@ class CtdetLoss(nn.Module):
                      t['edge_loss'] * 2000 * alpha + t['gcn_loss'] * 100 + t['gcn_2d_loss'] * 50 + t['abs_joints_loss'] * 0.1 +
                      t['joints2d_loss'] * 1000 * alpha + t['joints_loss'] * 500) + getattr(o, 'bone_dir_weight', 200.0) * t['bone_direc_loss'])
 
-    def total(self, t, epoch):
-        """The reference's weighted sum in the reference's order (:610-640) -> (loss [B], stats, None, None)."""
+    _ORDER = ('hm_loss', 'root_loss', 'verts_loss', 'abs_verts_loss', 'verts2d_loss', 'norm_loss', 'edge_loss', 'gcn_loss',
+              'gcn_2d_loss', 'mask_loss', 'abs_joints_loss', 'hms_loss', 'joints2d_loss', 'joints_loss', 'bone_direc_loss')
+
+    def coefficients(self, epoch):
+        """The weights of the reference's sum (:610-640), in _ORDER."""
         o = self.opt
         alpha = 0 if epoch < 20 else 1                                                                      # :610
         w = getattr(o, 'reproj_weight', 1.0)
-        loss = getattr(o, 'center_weight', 200.0) * t['hm_loss'] + w * t['root_loss']
-        loss = loss + w * (t['verts_loss'] * 500 + t['abs_verts_loss'] * 0.1 + t['verts2d_loss'] * 50 + t['norm_loss'] * 10 +
-                           t['edge_loss'] * 2000 * alpha + t['gcn_loss'] * 100 + t['gcn_2d_loss'] * 50)
-        loss = loss + w * (t['mask_loss'] * 2000 + t['abs_joints_loss'] * 0.1 + t['hms_loss'] * 2000 +
-                           t['joints2d_loss'] * 1000 * alpha + t['joints_loss'] * 500)
-        loss = loss + getattr(o, 'bone_dir_weight', 200.0) * t['bone_direc_loss']
-        order = ('hm_loss', 'root_loss', 'verts_loss', 'abs_verts_loss', 'verts2d_loss', 'norm_loss', 'edge_loss', 'gcn_loss',
-                 'gcn_2d_loss', 'mask_loss', 'abs_joints_loss', 'hms_loss', 'joints2d_loss', 'joints_loss', 'bone_direc_loss')
-        stats = {k: t[k] for k in order}
+        return (getattr(o, 'center_weight', 200.0), w, w * 500, w * 0.1, w * 50, w * 10, w * 2000 * alpha, w * 100, w * 50,
+                w * 2000, w * 0.1, w * 2000, w * 1000 * alpha, w * 500, getattr(o, 'bone_dir_weight', 200.0))
+
+    def total(self, t, epoch):
+        """The reference's weighted sum (:610-640) -> (loss [B], stats, None, None): one stacked product-sum over the 15 terms
+        (the term-by-term expression was ~30 launches forward and ~45 backward on [B]-sized tensors)."""
+        coefs = self.coefficients(epoch)
+        terms = [t[k] for k in self._ORDER]
+        dev = terms[0].device
+        c = self._coef_cache.get((coefs, dev))
+        if c is None:
+            c = self._coef_cache[(coefs, dev)] = torch.tensor(coefs, dtype=torch.float32, device=dev).view(-1, 1)
+        B = max(x.numel() for x in terms)
+        loss = (torch.stack([x.expand(B) if x.dim() == 0 else x for x in terms]) * c).sum(0)
+        stats = {k: t[k] for k in self._ORDER}
         stats['loss'] = loss
         return loss, stats, None, None
 
@@ -157,10 +168,10 @@ class CtdetLoss(nn.Module):
         regs = (self.full_regressor_left, self.full_regressor_right)
 
         verts2d_loss = F.rowloss(v2p, v2gt, 1, 'l2').sum() * k2                                             # :425-426
-        verts_loss = (F.rowloss(vp, vgt_off, 2, 'l1') * hv).sum(0)                                          # :427-428
+        verts_rows = F.rowloss(vp, vgt_off, 2, 'l1')                                                        # :427-428 (x valid, summed over hands below)
         jp_off = F.regress_joints_pair(*regs, vp)                                                           # :431-432
         jg_off = F.regress_joints_pair(*regs, vgt_off)
-        joints_loss = (F.rowloss(jp_off, jg_off, 2, 'l1') * hv).sum(0)                                      # :435-436
+        joints_rows = F.rowloss(jp_off, jg_off, 2, 'l1')                                                    # :435-436
         alpha = 0 if (epoch is None or epoch < 20) else 1                                                   # :610 (test mode passes None)
         # edge term: weighted by alpha in `total`; while alpha == 0 it is reported but its (exactly zero) gradient is skipped
         nl, el = F.face_loss(vp, vgt_off, self.faces_pair, edge_grad=alpha != 0)                            # :452-453
@@ -171,7 +182,7 @@ class CtdetLoss(nn.Module):
         g3 = _pool4(torch.stack((cl.vert_to_GCN(vgt_off[0]), cr.vert_to_GCN(vgt_off[0]))))
         g2 = _pool4(torch.stack((cl.vert_to_GCN(v2gt[0]), cr.vert_to_GCN(v2gt[1]))))
         hd = handDictList[0]
-        gcn_loss = (F.rowloss(_pair(hd['verts3d']), g3, 2, 'l1') * valid[:, 0]).sum(0)
+        gcn_rows = F.rowloss(_pair(hd['verts3d']), g3, 2, 'l1')
         gcn_2d_loss = F.rowloss(_pair(hd['verts2d']), g2, 1, 'l2').sum() * k2
 
         r = _pair(paramsDict['root'])                                                                       # :489-506
@@ -182,10 +193,16 @@ class CtdetLoss(nn.Module):
         if test:                                                                                            # :652-653
             return tuple(t.transpose(0, 1).contiguous() for t in (vpred, jp, vgt, jgt, lms, vp, jp_off, vgt_off, jg_off))
         joints2d_loss = (F.rowloss(lms, lmsgt, 1, 'l2').unsqueeze(1) * k2 * hv).sum(0)                      # :499-500
-        root_loss = (F.rowloss(root_pred, root_gt, 2, 'l1') * hv * 1000).sum(0)                             # :506-507
-        abs_joints_loss = (F.rowloss(jp, jgt, 2, 'l1') * hv).sum(0) * 1000
-        abs_verts_loss = (F.rowloss(vpred, vgt, 2, 'l1') * hv).sum(0) * 1000
-        bone = (bone_direction_loss(lms.reshape(2 * B, -1, 2), lmsgt.reshape(2 * B, -1, 2), self.bone_a, self.bone_c).view(2, B) * hv).sum(0)  # :517-525
+        # The seven per-hand, per-sample terms are weighted by `valid`, summed over the hands and scaled as ONE stacked product-sum
+        # ((x * valid).sum(0) [* 1000] each: 2-3 launches forward and 3-4 backward per term on the step's dependent chain;
+        # `tools/probe/loss_time.py`).  NB gcn_loss weights both hands by valid[:, 0] (reference :481-482).
+        rows = torch.stack((verts_rows, joints_rows, F.rowloss(root_pred, root_gt, 2, 'l1'),                # :506-507
+                            F.rowloss(jp, jgt, 2, 'l1'), F.rowloss(vpred, vgt, 2, 'l1'), gcn_rows,
+                            bone_direction_loss(lms.reshape(2 * B, -1, 2), lmsgt.reshape(2 * B, -1, 2), self.bone_a, self.bone_c).view(2, B)))  # :517-525
+        wts = hv.unsqueeze(0).repeat(7, 1, 1)
+        wts[5] = valid[:, 0]
+        wts = wts * self._hand_scales
+        verts_loss, joints_loss, root_loss, abs_joints_loss, abs_verts_loss, gcn_loss, bone = (rows * wts).sum(1).unbind(0)
         return {'root_loss': root_loss, 'verts_loss': verts_loss, 'abs_verts_loss': abs_verts_loss, 'verts2d_loss': verts2d_loss,
                 'norm_loss': norm_loss, 'edge_loss': edge_loss, 'gcn_loss': gcn_loss, 'gcn_2d_loss': gcn_2d_loss,
                 'abs_joints_loss': abs_joints_loss, 'joints2d_loss': joints2d_loss, 'joints_loss': joints_loss, 'bone_direc_loss': bone}

@@ -54,5 +54,9 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     run()
 ev = [e for e in prof.events() if e.device_type is not None and 'cuda' in str(e.device_type).lower()]
-tot = sum(e.cuda_time if hasattr(e, 'cuda_time') else e.device_time for e in ev)
+tot = sum(e.device_time for e in ev)
 print("kernels in one forward+backward: %d, summed kernel time %.3f ms" % (len(ev), tot / 1e3))
+import collections, re
+cnt = collections.Counter(re.sub(r"<.*|\(.*", "", e.name)[:60] for e in ev)
+for k, v in cnt.most_common(25):
+    print("%4d  %s" % (v, k))
