@@ -74,7 +74,11 @@ CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, act, bias
     # valid 3x3 on the 5x5 / 3x3 centre windows (few rows, long reduction: 32x32 tiles)
     (64, 256, 5, 5, 512, 3, 1, 0, 0, False), (64, 512, 3, 3, 1024, 3, 1, 0, 0, False),
     # the ResNet stem at output widths that are multiples of 64: its dedicated MFMA weight-gradient kernel (image borders on all sides)
-    (3, 3, 128, 128, 64, 7, 2, 3, 0, False), (2, 3, 64, 256, 64, 7, 2, 3, 1, False)]
+    (3, 3, 128, 128, 64, 7, 2, 3, 0, False), (2, 3, 64, 256, 64, 7, 2, 3, 1, False),
+    # the LDS-DMA weight-gradient kernel's issue paths: scalar offsets (16-pixel K-steps: stride 2, a 48-wide map that wraps every
+    # third step, plain 1x1 rows) and the per-row form (a 40-wide map)
+    (24, 128, 64, 64, 256, 3, 2, 1, 0, False), (12, 128, 48, 48, 256, 3, 1, 1, 0, False), (24, 256, 32, 32, 512, 1, 1, 0, 0, True),
+    (16, 128, 40, 40, 256, 3, 1, 1, 0, False)]
 
 
 @pytest.mark.parametrize("cfg", CONVS)
