@@ -18,6 +18,9 @@
 #define PDF_FRAG_PIPE 0
 #endif
 constexpr bool FRAG_PIPE = PDF_FRAG_PIPE != 0;
+#ifndef PDF_WG_ISSUE_AT
+#define PDF_WG_ISSUE_AT 1                       // wgemm_tn_dma, scalar-offset form: the k-pair after which the next tile's loads are issued
+#endif
 #ifndef PDF_IG_DEEP
 #define PDF_IG_DEEP 1
 #endif
@@ -980,7 +983,10 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
         // this wave's 4 DMAs of tile t have landed (the ST-2 younger tiles may still fly) ...
         if (ST == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // ... and everybody's; everybody also finished reading tile t-1
-        if (u16) issue_u16(t + ST - 1, stn); else if (uni) issue_uni(t + ST - 1, stn); else issue(t + ST - 1, stn);      // refill the stage tile t-1 used (rows past the end read zeros)
+        // refill the stage tile t-1 used (rows past the end read zeros).  The scalar-offset form is issued from INSIDE the MFMA
+        // sequence (after the second k-pair): its ~25 scalar / vector instructions and 4 DMA loads then overlap the matrix pipe
+        // instead of standing between the barrier and the first MFMA
+        if (!u16) { if (uni) issue_uni(t + ST - 1, stn); else issue(t + ST - 1, stn); }
         const float* ps = smem + (st * 2 + 0) * BK * 128;
         const float* qs = smem + (st * 2 + 1) * BK * 128;
         if (do_bias) {
@@ -1005,6 +1011,7 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
+            if (kk == PDF_WG_ISSUE_AT && u16) issue_u16(t + ST - 1, stn);
         }
         st = st == ST - 1 ? 0 : st + 1;
         stn = stn == ST - 1 ? 0 : stn + 1;
