@@ -275,6 +275,11 @@ int pdf_sft3_bwd(const float* g, int ldg, const float* fea, int ldf, const float
 int pdf_set_bf16_operands(const void* op0_bf16, const void* op1_bf16);
 int pdf_set_bf16_output(void* out_bf16);
 int pdf_set_bn_input_bf16(const void* x16);
+/* BatchNorm + ReLU applied by the CONSUMER (reference: the conv -> bn -> relu -> conv chains of the set-abstraction MLPs,
+ * intaghand_encoder.py:48-103): pdf_bn_train_fwd with y == NULL computes the statistics and (scale, shift) only; the next
+ * pdf_linear_fwd / pdf_linear_bwd_weight call of this thread, given them through pdf_set_input_affine_relu, reads its x operand as
+ * relu(x * scale[c] + shift[c]) -- the normalised tensor is never written.  fp32 kernels, plain rows, K % 16 == 0. */
+int pdf_set_input_affine_relu(const float* scale, const float* shift);
 int pdf_cast_bf16(const float* src, void* dst, long n, void* stream);
 int pdf_debug_shadow_operands(void);      /* shadow operands consumed by bf16 GEMM launches so far (tests) */
 /* nn.Dropout(p) with a stateless (seed, index) mask: the same call is its own backward (gcn.py:96, self_attn.py:51-52).

@@ -108,3 +108,4 @@ __device__ __forceinline__ unsigned int pdf_pk_bf16(float a, float b) {      // 
 }
 void pdf_tls_take_operands(const void** op0, const void** op1);
 void* pdf_tls_take_output();
+void pdf_tls_take_affine(const float** scale, const float** shift);

@@ -557,6 +557,11 @@ PDF_API int pdf_set_bf16_operands(const void* op0_bf16, const void* op1_bf16) { 
 PDF_API int pdf_set_bf16_output(void* out_bf16) { tl_out = out_bf16; return 0; }
 void pdf_tls_take_operands(const void** op0, const void** op1) { *op0 = tl_op0; *op1 = tl_op1; tl_op0 = tl_op1 = nullptr; }
 void* pdf_tls_take_output() { void* o = tl_out; tl_out = nullptr; return o; }
+// BatchNorm + ReLU of an input tensor applied by the NEXT pdf_linear_fwd (its x) / pdf_linear_bwd_weight (its x) of this thread
+static thread_local const float* tl_aff_scale = nullptr;
+static thread_local const float* tl_aff_shift = nullptr;
+PDF_API int pdf_set_input_affine_relu(const float* scale, const float* shift) { tl_aff_scale = scale; tl_aff_shift = shift; return 0; }
+void pdf_tls_take_affine(const float** scale, const float** shift) { *scale = tl_aff_scale; *shift = tl_aff_shift; tl_aff_scale = tl_aff_shift = nullptr; }
 // dst[i] = bf16(src[i]) (RNE): the weight shadows, refreshed from the flat fp32 master buffer once per step
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n4) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {

@@ -137,6 +137,15 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN >= 128 * 128 ? 3 : 1)) void 
             for (int i = 0; i < RA; ++i) ra[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, (aok[i] && live) ? aoffB[i] + sa : 0xffffffffu, 0, 0));
 #pragma unroll
             for (int i = 0; i < RB; ++i) rb[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsB, (bval[i] && live) ? boffB[i] + sb : 0xffffffffu, 0, 0));
+            if (g.a_scale != nullptr) {                      // BatchNorm + ReLU of the producer applied here (plain GEMM: k = channel)
+                const int ch = min(nt_ci + kq, g.K - 4);
+                const float4 sc = *reinterpret_cast<const float4*>(g.a_scale + ch), sh = *reinterpret_cast<const float4*>(g.a_shift + ch);
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {               // (rows past M become relu(shift): they only reach output rows nobody stores)
+                    ra[i].x = fmaxf(fmaf(ra[i].x, sc.x, sh.x), 0.f); ra[i].y = fmaxf(fmaf(ra[i].y, sc.y, sh.y), 0.f);
+                    ra[i].z = fmaxf(fmaf(ra[i].z, sc.z, sh.z), 0.f); ra[i].w = fmaxf(fmaf(ra[i].w, sc.w, sh.w), 0.f);
+                }
+            }
             nt_ci += BK;
             if (nt_ci >= g.Cin && nt_tap + 1 < g.T) {
                 ++nt_tap; nt_ci = 0;
@@ -619,6 +628,8 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     }
     const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)Pp, 0, BUF ? g.pbytes : 0, 0x00020000);
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qp, 0, BUF ? g.qbytes : 0, 0x00020000);
+    float4 qsc = make_float4(1.f, 1.f, 1.f, 1.f), qsh = make_float4(0.f, 0.f, 0.f, 0.f);      // WGemm::q_scale / q_shift of this thread's 4 columns
+    if (BUF && g.q_scale != nullptr && qok[0]) { qsc = *reinterpret_cast<const float4*>(g.q_scale + qch[0]); qsh = *reinterpret_cast<const float4*>(g.q_shift + qch[0]); }
     auto gload = [&](int mb) {
         if constexpr (BUF) {
 #pragma unroll
@@ -640,6 +651,16 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
                 }
                 const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, oq, 0, 0);
                 rq[i] = *reinterpret_cast<const float4*>(&v);
+                if (g.q_scale != nullptr) {                  // BatchNorm + ReLU of x applied here; rows past the split's end must stay zero
+                    if (mb + BK <= me && qok[0]) {           // (whole K-step: no per-row select)
+                        rq[i].x = fmaxf(fmaf(rq[i].x, qsc.x, qsh.x), 0.f); rq[i].y = fmaxf(fmaf(rq[i].y, qsc.y, qsh.y), 0.f);
+                        rq[i].z = fmaxf(fmaf(rq[i].z, qsc.z, qsh.z), 0.f); rq[i].w = fmaxf(fmaf(rq[i].w, qsc.w, qsh.w), 0.f);
+                    } else {
+                        const bool rok = oq != 0xffffffffu;
+                        rq[i].x = rok ? fmaxf(fmaf(rq[i].x, qsc.x, qsh.x), 0.f) : 0.f; rq[i].y = rok ? fmaxf(fmaf(rq[i].y, qsc.y, qsh.y), 0.f) : 0.f;
+                        rq[i].z = rok ? fmaxf(fmaf(rq[i].z, qsc.z, qsh.z), 0.f) : 0.f; rq[i].w = rok ? fmaxf(fmaf(rq[i].w, qsc.w, qsh.w), 0.f) : 0.f;
+                    }
+                }
                 q_x[i] += BK;
                 while (q_x[i] >= g.QW) {
                     q_x[i] -= g.QW;
@@ -976,6 +997,14 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
 
     const int aoff = (lane >> 5) * 128 + wm * TM * 32 + (lane & 31);
     const int boff = (lane >> 5) * 128 + wn * TN * 32 + (lane & 31);
+    const bool qaff = BUF && g.q_scale != nullptr;          // (host: only with uniform == 2 and plain rows -- no zero-filled partial K-step)
+    float fsc[TN], fsh[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = j0 + wn * TN * 32 + j * 32 + (lane & 31);
+        fsc[j] = (qaff && c < NJ) ? g.q_scale[c] : 1.f;
+        fsh[j] = (qaff && c < NJ) ? g.q_shift[c] : 0.f;
+    }
 #pragma unroll
     for (int p = 0; p < ST - 1; ++p) { if (u16) issue_u16(p, p); else if (uni) issue_uni(p, p); else issue(p, p); }
     int st = 0, stn = ST - 1;
@@ -999,6 +1028,10 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
             for (int i = 0; i < TM; ++i) a[set][i] = ps[aoff + kk * 2 * 128 + i * 32];
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[set][j] = qs[boff + kk * 2 * 128 + j * 32];
+            if (qaff) {                                      // WGemm::q_scale: BatchNorm + ReLU of x at fragment-read time (every K-step is whole here)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[set][j] = fmaxf(fmaf(b[set][j], fsc[j], fsh[j]), 0.f);
+            }
         };
         if (FRAG_PIPE) frag(0, 0);
 #pragma unroll
@@ -1282,6 +1315,8 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     if (g.A16 != nullptr && (g.lda % 8 != 0 || (reinterpret_cast<uintptr_t>(g.A16) & 15))) g.A16 = nullptr;      // 16-byte chunks of 8 bf16
     if (g.B16 != nullptr && ((!g.b_kn && g.ldb % 8 != 0) || (reinterpret_cast<uintptr_t>(g.B16) & 15))) g.B16 = nullptr;
     if (g.A == nullptr && g.A16 == nullptr) return PDF_E_BADARG;          // bf16 storage mode: A exists only as bf16 -- it must be usable
+    if (g.a_scale != nullptr && !(fast && !g_gemm_bf16 && groups == 1 && g.T == 1 && g.plain_in && g.abytes != 0 && g.K % 4 == 0 && env_int(ENV_IG_BUF, 1)))
+        return PDF_E_BADARG;                             // the operand transform lives in the buffer-load form of igemm_nt only
     if (g_gemm_bf16 && fast) {
         g_shadow_operands += (g.A16 != nullptr) + (g.B16 != nullptr);
         // BatchNorm statistics out of the fp32 accumulators: the bf16 kernels take them in their whole-tile epilogue only
@@ -1408,6 +1443,7 @@ PDF_API int pdf_linear_fwd(const float* x, const float* w, const float* bias, fl
     IGemm g = linear_desc(x, w, bias, y, M, N, K, ldx, ldw, ldy, act);
     g.A16 = sh.op0; g.B16 = sh.op1;
     g.stat = sr.part;
+    pdf_tls_take_affine(&g.a_scale, &g.a_shift);
     return launch_igemm(g, s, 1, sr.cap);
 }
 // Two same-shaped layers with their own parameters in ONE launch (the left / right hand branches of the mesh decoder,
@@ -1866,6 +1902,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     const double wflops = 2.0 * groups * g.M * g.NI * NJ, wbytes = wgemm_bytes(g, groups);
     // operand extents for the buffer-descriptor kernels (from the group's base pointer; every element the kernel may address)
     const double pext = 4.0 * g.M * g.ldp, qext = 4.0 * (g.plain_q ? (double)g.M * g.ldq : (double)cdiv(g.M, g.QH * g.QW) * g.H * g.W * g.ldq);
+    if (bf16 && g.q_scale != nullptr) return PDF_E_BADARG;
     if (bf16) {
         g_shadow_operands += (g.P16 != nullptr) + (g.Q16 != nullptr);
         const bool fits = pext < 4294967000.0 && qext < 4294967000.0;
@@ -1874,11 +1911,13 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         if (brc < 0) return -brc;
     }
     if (brc != 1 && (g.P == nullptr || g.Q == nullptr)) return PDF_E_BADARG;      // a bf16-only operand and no bf16 launch
+    if (g.q_scale != nullptr && (brc == 1 || !g.plain_q || groups != 1)) return PDF_E_BADARG;      // operand transform: fp32 buffer-load kernels only
     if (brc == 1) {
     } else if (small) {
         const bool bk32 = fast && env_int(ENV_WG_BK32, 1);
         const bool buf = bk32 && pext < 4294967000.0 && qext < 4294967000.0 && env_int(ENV_WG_BUF, 1);
         g.pbytes = buf ? (unsigned)pext : 0; g.qbytes = buf ? (unsigned)qext : 0;
+        if (g.q_scale != nullptr && !buf) return PDF_E_BADARG;
         KTimer kt(buf ? "wgemm_tn<64, 64, 2, 2, true, 32, true>" : bk32 ? "wgemm_tn<64, 64, 2, 2, true, 32, false>" : fast ? "wgemm_tn<64, 64, 2, 2, true, 16, false>" : "wgemm_tn<64, 64, 2, 2, false, 16, false>", wflops, wbytes, s);
         if (buf) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32, true>), grid, dim3(256), 0, s, g);
         else if (bk32) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
@@ -1891,6 +1930,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         g.pbytes = buf ? (unsigned)pext : 0; g.qbytes = buf ? (unsigned)qext : 0;
         g.uniform = (buf && (g.plain_q || (g.QW % 8 == 0 && g.Cq % 128 == 0)) && env_int(ENV_WG_UNIFORM, 2)) ? 1 : 0;
         if (g.uniform && env_int(ENV_WG_UNIFORM, 2) >= 2 && g.rows_per_split % 16 == 0 && g.M % 16 == 0 && (g.plain_q || g.QW % 16 == 0)) g.uniform = 2;
+        if (g.q_scale != nullptr && g.uniform != 2) return PDF_E_BADARG;      // (the fragment-read transform needs whole K-steps)
         KTimer kt(buf ? "wgemm_tn_dma<3, true>" : fast && dma == 4 ? "wgemm_tn_dma<4, false>" : fast && dma == 3 ? "wgemm_tn_dma<3, false>" : fast ? "wgemm_tn<128, 128, 2, 2, true, 16>" : "wgemm_tn<128, 128, 2, 2, false, 16>",
                   wflops, wbytes, s);
         if (buf) hipLaunchKernelGGL((wgemm_tn_dma<3, true>), grid, dim3(256), pad, s, g);
@@ -1937,6 +1977,7 @@ PDF_API int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, fl
     g.plain_q = 1; g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
     g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
     g.Q16 = sh.op0; g.P16 = sh.op1;
+    pdf_tls_take_affine(&g.q_scale, &g.q_shift);
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s, nullptr, db);
 }
 

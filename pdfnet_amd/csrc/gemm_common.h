@@ -39,6 +39,9 @@ struct IGemm {
     // bf16 storage mode (gemm_bf16.hip, whole tiles only): the output goes to C16 (same shape, ldc in ELEMENTS) rounded to bf16
     // (RNE) INSTEAD of C -- a conv output that only a training BatchNorm reads; statistics are taken from the rounded values
     unsigned short* C16;
+    // A = relu(A * a_scale[k] + a_shift[k]) while the tile is staged (plain GEMMs, fp32 kernels): the BatchNorm + ReLU in front of a
+    // PointNet++ linear layer applied by its consumer -- the normalised tensor is never written (functional._BatchNorm lazy=True)
+    const float* a_scale; const float* a_shift;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
@@ -191,6 +194,7 @@ struct WGemm {
     // global_atomic_add_f32 -- no slabs, no reduction pass; the summation order then varies from run to run
     int atomic;
     const void* P16; const void* Q16;         // bf16 shadows of P / Q (see IGemm::A16)
+    const float* q_scale; const float* q_shift;      // Q = relu(Q * q_scale[c] + q_shift[c]) on the fly (see IGemm::a_scale); plain_q only
     // byte extents of P / Q as seen from their (group-adjusted) base pointers, for the buffer descriptors of wgemm_tn_dma<.., true>
     // (0: an operand is >= 4 GiB - 32 and the flat-address form of the kernel is used)
     unsigned int pbytes, qbytes;

@@ -505,6 +505,7 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
                            running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
         PDF_LAUNCH_CHECK();
     }
+    if (y == nullptr) return res == nullptr && y16 == nullptr ? 0 : PDF_E_BADARG;      // statistics and coefficients only: the consumer applies them (pdf_set_input_affine_relu)
     if (x16 == nullptr && y16 != nullptr && !v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift, y16})) return PDF_E_BADARG;
     launch_affine_apply(x, ldx, scale, shift, res, ldr, y, ldy, C, R, relu, s, y16, x16);
     PDF_LAUNCH_CHECK();

@@ -155,6 +155,14 @@ def storage_on():
     return BF16_STORAGE and BF16_SHADOWS and _GEMM_BF16
 
 
+def _lazy_bn(t):
+    """(raw tensor, scale, shift) if `t` is the never-written output of a lazy BatchNorm + ReLU (see _BatchNorm, lazy=True)."""
+    v = getattr(t, '_pdf_lazy', None)
+    if v is None or v[3] != t._version:
+        return None
+    return v[:3]
+
+
 def _stored16(t):
     """The bf16 tensor that IS the value of phantom `t` (None for an ordinary tensor)."""
     v = getattr(t, '_pdf_y16', None)
@@ -546,18 +554,25 @@ class _Linear(Function):
     def forward(ctx, x, w, b, act, fp32=False, stats=False):
         hip.require_gpu(x, w)
         w_in = w
+        lz = _lazy_bn(x)                                   # x = relu(BN(raw)) that was never written: the GEMM applies it while staging
+        if lz is not None:
+            x, aff = lz[0], (lz[1], lz[2])
+        else:
+            aff = None
         x, w = x.contiguous(), w.contiguous()
         K = x.shape[-1]
         M = x.numel() // K
         Nn = w.shape[0]
         y = torch.empty(x.shape[:-1] + (Nn,), dtype=torch.float32, device=x.device)
-        x16, w16 = (None, None) if fp32 else (shadow_of(x), shadow_of(w))
+        x16, w16 = (None, None) if (fp32 or aff is not None) else (shadow_of(x), shadow_of(w))
         with _forced_fp32(fp32):
             _set_ops(x16, w16)
             part = _stats_request(stats, M, Nn, x.device)
+            if aff is not None:
+                _L().pdf_set_input_affine_relu(ptr(aff[0]), ptr(aff[1]))
             _L().pdf_linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), M, Nn, K, K, K, Nn, act, stream())
             _stats_attach(y, part)
-        ctx.save_for_backward(x, w, y if act else None)
+        ctx.save_for_backward(x, w, y if act else None, *(aff if aff is not None else ()))
         ctx.s16 = (x16, w16)
         ctx.fp32 = fp32
         ctx.cfg = (act, b is not None)
@@ -566,7 +581,8 @@ class _Linear(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors[:3]
+        aff = ctx.saved_tensors[3:5] if len(ctx.saved_tensors) > 3 else None
         act, has_b = ctx.cfg
         K = x.shape[-1]
         M = x.numel() // K
@@ -589,6 +605,8 @@ class _Linear(Function):
             ws, n = _wgrad_ws(M, Nn, K, x.device)
             with _forced_fp32(ctx.fp32):
                 _set_ops(x16, g16)
+                if aff is not None:
+                    L.pdf_set_input_affine_relu(ptr(aff[0]), ptr(aff[1]))
                 L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K, fused_bias=True, shadows=(x16, g16))
         return dx, dw, db, None, None, None
@@ -700,7 +718,7 @@ class _BatchNorm(Function):
     """y = [relu]( BN(x) [+ res] ) over rows; x 4-D channels_last or [..., C]."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, res, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, rmean, rvar, res, training, momentum, eps, relu, lazy=False):
         hip.require_gpu(x)
         x16 = _stored16(x) if training else None            # bf16 storage mode: x is a phantom, its value is this bf16 tensor
         if x16 is None:
@@ -721,15 +739,20 @@ class _BatchNorm(Function):
                 L.pdf_set_bn_tile_stats(ptr(tiles[0]), tiles[1], tiles[2])
             else:
                 ws = _ws(L.pdf_bn_workspace_floats(C, R), dev)
-            y16 = new_shadow(y) if C % 4 == 0 else None
+            # lazy: statistics and (scale, shift) only -- the ONE consumer, a linear layer, applies BN + ReLU while it stages its rows
+            # (pdf_set_input_affine_relu) and y is never written: it only carries (x, scale, shift) to that consumer (_lazy_bn)
+            lazy = bool(lazy) and relu and res is None and x16 is None and not _GEMM_BF16 and x.dim() == 2 and C % 16 == 0 and R % 16 == 0
+            y16 = new_shadow(y) if (C % 4 == 0 and not lazy) else None
             if y16 is not None:
                 L.pdf_set_bf16_output(ptr(y16))
             if x16 is not None:
                 L.pdf_set_bn_input_bf16(ptr(x16))
             L.pdf_bn_train_fwd(None if x16 is not None else ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
-                               ptr(res), C, int(relu), ptr(y), C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
+                               ptr(res), C, int(relu), None if lazy else ptr(y), C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
             if y16 is not None:
                 attach_shadow(y, y16)
+            if lazy:
+                y._pdf_lazy = (x, scale, shift, y._version)
             # ReLU without a residual: the backward recomputes the mask from x with (scale, shift); y is not kept for it
             recompute = relu and res is None
             ctx.save_for_backward(x16 if x16 is not None else x, gamma, mean, rstd, (scale if recompute else (y if relu else None)), (shift if recompute else None))
@@ -778,11 +801,13 @@ class _BatchNorm(Function):
             attach_shadow(dx, dx16)
         if direct:
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 
-def batch_norm(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False, res=None):
-    return _BatchNorm.apply(x, gamma, beta, rmean, rvar, res, training, momentum, eps, relu)
+def batch_norm(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False, res=None, lazy=False):
+    """lazy=True (training, ReLU, no residual, fp32 mode, rows of C % 16 == 0 channels): the result may ONLY be fed to F.linear --
+    it is never written; the linear layer applies the normalisation to its operand on the fly (forward and weight gradient)."""
+    return _BatchNorm.apply(x, gamma, beta, rmean, rvar, res, training, momentum, eps, relu, lazy)
 
 
 class _Act(Function):

@@ -8,6 +8,8 @@ NHWC (channels_last) and point features are row-major [cloud, point, channel].
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import functional as F
 from .layers import (BatchNorm, Conv2d, ConvTranspose2d, Linear, PointConv, Slot, kaiming_normal_, small_normal_)
 
@@ -107,6 +109,10 @@ def _sa_mlp(cin, dims):
 
 
 
+# the inner BatchNorm + ReLU of the set-abstraction MLPs applied by the consuming linear layer (F.batch_norm lazy=True)
+LAZY_SA_BN = os.environ.get("PDFNET_LAZY_SA_BN", "1") != "0"
+
+
 class PointNet_Plus(nn.Module):
     """intaghand_encoder.py:32-159.  One call per hand (BN batch statistics are per hand, :805-806)."""
 
@@ -126,8 +132,10 @@ class PointNet_Plus(nn.Module):
         MaxPool over the K neighbours.  y1: rows [cloud*centroid*neighbour, channel].  The last BatchNorm, its ReLU and the
         pooling are one pass over the last convolution's output (F.bn_relu_max_over_k)."""
         tr = seq[1].training
-        x = seq[1](F.carry_stats(y1, y1.reshape(-1, y1.shape[-1])), relu=True)
-        x = seq[4](seq[3](x, stats=tr), relu=True)
+        # (lazy: the two inner BatchNorm + ReLU are applied by the linear layer that consumes them -- no pass over the rows, no
+        # normalised tensor; F.batch_norm)
+        x = seq[1](F.carry_stats(y1, y1.reshape(-1, y1.shape[-1])), relu=True, lazy=LAZY_SA_BN)
+        x = seq[4](seq[3](x, stats=tr), relu=True, lazy=LAZY_SA_BN)
         return seq[7].relu_max_over_k(seq[6](x, stats=tr), K)
 
     @staticmethod

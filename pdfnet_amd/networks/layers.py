@@ -121,13 +121,13 @@ class BatchNorm(nn.Module):
         BatchNorm.flush_counters()
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
-    def forward(self, x, relu=False, res=None):
+    def forward(self, x, relu=False, res=None, lazy=False):
         if self.training:
             if self._pending == 0:
                 BatchNorm._dirty.append(self)
             self._pending += 1
         return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var,
-                            self.training, self.momentum, self.eps, relu, res)
+                            self.training, self.momentum, self.eps, relu, res, lazy)
 
 
     def relu_max_over_k(self, x, K):

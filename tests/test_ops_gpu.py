@@ -1012,6 +1012,34 @@ def test_gradient_chain_of_a_map_with_several_consumers(F):
 # (N, Cin, H, W, Cout, k, stride, pad, act): one per statistics-capable launch -- the LDS-halo 128x128 tile, igemm_nt 128x128,
 # 128x64 (narrow output), 64x64 with K-step 32 and 16, the one-wave 32x32 tile, ragged M / N, the per-element (non-FAST) form
 # the last entry (few tiles under a long reduction) takes the split-K launch, which has none: the BatchNorm must fall back
+@pytest.mark.parametrize("R,C,N", [(4096, 64, 128), (20480, 128, 256), (20480, 64, 64), (1000, 64, 64)])
+def test_lazy_batchnorm_applied_by_the_consuming_linear(F, R, C, N):
+    """F.batch_norm(..., relu=True, lazy=True) -> F.linear: the normalised rows are never written, the GEMM reads
+    relu(x * scale + shift) while it stages its operand (forward, and the weight gradient through the 64x64 and the LDS-DMA
+    kernels).  Same values in, so the forward is bit-identical to the materialised form and the gradients agree to rounding.
+    (R = 1000 is not a multiple of 16: the request is ignored and the ordinary path runs.)"""
+    x = rnd(R, C, seed=5) * 1.3 + 0.2
+    w = rnd(N, C, seed=6) / C ** 0.5
+    b = rnd(N, seed=7)
+    g, be = torch.rand(C) + 0.5, rnd(C, seed=8) * 0.3
+    dy = rnd(R, N, seed=9)
+    out = {}
+    for lazy in (True, False):
+        xd, wd, bd = dev(x).requires_grad_(), dev(w).requires_grad_(), dev(b).requires_grad_()
+        gd, bed = dev(g).requires_grad_(), dev(be).requires_grad_()
+        rm, rv = dev(torch.zeros(C)), dev(torch.ones(C))
+        z = F.batch_norm(xd, gd, bed, rm, rv, True, 0.1, 1e-5, relu=True, lazy=lazy)
+        assert (getattr(z, '_pdf_lazy', None) is not None) == (lazy and R % 16 == 0)
+        y = F.linear(z, wd, bd, F.ACT_NONE, stats=True)
+        y.backward(dev(dy))
+        F.join_wgrad()
+        out[lazy] = [t.detach().cpu() for t in (y, rm, rv, xd.grad, wd.grad, bd.grad, gd.grad, bed.grad)]
+    assert torch.equal(out[True][0], out[False][0]), "forward of the lazy form differs"
+    assert torch.equal(out[True][1], out[False][1]) and torch.equal(out[True][2], out[False][2])
+    for a, b_, name in zip(out[True][3:], out[False][3:], ('dx', 'dw', 'db', 'dgamma', 'dbeta')):
+        close(a, b_, 2e-5 * float(b_.abs().max()) + 1e-7, what=name)
+
+
 STAT_CONVS = [(10, 256, 64, 64, 256, 3, 1, 1, 0, True), (10, 128, 64, 64, 256, 3, 1, 1, 0, True), (40, 64, 64, 64, 64, 3, 1, 1, 0, True),
               (24, 128, 32, 32, 128, 3, 1, 1, 1, True), (8, 128, 32, 32, 128, 3, 1, 1, 1, False),      # (the second: 256 tiles, split over K)
               (40, 64, 64, 64, 256, 1, 1, 0, 0, True), (4, 48, 16, 16, 96, 3, 1, 1, 0, True),
