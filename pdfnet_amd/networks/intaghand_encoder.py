@@ -110,7 +110,7 @@ def _sa_mlp(cin, dims):
 
 
 # the inner BatchNorm + ReLU of the set-abstraction MLPs applied by the consuming linear layer (F.batch_norm lazy=True)
-LAZY_SA_BN = os.environ.get("PDFNET_LAZY_SA_BN", "1") != "0"
+LAZY_SA_BN = os.environ.get("PDFNET_LAZY_SA_BN", "0") != "0"     # (opt-in: measured neutral in time)
 
 
 class PointNet_Plus(nn.Module):
