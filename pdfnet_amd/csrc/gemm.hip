@@ -33,8 +33,10 @@ __device__ __forceinline__ float4 as_f4(const u32x4v& v) { return *reinterpret_c
 // that is one add, one select and the load.  The flat-address form costs ~25 instructions per load -- 64-bit multiply-adds under
 // exec-mask branches, the zero word's address re-read from the GOT behind an s_waitcnt lgkmcnt(0) -- ~240 instructions per
 // K-step of the 64x64 tile against 16 MFMAs: with four waves per SIMD the VALU, not the matrix pipe, was the bound.
-template <int BM, int BN, int WM, int WN, bool FAST, bool KN, int BKT = 16, bool BUF = false>
-__global__ __launch_bounds__(WM * WN * 64, (BM * BN >= 128 * 128 ? 3 : 1)) void igemm_nt(const IGemm g) {    // (128x128: 3 waves per SIMD = 3 blocks per CU, as its LDS allows)
+// AFF (BUF, plain GEMMs): IGemm::a_scale / a_shift are applied to the A tile while it is staged -- a compile-time variant with its own
+// kernel name (igemm_nt_aff), because even the unused run-time test cost the 64x64 tile 3 % (89 -> 86 TFLOP/s over the step's launches)
+template <int BM, int BN, int WM, int WN, bool FAST, bool KN, int BKT, bool BUF, bool AFF>
+__device__ __forceinline__ void igemm_nt_body(const IGemm& g) {    // (128x128: 3 waves per SIMD = 3 blocks per CU, as its LDS allows)
     constexpr int NT = WM * WN * 64;                     // threads: one wave per (BM/WM) x (BN/WN) sub-tile
     constexpr int BK = BKT, LD = BK + 1;                 // K-step: 16, or 32 for the small tile (half the barriers per flop)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN >= 128 * 128 ? 3 : 1)) void 
             for (int i = 0; i < RA; ++i) ra[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, (aok[i] && live) ? aoffB[i] + sa : 0xffffffffu, 0, 0));
 #pragma unroll
             for (int i = 0; i < RB; ++i) rb[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsB, (bval[i] && live) ? boffB[i] + sb : 0xffffffffu, 0, 0));
-            if (g.a_scale != nullptr) {                      // BatchNorm + ReLU of the producer applied here (plain GEMM: k = channel)
+            if constexpr (AFF) {                             // BatchNorm + ReLU of the producer applied here (plain GEMM: k = channel)
                 const int ch = min(nt_ci + kq, g.K - 4);
                 const float4 sc = *reinterpret_cast<const float4*>(g.a_scale + ch), sh = *reinterpret_cast<const float4*>(g.a_shift + ch);
 #pragma unroll
@@ -375,6 +377,16 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN >= 128 * 128 ? 3 : 1)) void 
     if (do_stat) stat_finish<TN, WM, WN, BN>(st, &As[0][0], g.stat, tmi, n0, g.N, wm, wn, lane, tid);     // (As: the loop's last barrier is behind us)
 }
 
+template <int BM, int BN, int WM, int WN, bool FAST, bool KN, int BKT = 16, bool BUF = false>
+__global__ __launch_bounds__(WM * WN * 64, (BM * BN >= 128 * 128 ? 3 : 1)) void igemm_nt(const IGemm g) {
+    igemm_nt_body<BM, BN, WM, WN, FAST, KN, BKT, BUF, false>(g);
+}
+// the same with IGemm::a_scale / a_shift applied to the A tile (buffer-load form, [N][K] weights)
+template <int BM, int BN, int WM, int WN, int BKT>
+__global__ __launch_bounds__(WM * WN * 64, (BM * BN >= 128 * 128 ? 3 : 1)) void igemm_nt_aff(const IGemm g) {
+    igemm_nt_body<BM, BN, WM, WN, true, false, BKT, true, true>(g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // igemm_halo3x3: the 128x128 implicit GEMM for 3x3 stride-1 convolutions (forward, and backward-data, which is a 3x3
 // stride-1 convolution of dy with the taps mirrored) that re-uses its input from LDS.  igemm_nt gathers the A tile from global
@@ -557,8 +569,8 @@ __global__ __launch_bounds__(256, 3) void igemm_halo3x3(const IGemm g) {
 // BUF (FAST only): operands through buffer descriptors -- a masked element (row past the split, padded tap, column past the
 // matrix) is an out-of-range 32-bit offset that the hardware returns as zeros; `if (ok) v = load` compiles to an exec-mask branch
 // with an s_waitcnt vmcnt(0) per load, which serialises the tile's loads (see wgemm_tn_dma).
-template <int BI, int BJ, int WM, int WN, bool FAST, int BKT = 16, bool BUF = false>
-__global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
+template <int BI, int BJ, int WM, int WN, bool FAST, int BKT, bool BUF, bool AFF>
+__device__ __forceinline__ void wgemm_tn_body(const WGemm& g) {
     constexpr int BK = BKT;
     constexpr int TM = BI / WM / 32, TN = BJ / WN / 32;
     constexpr int TPR_P = BI / 4, TPR_Q = BJ / 4;        // threads per LDS row
@@ -629,7 +641,7 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
     const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)Pp, 0, BUF ? g.pbytes : 0, 0x00020000);
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qp, 0, BUF ? g.qbytes : 0, 0x00020000);
     float4 qsc = make_float4(1.f, 1.f, 1.f, 1.f), qsh = make_float4(0.f, 0.f, 0.f, 0.f);      // WGemm::q_scale / q_shift of this thread's 4 columns
-    if (BUF && g.q_scale != nullptr && qok[0]) { qsc = *reinterpret_cast<const float4*>(g.q_scale + qch[0]); qsh = *reinterpret_cast<const float4*>(g.q_shift + qch[0]); }
+    if (AFF && qok[0]) { qsc = *reinterpret_cast<const float4*>(g.q_scale + qch[0]); qsh = *reinterpret_cast<const float4*>(g.q_shift + qch[0]); }
     auto gload = [&](int mb) {
         if constexpr (BUF) {
 #pragma unroll
@@ -651,7 +663,7 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
                 }
                 const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, oq, 0, 0);
                 rq[i] = *reinterpret_cast<const float4*>(&v);
-                if (g.q_scale != nullptr) {                  // BatchNorm + ReLU of x applied here; rows past the split's end must stay zero
+                if constexpr (AFF) {                         // BatchNorm + ReLU of x applied here; rows past the split's end must stay zero
                     if (mb + BK <= me && qok[0]) {           // (whole K-step: no per-row select)
                         rq[i].x = fmaxf(fmaf(rq[i].x, qsc.x, qsh.x), 0.f); rq[i].y = fmaxf(fmaf(rq[i].y, qsc.y, qsh.y), 0.f);
                         rq[i].z = fmaxf(fmaf(rq[i].z, qsc.z, qsh.z), 0.f); rq[i].w = fmaxf(fmaf(rq[i].w, qsc.w, qsh.w), 0.f);
@@ -775,6 +787,14 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
 }
 
 
+template <int BI, int BJ, int WM, int WN, bool FAST, int BKT = 16, bool BUF = false>
+__global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
+    wgemm_tn_body<BI, BJ, WM, WN, FAST, BKT, BUF, false>(g);
+}
+__global__ __launch_bounds__(256) void wgemm_tn64_aff(const WGemm g) {      // WGemm::q_scale / q_shift applied to the Q rows
+    wgemm_tn_body<64, 64, 2, 2, true, 32, true, true>(g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // wgemm_tn_dma: the 128x128 weight-gradient tile with LDS-DMA staging (global_load_lds, 16 B per lane).
 // The register-staged wgemm_tn is bound by L2->CU latency: every K-step reads fresh rows (no L1 reuse) and only one
@@ -792,8 +812,8 @@ __global__ __launch_bounds__(256) void wgemm_tn(const WGemm g) {
 // 64-bit multiply-adds under exec-mask branches and re-loads the zero word's address from the GOT four times per K-step, each
 // behind an s_waitcnt lgkmcnt(0) that also drains the wave's LDS reads (see the .s): ~150 scalar / vector instructions per K-step.
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-template <int ST, bool BUF>
-__global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
+template <int ST, bool BUF, bool AFF>
+__device__ __forceinline__ void wgemm_tn_dma_body(const WGemm& g) {
     constexpr int BI = 128, BJ = 128, BK = 16, WN = 2, TM = 2, TN = 2;
     __shared__ __attribute__((aligned(16))) float smem[ST * 2 * BK * 128];     // [stage][P|Q][k][128]  (48 KB, ONE array)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -997,7 +1017,7 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
 
     const int aoff = (lane >> 5) * 128 + wm * TM * 32 + (lane & 31);
     const int boff = (lane >> 5) * 128 + wn * TN * 32 + (lane & 31);
-    const bool qaff = BUF && g.q_scale != nullptr;          // (host: only with uniform == 2 and plain rows -- no zero-filled partial K-step)
+    constexpr bool qaff = BUF && AFF;                       // (host: only with uniform == 2 and plain rows -- no zero-filled partial K-step)
     float fsc[TN], fsh[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1028,7 +1048,7 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
             for (int i = 0; i < TM; ++i) a[set][i] = ps[aoff + kk * 2 * 128 + i * 32];
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[set][j] = qs[boff + kk * 2 * 128 + j * 32];
-            if (qaff) {                                      // WGemm::q_scale: BatchNorm + ReLU of x at fragment-read time (every K-step is whole here)
+            if constexpr (qaff) {                            // WGemm::q_scale: BatchNorm + ReLU of x at fragment-read time (every K-step is whole here)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[set][j] = fmaxf(fmaf(b[set][j], fsc[j], fsh[j]), 0.f);
             }
@@ -1052,6 +1072,14 @@ __global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
 
     wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && i0 + tid < g.NI, bsum, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(smem), i0 + 128 <= g.NI);
+}
+
+template <int ST, bool BUF>
+__global__ __launch_bounds__(256) void wgemm_tn_dma(const WGemm g) {
+    wgemm_tn_dma_body<ST, BUF, false>(g);
+}
+__global__ __launch_bounds__(256) void wgemm_tn_dma_aff(const WGemm g) {    // WGemm::q_scale / q_shift applied at fragment-read time
+    wgemm_tn_dma_body<3, true, true>(g);
 }
 
 // Slab reducers.  blockIdx.y == 1 is group 1 of a paired launch (slabs after group 0's, own outputs).  A launch may carry a
@@ -1241,9 +1269,11 @@ static void launch_igemm_tile(const IGemm& g, bool fast, dim3 grid, hipStream_t 
     constexpr int NT = WM * WN * 64;
     char nm[96] = "";
     const bool buf = fast && g.abytes != 0 && env_int(ENV_IG_BUF, 1);
-    if (g_ktiming) snprintf(nm, sizeof nm, "igemm_nt<%d, %d, %d, %d, %s, %s, %d, %s>", BM, BN, WM, WN, fast ? "true" : "false", g.b_kn ? "true" : "false", fast ? BKF : 16, buf ? "true" : "false");
+    if (g_ktiming && buf && !g.b_kn && g.a_scale != nullptr) snprintf(nm, sizeof nm, "igemm_nt_aff<%d, %d, %d, %d, %d>", BM, BN, WM, WN, BKF);
+    else if (g_ktiming) snprintf(nm, sizeof nm, "igemm_nt<%d, %d, %d, %d, %s, %s, %d, %s>", BM, BN, WM, WN, fast ? "true" : "false", g.b_kn ? "true" : "false", fast ? BKF : 16, buf ? "true" : "false");
     KTimer kt(nm, 2.0 * g.M * g.N * g.K * grid.y, igemm_bytes(g, grid.y), s);
     if (buf && g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, true, BKF, true>), grid, dim3(NT), 0, s, g);
+    else if (buf && g.a_scale != nullptr) hipLaunchKernelGGL((igemm_nt_aff<BM, BN, WM, WN, BKF>), grid, dim3(NT), 0, s, g);
     else if (buf) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, false, BKF, true>), grid, dim3(NT), 0, s, g);
     else if (fast && g.b_kn) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, true, BKF>), grid, dim3(NT), 0, s, g);
     else if (fast) hipLaunchKernelGGL((igemm_nt<BM, BN, WM, WN, true, false, BKF>), grid, dim3(NT), 0, s, g);
@@ -1315,7 +1345,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     if (g.A16 != nullptr && (g.lda % 8 != 0 || (reinterpret_cast<uintptr_t>(g.A16) & 15))) g.A16 = nullptr;      // 16-byte chunks of 8 bf16
     if (g.B16 != nullptr && ((!g.b_kn && g.ldb % 8 != 0) || (reinterpret_cast<uintptr_t>(g.B16) & 15))) g.B16 = nullptr;
     if (g.A == nullptr && g.A16 == nullptr) return PDF_E_BADARG;          // bf16 storage mode: A exists only as bf16 -- it must be usable
-    if (g.a_scale != nullptr && !(fast && !g_gemm_bf16 && groups == 1 && g.T == 1 && g.plain_in && g.abytes != 0 && g.K % 4 == 0 && env_int(ENV_IG_BUF, 1)))
+    if (g.a_scale != nullptr && !(fast && !g_gemm_bf16 && groups == 1 && g.T == 1 && g.plain_in && !g.b_kn && g.abytes != 0 && g.K % 4 == 0 && env_int(ENV_IG_BUF, 1)))
         return PDF_E_BADARG;                             // the operand transform lives in the buffer-load form of igemm_nt only
     if (g_gemm_bf16 && fast) {
         g_shadow_operands += (g.A16 != nullptr) + (g.B16 != nullptr);
@@ -1918,8 +1948,9 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         const bool buf = bk32 && pext < 4294967000.0 && qext < 4294967000.0 && env_int(ENV_WG_BUF, 1);
         g.pbytes = buf ? (unsigned)pext : 0; g.qbytes = buf ? (unsigned)qext : 0;
         if (g.q_scale != nullptr && !buf) return PDF_E_BADARG;
-        KTimer kt(buf ? "wgemm_tn<64, 64, 2, 2, true, 32, true>" : bk32 ? "wgemm_tn<64, 64, 2, 2, true, 32, false>" : fast ? "wgemm_tn<64, 64, 2, 2, true, 16, false>" : "wgemm_tn<64, 64, 2, 2, false, 16, false>", wflops, wbytes, s);
-        if (buf) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32, true>), grid, dim3(256), 0, s, g);
+        KTimer kt(buf && g.q_scale != nullptr ? "wgemm_tn64_aff" : buf ? "wgemm_tn<64, 64, 2, 2, true, 32, true>" : bk32 ? "wgemm_tn<64, 64, 2, 2, true, 32, false>" : fast ? "wgemm_tn<64, 64, 2, 2, true, 16, false>" : "wgemm_tn<64, 64, 2, 2, false, 16, false>", wflops, wbytes, s);
+        if (buf && g.q_scale != nullptr) hipLaunchKernelGGL(wgemm_tn64_aff, grid, dim3(256), 0, s, g);
+        else if (buf) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32, true>), grid, dim3(256), 0, s, g);
         else if (bk32) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true, 32>), grid, dim3(256), 0, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgemm_tn<64, 64, 2, 2, false>), grid, dim3(256), 0, s, g);
@@ -1931,9 +1962,10 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
         g.uniform = (buf && (g.plain_q || (g.QW % 8 == 0 && g.Cq % 128 == 0)) && env_int(ENV_WG_UNIFORM, 2)) ? 1 : 0;
         if (g.uniform && env_int(ENV_WG_UNIFORM, 2) >= 2 && g.rows_per_split % 16 == 0 && g.M % 16 == 0 && (g.plain_q || g.QW % 16 == 0)) g.uniform = 2;
         if (g.q_scale != nullptr && g.uniform != 2) return PDF_E_BADARG;      // (the fragment-read transform needs whole K-steps)
-        KTimer kt(buf ? "wgemm_tn_dma<3, true>" : fast && dma == 4 ? "wgemm_tn_dma<4, false>" : fast && dma == 3 ? "wgemm_tn_dma<3, false>" : fast ? "wgemm_tn<128, 128, 2, 2, true, 16>" : "wgemm_tn<128, 128, 2, 2, false, 16>",
+        KTimer kt(buf && g.q_scale != nullptr ? "wgemm_tn_dma_aff" : buf ? "wgemm_tn_dma<3, true>" : fast && dma == 4 ? "wgemm_tn_dma<4, false>" : fast && dma == 3 ? "wgemm_tn_dma<3, false>" : fast ? "wgemm_tn<128, 128, 2, 2, true, 16>" : "wgemm_tn<128, 128, 2, 2, false, 16>",
                   wflops, wbytes, s);
-        if (buf) hipLaunchKernelGGL((wgemm_tn_dma<3, true>), grid, dim3(256), pad, s, g);
+        if (buf && g.q_scale != nullptr) hipLaunchKernelGGL(wgemm_tn_dma_aff, grid, dim3(256), pad, s, g);
+        else if (buf) hipLaunchKernelGGL((wgemm_tn_dma<3, true>), grid, dim3(256), pad, s, g);
         else if (fast && dma == 4) hipLaunchKernelGGL((wgemm_tn_dma<4, false>), grid, dim3(256), pad, s, g);
         else if (fast && dma == 3) hipLaunchKernelGGL((wgemm_tn_dma<3, false>), grid, dim3(256), pad, s, g);
         else if (fast) hipLaunchKernelGGL((wgemm_tn<128, 128, 2, 2, true>), grid, dim3(256), 0, s, g);
