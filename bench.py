@@ -473,7 +473,10 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
         torch.manual_seed(0)
         F.manual_seed(4321)
         model = load_model_intag(opt).to(dev)
-        tr = Trainer(opt, model, CtdetLoss(opt, consts).to(dev), lr=1e-4, grad_comm_dtype=torch.bfloat16)
+        # use_graph='auto': the trainer times a few eager and a few hipGraph steps during the warm-up and keeps the faster mode (the B=32
+        # step is host-bound on slow hosts, where the graph wins; B=64 stays eager)
+        tr = Trainer(opt, model, CtdetLoss(opt, consts).to(dev), lr=1e-4, grad_comm_dtype=torch.bfloat16, use_graph='auto')
+        warmup = max(warmup, 2 * (Trainer.AUTO_SKIP + Trainer.AUTO_STEPS + 1) + 1)
         batch = to_device(synthetic_train_batch(B, R, seed=1, consts=consts), dev)
         for _ in range(warmup):
             tr.train_step(batch)
@@ -499,7 +502,10 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
         median_ms = per_step[steps // 2]
         loss_val = float(last)
         assert loss_val == loss_val, "bf16 leg: loss is NaN"
+        launch = "hipGraph" if tr.use_graph else "eager"
+        choice = getattr(tr, 'auto_choice', None)
         tr.collectives = False
+        tr.use_graph = False                                   # (the instrumented step launches kernel by kernel)
         F.USE_SIDE_STREAMS = False
         with KernelTimer() as kt:
             tr.train_step(batch)
@@ -509,7 +515,8 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
         fl, sec = sum(v[1] for v in sym.values()), sum(v[3] for v in sym.values())
         out = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
                "median_step_ms": round(median_ms, 3), "images_per_s_at_median_step": round(B / median_ms * 1e3, 2),
-               "batch": B, "steps": steps, "warmup": warmup,
+               "batch": B, "steps": steps, "warmup": warmup, "launch": launch,
+               "auto_choice_ms": {k: round(v, 3) for k, v in choice.items()} if choice else None,
                "final_loss": round(loss_val, 4),
                "dominant_kernel": {k: head[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "ms_per_step")},
                "all_gemm_kernels_tflops": round(fl / max(sec, 1e-9) / 1e12, 1), "gemm_ms_per_step_exclusive": round(sec * 1e3, 2),

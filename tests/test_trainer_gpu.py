@@ -218,3 +218,26 @@ def test_evaluation_writes_the_reference_score_and_submission_files(tmp_path):
     assert len(got) == 126 and max(abs(a - b) for a, b in zip(got, want)) <= 1e-6
     with pytest.raises(KeyError):
         tr.evaluation([batch], json_path=jp)                          # no id / frame_num in the batch
+
+
+def test_use_graph_auto_times_both_modes_and_keeps_one():
+    """Trainer(use_graph='auto'): AUTO_SKIP + AUTO_STEPS + 1 eager steps, as many hipGraph steps, then one mode stays; the losses keep falling on
+    a fixed batch through the switch (the graph replays the same step)."""
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch, to_device
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    from pdfnet_amd.trains.base_trainer import Trainer
+    opt = make_opt(256, size_train=[256, 256], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    torch.manual_seed(0)
+    dev = torch.device('cuda', 0)
+    model = load_model_intag(opt).to(dev)
+    consts = synthetic_loss_constants()
+    tr = Trainer(opt, model, CtdetLoss(opt, consts).to(dev), lr=1e-4, use_graph='auto')
+    batch = to_device(synthetic_train_batch(2, 256, seed=3, consts=consts), dev)
+    n = 2 * (Trainer.AUTO_SKIP + Trainer.AUTO_STEPS + 1)
+    losses = [float(tr.train_step(batch)) for _ in range(n + 3)]
+    assert tr._auto is None and tr.use_graph in (True, False)
+    assert set(tr.auto_choice) == {'eager_ms', 'graph_ms'} and all(v > 0 for v in tr.auto_choice.values())
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
+    if not tr.use_graph:
+        assert not tr._graphs
