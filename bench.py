@@ -723,9 +723,14 @@ def main():
         del trainer, model, loss, batch, mp_batch, last
         gc.collect()
         torch.cuda.empty_cache()
-        out["bf16_per_gpu"] = {"note": "per-rank step of configs[3] (B=32/GPU) and configs[4] (B=64/GPU): bf16 MFMA GEMMs + bf16 shadows, fp32 "
-                                       "accumulate / master weights / statistics / loss; eager, one GPU, no collective",
-                               "B32": bf16_leg(opt, R, 32, dev, consts, 12, 6), "B64": bf16_leg(opt, R, 64, dev, consts, 10, 6)}
+        legs = {"note": "per-rank step of configs[3] (B=32/GPU) and configs[4] (B=64/GPU): bf16 MFMA GEMMs + bf16 shadows, fp32 "
+                        "accumulate / master weights / statistics / loss; one GPU, no collective; launch mode chosen by Trainer(use_graph='auto')"}
+        for name, b, k in (("B32", 32, 12), ("B64", 64, 10)):
+            try:
+                legs[name] = bf16_leg(opt, R, b, dev, consts, k, 6)
+            except Exception as e:                             # noqa: BLE001 -- the fp32 headline line must still be printed
+                legs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["bf16_per_gpu"] = legs
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
