@@ -553,6 +553,38 @@ def check_grads(trainer, batch, world, dev):
     return {"max_abs_err_over_max_abs": err, "ok": bool(err < 1e-4), "elements": int(got.numel()), "ranks": world}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(n, argv, port=None):
+    """The command line `python bench.py --gpus N` turns itself into: one rank per GPU under torch.distributed.run, rendezvous on
+    127.0.0.1 (scripts/train.sh:21 + main.py:69-71 of the reference: `torch.distributed.launch --nproc_per_node N main.py`)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+            '--master-port', str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv, run=None, device_count=None):
+    """`python bench.py --gpus N` without torch.distributed.run around it: start the N ranks as a CHILD process (a process that
+    has initialised the GPU must never be replaced by exec, and this one has not initialised anything: torch.cuda.device_count()
+    only counts), relay rank 0's JSON line and the child's return code.  -> exit code."""
+    import subprocess
+    have = torch.cuda.device_count() if device_count is None else device_count
+    if have < n:
+        print("bench.py: --gpus %d asked for, %d GPU(s) visible on this machine: not launching" % (n, have), file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    cmd = launcher_command(n, argv)
+    print("bench.py: launching %d ranks: %s" % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    r = (run or subprocess.run)(cmd, env=env)                  # the child's stdout IS ours: rank 0's one JSON line passes through
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -579,6 +611,9 @@ def main():
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 8 if args.config == 'rgb-encoder' else 32
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started directly (`python bench.py --gpus N`): this process becomes the launcher.  Nothing here has touched the GPU.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from pdfnet_amd import functional as F
     from pdfnet_amd.networks.intaghand_model import load_model_intag
@@ -591,7 +626,9 @@ def main():
     if os.environ.get('NCCL_DEBUG', '').upper() == 'VERSION':
         os.environ['NCCL_DEBUG'] = 'WARN'
     rank, local, world = init_distributed()
-    assert world == args.gpus or (world == 1 and args.gpus == 1), "launch with torch.distributed.run for --gpus > 1"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or plain `python bench.py --gpus %d`)"
+                 % (args.gpus, world, args.gpus, args.gpus))
     dev = torch.device('cuda', local)
     if args.config == 'rgb-encoder':
         assert world == 1, "--config rgb-encoder is a one-GPU kernel benchmark"
@@ -684,7 +721,7 @@ def main():
                 "traffic": traffic_all,
                 "per_entry_point": {k: {"calls": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
                                         "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(per.items())}},
-            "formulation": "executed contraction = exact sparse centre features (SURVEY 8a6): ~214 GFLOP/img/step; "
+            "formulation": "executed contraction = exact sparse centre features (SURVEY 8a6): %.0f GFLOP/img/step (measured, this line); " % (flops / 1e9 / B) +
                            "reference formulation (dense centre convs) = 358 GFLOP/img/step",
             "step_level": {"gflop_per_img_step_reference_formulation": ALGO_GFLOP_PER_IMG_STEP_DENSE,
                            "tflops_reference_formulation": round(ALGO_GFLOP_PER_IMG_STEP_DENSE * out["value"] / world / 1e3, 2),

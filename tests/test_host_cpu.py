@@ -206,3 +206,40 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     from tests.util import build_c_client
     exe = build_c_client(tmp_path)
     assert os.path.exists(exe)
+
+
+def test_bench_gpus_n_launches_its_own_ranks_as_a_child_process():
+    """`python bench.py --gpus N` started directly (the driver's form): the parent builds the torch.distributed.run command
+    (reference: scripts/train.sh:21, main.py:69-71), runs it as a CHILD and relays its return code; it initialises no device.
+    On a box with fewer GPUs it exits non-zero with a one-line reason instead of an AssertionError."""
+    import subprocess
+    import sys
+    import types
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+    rc = bench.launch_ranks(8, ['--gpus', '8', '--steps', '3', '--warmup', '1'], run=fake_run, device_count=8)
+    assert rc == 7                                               # the child's return code is relayed
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-7:] == [os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert not torch.cuda.is_initialized()
+    # the real thing on this GPU-less container: non-zero, one line, no traceback
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, env=env, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and 'Traceback' not in r.stderr and 'AssertionError' not in r.stderr
+        assert r.stderr.strip().splitlines()[-1].startswith('bench.py: --gpus 2 asked for')
+        assert r.stdout.strip() == ''
+    # a world size that contradicts --gpus is refused with a reason too
+    env['WORLD_SIZE'], env['RANK'], env['LOCAL_RANK'] = '1', '0', '0'
+    if not torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr
