@@ -159,6 +159,16 @@ class FlatAdam:
             # flat_p16 -- would go on serving the PREVIOUS weights to whatever runs next (evaluation, a plain model call):
             # re-cast in place right here; the views stay attached and are current again.
             hip.lib().pdf_cast_bf16(hip.ptr(self.flat_p), hip.ptr(self.flat_p16), self.n_live, hip.stream())
+        else:
+            # fp32 mode (or shadows off): nothing re-cast, so a bf16 buffer from an earlier bf16 phase is stale from here on; the
+            # next bf16 train step / evaluation refreshes it (toggling the GEMM precision on a live Trainer).  The
+            # attached views are taken off the parameters -- once, on the first such step -- so that a plain model call made
+            # after switching back to bf16 converts the fp32 master weights instead of multiplying with the old copy.
+            if self._p16_synced:
+                for p in self.params:
+                    if getattr(p, '_pdf_bf16', None) is not None:
+                        p._pdf_bf16 = None
+            self._p16_synced = False
 
     def _view(self, flat, i):
         p, o = self.params[i], self.offsets[i]
@@ -514,41 +524,45 @@ class Trainer:
         mwl = self.model_with_loss
         was_training = mwl.training
         mwl.eval()
+        if F.shadows_on() and not self.optimizer._p16_synced:
+            self.optimizer.refresh_bf16_shadows()
         dev = device or self.optimizer.flat_p.device
-        acc = torch.zeros(11, dtype=torch.float64, device=dev)        # 5 metrics x 2 hands + sample count
-        poses = []
-        with torch.no_grad():
-            for batch in loader:
-                batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
-                tup = mwl(batch, 'test', None)
-                acc += evaluation_sums(tup, batch)
-                if json_path is not None:
-                    if 'id' not in batch or 'frame_num' not in batch:
-                        raise KeyError("Trainer.evaluation: hand_poses.json needs batch['id'] and batch['frame_num'] (interhand.py H2O entries)")
-                    jp = tup[1]
-                    key = torch.stack((torch.as_tensor(batch['id'], device=dev).reshape(-1).double(),
-                                       torch.as_tensor(batch['frame_num'], device=dev).reshape(-1).double()), 1)
-                    poses.append(torch.cat((key, jp.reshape(jp.shape[0], -1).double()), 1))          # [B, 2 + 126]
-        if self.world > 1:
-            dist.all_reduce(acc)
-        out = finish_evaluation(acc.cpu())
-        if json_path is not None:
-            rows = torch.cat(poses) if poses else torch.zeros((0, 128), dtype=torch.float64, device=dev)
-            if self.world > 1:                                 # ragged gather: pad every rank's block to the longest
-                n = torch.tensor([rows.shape[0]], device=dev)
-                ns = [torch.zeros_like(n) for _ in range(self.world)]
-                dist.all_gather(ns, n)
-                m = max(int(x) for x in ns)
-                pad = torch.zeros((m, rows.shape[1]), dtype=rows.dtype, device=dev)
-                pad[:rows.shape[0]] = rows
-                parts = [torch.empty_like(pad) for _ in range(self.world)]
-                dist.all_gather(parts, pad)
-                rows = torch.cat([p[:int(k)] for p, k in zip(parts, ns)])
-            if self.rank == 0:
-                write_hand_poses_json(json_path, rows.cpu())
-        if score_path is not None and self.rank == 0:
-            write_h2o_scores(score_path, out)
-        mwl.train(was_training)
+        try:
+            acc = torch.zeros(11, dtype=torch.float64, device=dev)        # 5 metrics x 2 hands + sample count
+            poses = []
+            with torch.no_grad():
+                for batch in loader:
+                    batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                    tup = mwl(batch, 'test', None)
+                    acc += evaluation_sums(tup, batch)
+                    if json_path is not None:
+                        if 'id' not in batch or 'frame_num' not in batch:
+                            raise KeyError("Trainer.evaluation: hand_poses.json needs batch['id'] and batch['frame_num'] (interhand.py H2O entries)")
+                        jp = tup[1]
+                        key = torch.stack((torch.as_tensor(batch['id'], device=dev).reshape(-1).double(),
+                                           torch.as_tensor(batch['frame_num'], device=dev).reshape(-1).double()), 1)
+                        poses.append(torch.cat((key, jp.reshape(jp.shape[0], -1).double()), 1))          # [B, 2 + 126]
+            if self.world > 1:
+                dist.all_reduce(acc)
+            out = finish_evaluation(acc.cpu())
+            if json_path is not None:
+                rows = torch.cat(poses) if poses else torch.zeros((0, 128), dtype=torch.float64, device=dev)
+                if self.world > 1:                                 # ragged gather: pad every rank's block to the longest
+                    n = torch.tensor([rows.shape[0]], device=dev)
+                    ns = [torch.zeros_like(n) for _ in range(self.world)]
+                    dist.all_gather(ns, n)
+                    m = max(int(x) for x in ns)
+                    pad = torch.zeros((m, rows.shape[1]), dtype=rows.dtype, device=dev)
+                    pad[:rows.shape[0]] = rows
+                    parts = [torch.empty_like(pad) for _ in range(self.world)]
+                    dist.all_gather(parts, pad)
+                    rows = torch.cat([p[:int(k)] for p, k in zip(parts, ns)])
+                if self.rank == 0:
+                    write_hand_poses_json(json_path, rows.cpu())
+            if score_path is not None and self.rank == 0 and out['samples'] > 0:      # (an empty loader writes no block)
+                write_h2o_scores(score_path, out)
+        finally:
+            mwl.train(was_training)                            # restored even when a batch raises
         return out
 
 

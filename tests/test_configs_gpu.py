@@ -142,3 +142,55 @@ def test_bf16_evaluation_after_a_train_step_sees_the_updated_weights():
         assert np.isfinite(ev['mpjpe_mm'])
     finally:
         F.set_gemm_precision('fp32')
+
+
+def test_precision_toggled_on_a_live_trainer_never_serves_stale_bf16_weights():
+    """train in bf16, switch to fp32 (step() then updates the master buffer without re-casting the bf16 copy),
+    switch back to bf16: a plain model call, an evaluation and the next train step must all see the CURRENT weights --
+    `flat_p16` equals the bf16 cast of `flat_p` whenever a shadow is attached."""
+    from pdfnet_amd import functional as F
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch, to_device
+    from pdfnet_amd.trains.base_trainer import Trainer
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    R, B = 128, 2
+    dev = torch.device('cuda')
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    batch = to_device(synthetic_train_batch(B, R, seed=9, consts=consts), dev)
+    torch.manual_seed(5)
+    m = load_model_intag(opt).to(dev)
+
+    def run():
+        m.eval()
+        with torch.no_grad():
+            return m(batch['input'], batch['choose'], batch['cloud'], batch['depth'], batch['ind'], batch['K_new'], batch['valid'])
+    try:
+        F.set_gemm_precision('bf16')
+        tr = Trainer(opt, m, CtdetLoss(opt, consts).to(dev), lr=1e-2)
+        tr.train_step(batch, 0)
+        o = tr.optimizer
+        n = o.n_live
+        assert torch.equal(o.flat_p16[:n], o.flat_p[:n].to(torch.bfloat16))
+        F.set_gemm_precision('fp32')
+        tr.train_step(batch, 0)                                  # fp32 step: master weights move, the bf16 copy does not
+        assert not torch.equal(o.flat_p16[:n], o.flat_p[:n].to(torch.bfloat16))
+        assert not o._p16_synced
+        F.set_gemm_precision('bf16')
+        assert all(F.shadow_of(p) is None for p in o.params)     # the stale views are off the parameters
+        plain = run()                                            # converts the fp32 master weights while staging
+        old, F.BF16_SHADOWS = F.BF16_SHADOWS, False
+        try:
+            want = run()
+        finally:
+            F.BF16_SHADOWS = old
+        assert torch.equal(plain[0]['verts3d']['left'], want[0]['verts3d']['left'])
+        ev = tr.evaluation([batch])                              # refreshes and re-attaches
+        assert np.isfinite(ev['mpjpe_mm']) and o._p16_synced
+        assert torch.equal(o.flat_p16[:n], o.flat_p[:n].to(torch.bfloat16))
+        again = run()
+        assert torch.equal(again[0]['verts3d']['left'], want[0]['verts3d']['left'])
+        tr.train_step(batch, 0)
+        assert torch.equal(o.flat_p16[:n], o.flat_p[:n].to(torch.bfloat16))
+    finally:
+        F.set_gemm_precision('fp32')
