@@ -1,0 +1,293 @@
+"""BASELINE configs[2] at its REAL size -- B = 32, 256x256, fp32: what `bench.py` times -- against VALUES, not properties
+(VERDICT r3 "missing" #2 / "next" #1).
+
+  * the HIP model vs the pinned CPU oracle (oracle/pdfnet_cpu.py + oracle/loss_cpu.py; pinned to the reference by
+    tests/test_oracle_vs_golden.py) on one B=32 batch with wrap-padded, far-outlier and all-zero clouds:
+      (i)  eval forward, centres predicted by the network: predicted `ind` bit-exact, every `pack_outputs` key at the 1e-4 / 1e-5 bars
+           (reference path: lib/models/networks/intaghand_model.py:21-46);
+      (ii) one train-mode step through `Trainer.train_step` (the bench's own call) with dropout 0: loss within 1e-4 relative of the
+           float64 oracle, EVERY parameter gradient at the App.-C bars (norm 1.5e-3, cosine 0.9999), every BatchNorm running statistic
+           (reference path: lib/trains/simplified.py:364-655, lib/trains/base_trainer.py:129-148).
+    The dispatch decisions that exist only at this size are thereby value-checked in situ: weight-gradient split counts, the halo kernel
+    on M = 131,072 rows, the split-K scratch ring, the 128x128 / 128x64 / 64x64 tile choices, statistics epilogues over 1,024 row blocks.
+  * the heaviest GEMM shapes of the step (profiles/r03_gemm_shapes.txt, top of the list by time) one by one against PyTorch's CPU
+    convolution / transposed convolution / linear in fp32: forward, input gradient, weight gradient, bias gradient.
+
+The oracle side runs on the GPU box's host cores (float64 at B=32: a few minutes on 128 threads); `PDFNET_HEADLINE_B` lowers the batch
+for a quick look on a small host."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from tests.util import ROOT, check_packed, make_opt, pack_outputs
+
+pytestmark = pytest.mark.gpu
+
+B_HEAD = int(os.environ.get("PDFNET_HEADLINE_B", "32"))
+R_HEAD = 256
+
+
+def _threads():
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+@pytest.fixture(scope="module")
+def headline():
+    from oracle import synth
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch
+    assert torch.cuda.is_available()
+    torch.set_num_threads(_threads())
+    opt = make_opt(R_HEAD, size_train=[R_HEAD, R_HEAD], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    batch = synthetic_train_batch(B_HEAD, R_HEAD, seed=11, consts=consts)
+    mixed = synth.to_torch(synth.synthetic_batch(B_HEAD, R_HEAD, seed=12, variant='mixed'))
+    for k in ('cloud', 'choose', 'valid'):                    # far outliers (ball masks fire), wrap-padded clouds, one all-zero cloud
+        batch[k] = mixed[k]
+    m = load_model_intag(opt)
+    sd = synth.det_state_dict(m.state_dict())
+    m.load_state_dict(sd)
+    m.cuda()
+    for mod in m.modules():
+        if isinstance(getattr(mod, 'p', None), float):
+            mod.p = 0.0                                       # dropout off: the device RNGs differ by design
+    return opt, consts, sd, batch, m
+
+
+def _oracle(opt, sd, double=False):
+    from oracle import pdfnet_cpu as O
+    o = O.load_model_cpu(opt)
+    o.load_state_dict(sd)
+    for mod in o.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return o.double() if double else o
+
+
+def test_eval_forward_at_the_headline_batch_matches_the_oracle(headline):
+    opt, consts, sd, batch, m = headline
+    B = B_HEAD
+    t0 = time.time()
+    o = _oracle(opt, sd).eval()
+    with torch.no_grad():
+        ro = o(batch['input'], batch['choose'], batch['cloud'], batch['depth'], None, batch['K_new'], batch['valid'])
+    t_cpu = time.time() - t0
+    ind_o = ro[3]['ind']
+    bg = {k: v.cuda() for k, v in batch.items()}
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        rg = m(bg['input'], bg['choose'], bg['cloud'], bg['depth'], None, bg['K_new'], bg['valid'])
+    ind_g = rg[3]['ind'].cpu()
+    assert ind_g.dtype == torch.int64 and ind_g.shape == (B, 2)
+    # the centre pick is decisive where the suppressed map has ONE positive maximum (`heat * keep` is 0 at
+    # non-maxima, so a channel without a positive peak is a tie among zeros and implementation-defined in the reference too)
+    hm = ro[3]['ret']['hm']
+    h = (hm * (TF.max_pool2d(hm, 5, 1, 2) == hm).float()).reshape(B, 2, -1)
+    top2 = torch.topk(h, 2, dim=2)[0]
+    decisive = (top2[..., 0] - top2[..., 1]) > 1e-4
+    assert float(decisive.float().mean()) >= 0.9, "synthetic weights give too few decisive centre picks for a meaningful check"
+    assert torch.equal(ind_g[decisive], ind_o[decisive]), (ind_g[decisive], ind_o[decisive])          # bit-exact
+    if not torch.equal(ind_g, ind_o):                         # a tie somewhere: feed the oracle's pick so that every sample is comparable
+        with torch.no_grad():
+            rg = m(bg['input'], bg['choose'], bg['cloud'], bg['depth'], ind_o.cuda(), bg['K_new'], bg['valid'])
+    exp = {k: v.numpy() for k, v in pack_outputs(ro, ind_o).items()}
+    check_packed(pack_outputs(rg, ind_o.cuda()), exp, abs_tol=1e-4, rel_tol=1e-5)
+    # the full dense maps, not only their crops and sums
+    for k in ('hms', 'mask'):
+        a, b = rg[3][k].cpu().double(), ro[3][k].double()
+        assert float((a - b).abs().max()) <= 1e-4 + 5e-5 * float(b.abs().max()), k
+    a, b = rg[3]['ret']['params'].cpu().double(), ro[3]['ret']['params'].double()
+    assert float((a - b).abs().max()) <= 1e-4, 'params head'
+    print("headline eval parity: B=%d, oracle forward %.1f s on %d threads, %d/%d decisive centre picks bit-exact"
+          % (B, t_cpu, _threads(), int(decisive.sum()), decisive.numel()))
+
+
+def test_train_step_at_the_headline_batch_matches_the_fp64_oracle(headline):
+    from oracle import loss_cpu as LC
+    from pdfnet_amd.trains.base_trainer import Trainer
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    opt, consts, sd, batch, m = headline
+    epoch = 25                                                # alpha = 1: every loss term is on (simplified.py:610)
+    # ---- oracle, float64, on the host cores
+    t0 = time.time()
+    o = _oracle(opt, sd, double=True).train()
+    bd = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+    z = np.load(os.path.join(ROOT, "pdfnet_amd", "data", "gcn_core.npz"))
+    result, params, hand, other = o(bd['input'], bd['choose'], bd['cloud'], bd['depth'], bd['ind'], bd['K_new'], bd['valid'])
+    for h in ('left', 'right'):
+        other['converter_' + h] = LC.Converter(z['graph_perm_' + h], z['graph_perm_reverse_' + h])
+    loss_o, stats_o = LC.ctdet_loss(opt, consts, result, params, hand, other, bd, 'train', epoch)
+    loss_o.mean().backward()
+    go = {n: (p.grad.clone() if p.grad is not None else None) for n, p in o.named_parameters()}
+    so = {k: v.clone() for k, v in o.state_dict().items() if k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
+    hms_o, mask_o, v3_o = other['hms'].detach(), other['mask'].detach(), {h: result['verts3d'][h].detach() for h in ('left', 'right')}
+    loss_o = float(loss_o.mean().detach())
+    del o, result, params, hand, other
+    t_cpu = time.time() - t0
+    # ---- HIP: the trainer's own step (flat gradient buffer, side-stream weight gradients, fused Adam at lr = 0)
+    m.load_state_dict(sd)
+    m.train()
+    tr = Trainer(opt, m, CtdetLoss(opt, consts).cuda(), lr=0.0)
+    bg = {k: v.cuda() for k, v in batch.items()}
+    loss_g = float(tr.train_step(bg, epoch))
+    torch.cuda.synchronize()
+    assert abs(loss_g - loss_o) <= 1e-4 * abs(loss_o), (loss_g, loss_o)
+    named = dict(m.named_parameters())
+    bad, checked, none_o = [], 0, 0
+    for n, g64 in go.items():
+        p = named[n]
+        if g64 is None:
+            none_o += 1
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        g = p.grad.detach().cpu().double()
+        na, nb = float(g64.norm()), float(g.norm())
+        if na == 0.0:                                         # wh / params heads: no loss term (simplified.py:397-399)
+            assert nb == 0.0, n
+            checked += 1
+            continue
+        cos = float((g64 * g).sum()) / (na * nb + 1e-300)
+        tol = 5e-3 if 'pointnet_plus.sft0' in n else 1.5e-3  # (the cancelling 3-channel layer, see test_full_gradient_gpu.py)
+        if abs(na - nb) <= tol * na + 1e-12 and cos >= 0.9999:
+            checked += 1
+            continue
+        wn = n[:-4] + 'weight'                                # a bias in front of a train-mode BatchNorm: exactly zero in exact arithmetic
+        if n.endswith('.bias') and wn in go and go[wn] is not None and na <= 1e-6 * float(go[wn].norm()) and nb <= 1e-2 * float(go[wn].norm()):
+            checked += 1
+            continue
+        bad.append((n, tuple(g.shape), na, nb, cos))
+    assert not bad, "%d gradients off:\n" % len(bad) + "\n".join("%s %s |g64|=%.4e |g32|=%.4e cos=%.6f" % b for b in bad[:40])
+    assert none_o == 332 and checked == len(go) - 332         # 324 unreachable tensors + the wh / params heads (no loss term)
+    sg = m.state_dict()
+    nstat = 0
+    for k, v in so.items():
+        if k.endswith('num_batches_tracked'):
+            assert int(sg[k]) == int(v), k
+        else:
+            a = sg[k].detach().cpu().double()
+            assert float((a - v).abs().max()) <= 2e-5 + 1e-4 * float(v.abs().max()), k
+            nstat += 1
+    assert nstat > 150
+    # the train-mode forward itself (lr = 0: same weights; batch statistics, so the running statistics do not matter)
+    with torch.no_grad():
+        res = m(bg['input'], bg['choose'], bg['cloud'], bg['depth'], bg['ind'], bg['K_new'], bg['valid'])
+    for name, a, b in (('hms', res[3]['hms'], hms_o), ('mask', res[3]['mask'], mask_o),
+                       ('verts3d_left', res[0]['verts3d']['left'], v3_o['left']), ('verts3d_right', res[0]['verts3d']['right'], v3_o['right'])):
+        err = float((a.detach().cpu().double() - b).abs().max())
+        assert err <= 1e-3 + 1e-4 * float(b.abs().max()), (name, err)
+    print("headline train-step parity: B=%d, fp64 oracle step %.1f s on %d threads, %d gradients checked, loss %.6f vs %.6f"
+          % (B_HEAD, t_cpu, _threads(), checked, loss_g, loss_o))
+
+
+# ---- the heaviest GEMM shapes of the B=32 step, exactly as profiles/r03_gemm_shapes.txt lists them -------------------------------
+
+def _close(a, b, atol, rtol, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err, lim = float((a - b).abs().max()), atol + rtol * float(b.abs().max())
+    assert err <= lim, "%s: max err %.3e > %.3e (max|ref| = %.3e)" % (what, err, lim, float(b.abs().max()))
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+HEAVY_CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, bias      (layer; entry of r03_gemm_shapes.txt)
+    (32, 1024, 64, 64, 256, 3, 1, 1, False),     # feat: halo kernel, 5-way weight-gradient split
+    (32, 256, 64, 64, 256, 3, 1, 1, True),       # p2 / hm, wh, params heads
+    (32, 128, 64, 64, 128, 3, 1, 1, True),       # up-sampling decoders, last stage
+    (32, 256, 16, 16, 256, 3, 1, 1, False),      # ResNet layer3 3x3
+    (32, 128, 32, 32, 128, 3, 1, 1, False),      # ResNet layer2 3x3
+    (32, 64, 64, 64, 64, 3, 1, 1, False),        # ResNet layer1 3x3
+    (32, 512, 8, 8, 512, 3, 1, 1, False),        # ResNet layer4 3x3 (split-K forward)
+    (32, 256, 16, 16, 1024, 1, 1, 0, False),     # ResNet layer3 expand
+    (32, 1024, 16, 16, 256, 1, 1, 0, False),     # ResNet layer3 reduce
+    (32, 64, 64, 64, 256, 1, 1, 0, False),       # ResNet layer1 expand (short reduction, a million output rows x 256)
+    (32, 512, 64, 64, 256, 1, 1, 0, True),       # 128x128 tile 1x1
+    (32, 3, 256, 256, 64, 7, 2, 3, False),       # stem
+]
+
+
+@pytest.mark.parametrize("cfg", HEAVY_CONVS)
+def test_heaviest_convolutions_of_the_step_at_their_real_size(cfg):
+    from pdfnet_amd import functional as F
+    N, Cin, H, W, Cout, k, s, p, bias = cfg
+    torch.set_num_threads(_threads())
+    x = _rnd(N, Cin, H, W, seed=1)
+    w = _rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    b = _rnd(Cout, seed=3) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    ref = TF.conv2d(xr, wr, br, s, p)
+    gy = _rnd(*ref.shape, seed=4)
+    ref.backward(gy)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    wd = w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    bd = b.cuda().requires_grad_() if bias else None
+    out = F.conv2d(xd, wd, bd, s, p, 0)
+    out.backward(gy.cuda())
+    F.join_wgrad()
+    K, M = Cin * k * k, N * ref.shape[2] * ref.shape[3]
+    _close(out, ref, 3e-5 * max(1, K ** 0.5 / 16), 1e-5, "conv fwd")
+    _close(xd.grad, xr.grad, 1e-4, 2e-5, "conv dx")
+    _close(wd.grad, wr.grad, 5e-5 * max(1, M ** 0.5 / 16), 5e-5, "conv dw")
+    if bias:
+        _close(bd.grad, br.grad, 1e-4 * max(1, M ** 0.5 / 64), 5e-5, "conv db")
+    with torch.no_grad():                                      # the fused ReLU epilogue at the same size (forward only: the mask of
+        _close(F.conv2d(xd, wd, bd, s, p, 1), TF.relu(ref), 3e-5 * max(1, K ** 0.5 / 16), 1e-5, "conv + relu fwd")   # ~0 values may flip)
+
+
+@pytest.mark.parametrize("cfg", [(32, 512, 32, 32, 256, 4, 2, 1), (32, 1024, 16, 16, 256, 4, 4, 0), (32, 2048, 8, 8, 256, 8, 8, 0)])
+def test_pyramid_transposed_convolutions_at_their_real_size(cfg):
+    """p3 / p4 / p5 (intaghand_encoder.py:602-605): p5's weight is the largest tensor of the model (33.5 M elements)."""
+    from pdfnet_amd import functional as F
+    N, Cin, H, W, Cout, k, s, p = cfg
+    torch.set_num_threads(_threads())
+    x = _rnd(N, Cin, H, W, seed=1)
+    w = _rnd(Cin, Cout, k, k, seed=2, scale=Cin ** -0.5)
+    b = _rnd(Cout, seed=3)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = TF.conv_transpose2d(xr, wr, br, s, p)
+    gy = _rnd(*ref.shape, seed=4)
+    ref.backward(gy)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    wd = w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    bd = b.cuda().requires_grad_()
+    out = F.deconv2d(xd, wd, bd, s, p)
+    out.backward(gy.cuda())
+    F.join_wgrad()
+    M = N * H * W
+    _close(out, ref, 5e-5 * max(1, Cin ** 0.5 / 16), 1e-5, "deconv fwd")
+    _close(xd.grad, xr.grad, 2e-4, 2e-5, "deconv dx")
+    _close(wd.grad, wr.grad, 5e-5 * max(1, M ** 0.5 / 16), 5e-5, "deconv dw")
+    _close(bd.grad, br.grad, 1e-4 * max(1, (N * ref.shape[2] * ref.shape[3]) ** 0.5 / 64), 5e-5, "deconv db")
+
+
+@pytest.mark.parametrize("M,K,N,act", [(1048576, 64, 128, 1), (1048576, 64, 64, 1), (262144, 128, 256, 1), (262144, 128, 128, 0),
+                                       (2 * 32 * 252, 64, 64, 0), (2 * 32 * 63, 512, 256, 0), (8192, 512, 1024, 0)])
+def test_pointnet_and_mesh_linears_at_their_real_size(M, K, N, act):
+    """The set-abstraction MLP rows of both hands' 512 x 64 / 128 x 64 neighbourhoods at B=32 (intaghand_encoder.py:48-103) and the
+    mesh decoder's per-vertex linears on 2 x 32 x V rows (model_attn/gcn.py:34-69)."""
+    from pdfnet_amd import functional as F
+    torch.set_num_threads(_threads())
+    x, w, b = _rnd(M, K, seed=1), _rnd(N, K, seed=2, scale=K ** -0.5), _rnd(N, seed=3)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = TF.linear(xr, wr, br)
+    gy = _rnd(M, N, seed=4)
+    ref.backward(gy)                                           # (gradients through the pre-activation: the ReLU is checked forward-only)
+    xd, wd, bd = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    out = F.linear(xd, wd, bd, 0)
+    out.backward(gy.cuda())
+    F.join_wgrad()
+    tol = 2e-5 * max(1.0, K ** 0.5 / 8)
+    _close(out, ref, tol, 1e-5, "linear fwd")
+    _close(xd.grad, xr.grad, tol * 4, 1e-5, "linear dx")
+    _close(wd.grad, wr.grad, 2e-5 * max(1.0, M ** 0.5 / 4), 2e-5, "linear dw")
+    _close(bd.grad, br.grad, 2e-5 * max(1.0, M ** 0.5 / 4), 2e-5, "linear db")
+    if act:
+        with torch.no_grad():
+            _close(F.linear(xd, wd, bd, 1), TF.relu(ref), tol, 1e-5, "linear + relu fwd")
