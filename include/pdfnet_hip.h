@@ -57,7 +57,7 @@ int pdf_debug_kernel_timing(int on);
  * afterwards pdf_stats_result_tiles() / pdf_stats_result_rows() give the number of row blocks and rows per block it wrote
  * (0 tiles: the kernel it chose has no statistics epilogue, or cap_floats < tiles * N * 2).  pdf_set_bn_tile_stats hands
  * such partials to the NEXT pdf_bn_train_fwd / pdf_bn_relu_maxk_fwd call, which then skips its own statistics pass. */
-int pdf_set_stats_output(float* part, long cap_floats);
+int pdf_set_stats_output(float* part, long cap_floats);      /* compat: arms PdfCallOpts::stats_out for the next plain call (see `_x` forms below) */
 long pdf_stats_result_tiles(void);
 long pdf_stats_result_rows(void);
 int pdf_set_bn_tile_stats(const float* part, long tiles, long rows_per_tile);
@@ -383,6 +383,55 @@ int pdf_mano_split_coeff(const float* params, int ldp, long HW, const long* ind,
                          float* orient, float* pose, float* shape, float* trans, void* stream);
 int pdf_mano_split_coeff_bwd(const float* params, float* dparams, int ldp, long HW, const long* ind, const float* K, int B, int input_res, int down,
                              const float* dorient, const float* dpose, const float* dtrans, void* stream);
+
+
+/* ---- explicit per-call options (round 4) ------------------------------------------------------------------------------
+ * Everything a call can take beyond its positional arguments travels in ONE structure handed to the `_x` form of the entry
+ * point (NULL = no options): the convention SURVEY 8(b) derives from the reference's only native op, whose forward / backward take
+ * every tensor they touch as an argument (lib/utils/roi_align/src/crop_and_resize_gpu.cpp:6-13,100-109).  Inputs are read by that
+ * call only; `stats_tiles` / `stats_rows` are written back by it.  The plain entry points above are thin wrappers: they TAKE AND
+ * CLEAR every slot the pdf_set_* functions armed on the calling thread before they look at a single argument, so no return path
+ * -- PDF_E_BADARG included -- leaves a slot armed for an unrelated later call (pdf_debug_armed_slots() == 0 after any call).
+ *
+ *   op0_bf16 / op1_bf16  bf16 shadows (same elements, RNE-rounded, same layout and leading dimensions in ELEMENTS) of the call's two
+ *                        operands -- forward: (x, w); backward-data: (dy, w); weight gradient: (x, dy).  bf16 mode only.
+ *   out_bf16             pdf_bn_train_fwd: shadow of y; pdf_bn_train_bwd: shadow of dx (dx == NULL: the only output);
+ *                        pdf_l2norm_cat_fwd: shadow of y; pdf_conv2d_fwd (bf16 mode): the output INSTEAD of y (storage mode).
+ *   bn_x_bf16            pdf_bn_train_fwd / _bwd: x is read from this bf16 tensor instead of the fp32 pointer.
+ *   stats_out, stats_cap pdf_conv2d_fwd / pdf_linear_fwd: per-row-block (mean, M2) pairs of the output columns,
+ *                        stats_out[(t * N + c) * 2 + {0,1}]; -> stats_tiles row blocks of stats_rows rows (0: not produced).
+ *   tile_stats, tile_n, tile_rows   pdf_bn_train_fwd / pdf_bn_relu_maxk_fwd: such partials; the call skips its statistics pass.
+ *   in_scale, in_shift   pdf_linear_fwd / pdf_linear_bwd_weight: x is read as relu(x * in_scale[k] + in_shift[k]). */
+typedef struct PdfCallOpts {
+    const void* op0_bf16; const void* op1_bf16;
+    void* out_bf16;
+    const void* bn_x_bf16;
+    float* stats_out; long stats_cap;
+    long stats_tiles; long stats_rows;
+    const float* tile_stats; long tile_n; long tile_rows;
+    const float* in_scale; const float* in_shift;
+} PdfCallOpts;
+int pdf_linear_fwd_x(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream, PdfCallOpts* opts);
+int pdf_linear_fwd_pair_x(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream, PdfCallOpts* opts);
+int pdf_linear_bwd_data_x(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx, void* stream, PdfCallOpts* opts);
+int pdf_linear_bwd_data_pair_x(const float* dy, const float* w0, const float* w1, float* dx, int M, int N, int K, int lddy, int ldw, int lddx, void* stream, PdfCallOpts* opts);
+int pdf_conv2d_fwd_x(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, int ldy, int act, void* stream, PdfCallOpts* opts);
+int pdf_conv2d_bwd_data_x(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, int lddy, void* stream, PdfCallOpts* opts);
+int pdf_conv2d_bwd_data_add_x(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, int lddy, void* stream, PdfCallOpts* opts);
+int pdf_linear_bwd_weight_x(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats, int M, int N, int K, int ldx, int lddy, int accumulate, void* stream, PdfCallOpts* opts);
+int pdf_linear_bwd_weight_pair_x(const float* x, const float* dy, float* dw0, float* dw1, float* db0, float* db1, float* ws, long ws_floats, int M, int N, int K, int ldx, int lddy, int accumulate, void* stream, PdfCallOpts* opts);
+int pdf_conv2d_bwd_weight_x(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats, int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, int lddy, int accumulate, void* stream, PdfCallOpts* opts);
+int pdf_deconv2d_fwd_x(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, int ldy, void* stream, PdfCallOpts* opts);
+int pdf_deconv2d_bwd_data_x(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, int lddy, void* stream, PdfCallOpts* opts);
+int pdf_deconv2d_bwd_weight_x(const float* x, const float* dy, float* dw, float* ws, long ws_floats, int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, int lddy, int accumulate, void* stream, PdfCallOpts* opts);
+int pdf_bn_train_fwd_x(const float* x, int ldx, int C, long R, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, const float* res, int ldr, int relu, float* y, int ldy, float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, void* stream, PdfCallOpts* opts);
+int pdf_bn_train_bwd_x(const float* dy, int lddy, const float* y, int ldy, int relu, const float* x, int ldx, const float* save_mean, const float* save_rstd, const float* gamma, const float* scale, const float* shift, int C, long R, float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate, float* ws, void* stream, PdfCallOpts* opts);
+int pdf_bn_relu_maxk_fwd_x(const float* y, int ldy, int C, long R, int K, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, int training, float* out, int ldo, int* arg, float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, void* stream, PdfCallOpts* opts);
+int pdf_l2norm_cat_fwd_x(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R, float* y, int ldy, float* const* norm, void* stream, PdfCallOpts* opts);
+/* number of hand-over slots currently armed on the calling thread (0 after every entry-point call), and sizeof(PdfCallOpts) as the
+ * library was built (a binding checks its own layout against it) */
+int pdf_debug_armed_slots(void);
+int pdf_debug_callopts_size(void);
 
 #ifdef __cplusplus
 }

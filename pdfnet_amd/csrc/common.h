@@ -106,6 +106,18 @@ __device__ __forceinline__ unsigned int pdf_pk_bf16(float a, float b) {      // 
     pdf_bf16x2 v = __builtin_convertvector(f, pdf_bf16x2);
     return *reinterpret_cast<unsigned int*>(&v);
 }
-void pdf_tls_take_operands(const void** op0, const void** op1);
-void* pdf_tls_take_output();
-void pdf_tls_take_affine(const float** scale, const float** shift);
+// Everything a call may take beyond its positional arguments -- must match `PdfCallOpts` of include/pdfnet_hip.h field for field
+// (tests/c_abi/c_client.c compares sizeof with pdf_debug_callopts_size()).  The `_x` form of an entry point takes it explicitly; the
+// plain form takes (and clears) the thread's hand-over slots FIRST THING, so no return path leaves a slot armed.
+struct PdfCallOpts {
+    const void* op0_bf16; const void* op1_bf16;     // bf16 shadows of the call's two operands (GEMM family)
+    void* out_bf16;                                  // bf16 shadow of the output, or the bf16-only output (storage mode)
+    const void* bn_x_bf16;                           // BatchNorm: x as bf16 instead of the fp32 pointer
+    float* stats_out; long stats_cap;                // conv / linear forward: BatchNorm statistics of the output from the epilogue
+    long stats_tiles, stats_rows;                    // OUT: row blocks / rows per block written to stats_out (0: none)
+    const float* tile_stats; long tile_n, tile_rows; // BatchNorm: such partials instead of its own statistics pass
+    const float* in_scale; const float* in_shift;    // x read as relu(x * scale[k] + shift[k]) (linear fwd / weight gradient)
+};
+PdfCallOpts pdf_tls_take_all();                      // the thread's armed slots, cleared
+void pdf_tls_publish(const PdfCallOpts& o);          // stats_tiles / stats_rows -> pdf_stats_result_*
+

@@ -549,19 +549,28 @@ float* pdf_scratch(long floats) {
 // bf16 shadows (bf16 mode): a producer that writes an fp32 tensor the GEMMs will read can write the same values rounded to bf16
 // (RNE) beside it; the consumer passes that copy along and the bf16 GEMM kernels stage 2-byte operands -- half the L2 -> LDS bytes
 // of the kernels that are bound by exactly those, results bit-identical to rounding while staging.  Carried through
-// thread-local slots so that the existing signatures stay as they are: set, then call, on the same thread.
-static thread_local const void* tl_op0 = nullptr;
-static thread_local const void* tl_op1 = nullptr;
-static thread_local void* tl_out = nullptr;
-PDF_API int pdf_set_bf16_operands(const void* op0_bf16, const void* op1_bf16) { tl_op0 = op0_bf16; tl_op1 = op1_bf16; return 0; }
-PDF_API int pdf_set_bf16_output(void* out_bf16) { tl_out = out_bf16; return 0; }
-void pdf_tls_take_operands(const void** op0, const void** op1) { *op0 = tl_op0; *op1 = tl_op1; tl_op0 = tl_op1 = nullptr; }
-void* pdf_tls_take_output() { void* o = tl_out; tl_out = nullptr; return o; }
+// the explicit PdfCallOpts of the `_x` entry points; the pdf_set_* functions below arm thread-local slots for the plain entry points
+// (set, then call, on the same thread), which take and clear ALL of them first thing.
+static thread_local PdfCallOpts tl_opts = {};
+static thread_local long tl_res_tiles = 0, tl_res_rows = 0;
+PDF_API int pdf_set_bf16_operands(const void* op0_bf16, const void* op1_bf16) { tl_opts.op0_bf16 = op0_bf16; tl_opts.op1_bf16 = op1_bf16; return 0; }
+PDF_API int pdf_set_bf16_output(void* out_bf16) { tl_opts.out_bf16 = out_bf16; return 0; }
+PDF_API int pdf_set_bn_input_bf16(const void* x16) { tl_opts.bn_x_bf16 = x16; return 0; }
+PDF_API int pdf_set_stats_output(float* part, long cap_floats) { tl_opts.stats_out = part; tl_opts.stats_cap = cap_floats; return 0; }
+PDF_API int pdf_set_bn_tile_stats(const float* part, long tiles, long rows_per_tile) { tl_opts.tile_stats = part; tl_opts.tile_n = tiles; tl_opts.tile_rows = rows_per_tile; return 0; }
 // BatchNorm + ReLU of an input tensor applied by the NEXT pdf_linear_fwd (its x) / pdf_linear_bwd_weight (its x) of this thread
-static thread_local const float* tl_aff_scale = nullptr;
-static thread_local const float* tl_aff_shift = nullptr;
-PDF_API int pdf_set_input_affine_relu(const float* scale, const float* shift) { tl_aff_scale = scale; tl_aff_shift = shift; return 0; }
-void pdf_tls_take_affine(const float** scale, const float** shift) { *scale = tl_aff_scale; *shift = tl_aff_shift; tl_aff_scale = tl_aff_shift = nullptr; }
+PDF_API int pdf_set_input_affine_relu(const float* scale, const float* shift) { tl_opts.in_scale = scale; tl_opts.in_shift = shift; return 0; }
+PDF_API long pdf_stats_result_tiles(void) { return tl_res_tiles; }
+PDF_API long pdf_stats_result_rows(void) { return tl_res_rows; }
+PdfCallOpts pdf_tls_take_all() { PdfCallOpts o = tl_opts; tl_opts = PdfCallOpts{}; o.stats_tiles = o.stats_rows = 0; tl_res_tiles = tl_res_rows = 0; return o; }
+void pdf_tls_publish(const PdfCallOpts& o) { tl_res_tiles = o.stats_tiles; tl_res_rows = o.stats_rows; }
+// how many hand-over slots of the calling thread are armed (tests: a rejected call must leave none)
+PDF_API int pdf_debug_armed_slots(void) {
+    const PdfCallOpts& o = tl_opts;
+    return (o.op0_bf16 != nullptr) + (o.op1_bf16 != nullptr) + (o.out_bf16 != nullptr) + (o.bn_x_bf16 != nullptr) + (o.stats_out != nullptr) +
+           (o.tile_stats != nullptr) + (o.in_scale != nullptr) + (o.in_shift != nullptr);
+}
+PDF_API int pdf_debug_callopts_size(void) { return (int)sizeof(PdfCallOpts); }
 // dst[i] = bf16(src[i]) (RNE): the weight shadows, refreshed from the flat fp32 master buffer once per step
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n4) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {

@@ -1130,10 +1130,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_IG_BUFSTORE, ENV_IG_BF16_STATS, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_IG_BUFSTORE, ENV_IG_BF16_STATS, ENV_IG_DMA, ENV_IG_DMA128, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM", "PDF_IG_BUFSTORE", "PDF_IG_BF16_STATS"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM", "PDF_IG_BUFSTORE", "PDF_IG_BF16_STATS", "PDF_IG_DMA", "PDF_IG_DMA128"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1298,20 +1298,16 @@ PDF_API int pdf_debug_igemm_launches() { return g_igemm_launches; }
 // BatchNorm statistics out of a forward GEMM's epilogue (IGemm::stat): the request of the NEXT conv2d / linear forward call of
 // this thread (pdf_set_stats_output) and what that call produced (pdf_stats_result_tiles / _rows; 0 tiles: the launch it chose
 // has no statistics epilogue -- the caller then runs the ordinary statistics pass).
-static thread_local float* tl_stat_req = nullptr;
-static thread_local long tl_stat_cap = 0;
-static thread_local long tl_stat_tiles = 0, tl_stat_rows = 0;
-PDF_API int pdf_set_stats_output(float* part, long cap_floats) { tl_stat_req = part; tl_stat_cap = cap_floats; return 0; }
-PDF_API long pdf_stats_result_tiles(void) { return tl_stat_tiles; }
-PDF_API long pdf_stats_result_rows(void) { return tl_stat_rows; }
 struct StatReq { float* part; long cap; };
-static StatReq take_stat_request() { StatReq r = {tl_stat_req, tl_stat_cap}; tl_stat_req = nullptr; tl_stat_cap = 0; tl_stat_tiles = tl_stat_rows = 0; return r; }
+static thread_local PdfCallOpts* tl_cur = nullptr;   // the call in progress on this thread (stat_plan publishes the layout it chose into it)
+struct CurCall { PdfCallOpts* prev; explicit CurCall(PdfCallOpts& co) : prev(tl_cur) { tl_cur = &co; } ~CurCall() { tl_cur = prev; } };
+static void stat_result(long tiles, long rows) { if (tl_cur != nullptr) { tl_cur->stats_tiles = tiles; tl_cur->stats_rows = rows; } }
 // the launch about to be issued uses row blocks of BM rows: keep the request if the partials fit, and publish the layout
 static void stat_plan(IGemm& g, long cap, int BM) {
     if (g.stat == nullptr) return;
     const long tiles = cdiv(g.M, BM);
     if (!g.plain_out || g.ps_cout > 0 || g.accum || tiles * g.N * 2 > cap) { g.stat = nullptr; return; }
-    tl_stat_tiles = tiles; tl_stat_rows = BM;
+    stat_result(tiles, BM);
 }
 
 // groups == 2: paired launch (see IGemm::B1), blockIdx.y selects the group
@@ -1357,7 +1353,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
         if (rc < 0) return -rc;
         if (rc == 1) { g_last_tile = 16; return 0; }
         g.stat = nullptr;
-        tl_stat_tiles = tl_stat_rows = 0;
+        stat_result(0, 0);
     }
     if (g.C16 != nullptr) return PDF_E_BADARG;             // (only the bf16 kernels write a bf16 output)
     if (g.A == nullptr) return PDF_E_BADARG;               // (... and only they read a bf16-only operand)
@@ -1365,7 +1361,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     // up-projections): a handful of CUs would walk K step by step at load latency.  Split K over blockIdx.z so that ~512 blocks
     // run, partial tiles through the scratch ring, bias / activation in splitk_finish.  (round 3: up to 256 tiles instead of 128 and
     // ~512 blocks instead of ~320 -- ResNet layer-4 3x3: 79 -> 90 TFLOP/s forward and backward-data, its 1x1 backward-data 75 -> 83;
-    // at 512 tiles the layer-3 1x1 layers lose 7 %, tools/run_r3q.sh)
+    // at 512 tiles the layer-3 1x1 layers lose 7 %, tools/experiments/r03/run_r3q.sh)
     const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
     // (also the valid 3x3 convolutions on the 5x5 / 3x3 centre windows: taps are walked in K order, a split may start inside any tap)
     const bool sk_plain = g.T == 1 && g.plain_in, sk_taps = g.T > 1 && !g.plain_in && fast && g.Cin % 32 == 0 && g.K == g.T * g.Cin;
@@ -1382,7 +1378,9 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
                 IGemm gs = g;
                 gs.ksteps = ksteps; gs.part = part;
                 const dim3 grid((unsigned)t64, 1, (unsigned)splits);
-                if (bk32) launch_igemm_tile<64, 64, 2, 2, 32>(gs, fast, grid, s);
+                const int dma = env_int(ENV_IG_DMA, 0);
+                if (dma > 0 && fast && bk32 && launch_igemm_dma(gs, 64, dma - 1, 1, splits, s)) {}
+                else if (bk32) launch_igemm_tile<64, 64, 2, 2, 32>(gs, fast, grid, s);
                 else launch_igemm_tile<64, 64, 2, 2>(gs, fast, grid, s);
                 KTimer kt("splitk_finish", 0.0, 4.0 * (splits + 1) * g.M * g.N, s);
                 hipLaunchKernelGGL(splitk_finish, dim3(grid_for((long)g.M * g.N)), dim3(256), 0, s, part, splits, g.M, g.N, g.bias, g.act, g.C, g.ldc);
@@ -1420,8 +1418,13 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
         else hipLaunchKernelGGL((igemm_halo3x3<false, false>), grid, dim3(256), 0, s, g);
         g_last_tile = 128128;
     }
-    else if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) && !short_k)
-        stat_plan(g, stat_cap, 128), launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s), g_last_tile = 128128;
+    else if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) && !short_k) {
+        stat_plan(g, stat_cap, 128);
+        const int dma = env_int(ENV_IG_DMA128, 0);
+        if (!(dma > 0 && fast && launch_igemm_dma(g, 128, dma - 1, groups, 0, s)))
+            launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
+        g_last_tile = 128128;
+    }
     else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= env_int(ENV_IG_T128, 600))
         stat_plan(g, stat_cap, 128), launch_igemm_tile<128, 64, 4, 1>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s), g_last_tile = 128064;   // (K-step 32: no gain here)
     else if (fast && (long)cdiv(g.M, 64) * cdiv(g.N, 64) * groups < 96 && g.K >= 512 && env_int(ENV_IG_T32, 1)) {
@@ -1434,8 +1437,10 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     {
         stat_plan(g, stat_cap, 64);
         const dim3 grid(cdiv(g.M, 64) * cdiv(g.N, 64), groups);
+        const int dma = env_int(ENV_IG_DMA, 0);
         // K-step 32 for the small tile: its 8 MFMAs per wave and 16-wide step leave the barrier exposed (l4 3x3: 62 -> 72 TFLOP/s)
-        if (fast && g.Cin % 32 == 0 && env_int(ENV_IG_BK32, 1)) launch_igemm_tile<64, 64, 2, 2, 32>(g, fast, grid, s);
+        if (dma > 0 && fast && launch_igemm_dma(g, 64, dma - 1, groups, 0, s)) {}
+        else if (fast && g.Cin % 32 == 0 && env_int(ENV_IG_BK32, 1)) launch_igemm_tile<64, 64, 2, 2, 32>(g, fast, grid, s);
         else launch_igemm_tile<64, 64, 2, 2>(g, fast, grid, s);
         g_last_tile = 64064;
     }
@@ -1453,7 +1458,6 @@ static void conv_taps(IGemm& g, int KH, int KW, int pad, int dil) {
 }
 
 struct Shadows { const void* op0; const void* op1; };
-static Shadows take_shadows() { Shadows sh; pdf_tls_take_operands(&sh.op0, &sh.op1); return sh; }
 
 // Linear / 1x1: y[M][N] = act(x[M][K] w[N][K]^T + b).  Reference: nn.Linear / 1x1 nn.Conv2d call sites
 // (e.g. model_attn/gcn.py:66, intaghand_encoder.py:48-103 netR_*, :205-219 SFT convs).
@@ -1466,42 +1470,61 @@ static IGemm linear_desc(const float* x, const float* w, const float* bias, floa
     g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
     return g;
 }
-PDF_API int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
-                           int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) {
-    const Shadows sh = take_shadows();
-    const StatReq sr = take_stat_request();
+static int pdf_linear_fwd_impl(const float* x, const float* w, const float* bias, float* y,
+                           int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s, PdfCallOpts& co) {
+    const Shadows sh = {co.op0_bf16, co.op1_bf16};
+    const StatReq sr = {co.stats_out, co.stats_cap};
+    const CurCall cur(co);
     IGemm g = linear_desc(x, w, bias, y, M, N, K, ldx, ldw, ldy, act);
     g.A16 = sh.op0; g.B16 = sh.op1;
     g.stat = sr.part;
-    pdf_tls_take_affine(&g.a_scale, &g.a_shift);
+    g.a_scale = co.in_scale; g.a_shift = co.in_shift;
     return launch_igemm(g, s, 1, sr.cap);
 }
+PDF_API int pdf_linear_fwd_x(const float* x, const float* w, const float* bias, float* y,
+                           int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_linear_fwd_impl(x, w, bias, y, M, N, K, ldx, ldw, ldy, act, s, co); }
+PDF_API int pdf_linear_fwd(const float* x, const float* w, const float* bias, float* y,
+                           int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_linear_fwd_impl(x, w, bias, y, M, N, K, ldx, ldw, ldy, act, s, co); pdf_tls_publish(co); return rc; }
+
 // Two same-shaped layers with their own parameters in ONE launch (the left / right hand branches of the mesh decoder,
 // DualGraph.py:83-84, inter_attn.py:66-67): rows [0, M) of x / y belong to (w0, b0), rows [M, 2M) to (w1, b1).
-PDF_API int pdf_linear_fwd_pair(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
-                                int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) {
-    take_shadows();
+static int pdf_linear_fwd_pair_impl(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
+                                int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s, PdfCallOpts& co) {
     IGemm g = linear_desc(x, w0, b0, y, M, N, K, ldx, ldw, ldy, act);
     g.B1 = w1; g.bias1 = b1; g.gsA = (long)M * ldx; g.gsC = (long)M * ldy;
     return launch_igemm(g, s, 2);
 }
+PDF_API int pdf_linear_fwd_pair_x(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
+                                int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_linear_fwd_pair_impl(x, w0, w1, b0, b1, y, M, N, K, ldx, ldw, ldy, act, s, co); }
+PDF_API int pdf_linear_fwd_pair(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y,
+                                int M, int N, int K, int ldx, int ldw, int ldy, int act, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_linear_fwd_pair_impl(x, w0, w1, b0, b1, y, M, N, K, ldx, ldw, ldy, act, s, co); pdf_tls_publish(co); return rc; }
+
 // dx[M][K] = dy[M][N] w[N][K]: the weight is read in its forward [N][K] storage (no transposed copy)
-PDF_API int pdf_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx,
-                                hipStream_t s) {
-    const Shadows sh = take_shadows();
+static int pdf_linear_bwd_data_impl(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx,
+                                hipStream_t s, PdfCallOpts& co) {
+    const Shadows sh = {co.op0_bf16, co.op1_bf16};
     IGemm g = linear_desc(dy, w, nullptr, dx, M, K, N, lddy, ldw, lddx, 0);
     g.b_kn = 1; g.btap = 0;
     g.A16 = sh.op0; g.B16 = sh.op1;
     return launch_igemm(g, s);
 }
-PDF_API int pdf_linear_bwd_data_pair(const float* dy, const float* w0, const float* w1, float* dx, int M, int N, int K,
-                                     int lddy, int ldw, int lddx, hipStream_t s) {
-    take_shadows();
+PDF_API int pdf_linear_bwd_data_x(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx,
+                                hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_linear_bwd_data_impl(dy, w, dx, M, N, K, lddy, ldw, lddx, s, co); }
+PDF_API int pdf_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx,
+                                hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_linear_bwd_data_impl(dy, w, dx, M, N, K, lddy, ldw, lddx, s, co); pdf_tls_publish(co); return rc; }
+
+static int pdf_linear_bwd_data_pair_impl(const float* dy, const float* w0, const float* w1, float* dx, int M, int N, int K,
+                                     int lddy, int ldw, int lddx, hipStream_t s, PdfCallOpts& co) {
     IGemm g = linear_desc(dy, w0, nullptr, dx, M, K, N, lddy, ldw, lddx, 0);
     g.b_kn = 1; g.btap = 0;
     g.B1 = w1; g.bias1 = nullptr; g.gsA = (long)M * lddy; g.gsC = (long)M * lddx;
     return launch_igemm(g, s, 2);
 }
+PDF_API int pdf_linear_bwd_data_pair_x(const float* dy, const float* w0, const float* w1, float* dx, int M, int N, int K,
+                                     int lddy, int ldw, int lddx, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_linear_bwd_data_pair_impl(dy, w0, w1, dx, M, N, K, lddy, ldw, lddx, s, co); }
+PDF_API int pdf_linear_bwd_data_pair(const float* dy, const float* w0, const float* w1, float* dx, int M, int N, int K,
+                                     int lddy, int ldw, int lddx, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_linear_bwd_data_pair_impl(dy, w0, w1, dx, M, N, K, lddy, ldw, lddx, s, co); pdf_tls_publish(co); return rc; }
+
 
 // ---------------------------------------------------------------------------------------------
 // Tiny-channel layers: HBM-bound streaming kernels instead of 128-wide MFMA tiles that would be > 95 % padding.
@@ -1718,12 +1741,13 @@ __global__ __launch_bounds__(256) void stem7x7_fwd_kernel(const float* __restric
     }
 }
 
-PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+static int pdf_conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* y,
                            int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
-                           int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s) {
-    const Shadows sh = take_shadows();
-    const StatReq sr = take_stat_request();
-    unsigned short* y16 = reinterpret_cast<unsigned short*>(pdf_tls_take_output());      // bf16 storage mode: the output goes here INSTEAD of y
+                           int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s, PdfCallOpts& co) {
+    const Shadows sh = {co.op0_bf16, co.op1_bf16};
+    const StatReq sr = {co.stats_out, co.stats_cap};
+    const CurCall cur(co);
+    unsigned short* y16 = reinterpret_cast<unsigned short*>(co.out_bf16);      // bf16 storage mode: the output goes here INSTEAD of y
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (y16 != nullptr && !(g_gemm_bf16 && Cout % 2 == 0 && ldy % 2 == 0)) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && (long)N * OH * OW >= (1L << 16)) {
@@ -1743,7 +1767,7 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
         nblk = (int)cdiv(total, cpb);
         KTimer kt("stem7x7_fwd_kernel", 2.0 * N * OH * OW * 64 * 147, 4.0 * N * ((double)H * W * 3 + (double)OH * OW * 64), s);
         float* stat = (sr.part != nullptr && (long)nblk * 64 * 2 <= sr.cap) ? sr.part : nullptr;
-        if (stat != nullptr) { tl_stat_tiles = nblk; tl_stat_rows = (long)cpb * 64; }
+        if (stat != nullptr) stat_result(nblk, (long)cpb * 64);
         hipLaunchKernelGGL(stem7x7_fwd_kernel, dim3(nblk), dim3(256), 0, s, x, w, y, N, H, W, OH, OW, ldy, act, cpb, stat);
         g_last_tile = 0;
         PDF_LAUNCH_CHECK();
@@ -1761,14 +1785,21 @@ PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, fl
     g.C16 = y16;
     return launch_igemm(g, s, 1, sr.cap);
 }
+PDF_API int pdf_conv2d_fwd_x(const float* x, const float* w, const float* bias, float* y,
+                           int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                           int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_conv2d_fwd_impl(x, w, bias, y, N, H, W, Cin, ldx, Cout, KH, KW, stride, pad, OH, OW, ldy, act, s, co); }
+PDF_API int pdf_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                           int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                           int stride, int pad, int OH, int OW, int ldy, int act, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_conv2d_fwd_impl(x, w, bias, y, N, H, W, Cin, ldx, Cout, KH, KW, stride, pad, OH, OW, ldy, act, s, co); pdf_tls_publish(co); return rc; }
+
 
 // Conv2d backward-data: dx[N,H,W,Cin] from dy[N,OH,OW,Cout] and the FORWARD weight w = [Cout][KH][KW][Cin], read as
 // the [K = (tap, co)][N = ci] operand it is.  One launch per input-parity class so a stride-s conv
 // never multiplies zeros.  dx must be zero-filled by the caller when stride > kernel (1x1 s2).
 static int conv2d_bwd_data(const float* dy, const float* w, float* dx,
                            int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
-                           int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
-    const Shadows sh = take_shadows();
+                           int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s, const PdfCallOpts& co) {
+    const Shadows sh = {co.op0_bf16, co.op1_bf16};
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (accumulate && stride > 1) return PDF_E_BADARG;       // (every dx element must be written by exactly one launch)
     for (int py = 0; py < stride; ++py)
@@ -1807,18 +1838,32 @@ static int conv2d_bwd_data(const float* dy, const float* w, float* dx,
     return 0;
 }
 
+static int pdf_conv2d_bwd_data_impl(const float* dy, const float* w, float* dx,
+                                int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                int stride, int pad, int OH, int OW, int lddy, hipStream_t s, PdfCallOpts& co) {
+    return conv2d_bwd_data(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, 0, s, co);
+}
+PDF_API int pdf_conv2d_bwd_data_x(const float* dy, const float* w, float* dx,
+                                int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                int stride, int pad, int OH, int OW, int lddy, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_conv2d_bwd_data_impl(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, s, co); }
 PDF_API int pdf_conv2d_bwd_data(const float* dy, const float* w, float* dx,
                                 int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
-                                int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
-    return conv2d_bwd_data(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, 0, s);
-}
+                                int stride, int pad, int OH, int OW, int lddy, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_conv2d_bwd_data_impl(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, s, co); pdf_tls_publish(co); return rc; }
+
 // dx += the same (stride 1): the gradient of a tensor with two consumers -- a ResNet block input feeds conv1 and the shortcut --
 // is accumulated by the second producer's epilogue instead of a separate add pass over both gradients
+static int pdf_conv2d_bwd_data_add_impl(const float* dy, const float* w, float* dx,
+                                    int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                    int stride, int pad, int OH, int OW, int lddy, hipStream_t s, PdfCallOpts& co) {
+    return conv2d_bwd_data(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, 1, s, co);
+}
+PDF_API int pdf_conv2d_bwd_data_add_x(const float* dy, const float* w, float* dx,
+                                    int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                    int stride, int pad, int OH, int OW, int lddy, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_conv2d_bwd_data_add_impl(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, s, co); }
 PDF_API int pdf_conv2d_bwd_data_add(const float* dy, const float* w, float* dx,
                                     int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
-                                    int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
-    return conv2d_bwd_data(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, 1, s);
-}
+                                    int stride, int pad, int OH, int OW, int lddy, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_conv2d_bwd_data_add_impl(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, s, co); pdf_tls_publish(co); return rc; }
+
 
 // Split count of a weight-gradient launch: the candidate with the smallest modelled time (see launch_wgemm).
 //   tiles: output tiles x groups; occ: blocks a CU holds; cap: most splits allowed (rows, workspace); rq: row quantum of a split;
@@ -1870,7 +1915,7 @@ static int launch_wgemm(WGemm& g, float* out, float* ws, long ws_floats, int acc
     // (tools/gemm_bench.py, TFLOP/s): feat 104.8 -> 112, p2 / hm 102.6 -> 116, decoder 3x3 88.9 -> 101, l3 3x3 70.8 -> 82.6,
     // l4 3x3 71.7 -> 82.3; PDF_WG_TARGET=<blocks> restores the r02 rule.
     const bool bf16_mode = g_gemm_bf16 && fast;
-    const int occ = env_int(ENV_WG_SLOTS, 0) > 0 ? env_int(ENV_WG_SLOTS, 0) / 256 : (bf16_mode ? (small ? 3 : 2) : (small ? 4 : 3));
+    const int occ = env_int(ENV_WG_SLOTS, 0) > 0 ? max(1, min(4, env_int(ENV_WG_SLOTS, 0) / 256)) : (bf16_mode ? (small ? 3 : 2) : (small ? 4 : 3));      // (the efficiency table of wg_choose_splits covers 1-4 co-resident blocks)
     const int target = env_int(ENV_WG_TARGET, 0);
     int splits = target > 0 ? (int)((target + tiles * groups - 1) / (tiles * groups)) : 0;
     int max_by_rows = cdiv(g.M, env_int(ENV_WG_MINROWS, g.M >= 16384 ? 512 : 128));
@@ -2001,22 +2046,26 @@ PDF_API long pdf_wgrad_workspace_floats(int M, int NI, int NJ) {
 }
 
 // dW[N][K] (+)= dy[M][N]^T x[M][K]   (Linear / 1x1 weight gradient)
-PDF_API int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
-                                  int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) {
-    const Shadows sh = take_shadows();                       // op0: x, op1: dy
+static int pdf_linear_bwd_weight_impl(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+                                  int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s, PdfCallOpts& co) {
+    const Shadows sh = {co.op0_bf16, co.op1_bf16};                       // op0: x, op1: dy
     WGemm g = {};
     g.P = dy; g.Q = x; g.M = M; g.NI = N; g.Cq = K; g.T = 1; g.ldp = lddy; g.ldq = ldx; g.ldw = K;
     g.plain_q = 1; g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
     g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
     g.Q16 = sh.op0; g.P16 = sh.op1;
-    pdf_tls_take_affine(&g.q_scale, &g.q_shift);
+    g.q_scale = co.in_scale; g.q_shift = co.in_shift;
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s, nullptr, db);
 }
+PDF_API int pdf_linear_bwd_weight_x(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+                                  int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_linear_bwd_weight_impl(x, dy, dw, db, ws, ws_floats, M, N, K, ldx, lddy, accumulate, s, co); }
+PDF_API int pdf_linear_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+                                  int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_linear_bwd_weight_impl(x, dy, dw, db, ws, ws_floats, M, N, K, ldx, lddy, accumulate, s, co); pdf_tls_publish(co); return rc; }
+
 
 // paired form of the above: rows [0, M) -> dw0, rows [M, 2M) -> dw1; ws >= 2 * pdf_wgrad_workspace_floats(M, N, K)
-PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* dw0, float* dw1, float* db0, float* db1,
-                                       float* ws, long ws_floats, int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) {
-    take_shadows();
+static int pdf_linear_bwd_weight_pair_impl(const float* x, const float* dy, float* dw0, float* dw1, float* db0, float* db1,
+                                       float* ws, long ws_floats, int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s, PdfCallOpts& co) {
     WGemm g = {};
     g.P = dy; g.Q = x; g.M = M; g.NI = N; g.Cq = K; g.T = 1; g.ldp = lddy; g.ldq = ldx; g.ldw = K;
     g.plain_q = 1; g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
@@ -2024,6 +2073,11 @@ PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* d
     g.gsP = (long)M * lddy; g.gsQ = (long)M * ldx;
     return launch_wgemm(g, dw0, ws, ws_floats, accumulate, s, dw1, db0, db1);
 }
+PDF_API int pdf_linear_bwd_weight_pair_x(const float* x, const float* dy, float* dw0, float* dw1, float* db0, float* db1,
+                                       float* ws, long ws_floats, int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_linear_bwd_weight_pair_impl(x, dy, dw0, dw1, db0, db1, ws, ws_floats, M, N, K, ldx, lddy, accumulate, s, co); }
+PDF_API int pdf_linear_bwd_weight_pair(const float* x, const float* dy, float* dw0, float* dw1, float* db0, float* db1,
+                                       float* ws, long ws_floats, int M, int N, int K, int ldx, int lddy, int accumulate, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_linear_bwd_weight_pair_impl(x, dy, dw0, dw1, db0, db1, ws, ws_floats, M, N, K, ldx, lddy, accumulate, s, co); pdf_tls_publish(co); return rc; }
+
 
 // dW[Cout][KH][KW][Cin] (+)= sum over output pixels dy[m][co] * x[pos(m,tap)][ci]
 
@@ -2125,10 +2179,10 @@ __global__ __launch_bounds__(256) void stem7x7_wgrad_kernel(const float* __restr
     }
 }
 
-PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+static int pdf_conv2d_bwd_weight_impl(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
                                   int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
-                                  int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
-    const Shadows sh = take_shadows();                       // op0: x, op1: dy
+                                  int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s, PdfCallOpts& co) {
+    const Shadows sh = {co.op0_bf16, co.op1_bf16};                       // op0: x, op1: dy
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     // bf16 storage mode: dy exists only as bf16 (dy == NULL) -- the launch must be one the bf16 kernel takes with a shadow operand
     if (dy == nullptr && (sh.op1 == nullptr || db != nullptr || !g_gemm_bf16 || Cin % 16 != 0 || Cout % 16 != 0 || lddy % 8 != 0)) return PDF_E_BADARG;
@@ -2185,15 +2239,22 @@ PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, fl
     g.Q16 = sh.op0; g.P16 = sh.op1;
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s, nullptr, db);
 }
+PDF_API int pdf_conv2d_bwd_weight_x(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+                                  int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                                  int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_conv2d_bwd_weight_impl(x, dy, dw, db, ws, ws_floats, N, H, W, Cin, ldx, Cout, KH, KW, stride, pad, OH, OW, lddy, accumulate, s, co); }
+PDF_API int pdf_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats,
+                                  int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                                  int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_conv2d_bwd_weight_impl(x, dy, dw, db, ws, ws_floats, N, H, W, Cin, ldx, Cout, KH, KW, stride, pad, OH, OW, lddy, accumulate, s, co); pdf_tls_publish(co); return rc; }
+
 
 // ConvTranspose2d forward on NHWC: y[n, iy*s - pad + ky, ix*s - pad + kx, co] += x[n,iy,ix,ci] w[ci][co][ky][kx].
 // w = the weight in its natural [Cin][KH][KW][Cout] storage, read as the [K = (tap, ci)][N = co] operand it is.
 // kernel == stride (p4/p5, intaghand_encoder.py:604-605): ONE plain GEMM + pixel-shuffle epilogue;
 // otherwise (p3: k4 s2 p1, :603) one launch per output-parity class.
-PDF_API int pdf_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+static int pdf_deconv2d_fwd_impl(const float* x, const float* w, const float* bias, float* y,
                              int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
-                             int stride, int pad, int OH, int OW, int ldy, hipStream_t s) {
-    const Shadows sh = take_shadows();                       // op0: x, op1: w
+                             int stride, int pad, int OH, int OW, int ldy, hipStream_t s, PdfCallOpts& co) {
+    const Shadows sh = {co.op0_bf16, co.op1_bf16};                       // op0: x, op1: w
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (KH == stride && KW == stride && pad == 0) {
         IGemm g = {};
@@ -2238,13 +2299,20 @@ PDF_API int pdf_deconv2d_fwd(const float* x, const float* w, const float* bias, 
         }
     return 0;
 }
+PDF_API int pdf_deconv2d_fwd_x(const float* x, const float* w, const float* bias, float* y,
+                             int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                             int stride, int pad, int OH, int OW, int ldy, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_deconv2d_fwd_impl(x, w, bias, y, N, H, W, Cin, ldx, Cout, KH, KW, stride, pad, OH, OW, ldy, s, co); }
+PDF_API int pdf_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                             int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                             int stride, int pad, int OH, int OW, int ldy, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_deconv2d_fwd_impl(x, w, bias, y, N, H, W, Cin, ldx, Cout, KH, KW, stride, pad, OH, OW, ldy, s, co); pdf_tls_publish(co); return rc; }
+
 
 // ConvTranspose2d backward-data: dx[n,iy,ix,ci] = sum dy[n, iy*s-pad+ky, ix*s-pad+kx, co] w[ci][ky][kx][co]
 // -- a plain strided conv over dy with the weight in its natural [Cin][KH][KW][Cout] storage.
-PDF_API int pdf_deconv2d_bwd_data(const float* dy, const float* w, float* dx,
+static int pdf_deconv2d_bwd_data_impl(const float* dy, const float* w, float* dx,
                                   int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
-                                  int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
-    const Shadows sh = take_shadows();                       // op0: dy, op1: w
+                                  int stride, int pad, int OH, int OW, int lddy, hipStream_t s, PdfCallOpts& co) {
+    const Shadows sh = {co.op0_bf16, co.op1_bf16};                       // op0: dy, op1: w
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     IGemm g = {};
     g.A = dy; g.B = w; g.C = dx; g.bias = nullptr; g.A16 = sh.op0; g.B16 = sh.op1;
@@ -2254,12 +2322,19 @@ PDF_API int pdf_deconv2d_bwd_data(const float* dy, const float* w, float* dx,
     g.plain_in = 0; g.plain_out = 1;
     return launch_igemm(g, s);
 }
+PDF_API int pdf_deconv2d_bwd_data_x(const float* dy, const float* w, float* dx,
+                                  int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                  int stride, int pad, int OH, int OW, int lddy, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_deconv2d_bwd_data_impl(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, s, co); }
+PDF_API int pdf_deconv2d_bwd_data(const float* dy, const float* w, float* dx,
+                                  int N, int H, int W, int Cin, int lddx, int Cout, int KH, int KW,
+                                  int stride, int pad, int OH, int OW, int lddy, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_deconv2d_bwd_data_impl(dy, w, dx, N, H, W, Cin, lddx, Cout, KH, KW, stride, pad, OH, OW, lddy, s, co); pdf_tls_publish(co); return rc; }
+
 
 // ConvTranspose2d weight gradient in the natural [Cin][KH][KW][Cout] storage.
-PDF_API int pdf_deconv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+static int pdf_deconv2d_bwd_weight_impl(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
                                     int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
-                                    int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
-    const Shadows sh = take_shadows();                       // op0: x, op1: dy
+                                    int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s, PdfCallOpts& co) {
+    const Shadows sh = {co.op0_bf16, co.op1_bf16};                       // op0: x, op1: dy
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     WGemm g = {};
     g.P = x; g.Q = dy; g.P16 = sh.op0; g.Q16 = sh.op1; g.M = N * H * W; g.NI = Cin; g.Cq = Cout; g.T = KH * KW;
@@ -2272,3 +2347,10 @@ PDF_API int pdf_deconv2d_bwd_weight(const float* x, const float* dy, float* dw, 
         }
     return launch_wgemm(g, dw, ws, ws_floats, accumulate, s);
 }
+PDF_API int pdf_deconv2d_bwd_weight_x(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+                                    int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                                    int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_deconv2d_bwd_weight_impl(x, dy, dw, ws, ws_floats, N, H, W, Cin, ldx, Cout, KH, KW, stride, pad, OH, OW, lddy, accumulate, s, co); }
+PDF_API int pdf_deconv2d_bwd_weight(const float* x, const float* dy, float* dw, float* ws, long ws_floats,
+                                    int N, int H, int W, int Cin, int ldx, int Cout, int KH, int KW,
+                                    int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_deconv2d_bwd_weight_impl(x, dy, dw, ws, ws_floats, N, H, W, Cin, ldx, Cout, KH, KW, stride, pad, OH, OW, lddy, accumulate, s, co); pdf_tls_publish(co); return rc; }
+

@@ -333,3 +333,6 @@ struct KTimer {
 int launch_igemm_bf16(const IGemm& g, hipStream_t s, int groups);
 int igemm_bf16_tile_rows(const IGemm& g, int groups);
 int launch_wgemm_bf16(const WGemm& g, int splits, int groups, int small, hipStream_t s);
+// LDS-DMA form of the fp32 implicit GEMM (gemm_dma.hip).  tile: 64 (64x64) | 128 (128x128) | 12864 | 64128; variant: ring depth / K-step
+// choice; splits > 0: split-K launch (g.ksteps / g.part set).  -> 1 launched, 0 shape not taken.
+int launch_igemm_dma(const IGemm& g, int tile, int variant, int groups, int splits, hipStream_t s);

@@ -196,12 +196,7 @@ __global__ __launch_bounds__(FT_C * FT_L) void bn_finalize_tiles_kernel(const fl
     scale[c] = sc;
     shift[c] = beta[c] - (float)mean * sc;
 }
-// handed over for the NEXT pdf_bn_train_fwd / pdf_bn_relu_maxk_fwd call of this thread (like pdf_set_bf16_output)
-static thread_local const float* tl_tile_part = nullptr;
-static thread_local long tl_tile_n = 0, tl_tile_rows = 0;
-PDF_API int pdf_set_bn_tile_stats(const float* part, long tiles, long rows_per_tile) { tl_tile_part = part; tl_tile_n = tiles; tl_tile_rows = rows_per_tile; return 0; }
 struct TileStats { const float* part; long tiles, rows; };
-static TileStats take_tile_stats() { TileStats t = {tl_tile_part, tl_tile_n, tl_tile_rows}; tl_tile_part = nullptr; tl_tile_n = tl_tile_rows = 0; return t; }
 
 __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
@@ -467,19 +462,16 @@ PDF_API long pdf_bn_workspace_floats(int C, long R) {
     long chunks = bn_chunks(C, R);
     return chunks * C * 2 + C;                              // (+ C: row 0 of a bf16 input as floats, BnFin::shift0)
 }
-// bf16 storage mode: the NEXT pdf_bn_train_fwd / pdf_bn_train_bwd call of this thread reads its input x from this bf16 tensor
-// (same shape and leading dimension in elements) instead of the fp32 pointer it is given
-static thread_local const void* tl_bn_x16 = nullptr;
-PDF_API int pdf_set_bn_input_bf16(const void* x16) { tl_bn_x16 = x16; return 0; }
-static const void* take_bn_x16() { const void* p = tl_bn_x16; tl_bn_x16 = nullptr; return p; }
+// bf16 storage mode (PdfCallOpts::bn_x_bf16): pdf_bn_train_fwd / pdf_bn_train_bwd read their input x from a bf16 tensor (same shape and
+// leading dimension in elements) instead of the fp32 pointer they are given
 
-PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
+static int pdf_bn_train_fwd_impl(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps,
                              const float* res, int ldr, int relu, float* y, int ldy,
-                             float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, hipStream_t s) {
-    void* y16 = pdf_tls_take_output();                       // bf16 shadow of y (pdf_set_bf16_output), vectorised path only
-    const TileStats ts = take_tile_stats();
-    const void* x16 = take_bn_x16();
+                             float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, hipStream_t s, PdfCallOpts& co) {
+    void* y16 = co.out_bf16;                                 // bf16 shadow of y, vectorised path only
+    const TileStats ts = {co.tile_stats, co.tile_n, co.tile_rows};
+    const void* x16 = co.bn_x_bf16;
     if (R <= 0 || C <= 0) return 0;
     if (x16 != nullptr && !v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x16, y, res, scale, shift})) return PDF_E_BADARG;
     long chunks = bn_chunks(C, R);
@@ -511,6 +503,15 @@ PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float
     PDF_LAUNCH_CHECK();
     return 0;
 }
+PDF_API int pdf_bn_train_fwd_x(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps,
+                             const float* res, int ldr, int relu, float* y, int ldy,
+                             float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_bn_train_fwd_impl(x, ldx, C, R, gamma, beta, running_mean, running_var, momentum, eps, res, ldr, relu, y, ldy, save_mean, save_rstd, scale, shift, ws, s, co); }
+PDF_API int pdf_bn_train_fwd(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps,
+                             const float* res, int ldr, int relu, float* y, int ldy,
+                             float* save_mean, float* save_rstd, float* scale, float* shift, float* ws, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_bn_train_fwd_impl(x, ldx, C, R, gamma, beta, running_mean, running_var, momentum, eps, res, ldr, relu, y, ldy, save_mean, save_rstd, scale, shift, ws, s, co); pdf_tls_publish(co); return rc; }
+
 
 PDF_API int pdf_bn_eval_fwd(const float* x, int ldx, int C, long R, const float* gamma, const float* beta,
                             const float* running_mean, const float* running_var, float eps,
@@ -586,13 +587,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ws: pdf_bn_workspace_floats(C,R) + 3*C floats
 // relu: 0 none; 1 ReLU, mask from the saved output y; 2 ReLU without residual, mask recomputed from x with the forward's
 // scale / shift (y may be NULL: two fewer full-tensor reads)
-PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy, int relu, const float* x, int ldx,
+static int pdf_bn_train_bwd_impl(const float* dy, int lddy, const float* y, int ldy, int relu, const float* x, int ldx,
                              const float* save_mean, const float* save_rstd, const float* gamma,
                              const float* scale, const float* shift, int C, long R,
                              float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
-                             float* ws, hipStream_t s) {
-    void* dx16 = pdf_tls_take_output();                      // bf16 shadow of dx
-    const void* x16 = take_bn_x16();                         // bf16 storage mode: x comes as bf16; dx == NULL: only the bf16 gradient is written
+                             float* ws, hipStream_t s, PdfCallOpts& co) {
+    void* dx16 = co.out_bf16;                                  // bf16 shadow of dx
+    const void* x16 = co.bn_x_bf16;                         // bf16 storage mode: x comes as bf16; dx == NULL: only the bf16 gradient is written
     if (R <= 0 || C <= 0) return 0;
     if ((relu == 1 && y == nullptr) || (relu == 2 && (scale == nullptr || shift == nullptr || dres != nullptr))) return PDF_E_BADARG;
     if (dx == nullptr && dx16 == nullptr) return PDF_E_BADARG;
@@ -637,6 +638,17 @@ PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy,
     PDF_LAUNCH_CHECK();
     return 0;
 }
+PDF_API int pdf_bn_train_bwd_x(const float* dy, int lddy, const float* y, int ldy, int relu, const float* x, int ldx,
+                             const float* save_mean, const float* save_rstd, const float* gamma,
+                             const float* scale, const float* shift, int C, long R,
+                             float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
+                             float* ws, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_bn_train_bwd_impl(dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, gamma, scale, shift, C, R, dx, lddx, dres, lddr, dgamma, dbeta, accumulate, ws, s, co); }
+PDF_API int pdf_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy, int relu, const float* x, int ldx,
+                             const float* save_mean, const float* save_rstd, const float* gamma,
+                             const float* scale, const float* shift, int C, long R,
+                             float* dx, int lddx, float* dres, int lddr, float* dgamma, float* dbeta, int accumulate,
+                             float* ws, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_bn_train_bwd_impl(dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, gamma, scale, shift, C, R, dx, lddx, dres, lddr, dgamma, dbeta, accumulate, ws, s, co); pdf_tls_publish(co); return rc; }
+
 
 // ---------------------------------------------------------------------------------------------
 // Set-abstraction tail (intaghand_encoder.py:59-62,79-82,97-100: BatchNorm2d -> ReLU -> MaxPool2d over the K neighbours) in
@@ -736,14 +748,14 @@ __global__ __launch_bounds__(256) void bn_maxk_bwd_apply_kernel(const float* __r
 }
 // training != 0: batch statistics over all R*K rows (running statistics updated with `momentum`); else running statistics.
 // C % 4 == 0, 16-byte aligned rows.  ws: pdf_bn_workspace_floats(C, R*K) floats.
-PDF_API int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, const float* gamma, const float* beta,
+static int pdf_bn_relu_maxk_fwd_impl(const float* y, int ldy, int C, long R, int K, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, int training,
                                  float* out, int ldo, int* arg, float* save_mean, float* save_rstd, float* scale, float* shift,
-                                 float* ws, hipStream_t s) {
+                                 float* ws, hipStream_t s, PdfCallOpts& co) {
     if (R <= 0 || C <= 0 || K <= 0) return 0;
     if (!v4_ok(C, {ldy, ldo}, {y, out, arg, scale, shift})) return PDF_E_BADARG;
     const long rows = R * K;
-    const TileStats ts = take_tile_stats();
+    const TileStats ts = {co.tile_stats, co.tile_n, co.tile_rows};
     if (training && ts.part != nullptr) {
         if (ts.tiles * ts.rows < rows || (ts.tiles - 1) * ts.rows >= rows) return PDF_E_BADARG;
         hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(C, FT_C)), dim3(FT_C * FT_L), 0, s, ts.part, (int)ts.tiles, ts.rows, C, rows, gamma, beta,
@@ -766,6 +778,15 @@ PDF_API int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, 
     PDF_LAUNCH_CHECK();
     return 0;
 }
+PDF_API int pdf_bn_relu_maxk_fwd_x(const float* y, int ldy, int C, long R, int K, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, int training,
+                                 float* out, int ldo, int* arg, float* save_mean, float* save_rstd, float* scale, float* shift,
+                                 float* ws, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_bn_relu_maxk_fwd_impl(y, ldy, C, R, K, gamma, beta, running_mean, running_var, momentum, eps, training, out, ldo, arg, save_mean, save_rstd, scale, shift, ws, s, co); }
+PDF_API int pdf_bn_relu_maxk_fwd(const float* y, int ldy, int C, long R, int K, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, int training,
+                                 float* out, int ldo, int* arg, float* save_mean, float* save_rstd, float* scale, float* shift,
+                                 float* ws, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_bn_relu_maxk_fwd_impl(y, ldy, C, R, K, gamma, beta, running_mean, running_var, momentum, eps, training, out, ldo, arg, save_mean, save_rstd, scale, shift, ws, s, co); pdf_tls_publish(co); return rc; }
+
 // ws: pdf_bn_workspace_floats(C, R) + 3*C floats
 PDF_API int pdf_bn_relu_maxk_bwd(const float* dout, int lddo, const int* arg, const float* y, int ldy, const float* save_mean, const float* save_rstd,
                                  const float* gamma, const float* scale, const float* shift, int C, long R, int K,
@@ -1245,9 +1266,9 @@ static int l2_parts(L2Parts& p, int nparts, const float* const* x, const float* 
     return 0;
 }
 // x[i]: [R][C[i]] contiguous rows; y: [R][ldy] with part i at channel offset C[0] + ... + C[i-1]; norm[i]: [R]
-PDF_API int pdf_l2norm_cat_fwd(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R,
-                               float* y, int ldy, float* const* norm, hipStream_t s) {
-    void* y16 = pdf_tls_take_output();                       // bf16 shadow of y (needs even channel counts)
+static int pdf_l2norm_cat_fwd_impl(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R,
+                               float* y, int ldy, float* const* norm, hipStream_t s, PdfCallOpts& co) {
+    void* y16 = co.out_bf16;                                 // bf16 shadow of y (needs even channel counts)
     if (R <= 0) return 0;
     L2Parts p = {};
     if (int rc = l2_parts(p, nparts, x, w, norm, nullptr, nullptr, C)) return rc;
@@ -1262,6 +1283,11 @@ PDF_API int pdf_l2norm_cat_fwd(int nparts, const float* const* x, const int* C, 
     PDF_LAUNCH_CHECK();
     return 0;
 }
+PDF_API int pdf_l2norm_cat_fwd_x(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R,
+                               float* y, int ldy, float* const* norm, hipStream_t s, PdfCallOpts* opts) { PdfCallOpts z = {}; PdfCallOpts& co = opts ? *opts : z; co.stats_tiles = co.stats_rows = 0; return pdf_l2norm_cat_fwd_impl(nparts, x, C, w, eps, R, y, ldy, norm, s, co); }
+PDF_API int pdf_l2norm_cat_fwd(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R,
+                               float* y, int ldy, float* const* norm, hipStream_t s) { PdfCallOpts co = pdf_tls_take_all(); const int rc = pdf_l2norm_cat_fwd_impl(nparts, x, C, w, eps, R, y, ldy, norm, s, co); pdf_tls_publish(co); return rc; }
+
 // dw[i] must be zero-filled (atomically accumulated)
 PDF_API int pdf_l2norm_cat_bwd(int nparts, const float* dy, int lddy, const float* const* x, const int* C, const float* const* w, float eps, long R,
                                float* const* norm, float* const* dx, float* const* dw, void* const* dx16, hipStream_t s) {

@@ -2,6 +2,7 @@
 // row gathers/scatters on NHWC maps, and the max-over-neighbours pool.  All HBM-bound: coalesced
 // row reads, the cloud staged once per 16 centroids in LDS, wavefront ballots for the selection.
 #include "common.h"
+#include <cstdlib>
 #include <mutex>
 
 // ---------------------------------------------------------------------------------------------
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(INV_NT) void invert_index_kernel(const int* __restr
     int* lst = list + (long)b * E;
     for (int n = tid; n < N; n += INV_NT) cnt[n] = 0;
     __syncthreads();
-    for (int e = tid; e < E; e += INV_NT) atomicAdd(&cnt[id[e]], 1);
+    // (indices are clamped into [0, N): an index outside the cloud must not reach past the LDS arrays -- ADVICE r3)
+    for (int e = tid; e < E; e += INV_NT) atomicAdd(&cnt[min(max(id[e], 0), N - 1)], 1);
     __syncthreads();
     if (wave == 0) {                                         // exclusive scan of the counts by one wave, 64 points per round
         int run = 0;
@@ -258,14 +260,35 @@ __global__ __launch_bounds__(INV_NT) void invert_index_kernel(const int* __restr
     for (int n = tid; n <= N; n += INV_NT) start[(long)b * (N + 1) + n] = st[n];
     for (int n = tid; n < N; n += INV_NT) cnt[n] = st[n];  // cursors
     __syncthreads();
-    for (int e = tid; e < E; e += INV_NT) tm[atomicAdd(&cnt[id[e]], 1)] = (unsigned short)e;      // arbitrary order inside a segment ...
+    for (int e = tid; e < E; e += INV_NT) tm[atomicAdd(&cnt[min(max(id[e], 0), N - 1)], 1)] = (unsigned short)e;      // arbitrary order inside a segment ...
     __syncthreads();
-    for (int n = wave; n < N; n += INV_NT / 64) {            // ... then every segment is rank-sorted by one wave (slots are distinct), all in LDS
+    // ... then every segment is rank-sorted (slots are distinct), all in LDS: O(L^2) compares per segment.  Typical segments hold
+    // E / N = 16-32 slots and one wave sorts one; a degenerate cloud (an invalid hand's all-zero cloud: every centroid picks the same 64
+    // points, 512 slots each; ball-query padding that repeats one neighbour) makes a few segments long, and one wave grinding through
+    // L^2 / 64 compares while the block idles was a multi-millisecond cliff.  Segments above INV_LONG are therefore sorted
+    // by the WHOLE block (L^2 / 1024 per thread), and above INV_NOSORT -- one point owning a sixth of a 64k-slot cloud -- left in cursor
+    // order: the sums stay correct, only their order (bit-reproducibility of that one row) is given up for such an input.
+    constexpr int INV_LONG = 128, INV_NOSORT = 8192;
+    for (int n = wave; n < N; n += INV_NT / 64) {
         const int s0 = st[n], L = st[n + 1] - s0;
+        if (L > INV_LONG) continue;
         for (int i = lane; i < L; i += 64) {
             const int v = tm[s0 + i];
             int r = 0;
             for (int j = 0; j < L; ++j) r += tm[s0 + j] < v;
+            lst[s0 + r] = v;
+        }
+    }
+    for (int n = 0; n < N; ++n) {                            // (uniform: every thread sees the same st[])
+        const int s0 = st[n], L = st[n + 1] - s0;
+        if (L <= INV_LONG) continue;
+        for (int i = tid; i < L; i += INV_NT) {
+            const int v = tm[s0 + i];
+            int r = i;
+            if (L <= INV_NOSORT) {
+                r = 0;
+                for (int j = 0; j < L; ++j) r += tm[s0 + j] < v;
+            }
             lst[s0 + r] = v;
         }
     }
@@ -623,9 +646,73 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
         cur = s_best;
     }
 }
+// Single-wave form for clouds of at most 1,024 points (the reference's SAMPLE_NUM, opts.py:228): ONE wave per cloud, 16 points per
+// lane in registers, no __syncthreads and no LDS round trip in the arg-max (round 3: 1,024 threads, two block barriers and an LDS
+// exchange per pick -- 1.77 us per pick for a cloud that fits one wave's registers).  Per pick: 16 x (distance, frozen-minimum
+// update, running arg-max) of straight-line VALU work, a 64-bit key (distance bits << 32 | ~index: the maximum is the largest
+// distance, lowest index on ties, distances being non-negative) reduced with six DPP steps (quad swaps, half-mirror, mirror, two row
+// broadcasts), v_readlane of lane 63 into scalar registers, and the winner's coordinates read back from an LDS copy of the cloud at a
+// wave-uniform address.  A block is 64 threads: 16 times the clouds in flight per CU.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > v ? o : v;
+}
+#define FPS1_MAXN 1024
+__global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ xyz, int ld, int N, int S,
+                                                      const int* __restrict__ start, int* __restrict__ idx) {
+    __shared__ float sp[FPS1_MAXN * 3];
+    const int lane = threadIdx.x;
+    const float* p = xyz + (long)blockIdx.x * N * ld;
+    int* out = idx + (long)blockIdx.x * S;
+    float px[16], py[16], pz[16], d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = min(lane + k * 64, N - 1);               // (slots past N repeat the last point: equal distance, higher index -- never picked first)
+        px[k] = p[(long)i * ld]; py[k] = p[(long)i * ld + 1]; pz[k] = p[(long)i * ld + 2];
+        const int j = lane + k * 64;
+        if (j < N) { sp[j * 3] = px[k]; sp[j * 3 + 1] = py[k]; sp[j * 3 + 2] = pz[k]; }
+        d[k] = __builtin_inff();                               // first round: min(inf, nd) = nd
+    }
+    __syncthreads();                                           // (one wave: orders the LDS writes before the first read)
+    int cur = start != nullptr ? start[blockIdx.x] : 0;
+    cur = __builtin_amdgcn_readfirstlane(min(max(cur, 0), N - 1));
+    for (int it = 0; it < S; ++it) {
+        if (lane == 0) out[it] = cur;
+        const float cx = sp[cur * 3], cy = sp[cur * 3 + 1], cz = sp[cur * 3 + 2];
+        float best = -1.f; int bk = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+            // (dx*dx + dy*dy) + dz*dz without fused multiply-adds: the NumPy helper's float32 arithmetic
+            const float nd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            d[k] = d[k] > 1e-8f ? fminf(d[k], nd) : d[k];
+            if (d[k] > best) { best = d[k]; bk = k; }          // k ascending => index ascending: this lane's first maximum
+        }
+        const unsigned bi = (unsigned)(lane + bk * 64);
+        unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (0xffffffffu - (bi < (unsigned)N ? bi : 0x7fffffffu));
+        key = dpp_max_u64<0xB1, 0xf>(key);                    // quad_perm [1,0,3,2]
+        key = dpp_max_u64<0x4E, 0xf>(key);                    // quad_perm [2,3,0,1]
+        key = dpp_max_u64<0x141, 0xf>(key);                   // row_half_mirror
+        key = dpp_max_u64<0x140, 0xf>(key);                   // row_mirror: every lane of a row holds the row's maximum
+        key = dpp_max_u64<0x142, 0xa>(key);                   // row_bcast:15 into rows 1 and 3
+        key = dpp_max_u64<0x143, 0xc>(key);                   // row_bcast:31 into rows 2 and 3: lane 63 holds the cloud's maximum
+        const unsigned wlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, 63);
+        cur = (int)(0xffffffffu - wlo);
+    }
+}
 PDF_API int pdf_fps(const float* xyz, int ld, int Bc, int N, int S, const int* start, int* idx, hipStream_t s) {
     if (N <= 0 || S <= 0 || N > FPS_THREADS * FPS_MAXPT || ld < 3) return PDF_E_BADARG;
     if (Bc <= 0) return 0;
+    static const bool wave_form = getenv("PDF_FPS_WAVE") == nullptr || atoi(getenv("PDF_FPS_WAVE")) != 0;
+    if (N <= FPS1_MAXN && wave_form) {
+        hipLaunchKernelGGL(fps_wave_kernel, dim3(Bc), dim3(64), 0, s, xyz, ld, N, S, start, idx);
+        PDF_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(fps_kernel, dim3(Bc), dim3(FPS_THREADS), 0, s, xyz, ld, N, S, start, idx);
     PDF_LAUNCH_CHECK();
     return 0;

@@ -13,6 +13,8 @@ from .hip import ptr, ptr_at, stream
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 import os as _os
+
+_byref = ctypes.byref
 USE_SIDE_STREAMS = _os.environ.get("PDFNET_SIDE_STREAMS", "1") != "0"
 _side = {}
 
@@ -110,7 +112,7 @@ def gemm_precision():
 
 # ---- bf16 shadows (bf16 mode): BatchNorm (forward output, backward dx), the pyramid L2Norm and the trainer (weights) write a bf16
 # copy of what they produce; the conv / deconv / linear launches that read those tensors hand the copy to the library
-# (pdf_set_bf16_operands), whose bf16 GEMM kernels then stage 2-byte operands.  Results are bit-identical to the plain bf16 mode
+# (PdfCallOpts::op0_bf16 / op1_bf16), whose bf16 GEMM kernels then stage 2-byte operands.  Results are bit-identical to the plain bf16 mode
 # (same round-to-nearest-even, done by the producer instead of the consumer).  A shadow travels as an attribute of the tensor
 # it mirrors and is ignored once that tensor has been modified in place.
 BF16_SHADOWS = _os.environ.get("PDFNET_BF16_SHADOWS", "1") != "0"
@@ -172,15 +174,20 @@ def _stored16(t):
 
 
 
-def _set_ops(a, b):
-    """Shadows of the next GEMM-family call's two operands (None = none)."""
-    if a is not None or b is not None:
-        _L().pdf_set_bf16_operands(ptr(a), ptr(b))
+def _O(**kw):
+    """The explicit per-call options of an `_x` entry point (include/pdfnet_hip.h PdfCallOpts): -> (structure, argument).  Every field a
+    call takes beyond its positional arguments -- bf16 shadows of its operands, a bf16 output, a statistics request, an operand
+    transform -- is in ITS argument list; nothing is armed on the thread for "the next call"."""
+    kw = {k: v for k, v in kw.items() if v is not None}
+    if not kw:
+        return None, None
+    o = hip.CallOpts(**kw)
+    return o, _byref(o)
 
 
 # ---- BatchNorm statistics out of the producing GEMM's epilogue (fp32 and bf16 kernels): a conv / linear forward called with stats=True
-# asks the library for per-row-block (mean, M2) pairs of its output columns (pdf_set_stats_output); they travel as an attribute
-# of the output tensor and the BatchNorm that consumes it skips its own statistics pass over the tensor (pdf_set_bn_tile_stats).
+# asks the library for per-row-block (mean, M2) pairs of its output columns (PdfCallOpts::stats_out); they travel as an attribute
+# of the output tensor and the BatchNorm that consumes it skips its own statistics pass over the tensor (PdfCallOpts::tile_stats).
 BN_EPILOGUE_STATS = _os.environ.get("PDFNET_BN_EPILOGUE_STATS", "1") != "0"
 # bf16 mode: the kernels can do it too (whole tiles), but their MFMA time is so short that the epilogue work costs what the saved
 # pass gains -- measured B=32 850 -> 868 img/s, B=64 1,038 -> 1,013 -- so it is opt-in there
@@ -188,22 +195,19 @@ BN_EPILOGUE_STATS_BF16 = _os.environ.get("PDFNET_BN_EPILOGUE_STATS_BF16", "0") !
 
 
 def _stats_request(stats, rows, cols, dev):
-    """-> the partials buffer for the next conv / linear forward launch, or None."""
+    """-> the partials buffer for a conv / linear forward launch (PdfCallOpts::stats_out, cap = numel), or None."""
     if not (stats and BN_EPILOGUE_STATS) or (_GEMM_BF16 and not BN_EPILOGUE_STATS_BF16):
         return None
     cap = ((rows + 31) // 32) * cols * 2
-    part = torch.empty(cap, dtype=torch.float32, device=dev)
-    _L().pdf_set_stats_output(ptr(part), cap)
-    return part
+    return torch.empty(cap, dtype=torch.float32, device=dev)
 
 
-def _stats_attach(y, part):
+def _stats_attach(y, part, o):
+    """o: the call's PdfCallOpts after the call (stats_tiles / stats_rows written back by the library)."""
     if part is None:
         return
-    L = _L()
-    tiles = L.pdf_stats_result_tiles()
-    if tiles > 0:
-        y._pdf_bn_tiles = (part, tiles, L.pdf_stats_result_rows(), y._version)
+    if o.stats_tiles > 0:
+        y._pdf_bn_tiles = (part, o.stats_tiles, o.stats_rows, y._version)
 
 
 def tile_stats_of(x):
@@ -423,15 +427,14 @@ class _Conv2d(Function):
         OW = (W + 2 * pad - KW) // stride + 1
         y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
         x16, w16 = shadow_of(x), shadow_of(w)
-        _set_ops(x16, w16)
         part = _stats_request(stats, N * OH * OW, Cout, x.device)
         y16 = None
         if (stats and storage_on() and b is None and act == ACT_NONE and Cin % 16 == 0 and Cout % 16 == 0
                 and (N * OH * OW) % 128 == 0):
             y16 = torch.empty_like(y, dtype=torch.bfloat16)  # the output: y itself stays unwritten (see BF16_STORAGE)
-            _L().pdf_set_bf16_output(ptr(y16))
-        _L().pdf_conv2d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream())
-        _stats_attach(y, part)
+        o, oa = _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16), out_bf16=ptr(y16), stats_out=ptr(part), stats_cap=part.numel() if part is not None else None)
+        _L().pdf_conv2d_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream(), oa)
+        _stats_attach(y, part, o)
         if y16 is not None:
             y._pdf_y16 = (y16, y._version)
         ctx.save_for_backward(x, w, y if act else None)
@@ -461,13 +464,13 @@ class _Conv2d(Function):
         dx = dw = db = None
         L = _L()
         if ctx.needs_input_grad[0]:
-            _set_ops(g16, w16)
+            _, oa = _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16))
             if dskip is not None and stride == 1 and dskip.shape == x.shape and dskip.is_contiguous(memory_format=CL):
                 dx = dskip                                  # the shortcut's gradient (sole consumer: this node); += in the epilogue
-                L.pdf_conv2d_bwd_data_add(gp, ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+                L.pdf_conv2d_bwd_data_add_x(gp, ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(), oa)
             else:
                 dx = torch.zeros_like(x) if stride > KH else torch.empty_like(x)
-                L.pdf_conv2d_bwd_data(gp, ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+                L.pdf_conv2d_bwd_data_x(gp, ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(), oa)
                 if dskip is not None:
                     dx = dx + dskip
         w_par, b_par = ctx.params
@@ -475,9 +478,8 @@ class _Conv2d(Function):
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(R, Cout, KH * KW * Cin, x.device)
-            _set_ops(x16, g16)
-            L.pdf_conv2d_bwd_weight(ptr(x), gp, ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                    stride, pad, OH, OW, Cout, acc, stream())
+            L.pdf_conv2d_bwd_weight_x(ptr(x), gp, ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+                                      stride, pad, OH, OW, Cout, acc, stream(), _O(op0_bf16=ptr(x16), op1_bf16=ptr(g16))[1])
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True, shadows=(x16, g16))
         return dx, dw, db, None, None, None, None, None
 
@@ -508,8 +510,8 @@ class _Deconv2d(Function):
         L = _L()
         y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
         x16, w16 = shadow_of(x), shadow_of(w)
-        _set_ops(x16, w16)
-        L.pdf_deconv2d_fwd(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+        L.pdf_deconv2d_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(),
+                             _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16))[1])
         ctx.save_for_backward(x, w)
         ctx.s16 = (x16, w16)
         ctx.cfg = (stride, pad, b is not None)
@@ -530,15 +532,14 @@ class _Deconv2d(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _set_ops(g16, w16)
-            L.pdf_deconv2d_bwd_data(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream())
+            L.pdf_deconv2d_bwd_data_x(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(),
+                                      _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16))[1])
         w_par, b_par = ctx.params
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
-            _set_ops(x16, g16)
-            L.pdf_deconv2d_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                      stride, pad, OH, OW, Cout, acc, stream())
+            L.pdf_deconv2d_bwd_weight_x(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
+                                        stride, pad, OH, OW, Cout, acc, stream(), _O(op0_bf16=ptr(x16), op1_bf16=ptr(g16))[1])
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, N * OH * OW, 2.0 * N * H * W * Cin * KH * KW * Cout, shadows=(x16, g16))
         return dx, dw, db, None, None
 
@@ -566,12 +567,11 @@ class _Linear(Function):
         y = torch.empty(x.shape[:-1] + (Nn,), dtype=torch.float32, device=x.device)
         x16, w16 = (None, None) if (fp32 or aff is not None) else (shadow_of(x), shadow_of(w))
         with _forced_fp32(fp32):
-            _set_ops(x16, w16)
             part = _stats_request(stats, M, Nn, x.device)
-            if aff is not None:
-                _L().pdf_set_input_affine_relu(ptr(aff[0]), ptr(aff[1]))
-            _L().pdf_linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), M, Nn, K, K, K, Nn, act, stream())
-            _stats_attach(y, part)
+            o, oa = _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16), stats_out=ptr(part), stats_cap=part.numel() if part is not None else None,
+                       in_scale=ptr(aff[0]) if aff is not None else None, in_shift=ptr(aff[1]) if aff is not None else None)
+            _L().pdf_linear_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), M, Nn, K, K, K, Nn, act, stream(), oa)
+            _stats_attach(y, part, o)
         ctx.save_for_backward(x, w, y if act else None, *(aff if aff is not None else ()))
         ctx.s16 = (x16, w16)
         ctx.fp32 = fp32
@@ -597,17 +597,15 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with _forced_fp32(ctx.fp32):
-                _set_ops(g16, w16)
-                L.pdf_linear_bwd_data(ptr(g), ptr(w), ptr(dx), M, Nn, K, Nn, K, K, stream())
+                L.pdf_linear_bwd_data_x(ptr(g), ptr(w), ptr(dx), M, Nn, K, Nn, K, K, stream(), _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16))[1])
         w_par, b_par = ctx.params
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(M, Nn, K, x.device)
             with _forced_fp32(ctx.fp32):
-                _set_ops(x16, g16)
-                if aff is not None:
-                    L.pdf_set_input_affine_relu(ptr(aff[0]), ptr(aff[1]))
-                L.pdf_linear_bwd_weight(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, M, Nn, K, K, Nn, acc, stream())
+                _, oa = _O(op0_bf16=ptr(x16), op1_bf16=ptr(g16), in_scale=ptr(aff[0]) if aff is not None else None,
+                           in_shift=ptr(aff[1]) if aff is not None else None)
+                L.pdf_linear_bwd_weight_x(ptr(x), ptr(g), ptr(out), ptr(out_b), ptr(ws), n, M, Nn, K, K, Nn, acc, stream(), oa)
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Nn, M, 2.0 * M * Nn * K, fused_bias=True, shadows=(x16, g16))
         return dx, dw, db, None, None, None
 
@@ -736,19 +734,16 @@ class _BatchNorm(Function):
             tiles = tile_stats_of(x)
             if tiles is not None:                           # statistics came out of the producing GEMM's epilogue
                 ws = None
-                L.pdf_set_bn_tile_stats(ptr(tiles[0]), tiles[1], tiles[2])
             else:
                 ws = _ws(L.pdf_bn_workspace_floats(C, R), dev)
             # lazy: statistics and (scale, shift) only -- the ONE consumer, a linear layer, applies BN + ReLU while it stages its rows
-            # (pdf_set_input_affine_relu) and y is never written: it only carries (x, scale, shift) to that consumer (_lazy_bn)
+            # (PdfCallOpts::in_scale / in_shift) and y is never written: it only carries (x, scale, shift) to that consumer (_lazy_bn)
             lazy = bool(lazy) and relu and res is None and x16 is None and not _GEMM_BF16 and x.dim() == 2 and C % 16 == 0 and R % 16 == 0
             y16 = new_shadow(y) if (C % 4 == 0 and not lazy) else None
-            if y16 is not None:
-                L.pdf_set_bf16_output(ptr(y16))
-            if x16 is not None:
-                L.pdf_set_bn_input_bf16(ptr(x16))
-            L.pdf_bn_train_fwd(None if x16 is not None else ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
-                               ptr(res), C, int(relu), None if lazy else ptr(y), C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
+            _, oa = _O(out_bf16=ptr(y16), bn_x_bf16=ptr(x16), tile_stats=ptr(tiles[0]) if tiles is not None else None,
+                       tile_n=tiles[1] if tiles is not None else None, tile_rows=tiles[2] if tiles is not None else None)
+            L.pdf_bn_train_fwd_x(None if x16 is not None else ptr(x), C, C, R, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
+                                 ptr(res), C, int(relu), None if lazy else ptr(y), C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream(), oa)
             if y16 is not None:
                 attach_shadow(y, y16)
             if lazy:
@@ -789,12 +784,9 @@ class _BatchNorm(Function):
         L = _L()
         ws = _ws(L.pdf_bn_workspace_floats(C, R) + 3 * C, x.device)
         dx16 = new_shadow(dx) if C % 4 == 0 else None
-        if dx16 is not None:
-            L.pdf_set_bf16_output(ptr(dx16))
-        if x_is_16:
-            L.pdf_set_bn_input_bf16(ptr(x))
-        L.pdf_bn_train_bwd(ptr(g), C, ptr(y), C, mode, None if x_is_16 else ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R,
-                           None if x_is_16 else ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream())
+        _, oa = _O(out_bf16=ptr(dx16), bn_x_bf16=ptr(x) if x_is_16 else None)
+        L.pdf_bn_train_bwd_x(ptr(g), C, ptr(y), C, mode, None if x_is_16 else ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R,
+                             None if x_is_16 else ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream(), oa)
         if x_is_16:
             dx._pdf_y16 = (dx16, dx._version)               # the conv's backward takes the bf16 gradient; dx itself was not written
         elif dx16 is not None:
@@ -950,9 +942,8 @@ class _L2NormCat(Function):
         norms = [torch.empty(R, device=out.device) for _ in xs]
         out16 = new_shadow(out) if all(C % 64 == 0 for C in Cs) else None
         if out16 is not None:
-            _L().pdf_set_bf16_output(ptr(out16))
             attach_shadow(out, out16)
-        _L().pdf_l2norm_cat_fwd(n, _ptr_array(xs), _int_array(Cs), _ptr_array(ws), eps, R, ptr(out), Ct, _ptr_array(norms), stream())
+        _L().pdf_l2norm_cat_fwd_x(n, _ptr_array(xs), _int_array(Cs), _ptr_array(ws), eps, R, ptr(out), Ct, _ptr_array(norms), stream(), _O(out_bf16=ptr(out16))[1])
         ctx.save_for_backward(*xs, *ws, *norms)
         ctx.cfg = (eps, n, Cs)
         return out
@@ -1495,11 +1486,12 @@ class _BnReluMaxK(Function):
         tiles = tile_stats_of(x) if training else None
         if tiles is not None:
             ws = None
-            L.pdf_set_bn_tile_stats(ptr(tiles[0]), tiles[1], tiles[2])
         else:
             ws = _ws(L.pdf_bn_workspace_floats(C, R * K), dev)
-        L.pdf_bn_relu_maxk_fwd(ptr(x), C, C, R, K, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps, int(training),
-                               ptr(out), C, ptr(arg), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream())
+        _, oa = _O(tile_stats=ptr(tiles[0]) if tiles is not None else None, tile_n=tiles[1] if tiles is not None else None,
+                   tile_rows=tiles[2] if tiles is not None else None)
+        L.pdf_bn_relu_maxk_fwd_x(ptr(x), C, C, R, K, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps, int(training),
+                                 ptr(out), C, ptr(arg), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), stream(), oa)
         ctx.save_for_backward(x, gamma, arg, mean, rstd, scale, shift)
         ctx.cfg = (R, K, C, training)
         ctx.params = (gamma, beta)
@@ -1640,6 +1632,35 @@ def depth2pcl(depth, mask, K, valid, seed=None):
     _L().pdf_depth2pcl(ptr(d), ptr(m), ptr(K.detach().float().contiguous()), ptr(valid.detach().float().contiguous()), B, H, W,
                        next_seed() if seed is None else int(seed), ptr(choose), ptr(cloud), ptr(count), stream())
     return choose, cloud, count
+
+
+def fps_reorder(cloud, choose, S1, S2, start1=None, start2=None):
+    """The reference's `--sample_strategy FPS` (lib/opts.py:231; the block it keeps commented out at lib/datasets/interhand.py:857-900,
+    in its `farthest_point_sampling_fast` variant): after the 1,024 points of a hand were drawn, they are REORDERED so that the first
+    S1 are the level-1 farthest-point picks and, among those, the first S2 the level-2 picks -- PointNet++ takes "the first S points"
+    as centroids (lib/utils/utils.py:143,156), so this turns random centroids into farthest-point centroids.  Per cloud:
+        s1 = unique(fps(points, S1));  order = [s1 ascending, the other indices ascending];  points, choose = points[order], choose[order]
+        s2 = unique(fps(points[:S1], S2));  the first S1 entries are reordered the same way.
+    cloud [Bc,N,3] f32, choose [Bc,N] i64, start1 / start2 int32 [Bc] (the reference draws them at random; default 0) -> (cloud, choose).
+    The picks come from pdf_fps (single-wave kernel for N <= 1,024); the index bookkeeping is a handful of torch ops (off the train path)."""
+    hip.require_gpu(cloud, choose)
+    Bc, N, _ = cloud.shape
+    if not (0 < S2 <= S1 <= N):
+        raise ValueError("fps_reorder: need 0 < S2 <= S1 <= N")
+    dev = cloud.device
+
+    def order_of(picks, n):
+        m = torch.ones((Bc, n), dtype=torch.int64, device=dev)
+        m.scatter_(1, picks.long(), 0)                               # 0 = picked (duplicates collapse like np.unique), 1 = other
+        return torch.argsort(m * n + torch.arange(n, device=dev)[None], dim=1)    # [picked ascending, others ascending]
+    o1 = order_of(fps(cloud, S1, start1), N)
+    cloud = torch.gather(cloud, 1, o1[:, :, None].expand(-1, -1, cloud.shape[2]))
+    choose = torch.gather(choose, 1, o1)
+    o2 = order_of(fps(cloud[:, :S1].contiguous(), S2, start2), S1)
+    o2 = torch.cat((o2, torch.arange(S1, N, device=dev)[None].expand(Bc, -1)), 1)
+    cloud = torch.gather(cloud, 1, o2[:, :, None].expand(-1, -1, cloud.shape[2]))
+    choose = torch.gather(choose, 1, o2)
+    return cloud, choose
 
 
 def nms_top1(hm):

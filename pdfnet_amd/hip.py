@@ -40,6 +40,14 @@ def parse_header(path=HEADER_PATH):
     return protos
 
 
+class CallOpts(ctypes.Structure):
+    """PdfCallOpts of include/pdfnet_hip.h: the explicit options of the `_x` entry points (field for field)."""
+    _fields_ = [("op0_bf16", ctypes.c_void_p), ("op1_bf16", ctypes.c_void_p), ("out_bf16", ctypes.c_void_p), ("bn_x_bf16", ctypes.c_void_p),
+                ("stats_out", ctypes.c_void_p), ("stats_cap", ctypes.c_long), ("stats_tiles", ctypes.c_long), ("stats_rows", ctypes.c_long),
+                ("tile_stats", ctypes.c_void_p), ("tile_n", ctypes.c_long), ("tile_rows", ctypes.c_long),
+                ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p)]
+
+
 class _Lib:
     def __init__(self):
         if not os.path.exists(LIB_PATH):
@@ -52,6 +60,9 @@ class _Lib:
             fn = getattr(self.cdll, name)          # AttributeError if the .so does not export it
             fn.restype = ret
             fn.argtypes = args
+        if self.cdll.pdf_debug_callopts_size() != ctypes.sizeof(CallOpts):
+            raise ImportError("pdfnet_amd: PdfCallOpts of %s has %d bytes, this binding's has %d -- rebuild the library"
+                              % (LIB_PATH, self.cdll.pdf_debug_callopts_size(), ctypes.sizeof(CallOpts)))
 
     def __getattr__(self, name):
         fn = getattr(self.cdll, name)

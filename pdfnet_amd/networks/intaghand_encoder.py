@@ -365,6 +365,10 @@ class ResNetSimple(nn.Module):
             if valid is None:
                 valid = torch.ones((img.shape[0], 2), device=img.device)
             choose, cloud, _ = F.depth2pcl(depth, st['dp'][0], K_new, valid)
+            if getattr(self.opt, 'sample_strategy', 'Random') == 'FPS':                   # lib/opts.py:231; interhand.py:857-900
+                B_ = cloud.shape[0]
+                c2, ch2 = F.fps_reorder(cloud.reshape(B_ * 2, 1024, 3), choose.reshape(B_ * 2, 1024), self.opt.sample_num_level1, self.opt.sample_num_level2)
+                cloud, choose = c2.reshape(B_, 2, 1024, 3), ch2.reshape(B_, 2, 1024)
         if f_pn is not None:
             al, ar = f_pn.join()
             if chain0:

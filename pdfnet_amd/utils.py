@@ -82,3 +82,31 @@ def mano_from_params(mano_consts, params_map, ind, K, input_res, down_ratio=4):
     orient, pose, shape, trans = F.mano_split_coeff(params_map, ind, K, input_res, down_ratio)
     out = [F.mano_lbs(mano_consts[h], orient[i], pose[i], shape[i], None, side=h) for i, h in enumerate(('left', 'right'))]
     return torch.stack([o[0] for o in out]), torch.stack([o[1] for o in out]), trans
+
+
+def load_mano_constants(npz_path, device=None):
+    """`mano_constants.npz` (written at the user's site by tools/convert_mano.py from MANO_LEFT.pkl / MANO_RIGHT.pkl) ->
+    (loss_consts, lbs_consts): what the reference builds in `ManoLayer.__init__` (lib/models/networks/manolayer.py:100-160),
+    `ManoModel.process_J_regressor` (lib/models/hand3d/Mano_model.py:309-323) and `fix_shape` (lib/datasets/interhand.py:120-123).
+
+      loss_consts : {'full_regressor_left/right' [21,778] f32, 'faces_left/right' [1538,3] i64}        -> CtdetLoss(opt, loss_consts)
+      lbs_consts  : {'left' / 'right': {'v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights'}}  -> F.mano_lbs(lbs_consts[side], ...)
+    """
+    import numpy as np
+    z = np.load(npz_path)
+    need = [k + '_' + s for s in ('left', 'right') for k in ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights', 'faces', 'full_regressor')]
+    missing = [k for k in need if k not in z.files]
+    if missing:
+        raise KeyError("load_mano_constants: %s lacks %s (was it written by tools/convert_mano.py?)" % (npz_path, missing))
+    shapes = {'v_template': (778, 3), 'shapedirs': (778, 3, 10), 'posedirs': (778, 3, 135), 'J_regressor': (16, 778), 'weights': (778, 16),
+              'faces': (1538, 3), 'full_regressor': (21, 778)}
+    for k in need:
+        if tuple(z[k].shape) != shapes[k.rsplit('_', 1)[0]]:
+            raise ValueError("load_mano_constants: %s has shape %s" % (k, tuple(z[k].shape)))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device) if device is not None else torch.from_numpy(np.ascontiguousarray(a))
+    loss_consts, lbs_consts = {}, {}
+    for s in ('left', 'right'):
+        loss_consts['full_regressor_' + s] = t(z['full_regressor_' + s].astype(np.float32))
+        loss_consts['faces_' + s] = t(z['faces_' + s].astype(np.int64))
+        lbs_consts[s] = {k: t(z[k + '_' + s].astype(np.float32)) for k in ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights')}
+    return loss_consts, lbs_consts

@@ -6,6 +6,7 @@
  *       -L pdfnet_amd -lpdfnet_hip -L /opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$PWD/pdfnet_amd -Wl,-rpath,/opt/rocm/lib */
 #include <math.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 #include <hip/hip_runtime_api.h>
 #include "pdfnet_hip.h"
@@ -34,7 +35,12 @@ int main(void) {
     hipStream_t s0, s1;
     CHECK(hipStreamCreate(&s0)); CHECK(hipStreamCreate(&s1));
     CHECK(pdf_init());
-    CHECK(pdf_linear_fwd(dx, dwt, dbias, dy, M, N, K, K, K, N, PDF_ACT_RELU, s0));
+    if (pdf_debug_callopts_size() != (int)sizeof(PdfCallOpts)) { fprintf(stderr, "PdfCallOpts layout mismatch\n"); return 3; }
+    /* the explicit form: every option of the call in its argument list (here: none armed, statistics not requested) */
+    PdfCallOpts opts;
+    memset(&opts, 0, sizeof opts);
+    CHECK(pdf_linear_fwd_x(dx, dwt, dbias, dy, M, N, K, K, K, N, PDF_ACT_RELU, s0, &opts));
+    if (opts.stats_tiles != 0 || pdf_debug_armed_slots() != 0) { fprintf(stderr, "unexpected option state\n"); return 4; }
     CHECK(pdf_stream_wait(s1, s0));                      /* the weight gradient (of L = sum y, dy = 1[y > 0]... here dy := y) waits for y */
     CHECK(pdf_linear_bwd_weight(dx, dy, ddw, ddb, ws, wsf, M, N, K, K, N, 0, s1));
     CHECK(hipStreamSynchronize(s1));

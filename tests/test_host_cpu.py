@@ -243,3 +243,41 @@ def test_bench_gpus_n_launches_its_own_ranks_as_a_child_process():
         return
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr
+
+
+def test_rejected_call_leaves_no_armed_slot():
+    """the pdf_set_* hand-overs are compat wrappers over the explicit PdfCallOpts of the `_x` entry points; a plain
+    entry point takes AND CLEARS every slot before it looks at an argument, so a call that is rejected (PDF_E_BADARG) or returns early
+    (empty problem) cannot leave a slot armed for an unrelated later call.  Runs without a GPU: both returns happen before any launch."""
+    from pdfnet_amd import hip
+    L = hip.lib()
+    c = L.cdll
+    assert c.pdf_debug_callopts_size() == ctypes.sizeof(hip.CallOpts)
+
+    def arm():
+        L.pdf_set_bf16_operands(0x1000, 0x2000)
+        L.pdf_set_bf16_output(0x3000)
+        L.pdf_set_bn_input_bf16(0x4000)
+        L.pdf_set_stats_output(0x5000, 64)
+        L.pdf_set_bn_tile_stats(0x6000, 1, 64)
+        L.pdf_set_input_affine_relu(0x7000, 0x8000)
+        assert L.pdf_debug_armed_slots() == 8
+    arm()
+    # 9 x 9 taps > MAX_TAPS: rejected
+    rc = c.pdf_conv2d_fwd(None, None, None, None, 1, 8, 8, 16, 16, 16, 9, 9, 1, 4, 8, 8, 16, 0, None)
+    assert rc == -1 and L.pdf_debug_armed_slots() == 0
+    assert L.pdf_stats_result_tiles() == 0
+    arm()
+    # misaligned leading dimension: pdf_bn_relu_maxk_fwd used to return BEFORE it took its slot
+    rc = c.pdf_bn_relu_maxk_fwd(0x10, 5, 6, 4, 4, None, None, None, None, 0.1, 1e-5, 1, 0x20, 6, 0x30, None, None, 0x40, 0x50, None, None)
+    assert rc == -1 and L.pdf_debug_armed_slots() == 0
+    arm()
+    rc = c.pdf_bn_train_fwd(None, 16, 16, 0, None, None, None, None, 0.1, 1e-5, None, 16, 0, None, 16, None, None, None, None, None, None)
+    assert rc == 0 and L.pdf_debug_armed_slots() == 0          # empty problem: early return, slots cleared all the same
+    # the explicit form reads its options from its argument and never from the thread
+    arm()
+    o = hip.CallOpts(stats_out=0x5000, stats_cap=64)
+    rc = c.pdf_conv2d_fwd_x(None, None, None, None, 1, 8, 8, 16, 16, 16, 9, 9, 1, 4, 8, 8, 16, 0, None, ctypes.byref(o))
+    assert rc == -1 and o.stats_tiles == 0 and L.pdf_debug_armed_slots() == 8      # (an `_x` call does not touch the compat slots)
+    c.pdf_linear_fwd_pair(None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, None)                 # any plain GEMM-family call clears them
+    assert L.pdf_debug_armed_slots() == 0

@@ -906,6 +906,32 @@ def test_fps(F):
 
 
 
+def test_fps_single_wave_kernel_and_the_reorder_option(F):
+    """Clouds of <= 1,024 points take the single-wave kernel (16 points per lane, DPP arg-max): picks bit-exact against the oracle
+    for ragged sizes, duplicated points (frozen distances) and explicit first picks; `fps_reorder` -- the reference's
+    `--sample_strategy FPS` (lib/opts.py:231, the commented block lib/datasets/interhand.py:857-900) -- against its restatement."""
+    from oracle import pdfnet_cpu as O
+    gen = torch.Generator().manual_seed(11)
+    for N, S in ((1024, 512), (1000, 128), (65, 64), (300, 300), (64, 7)):
+        pts = torch.rand(5, N, 3, generator=gen)
+        pts[1, N // 2:] = pts[1, :N - N // 2]                     # duplicates: their distances freeze at <= 1e-8
+        start = torch.randint(0, N, (5,), generator=gen, dtype=torch.int32)
+        got = F.fps(dev(pts), S, dev(start)).cpu().numpy()
+        for b in range(5):
+            assert np.array_equal(got[b].astype(np.int64), O.fps_order(pts[b].numpy(), S, int(start[b]))), (N, S, b)
+    pts = torch.rand(6, 1024, 3, generator=gen)
+    pts[2, 700:] = pts[2, :324]
+    choose = torch.randint(0, 65536, (6, 1024), generator=gen)
+    s1 = torch.randint(0, 1024, (6,), generator=gen, dtype=torch.int32)
+    s2 = torch.randint(0, 512, (6,), generator=gen, dtype=torch.int32)
+    c, ch = F.fps_reorder(dev(pts), dev(choose), 512, 128, dev(s1), dev(s2))
+    for b in range(6):
+        rc, rch = O.fps_reorder(pts[b].numpy(), choose[b].numpy(), 512, 128, int(s1[b]), int(s2[b]))
+        assert np.array_equal(ch[b].cpu().numpy(), rch), b
+        assert np.array_equal(c[b].cpu().numpy(), rc), b
+        assert sorted(ch[b].cpu().tolist()) == sorted(choose[b].tolist())        # a permutation of the drawn points
+
+
 def test_limits_and_empty_inputs(F):
     """Error behaviour at the documented limits (RuntimeError, not a crash or a silent fallback) and empty inputs."""
     with pytest.raises(RuntimeError):
