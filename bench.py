@@ -38,6 +38,12 @@ def make_opt(R):
         size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
 
 
+def _with_explicit_form(lib, name):
+    """-> [name, name + '_x'] when the library has the explicit-options form of the entry point (include/pdfnet_hip.h PdfCallOpts):
+    same positional arguments, the options structure appended -- the argument positions the profilers read are unchanged."""
+    return [name, name + '_x'] if (name + '_x') in lib.protos else [name]
+
+
 class GemmProfiler:
     """Wraps the GEMM-family C-ABI entry points with start/stop events on the current stream and counts the
     algorithmic FLOPs (2*M*N*K of the contraction each call performs) from the call's own arguments."""
@@ -68,22 +74,23 @@ class GemmProfiler:
         return 2.0 * N * H * W * Cin * Cout * KH * KW          # transposed conv: per input pixel
 
     def __enter__(self):
-        for n in self.NAMES:
-            fn = getattr(self.lib, n)                           # materialises the bound wrapper
-            self.saved[n] = fn
+        for base in self.NAMES:
+            for n in _with_explicit_form(self.lib, base):         # the plain entry point and its `_x` form (explicit PdfCallOpts last)
+                fn = getattr(self.lib, n)                           # materialises the bound wrapper
+                self.saved[n] = fn
 
-            def wrapped(*a, _fn=fn, _n=n):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                n0 = self.lib.pdf_debug_igemm_launches()
-                e0.record()
-                r = _fn(*a)
-                e1.record()
-                weight = 'weight' in _n
-                tile = -1 if weight else self.lib.pdf_debug_last_tile()
-                launches = 1 if weight else self.lib.pdf_debug_igemm_launches() - n0
-                self.records.append((_n, self.flops(_n, a), e0, e1, tuple(v for v in a if isinstance(v, int) and abs(v) < (1 << 31)), tile, launches))
-                return r
-            setattr(self.lib, n, wrapped)
+                def wrapped(*a, _fn=fn, _n=base):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    n0 = self.lib.pdf_debug_igemm_launches()
+                    e0.record()
+                    r = _fn(*a)
+                    e1.record()
+                    weight = 'weight' in _n
+                    tile = -1 if weight else self.lib.pdf_debug_last_tile()
+                    launches = 1 if weight else self.lib.pdf_debug_igemm_launches() - n0
+                    self.records.append((_n, self.flops(_n, a), e0, e1, tuple(v for v in a if isinstance(v, int) and abs(v) < (1 << 31)), tile, launches))
+                    return r
+                setattr(self.lib, n, wrapped)
         return self
 
     def __exit__(self, *exc):
@@ -233,18 +240,19 @@ class HbmProfiler:
         self.records, self.saved = [], {}
 
     def __enter__(self):
-        for n in self.NAMES:
-            fn = getattr(self.lib, n)
-            self.saved[n] = fn
+        for base in self.NAMES:
+            for n in _with_explicit_form(self.lib, base):
+                fn = getattr(self.lib, n)
+                self.saved[n] = fn
 
-            def wrapped(*a, _fn=fn, _n=n):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                r = _fn(*a)
-                e1.record()
-                self.records.append((_n, float(self.nbytes(_n, a)), e0, e1))
-                return r
-            setattr(self.lib, n, wrapped)
+                def wrapped(*a, _fn=fn, _n=base):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    r = _fn(*a)
+                    e1.record()
+                    self.records.append((_n, float(self.nbytes(_n, a)), e0, e1))
+                    return r
+                setattr(self.lib, n, wrapped)
         return self
 
     def __exit__(self, *exc):

@@ -281,6 +281,10 @@ int pdf_set_bn_input_bf16(const void* x16);
  * relu(x * scale[c] + shift[c]) -- the normalised tensor is never written.  fp32 kernels, plain rows, K % 16 == 0. */
 int pdf_set_input_affine_relu(const float* scale, const float* shift);
 int pdf_cast_bf16(const float* src, void* dst, long n, void* stream);
+/* Transposed bf16 shadows of many weight tensors in ONE launch: for every table entry {long src (floats into `src`), long dst
+ * (elements into `dst`), int R, int T, int C, int tile0} the tensor w[R][T][C] is written as wt[C][T][R] (bf16, RNE); tile0 = number of
+ * 32x32 tiles of the entries before it (T * ceil(R/32) * ceil(C/32) each), total_tiles their sum.  `table` is DEVICE memory. */
+int pdf_cast_bf16_transposed(const float* src, void* dst, const void* table, int nlayers, long total_tiles, void* stream);
 int pdf_debug_shadow_operands(void);      /* shadow operands consumed by bf16 GEMM launches so far (tests) */
 /* nn.Dropout(p) with a stateless (seed, index) mask: the same call is its own backward (gcn.py:96, self_attn.py:51-52).
  * step: optional DEVICE counter mixed into the seed so a replayed hipGraph draws a fresh mask every step. */
@@ -401,7 +405,9 @@ int pdf_mano_split_coeff_bwd(const float* params, float* dparams, int ldp, long 
  *   stats_out, stats_cap pdf_conv2d_fwd / pdf_linear_fwd: per-row-block (mean, M2) pairs of the output columns,
  *                        stats_out[(t * N + c) * 2 + {0,1}]; -> stats_tiles row blocks of stats_rows rows (0: not produced).
  *   tile_stats, tile_n, tile_rows   pdf_bn_train_fwd / pdf_bn_relu_maxk_fwd: such partials; the call skips its statistics pass.
- *   in_scale, in_shift   pdf_linear_fwd / pdf_linear_bwd_weight: x is read as relu(x * in_scale[k] + in_shift[k]). */
+ *   in_scale, in_shift   pdf_linear_fwd / pdf_linear_bwd_weight: x is read as relu(x * in_scale[k] + in_shift[k]).
+ *   op1_bf16_t           pdf_conv2d_bwd_data(_add) / pdf_linear_bwd_data (bf16 mode): the weight's transposed bf16 shadow,
+ *                        wt[c][tap][r] for w[r][tap][c] (pdf_cast_bf16_transposed); lets the LDS-DMA kernel take the launch. */
 typedef struct PdfCallOpts {
     const void* op0_bf16; const void* op1_bf16;
     void* out_bf16;
@@ -410,6 +416,7 @@ typedef struct PdfCallOpts {
     long stats_tiles; long stats_rows;
     const float* tile_stats; long tile_n; long tile_rows;
     const float* in_scale; const float* in_shift;
+    const void* op1_bf16_t;
 } PdfCallOpts;
 int pdf_linear_fwd_x(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream, PdfCallOpts* opts);
 int pdf_linear_fwd_pair_x(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream, PdfCallOpts* opts);

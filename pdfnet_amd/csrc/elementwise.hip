@@ -568,7 +568,7 @@ void pdf_tls_publish(const PdfCallOpts& o) { tl_res_tiles = o.stats_tiles; tl_re
 PDF_API int pdf_debug_armed_slots(void) {
     const PdfCallOpts& o = tl_opts;
     return (o.op0_bf16 != nullptr) + (o.op1_bf16 != nullptr) + (o.out_bf16 != nullptr) + (o.bn_x_bf16 != nullptr) + (o.stats_out != nullptr) +
-           (o.tile_stats != nullptr) + (o.in_scale != nullptr) + (o.in_shift != nullptr);
+           (o.tile_stats != nullptr) + (o.in_scale != nullptr) + (o.in_shift != nullptr) + (o.op1_bf16_t != nullptr);
 }
 PDF_API int pdf_debug_callopts_size(void) { return (int)sizeof(PdfCallOpts); }
 // dst[i] = bf16(src[i]) (RNE): the weight shadows, refreshed from the flat fp32 master buffer once per step
@@ -582,6 +582,49 @@ PDF_API int pdf_cast_bf16(const float* src, void* dst, long n, hipStream_t s) {
     if (n <= 0) return 0;
     if (n % 4 != 0) return PDF_E_BADARG;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, src, reinterpret_cast<unsigned short*>(dst), n / 4);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Transposed bf16 weight shadows (bf16 mode, round 4).  A backward-data contraction reads the weight as [K][N] rows -- an operand whose
+// K runs ACROSS rows, which the LDS-DMA kernel (gemm_dma.hip) cannot take: its lanes fetch 16-byte chunks of K-contiguous rows.  So the
+// trainer keeps, beside the bf16 copy of every large conv / linear weight, the same values TRANSPOSED: weight w[r][t][c] (r = output
+// channel, t = tap, c = input channel; a linear layer has one tap) -> wt[c][t][r].  For the backward-data GEMM (rows = input channels,
+// reduction over (tap, output channel)) that is an ordinary [N][K] row operand.  One launch transposes every listed tensor:
+// table[l] = {src offset (floats), dst offset (elements), R, T, C, first tile}; tiles are 32 x 32 over (r, c) per tap.
+struct PdfTDesc { long src, dst; int R, T, C, tile0; };
+__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                          const PdfTDesc* __restrict__ tab, int nl) {
+    __shared__ float tile[32][33];
+    const int bid = blockIdx.x;
+    int lo = 0, hi = nl - 1;                                 // the layer whose tile range holds this block (tile0 ascending)
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].tile0 <= bid) lo = mid; else hi = mid - 1; }
+    const PdfTDesc d = tab[lo];
+    const int tr = (d.R + 31) / 32, tc = (d.C + 31) / 32;
+    int t = bid - d.tile0;
+    const int tap = t / (tr * tc);
+    t -= tap * tr * tc;
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* sp = src + d.src;
+    unsigned short* dp = dst + d.dst;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < d.R && c < d.C) ? sp[((long)r * d.T + tap) * d.C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < d.R && c < d.C) dp[((long)c * d.T + tap) * d.R + r] = (unsigned short)(pdf_pk_bf16(tile[tx][ty + 8 * i], 0.f) & 0xffffu);
+    }
+}
+PDF_API int pdf_cast_bf16_transposed(const float* src, void* dst, const void* table, int nlayers, long total_tiles, hipStream_t s) {
+    if (nlayers <= 0 || total_tiles <= 0) return 0;
+    if (total_tiles > 0x7fffffffL) return PDF_E_BADARG;
+    hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, src, reinterpret_cast<unsigned short*>(dst),
+                       reinterpret_cast<const PdfTDesc*>(table), nlayers);
     PDF_LAUNCH_CHECK();
     return 0;
 }

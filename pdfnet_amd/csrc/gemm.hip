@@ -1337,7 +1337,8 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
         PDF_LAUNCH_CHECK();
         return 0;
     }
-    if (!(g_gemm_bf16 && fast) || groups > 1) { g.A16 = nullptr; g.B16 = nullptr; }
+    if (!(g_gemm_bf16 && fast) || groups > 1) { g.A16 = nullptr; g.B16 = nullptr; g.B16T = nullptr; }
+    if (g.B16T != nullptr && (!g.b_kn || g.ldbT % 8 != 0 || (reinterpret_cast<uintptr_t>(g.B16T) & 15))) g.B16T = nullptr;
     if (g.A16 != nullptr && (g.lda % 8 != 0 || (reinterpret_cast<uintptr_t>(g.A16) & 15))) g.A16 = nullptr;      // 16-byte chunks of 8 bf16
     if (g.B16 != nullptr && ((!g.b_kn && g.ldb % 8 != 0) || (reinterpret_cast<uintptr_t>(g.B16) & 15))) g.B16 = nullptr;
     if (g.A == nullptr && g.A16 == nullptr) return PDF_E_BADARG;          // bf16 storage mode: A exists only as bf16 -- it must be usable
@@ -1506,6 +1507,7 @@ static int pdf_linear_bwd_data_impl(const float* dy, const float* w, float* dx, 
     IGemm g = linear_desc(dy, w, nullptr, dx, M, K, N, lddy, ldw, lddx, 0);
     g.b_kn = 1; g.btap = 0;
     g.A16 = sh.op0; g.B16 = sh.op1;
+    if (ldw == K) { g.B16T = co.op1_bf16_t; g.ldbT = N; }   // (the transposed shadow is of the dense [N][K] matrix)
     return launch_igemm(g, s);
 }
 PDF_API int pdf_linear_bwd_data_x(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx,
@@ -1813,6 +1815,7 @@ static int conv2d_bwd_data(const float* dy, const float* w, float* dx,
             g.M = N * g.QH * g.QW;
             g.sy = 1; g.sx = 1; g.accum = accumulate;
             g.A16 = sh.op0; g.B16 = sh.op1;
+            g.B16T = co.op1_bf16_t; g.ldbT = KH * KW * Cout;
             // input row iy = qy*stride + py; contributing taps: (iy + pad - ky) % stride == 0, oy = (iy+pad-ky)/stride
             int T = 0;
             for (int ky = 0; ky < KH; ++ky) {

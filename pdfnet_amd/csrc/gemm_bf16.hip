@@ -15,6 +15,7 @@
 //       weight-gradient kernel ran at 54-80 TFLOP/s, below the fp32 kernel.)
 #include "gemm_common.h"
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -369,9 +370,23 @@ int launch_igemm_bf16(const IGemm& g, hipStream_t s, int groups) {
     if (g.abytes == 0 || g.bbytes == 0) return 0;        // an operand of 4 GiB or more: the fp32 kernels' flat-address form takes it
     if (g.b_kn && (g.N % 4 != 0 || g.btap % 4 != 0)) return 0;
     const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * groups;
-    if (g.N > 64 && t128 >= 192) launch_tile_bf16<128, 128, 2, 2>(g, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
-    else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= 192) launch_tile_bf16<128, 64, 4, 1>(g, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s);
-    else launch_tile_bf16<64, 64, 2, 2>(g, dim3(cdiv(g.M, 64) * cdiv(g.N, 64), groups), s);
+    static const int dma = getenv("PDF_BF16_DMA") ? atoi(getenv("PDF_BF16_DMA")) : 1;       // LDS-DMA form (gemm_dma.hip) when both operands are K-contiguous bf16 shadows: variant + 1, 0 = off
+    static const int dma_tiles = getenv("PDF_BF16_DMA_TILES") ? atoi(getenv("PDF_BF16_DMA_TILES")) : 3;       // 1: 128x128 only, 2: + 128x64, 3: + 64x64
+    if (dma > 0 && g.b_kn && g.B16T != nullptr && g.A16 != nullptr && groups == 1) {
+        // backward-data with a transposed weight shadow: the same contraction as a [N][K] row operand -> the LDS-DMA kernel
+        IGemm t = g;
+        t.b_kn = 0; t.B16 = g.B16T; t.ldb = g.ldbT; t.btap = 0;
+        const int tile = (g.N > 64 && t128 >= 192) ? 128 : (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= 192) ? (dma_tiles >= 2 ? 12864 : 0) : (dma_tiles >= 3 ? 64 : 0);
+        if (tile != 0 && launch_igemm_bf16_dma(t, tile, dma - 1, groups, s)) { hipError_t e = hipGetLastError(); return e == hipSuccess ? 1 : -(int)e; }
+    }
+    if (g.N > 64 && t128 >= 192) {
+        if (!(dma > 0 && launch_igemm_bf16_dma(g, 128, dma - 1, groups, s)))
+            launch_tile_bf16<128, 128, 2, 2>(g, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
+    } else if (g.N <= 64 && (long)cdiv(g.M, 128) * groups >= 192) {
+        if (!(dma > 0 && dma_tiles >= 2 && launch_igemm_bf16_dma(g, 12864, dma - 1, groups, s)))
+            launch_tile_bf16<128, 64, 4, 1>(g, dim3(cdiv(g.M, 128) * cdiv(g.N, 64), groups), s);
+    } else if (!(dma > 0 && dma_tiles >= 3 && launch_igemm_bf16_dma(g, 64, dma - 1, groups, s)))
+        launch_tile_bf16<64, 64, 2, 2>(g, dim3(cdiv(g.M, 64) * cdiv(g.N, 64), groups), s);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : -(int)e;
 }

@@ -42,6 +42,9 @@ struct IGemm {
     // A = relu(A * a_scale[k] + a_shift[k]) while the tile is staged (plain GEMMs, fp32 kernels): the BatchNorm + ReLU in front of a
     // PointNet++ linear layer applied by its consumer -- the normalised tensor is never written (functional._BatchNorm lazy=True)
     const float* a_scale; const float* a_shift;
+    // b_kn launches in bf16 mode: the same B as a [N][K] ROW operand -- the weight's transposed bf16 shadow, element (n, tap, c) at
+    // n * ldbT + wt[tap] * Cin + c (PdfCallOpts::op1_bf16_t) -- so that the LDS-DMA kernel can take a backward-data launch
+    const void* B16T; int ldbT;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
@@ -336,3 +339,4 @@ int launch_wgemm_bf16(const WGemm& g, int splits, int groups, int small, hipStre
 // LDS-DMA form of the fp32 implicit GEMM (gemm_dma.hip).  tile: 64 (64x64) | 128 (128x128) | 12864 | 64128; variant: ring depth / K-step
 // choice; splits > 0: split-K launch (g.ksteps / g.part set).  -> 1 launched, 0 shape not taken.
 int launch_igemm_dma(const IGemm& g, int tile, int variant, int groups, int splits, hipStream_t s);
+int launch_igemm_bf16_dma(const IGemm& g, int tile, int variant, int groups, hipStream_t s);

@@ -276,6 +276,217 @@ __global__ __launch_bounds__(256) void igemm_dma(const IGemm g) {
     if (do_stat) stat_finish<TN, WM, WN, BN>(sacc, smem, g.stat, tmi, n0, g.N, wm, wn, lane, tid);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// igemm_bf16_dma: the bf16-input implicit GEMM (gemm_bf16.hip igemm_bf16_kernel) for launches whose operands BOTH come as bf16 shadows
+// with K contiguous (forward convolutions / linears: A = activation rows, B = [N][K] weights).  The register-staged kernel is bound by
+// its LDS store path -- 8 ds_write_b128 per thread and K-step (13 cycles each through a path the CU's SIMD pairs share) against 16 MFMAs of
+// 32 cycles -- and by a barrier per 16 MFMAs with two blocks per CU (LDS index-active 0.15-0.22, MFMA busy 9-13 of 32).
+// Here the 16-byte chunks (8 bf16 of one row) go global -> LDS by DMA, the chunk order inside a row XOR-swizzled by the row exactly as in
+// igemm_dma above (a row of the K-step is CPR = 8 chunks = 64 elements, or 4 = 32), and a lane's MFMA operand -- 8 consecutive k of row
+// lane & 31, k-offset 8 (lane >> 5) -- is ONE conflict-free ds_read_b128: chunk 2 ks + (lane >> 5) of its row.
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+template <int TM, int TN, int CPR, int ST>
+__global__ __launch_bounds__(256) void igemm_bf16_dma(const IGemm g) {
+    constexpr int WM = 2, WN = 2, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int BK = CPR * 8;                          // bf16 elements per K-step
+    constexpr int NIA = BM * CPR / 256, NIB = BN * CPR / 256;
+    constexpr int ASZ = BM * CPR * 16, BSZ = BN * CPR * 16;        // bytes per stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ST * (ASZ + BSZ)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned short* A16 = reinterpret_cast<const unsigned short*>(g.A16);
+    const unsigned short* B16 = reinterpret_cast<const unsigned short*>(g.B16);
+    const float* __restrict__ biasp = g.bias;
+    float* __restrict__ Cp = g.C;
+    if (blockIdx.y) { A16 += g.gsA; Cp += g.gsC; B16 = reinterpret_cast<const unsigned short*>(g.B116); biasp = g.bias1; }
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    int tmi, tni;
+    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
+    const int m0 = tmi * BM, n0 = tni * BN;
+    const i32x4 rsA = dma_rsrc(A16, g.abytes / 2), rsB = dma_rsrc(B16, g.bbytes / 2);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const unsigned char*)smem;
+
+    constexpr int RPI = 64 / CPR;
+    auto swz = [](int r) { return CPR == 8 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+    unsigned aoff[NIA]; int iy0[NIA], ix0[NIA], akc[NIA]; bool aval[NIA], aok[NIA];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int row = (wave * NIA + i) * RPI + lane / CPR;
+        akc[i] = ((lane % CPR) ^ swz(row)) * 8;                            // first element of the chunk this lane fetches
+        const int r = m0 + row;
+        aval[i] = r < g.M;
+        long base;
+        if (g.plain_in) { base = (long)r * g.lda; iy0[i] = 0; ix0[i] = 0; }
+        else {
+            const int hw = g.QH * g.QW;
+            const int ni = r / hw, rem = r - ni * hw;
+            const int qy = rem / g.QW, qx = rem - qy * g.QW;
+            iy0[i] = qy * g.sy; ix0[i] = qx * g.sx;
+            base = (long)ni * g.H * g.W * g.lda + ((long)iy0[i] * g.W + ix0[i]) * g.lda;
+        }
+        aoff[i] = (unsigned)(base + akc[i]) * 2u;
+    }
+    unsigned boff[NIB]; int bkc[NIB]; bool bval[NIB];
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int row = (wave * NIB + i) * RPI + lane / CPR;
+        bkc[i] = ((lane % CPR) ^ swz(row)) * 8;
+        bval[i] = n0 + row < g.N;
+        boff[i] = (unsigned)((long)(n0 + row) * g.ldb + bkc[i]) * 2u;
+    }
+    const int spt = (g.Cin + BK - 1) / BK;               // K-steps per tap (chunks past Cin read zeros; Cin % 8 == 0)
+    const int nk = g.T * spt;
+    int nt_tap = 0, nt_ci = 0;
+    int ddy = g.dy[0], ddx = g.dx[0], wbase = g.wt[0] * g.Cin;
+    int tapoff = 0;
+    auto tap_valid = [&]() {
+        tapoff = g.plain_in ? 0 : (ddy * g.W + ddx) * g.lda;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int iy = iy0[i] + ddy, ix = ix0[i] + ddx;
+            aok[i] = aval[i] & (g.plain_in | (((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W)));
+        }
+    };
+    tap_valid();
+    int nissued = 0;
+    auto issue = [&](int stage) {
+        const bool live = nissued < nk;
+        ++nissued;
+        const unsigned sa = lds0 + (unsigned)(stage * (ASZ + BSZ) + wave * NIA * 1024);
+        const unsigned sb = lds0 + (unsigned)(stage * (ASZ + BSZ) + ASZ + wave * NIB * 1024);
+        const unsigned soa = (unsigned)(tapoff + nt_ci) * 2u, sob = (unsigned)(wbase + nt_ci) * 2u;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i)
+            dma16(rsA, sa + i * 1024, (aok[i] && live && nt_ci + akc[i] < g.Cin) ? aoff[i] + soa : 0xffffffffu);
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            dma16(rsB, sb + i * 1024, (bval[i] && live && nt_ci + bkc[i] < g.Cin) ? boff[i] + sob : 0xffffffffu);
+        nt_ci += BK;
+        if (nt_ci >= g.Cin && nt_tap + 1 < g.T) {
+            ++nt_tap; nt_ci = 0;
+            ddy = g.dy[nt_tap]; ddx = g.dx[nt_tap]; wbase = g.wt[nt_tap] * g.Cin;
+            tap_valid();
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int h = lane >> 5;
+    int arow[TM], acx[TM], brow[TN], bcx[TN];            // byte offsets of the rows, swizzle ^ h
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { const int r = (wm * TM + i) * 32 + (lane & 31); arow[i] = r * CPR * 16; acx[i] = h ^ swz(r); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int r = (wn * TN + j) * 32 + (lane & 31); brow[j] = r * CPR * 16; bcx[j] = h ^ swz(r); }
+
+#pragma unroll
+    for (int p = 0; p < ST - 1; ++p) issue(p);
+    int st = 0, stn = ST - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * (NIA + NIB)) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        issue(stn);
+        const unsigned char* as = smem + st * (ASZ + BSZ);
+        const unsigned char* bs = as + ASZ;
+        bf16x8v af[CPR / 2][TM], bfr[CPR / 2][TN];
+#pragma unroll
+        for (int ks = 0; ks < CPR / 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8v*>(as + arow[i] + ((acx[i] ^ (2 * ks)) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8v*>(bs + brow[j] + ((bcx[j] ^ (2 * ks)) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < CPR / 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        st = st == ST - 1 ? 0 : st + 1;
+        stn = stn == ST - 1 ? 0 : stn + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    if (g.cbytes != 0 && m0 + BM <= g.M) {
+        lean_epilogue<TM, TN, WM, WN, BN>(acc, g, Cp, biasp, m0, n0, tmi, wm, wn, lane, tid, reinterpret_cast<float*>(smem));
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool cok = col < g.N;
+        int co = col, padd_y = 0, padd_x = 0;
+        if (g.ps_cout > 0) {
+            const int tap = col / g.ps_cout;
+            co = col - tap * g.ps_cout;
+            padd_y = tap / g.ps_kw;
+            padd_x = tap - padd_y * g.ps_kw;
+        }
+        const float bv = (biasp != nullptr && cok) ? biasp[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (cok && row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+                    long o;
+                    if (g.plain_out) o = (long)row * g.ldc + co;
+                    else {
+                        const int hw = g.QH * g.QW;
+                        const int ni = row / hw, rem = row - ni * hw;
+                        const int qy = rem / g.QW, qx = rem - qy * g.QW;
+                        const int oy = qy * g.osy + g.ooy + padd_y, ox = qx * g.osx + g.oox + padd_x;
+                        o = (((long)ni * g.OH + oy) * g.OW + ox) * g.ldc + co;
+                    }
+                    if (g.accum) v += Cp[o];
+                    Cp[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int CPR, int ST>
+static void launch_bf16_one(const IGemm& g, dim3 grid, hipStream_t s) {
+    char nm[96] = "";
+    snprintf(nm, sizeof nm, "igemm_bf16_dma<%d, %d, %d, %d>", TM, TN, CPR, ST);
+    const double a = g.plain_in ? (double)g.M * g.Cin : (double)(g.M / max(1, g.QH * g.QW)) * g.H * g.W * g.Cin;
+    KTimer kt(nm, 2.0 * g.M * g.N * g.K * grid.y, grid.y * (2.0 * a + 2.0 * g.N * g.K + 4.0 * g.M * g.N * (g.accum ? 2 : 1)), s);
+    hipLaunchKernelGGL((igemm_bf16_dma<TM, TN, CPR, ST>), grid, dim3(256), 0, s, g);
+}
+// bf16 shadows of BOTH operands, [N][K] weights.  tile: 128 (128x128) | 64 (64x64) | 12864 (128x64).  -> 1 launched, 0 not taken
+int launch_igemm_bf16_dma(const IGemm& g, int tile, int variant, int groups, hipStream_t s) {
+    if (g.A16 == nullptr || g.B16 == nullptr || g.b_kn || g.abytes == 0 || g.bbytes == 0 || g.Cin % 8 != 0 || g.lda % 8 != 0 || g.ldb % 8 != 0 || g.C16 != nullptr) return 0;
+    if (groups > 1 && (g.B116 == nullptr || g.gsA % 8 != 0)) return 0;
+    const int bm = tile == 64 ? 64 : 128, bn = tile == 128 ? 128 : 64;
+    const dim3 grid((unsigned)(cdiv(g.M, bm) * cdiv(g.N, bn)), (unsigned)groups);
+    if (tile == 128) {
+        if (variant == 0) { launch_bf16_one<2, 2, 8, 2>(g, grid, s); return 1; }
+        if (variant == 1) { launch_bf16_one<2, 2, 4, 4>(g, grid, s); return 1; }
+        if (variant == 2) { launch_bf16_one<2, 2, 8, 3>(g, grid, s); return 1; }
+        if (variant == 3) { launch_bf16_one<2, 2, 4, 3>(g, grid, s); return 1; }
+    } else if (tile == 12864) {
+        if (variant == 0 || variant == 2) { launch_bf16_one<2, 1, 8, 2>(g, grid, s); return 1; }
+        if (variant == 1 || variant == 3) { launch_bf16_one<2, 1, 4, 4>(g, grid, s); return 1; }
+    } else if (tile == 64) {
+        if (variant == 0 || variant == 2) { launch_bf16_one<1, 1, 8, 3>(g, grid, s); return 1; }
+        if (variant == 1 || variant == 3) { launch_bf16_one<1, 1, 4, 4>(g, grid, s); return 1; }
+    }
+    return 0;
+}
+
 // -> 1: launched, 0: shape not taken (the caller uses igemm_nt).  `tile`: 64 (64x64) | 128 (128x128) | 12864 (128x64) | 64128 (64x128)
 int igemm_dma_tile_ok(const IGemm& g, int bk) {
     return g.abytes != 0 && g.bbytes != 0 && g.a_scale == nullptr && g.Cin % bk == 0 && g.K == g.T * g.Cin && g.lda % 4 == 0 && g.ldb % 4 == 0 &&

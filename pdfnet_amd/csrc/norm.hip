@@ -363,7 +363,9 @@ __global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __res
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
     if (c0 >= C) return;
-    const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    const long r0 = (rows_per_chunk < 0 ? (long)(gridDim.y - 1 - blockIdx.y) : (long)blockIdx.y) * (rows_per_chunk < 0 ? -rows_per_chunk : rows_per_chunk);
+    rows_per_chunk = rows_per_chunk < 0 ? -rows_per_chunk : rows_per_chunk;        // (negative: chunks walked from the END of the tensor, see bn_second_pass_order)
+    const long r1 = min(R, r0 + rows_per_chunk);
     const float4 sc = *reinterpret_cast<const float4*>(scale + c0), sh = *reinterpret_cast<const float4*>(shift + c0);
 #pragma unroll 4
     for (long r = r0 + ty; r < r1; r += V4_TY) {
@@ -389,7 +391,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
     if (c0 >= C) return;
-    const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    const long r0 = (rows_per_chunk < 0 ? (long)(gridDim.y - 1 - blockIdx.y) : (long)blockIdx.y) * (rows_per_chunk < 0 ? -rows_per_chunk : rows_per_chunk);
+    rows_per_chunk = rows_per_chunk < 0 ? -rows_per_chunk : rows_per_chunk;
+    const long r1 = min(R, r0 + rows_per_chunk);
     const float4 m = *reinterpret_cast<const float4*>(mean + c0), rs = *reinterpret_cast<const float4*>(rstd + c0);
     const float4 ka = *reinterpret_cast<const float4*>(coef + c0), k1 = *reinterpret_cast<const float4*>(coef + C + c0),
                  k2 = *reinterpret_cast<const float4*>(coef + 2 * C + c0);
@@ -427,6 +431,14 @@ static long apply_rows_per_chunk(int C, long R) {
     return (rpc + V4_TY - 1) / V4_TY * V4_TY;
 }
 
+// The second pass of a two-pass operator (BatchNorm forward: statistics, then apply; backward: sums, then apply) re-reads what the first
+// pass has just streamed.  The 256 MiB Infinity Cache is memory-side and keeps what was touched most recently (MI355X_MICROARCH.md
+// "Infinity Cache"): walking the tensor in the SAME order evicts a line just before it is wanted again once the operands exceed the
+// cache; walking it BACKWARDS meets the most recently read rows first.  sign(rows_per_chunk) carries the order into the kernels.
+static int bn_second_pass_reverse() {
+    static const int v = getenv("PDF_BN_REVERSE") ? atoi(getenv("PDF_BN_REVERSE")) : 0;
+    return v;
+}
 static bool v4_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
     if (C % 4) return false;
     for (int l : lds) if (l % 4) return false;
@@ -439,11 +451,11 @@ static void launch_affine_apply(const float* x, int ldx, const float* scale, con
     if (x16 != nullptr) {                                    // (the caller checked v4_ok)
         const long rpc = apply_rows_per_chunk(C, R);
         hipLaunchKernelGGL((affine_apply_v4_kernel<true>), dim3(cdiv(C, BN_CT), (unsigned)((R + rpc - 1) / rpc)), dim3(256), 0, s,
-                           reinterpret_cast<const float*>(x16), ldx, scale, shift, res, ldr, y, ldy, C, R, rpc, relu, reinterpret_cast<unsigned short*>(y16));
+                           reinterpret_cast<const float*>(x16), ldx, scale, shift, res, ldr, y, ldy, C, R, bn_second_pass_reverse() ? -rpc : rpc, relu, reinterpret_cast<unsigned short*>(y16));
     } else if (v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift})) {
         const long rpc = apply_rows_per_chunk(C, R);
         hipLaunchKernelGGL((affine_apply_v4_kernel<false>), dim3(cdiv(C, BN_CT), (unsigned)((R + rpc - 1) / rpc)), dim3(256), 0, s,
-                           x, ldx, scale, shift, res, ldr, y, ldy, C, R, rpc, relu, reinterpret_cast<unsigned short*>(y16));
+                           x, ldx, scale, shift, res, ldr, y, ldy, C, R, bn_second_pass_reverse() ? -rpc : rpc, relu, reinterpret_cast<unsigned short*>(y16));
     } else
         hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
 }
@@ -627,10 +639,10 @@ static int pdf_bn_train_bwd_impl(const float* dy, int lddy, const float* y, int 
         const dim3 grid(cdiv(C, BN_CT), (unsigned)((R + arpc - 1) / arpc));
         if (x16 != nullptr)
             hipLaunchKernelGGL((bn_bwd_apply_v4_kernel<true>), grid, dim3(256), 0, s, dy, lddy, y, ldy, relu,
-                               xin, ldx, save_mean, save_rstd, coef, scale, shift, C, R, arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
+                               xin, ldx, save_mean, save_rstd, coef, scale, shift, C, R, bn_second_pass_reverse() ? -arpc : arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
         else
             hipLaunchKernelGGL((bn_bwd_apply_v4_kernel<false>), grid, dim3(256), 0, s, dy, lddy, y, ldy, relu,
-                               x, ldx, save_mean, save_rstd, coef, scale, shift, C, R, arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
+                               x, ldx, save_mean, save_rstd, coef, scale, shift, C, R, bn_second_pass_reverse() ? -arpc : arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
     } else if (dx16 != nullptr) return PDF_E_BADARG;
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef,

@@ -140,6 +140,16 @@ def shadow_of(t):
     return s16
 
 
+# Transposed bf16 shadows of the weights (trains.base_trainer.FlatAdam._cast_transposed): valid exactly when the plain shadow is.
+TRANSPOSED_SHADOWS = _os.environ.get("PDFNET_BF16_TRANSPOSED", "1") != "0"
+
+
+def shadow_t_of(w):
+    if not TRANSPOSED_SHADOWS or shadow_of(w) is None:
+        return None
+    return getattr(w, '_pdf_bf16_t', None)
+
+
 def new_shadow(t):
     return torch.empty_like(t, dtype=torch.bfloat16) if shadows_on() else None
 
@@ -439,6 +449,7 @@ class _Conv2d(Function):
             y._pdf_y16 = (y16, y._version)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.s16 = (x16, w16)
+        ctx.w16t = shadow_t_of(w) if w16 is not None else None
         ctx.cfg = (stride, pad, act, b is not None)
         ctx.params = (w_in, b)
         if skip:
@@ -464,7 +475,7 @@ class _Conv2d(Function):
         dx = dw = db = None
         L = _L()
         if ctx.needs_input_grad[0]:
-            _, oa = _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16))
+            _, oa = _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16), op1_bf16_t=ptr(ctx.w16t) if g16 is not None else None)
             if dskip is not None and stride == 1 and dskip.shape == x.shape and dskip.is_contiguous(memory_format=CL):
                 dx = dskip                                  # the shortcut's gradient (sole consumer: this node); += in the epilogue
                 L.pdf_conv2d_bwd_data_add_x(gp, ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(), oa)
@@ -574,6 +585,7 @@ class _Linear(Function):
             _stats_attach(y, part, o)
         ctx.save_for_backward(x, w, y if act else None, *(aff if aff is not None else ()))
         ctx.s16 = (x16, w16)
+        ctx.w16t = shadow_t_of(w) if w16 is not None else None
         ctx.fp32 = fp32
         ctx.cfg = (act, b is not None)
         ctx.params = (w_in, b)
@@ -597,7 +609,8 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with _forced_fp32(ctx.fp32):
-                L.pdf_linear_bwd_data_x(ptr(g), ptr(w), ptr(dx), M, Nn, K, Nn, K, K, stream(), _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16))[1])
+                L.pdf_linear_bwd_data_x(ptr(g), ptr(w), ptr(dx), M, Nn, K, Nn, K, K, stream(),
+                                        _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16), op1_bf16_t=ptr(ctx.w16t) if g16 is not None else None)[1])
         w_par, b_par = ctx.params
 
         def launch_w(out, out_b, acc):

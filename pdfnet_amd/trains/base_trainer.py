@@ -110,11 +110,41 @@ class FlatAdam:
             self.flat_p16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat_p.device)
             self._p16_views = [self.flat_p16[o:o + p.numel()].as_strided(p.shape, p.stride()) for p, o in zip(self.params, self.offsets)]
         hip.lib().pdf_cast_bf16(hip.ptr(self.flat_p), hip.ptr(self.flat_p16), self.numel, hip.stream())
+        self._cast_transposed()
         base = self.flat_p.data_ptr()
         for p, v, o in zip(self.params, self._p16_views, self.offsets):
             if p.data_ptr() == base + 4 * o:                  # still the view into the flat buffer
                 F.attach_shadow(p, v)
+        if getattr(self, 'flat_p16t', None) is not None:
+            for i, v in self._t_views:
+                p = self.params[i]
+                p._pdf_bf16_t = v if p.data_ptr() == base + 4 * self.offsets[i] else None
         self._p16_synced = True
+
+    def set_transposed(self, entries):
+        """entries: [(parameter, R, T, C)] -- tensors that also get a TRANSPOSED bf16 shadow (bf16 mode; see refresh_bf16_shadows)."""
+        pos = {id(p): i for i, p in enumerate(self.params)}
+        self._t_entries = [(pos[id(p)], int(R), int(T), int(C)) for p, R, T, C in entries if id(p) in pos]
+        self.flat_p16t = None
+
+    def _cast_transposed(self):
+        """wt[C][T][R] (bf16) of every listed weight w[R][T][C], one launch (pdf_cast_bf16_transposed) -- the operand the LDS-DMA
+        kernel reads in a backward-data GEMM (PdfCallOpts::op1_bf16_t)."""
+        ent = getattr(self, '_t_entries', None)
+        if not ent or not F.TRANSPOSED_SHADOWS:
+            return
+        if self.flat_p16t is None:
+            import numpy as np
+            self.flat_p16t = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat_p.device)
+            tab = np.zeros(len(ent), dtype=np.dtype([('src', '<i8'), ('dst', '<i8'), ('R', '<i4'), ('T', '<i4'), ('C', '<i4'), ('tile0', '<i4')]))
+            tiles = 0
+            for k, (i, R, T, C) in enumerate(ent):
+                tab[k] = (self.offsets[i], self.offsets[i], R, T, C, tiles)
+                tiles += T * ((R + 31) // 32) * ((C + 31) // 32)
+            self._t_tiles = tiles
+            self._t_table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.flat_p.device)
+            self._t_views = [(i, self.flat_p16t[self.offsets[i]:self.offsets[i] + self.params[i].numel()]) for i, _, _, _ in ent]
+        hip.lib().pdf_cast_bf16_transposed(hip.ptr(self.flat_p), hip.ptr(self.flat_p16t), hip.ptr(self._t_table), len(ent), self._t_tiles, hip.stream())
 
     def params_changed(self):
         """Something other than `step()` wrote the parameters (checkpoint load, replica broadcast, user code): the next train
@@ -159,6 +189,8 @@ class FlatAdam:
             # flat_p16 -- would go on serving the PREVIOUS weights to whatever runs next (evaluation, a plain model call):
             # re-cast in place right here; the views stay attached and are current again.
             hip.lib().pdf_cast_bf16(hip.ptr(self.flat_p), hip.ptr(self.flat_p16), self.n_live, hip.stream())
+            if getattr(self, 'flat_p16t', None) is not None:
+                self._cast_transposed()
         else:
             # fp32 mode (or shadows off): nothing re-cast, so a bf16 buffer from an earlier bf16 phase is stale from here on; the
             # next bf16 train step / evaluation refreshes it (toggling the GEMM precision on a live Trainer).  The
@@ -168,6 +200,8 @@ class FlatAdam:
                 for p in self.params:
                     if getattr(p, '_pdf_bf16', None) is not None:
                         p._pdf_bf16 = None
+                    if getattr(p, '_pdf_bf16_t', None) is not None:
+                        p._pdf_bf16_t = None
             self._p16_synced = False
 
     def _view(self, flat, i):
@@ -306,6 +340,24 @@ def split_parameters(named):
     return early, late, dead
 
 
+def _transposed_entries(model):
+    """[(weight parameter, R, T, C)] for the conv / linear layers whose backward-data GEMM is worth handing to the LDS-DMA bf16 kernel
+    (pdf_cast_bf16_transposed: w[R][T][C] -> wt[C][T][R]; conv weights are stored channels_last = [Cout][KH][KW][Cin])."""
+    from ..networks import layers
+    out = []
+    for m in model.modules():
+        w = getattr(m, 'weight', None)
+        if isinstance(m, layers.Conv2d) and w.is_contiguous(memory_format=torch.channels_last):
+            R, C, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+        elif isinstance(m, layers.Linear) and w.is_contiguous():
+            R, C, T = w.shape[0], w.shape[1], 1
+        else:
+            continue
+        if R % 8 == 0 and C % 8 == 0 and w.numel() >= 16384:
+            out.append((w, R, T, C))
+    return out
+
+
 class Trainer:
     """train(epoch, loader) / train_step(batch) for `HandNET_GCN` + `CtdetLoss`."""
 
@@ -317,6 +369,7 @@ class Trainer:
         early, late, dead = split_parameters(named)
         flat = [p for _, p in early + late + dead]             # flat order: [early | late | never used]
         self.optimizer = FlatAdam(flat, lr=lr, ckpt_order=[p for _, p in named], n_live_params=len(early) + len(late))
+        self.optimizer.set_transposed(_transposed_entries(model))   # bf16 mode: transposed shadows of the large conv / linear weights
         self.n_early = self.optimizer.offsets[len(early)] if late else self.optimizer.n_live
         self.n_live = self.optimizer.n_live
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

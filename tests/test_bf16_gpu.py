@@ -537,3 +537,74 @@ def test_bf16_shadows_written_by_the_producers_are_the_rne_rounding(bf16_mode):
     assert len(seen) == 3
     for g in seen:
         assert F.shadow_of(g) is not None and torch.equal(F.shadow_of(g), g.to(torch.bfloat16))
+
+
+def test_transposed_weight_shadows_feed_the_lds_dma_kernel_in_backward_data():
+    """Round 4: a backward-data GEMM reads the weight as [K][N] rows, which the LDS-DMA bf16 kernel (csrc/gemm_dma.hip) cannot stage;
+    with the weight's TRANSPOSED bf16 shadow (pdf_cast_bf16_transposed, PdfCallOpts::op1_bf16_t) the same contraction is an ordinary
+    [N][K] row operand.  (i) the transposing cast against torch, several tensors in one launch; (ii) conv / linear backward-data with
+    the transposed shadow == without it (same bf16 operands, fp32 accumulation in another order) and == an fp32 evaluation of the
+    rounded operands; (iii) the launch really is the DMA kernel."""
+    import ctypes
+    from pdfnet_amd import functional as F
+    from pdfnet_amd import hip
+    from pdfnet_amd.hip import ptr, stream
+    L = hip.lib()
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(3)
+    # (i)
+    shapes = [(64, 9, 32), (40, 1, 72), (256, 9, 128), (128, 1, 512)]            # (R, T, C)
+    offs, n = [], 0
+    for R, T, C in shapes:
+        offs.append(n)
+        n += (R * T * C + 63) // 64 * 64
+    flat = torch.randn(n, generator=g).to(dev)
+    dst = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    tab = np.zeros(len(shapes), dtype=np.dtype([('src', '<i8'), ('dst', '<i8'), ('R', '<i4'), ('T', '<i4'), ('C', '<i4'), ('tile0', '<i4')]))
+    tiles = 0
+    for k, ((R, T, C), o) in enumerate(zip(shapes, offs)):
+        tab[k] = (o, o, R, T, C, tiles)
+        tiles += T * ((R + 31) // 32) * ((C + 31) // 32)
+    table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+    L.pdf_cast_bf16_transposed(ptr(flat), ptr(dst), ptr(table), len(shapes), tiles, stream())
+    for (R, T, C), o in zip(shapes, offs):
+        w = flat[o:o + R * T * C].reshape(R, T, C)
+        want = w.permute(2, 1, 0).contiguous().to(torch.bfloat16)
+        assert torch.equal(dst[o:o + R * T * C].reshape(C, T, R), want), (R, T, C)
+    # (ii) + (iii)
+    F.set_gemm_precision('bf16')
+    try:
+        N, Cin, H, W, Cout, k = 8, 128, 32, 32, 256, 3
+        w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(N, Cout, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        w16, dy16 = w.to(torch.bfloat16), dy.to(torch.bfloat16)                 # (channels_last preserved: [Cout][k][k][Cin] / NHWC)
+        w16t = w.permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)             # [Cin][k][k][Cout]
+        outs = {}
+        for name, wt in (('plain', None), ('transposed', w16t)):
+            dx = torch.empty(N, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+            o = hip.CallOpts(op0_bf16=ptr(dy16), op1_bf16=ptr(w16), op1_bf16_t=ptr(wt))
+            L.pdf_debug_kernel_timing(1)
+            L.pdf_conv2d_bwd_data_x(ptr(dy), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, k, k, 1, 1, H, W, Cout, stream(), ctypes.byref(o))
+            torch.cuda.synchronize()
+            nm = ctypes.create_string_buffer(128)
+            fl, by, ms = ctypes.c_double(), ctypes.c_double(), ctypes.c_float()
+            L.pdf_debug_kernel_record(0, nm, 128, ctypes.byref(fl), ctypes.byref(by), ctypes.byref(ms))
+            L.pdf_debug_kernel_timing(0)
+            outs[name] = (dx, nm.value.decode())
+        assert 'igemm_bf16_dma' in outs['transposed'][1] and 'igemm_bf16_kernel' in outs['plain'][1], (outs['plain'][1], outs['transposed'][1])
+        ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w16.float().cpu().contiguous(), dy16.float().cpu().contiguous(), stride=1, padding=1)
+        for name in outs:
+            a = outs[name][0].cpu().double()
+            assert float((a - ref.double()).abs().max()) <= 2e-5 * float(ref.abs().max()) * 8, name
+        # linear: dx[M][K] = dy[M][N] w[N][K]
+        M, Nn, K = 4096, 256, 512
+        wl = (torch.randn(Nn, K, generator=g) * 0.05).to(dev)
+        gl = torch.randn(M, Nn, generator=g).to(dev)
+        wl16, gl16, wl16t = wl.to(torch.bfloat16), gl.to(torch.bfloat16), wl.t().contiguous().to(torch.bfloat16)
+        dxl = torch.empty(M, K, device=dev)
+        o = hip.CallOpts(op0_bf16=ptr(gl16), op1_bf16=ptr(wl16), op1_bf16_t=ptr(wl16t))
+        L.pdf_linear_bwd_data_x(ptr(gl), ptr(wl), ptr(dxl), M, Nn, K, Nn, K, K, stream(), ctypes.byref(o))
+        refl = gl16.float() @ wl16.float()
+        assert float((dxl - refl).abs().max()) <= 2e-5 * float(refl.abs().max()) * 8
+    finally:
+        F.set_gemm_precision('fp32')
