@@ -287,7 +287,8 @@ def fps_hbm(dev, Bc=64, N=4096, S=1024):
     t = e0.elapsed_time(e1) * 1e-3 / 3
     nb = Bc * (N * 12 + S * 4)
     return {"clouds": Bc, "points": N, "picks": S, "ms": round(t * 1e3, 3), "us_per_pick": round(t / S * 1e6, 3),
-            "algorithmic_MB": round(nb / 1e6, 2), "achieved_GBs": round(nb / t / 1e9, 2), "bound": "latency (S dependent arg-max rounds per cloud)"}
+            "algorithmic_MB": round(nb / 1e6, 2), "achieved_GBs": round(nb / t / 1e9, 2), "bound": "latency (S dependent arg-max rounds per cloud)",
+            "kernel": "fps_wave_kernel (one wave per cloud, 16 points per lane, DPP arg-max)" if N <= 1024 else "fps_kernel (one 1,024-thread block per cloud)"}
 
 
 def _flush_c_stdout():
@@ -319,6 +320,30 @@ def pmc_traffic():
                 "%s (rocprofv3 --pmc, %s)" % (os.path.basename(p), d.get("tag", "")))
     except Exception as e:                                     # noqa: BLE001
         return None, None, "unreadable profile: %s" % e
+
+
+def pmc_traffic_bf16():
+    """{bf16 kernel symbol: HBM bytes per launch} from the last committed PMC profile's `bf16_symbols` (tools/profile_step.sh: separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --dtype bf16 --batch 64`), withheld when csrc/gemm_bf16.hip / gemm_dma.hip
+    have changed since (same rule as pmc_traffic)."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, "no PMC profile committed"
+    p = files[-1]
+    try:
+        d = json.load(open(p))
+        if "bf16_symbols" not in d:
+            return None, "%s has no bf16 pass" % os.path.basename(p)
+        h = hashlib.sha256()
+        for f in ("gemm_bf16.hip", "gemm_dma.hip"):
+            h.update(open(os.path.join(ROOT, "pdfnet_amd", "csrc", f), "rb").read())
+        if d.get("bf16_src_sha256") != h.hexdigest():
+            return None, "%s is older than csrc/gemm_bf16.hip / gemm_dma.hip (withheld)" % os.path.basename(p)
+        return {k: round(v["bytes_per_launch"]) for k, v in d["bf16_symbols"].items()}, "%s (rocprofv3 --pmc, bf16 B=64 run)" % os.path.basename(p)
+    except Exception as e:                                     # noqa: BLE001
+        return None, "unreadable profile: %s" % e
 
 
 def pmc_traffic_hbm():
@@ -496,6 +521,12 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
         gc.freeze()
         gc.disable()
         try:
+            # the collection above destroys what the launch-mode trial left behind (the losing mode's hipGraph and its private memory
+            # pool: tens of GB of hipFree), and the first steps after it re-grow the allocator's cache -- r04: a 1.6 s stall INSIDE the
+            # timed loop of the B=64 leg (226 ms/step at a median of 62.7), r03: 75 vs 60 ms.  Settle before the clock starts.
+            for _ in range(3):
+                tr.train_step(batch)
+            torch.cuda.synchronize()
             t0 = time.time()
             marks[0].record()
             for i in range(steps):
@@ -519,14 +550,15 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
             tr.train_step(batch)
         sym = kt.by_symbol()
         F.USE_SIDE_STREAMS = True
-        head, _ = symbol_roofline(sym, PEAK_BF16_MFMA_TFLOPS)
+        tr16, tr16_src = pmc_traffic_bf16()
+        head, _ = symbol_roofline(sym, PEAK_BF16_MFMA_TFLOPS, tr16, tr16_src)
         fl, sec = sum(v[1] for v in sym.values()), sum(v[3] for v in sym.values())
         out = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
                "median_step_ms": round(median_ms, 3), "images_per_s_at_median_step": round(B / median_ms * 1e3, 2),
                "batch": B, "steps": steps, "warmup": warmup, "launch": launch,
                "auto_choice_ms": {k: round(v, 3) for k, v in choice.items()} if choice else None,
                "final_loss": round(loss_val, 4),
-               "dominant_kernel": {k: head[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "ms_per_step")},
+               "dominant_kernel": {k: head[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "ms_per_step", "algorithmic_bytes_per_launch", "traffic", "traffic_source")},
                "all_gemm_kernels_tflops": round(fl / max(sec, 1e-9) / 1e12, 1), "gemm_ms_per_step_exclusive": round(sec * 1e3, 2),
                "step_level_frac_of_bf16_mfma_peak": round(fl / B * (B * steps / dt) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
         del tr, model, batch
@@ -716,7 +748,11 @@ def main():
         flops = sum(v[1] for v in per.values())
         secs = sum(v[2] for v in per.values())
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-        traffic, traffic_all, traffic_src = pmc_traffic() if not bf16 else (None, None, 'no PMC profile of the bf16 kernels')
+        if bf16:
+            traffic, traffic_src = pmc_traffic_bf16()
+            traffic_all = None
+        else:
+            traffic, traffic_all, traffic_src = pmc_traffic()
         # the rocprofv3 symbol with the most time per step, timed per kernel launch by the library itself (events on the launch
         # stream): name, launches and ms are one row of profiles/*_kernel_stats_exclusive.csv
         head, table = symbol_roofline(sym, peak, traffic, traffic_src)
@@ -753,6 +789,7 @@ def main():
             "per_entry_point": {k: {"calls": v[0], "MB": round(v[1] / 1e6, 1), "ms": round(v[2] * 1e3, 3), "GBs": round(v[1] / max(v[2], 1e-9) / 1e9, 1)}
                                 for k, v in sorted(hper.items())},
             "fps": fps_hbm(dev),
+            "fps_single_wave": fps_hbm(dev, Bc=64, N=1024, S=512),   # the reference's SAMPLE_NUM / sample_num_level1 (opts.py:226-228): one wave per cloud
         }
         F.USE_SIDE_STREAMS = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -15,6 +15,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 import os as _os
 
 _byref = ctypes.byref
+_CallOpts = hip.CallOpts
 USE_SIDE_STREAMS = _os.environ.get("PDFNET_SIDE_STREAMS", "1") != "0"
 _side = {}
 
@@ -175,11 +176,18 @@ def _lazy_bn(t):
     return v[:3]
 
 
+# debug aid for the bf16 storage mode: phantoms (allocated, never written) are NaN-filled so that a stray reader cannot go unnoticed
+DEBUG_PHANTOMS = _os.environ.get("PDFNET_DEBUG_PHANTOMS", "0") != "0"
+
+
 def _stored16(t):
     """The bf16 tensor that IS the value of phantom `t` (None for an ordinary tensor)."""
     v = getattr(t, '_pdf_y16', None)
-    if v is None or v[1] != t._version:
+    if v is None:
         return None
+    if v[1] != t._version:
+        # a phantom's fp32 storage was never written: once it has been modified in place there is no value left to read (ADVICE r3)
+        raise RuntimeError("pdfnet_amd: a bf16-storage phantom tensor was modified in place; its fp32 storage holds no value (PDFNET_BF16_STORAGE)")
     return v[0]
 
 
@@ -188,11 +196,27 @@ def _O(**kw):
     """The explicit per-call options of an `_x` entry point (include/pdfnet_hip.h PdfCallOpts): -> (structure, argument).  Every field a
     call takes beyond its positional arguments -- bf16 shadows of its operands, a bf16 output, a statistics request, an operand
     transform -- is in ITS argument list; nothing is armed on the thread for "the next call"."""
-    kw = {k: v for k, v in kw.items() if v is not None}
-    if not kw:
+    o = None
+    for k, v in kw.items():                                  # (the common case -- fp32 mode, no statistics -- allocates nothing)
+        if v is not None:
+            if o is None:
+                o = _CallOpts()
+            setattr(o, k, v)
+    if o is None:
         return None, None
-    o = hip.CallOpts(**kw)
     return o, _byref(o)
+
+
+def _O2(a, b):
+    """_O2(a, b) for the most frequent call shape: the two operand shadows of a GEMM-family launch."""
+    if a is None and b is None:
+        return None
+    o = _CallOpts()
+    if a is not None:
+        o.op0_bf16 = a.data_ptr()
+    if b is not None:
+        o.op1_bf16 = b.data_ptr()
+    return _byref(o)
 
 
 # ---- BatchNorm statistics out of the producing GEMM's epilogue (fp32 and bf16 kernels): a conv / linear forward called with stats=True
@@ -446,6 +470,8 @@ class _Conv2d(Function):
         _L().pdf_conv2d_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream(), oa)
         _stats_attach(y, part, o)
         if y16 is not None:
+            if DEBUG_PHANTOMS:
+                y.fill_(float('nan'))                       # any reader of the unwritten fp32 storage then shows up as NaN downstream
             y._pdf_y16 = (y16, y._version)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.s16 = (x16, w16)
@@ -490,7 +516,7 @@ class _Conv2d(Function):
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(R, Cout, KH * KW * Cin, x.device)
             L.pdf_conv2d_bwd_weight_x(ptr(x), gp, ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                      stride, pad, OH, OW, Cout, acc, stream(), _O(op0_bf16=ptr(x16), op1_bf16=ptr(g16))[1])
+                                      stride, pad, OH, OW, Cout, acc, stream(), _O2(x16, g16))
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True, shadows=(x16, g16))
         return dx, dw, db, None, None, None, None, None
 
@@ -522,7 +548,7 @@ class _Deconv2d(Function):
         y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
         x16, w16 = shadow_of(x), shadow_of(w)
         L.pdf_deconv2d_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(),
-                             _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16))[1])
+                             _O2(x16, w16))
         ctx.save_for_backward(x, w)
         ctx.s16 = (x16, w16)
         ctx.cfg = (stride, pad, b is not None)
@@ -544,13 +570,13 @@ class _Deconv2d(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.pdf_deconv2d_bwd_data_x(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(),
-                                      _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16))[1])
+                                      _O2(g16, w16))
         w_par, b_par = ctx.params
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
             L.pdf_deconv2d_bwd_weight_x(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                        stride, pad, OH, OW, Cout, acc, stream(), _O(op0_bf16=ptr(x16), op1_bf16=ptr(g16))[1])
+                                        stride, pad, OH, OW, Cout, acc, stream(), _O2(x16, g16))
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, N * OH * OW, 2.0 * N * H * W * Cin * KH * KW * Cout, shadows=(x16, g16))
         return dx, dw, db, None, None
 
@@ -731,7 +757,12 @@ class _BatchNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, res, training, momentum, eps, relu, lazy=False):
         hip.require_gpu(x)
-        x16 = _stored16(x) if training else None            # bf16 storage mode: x is a phantom, its value is this bf16 tensor
+        x16 = _stored16(x)                                  # bf16 storage mode: x is a phantom, its value is this bf16 tensor
+        if x16 is not None and not training:
+            raise RuntimeError("pdfnet_amd: a bf16-storage phantom reached a BatchNorm in eval mode -- the producing convolution must "
+                               "be called with stats=<that BatchNorm>.training (only a training-mode BatchNorm reads the bf16 tensor)")
+        if _lazy_bn(x) is not None:
+            raise RuntimeError("pdfnet_amd: the unwritten output of a lazy BatchNorm reached another BatchNorm; only a linear layer may consume it")
         if x16 is None:
             x = _canon(x)
         res = _canon(res) if res is not None else None
@@ -801,6 +832,8 @@ class _BatchNorm(Function):
         L.pdf_bn_train_bwd_x(ptr(g), C, ptr(y), C, mode, None if x_is_16 else ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R,
                              None if x_is_16 else ptr(dx), C, ptr(dres), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream(), oa)
         if x_is_16:
+            if DEBUG_PHANTOMS:
+                dx.fill_(float('nan'))
             dx._pdf_y16 = (dx16, dx._version)               # the conv's backward takes the bf16 gradient; dx itself was not written
         elif dx16 is not None:
             attach_shadow(dx, dx16)

@@ -34,19 +34,20 @@ class Bottleneck(nn.Module):
             self.downsample = nn.Sequential(Conv2d(cin, width * 4, 1, stride, 0, bias=False), BatchNorm(width * 4))
 
     def forward(self, x):
-        tr = self.training                             # every convolution feeds a BatchNorm: statistics in the GEMM epilogue
+        # every convolution feeds a BatchNorm: statistics in the GEMM epilogue -- asked for by the CONSUMING BatchNorm's own mode
+        # (a frozen `bn.eval()` inside a train-mode block must read a materialised tensor)
         if x.requires_grad:
             # conv1 hands the input back as the shortcut's source so both gradients of x meet in conv1's backward, which
             # accumulates onto the shortcut's gradient (identity, or the projection's backward-data) in the GEMM epilogue
             # -- no separate add pass over the block input's gradient
-            y, sc = F.conv2d_with_skip(x, self.conv1.weight, None, 1, 0, stats=tr)
+            y, sc = F.conv2d_with_skip(x, self.conv1.weight, None, 1, 0, stats=self.bn1.training)
         else:
-            y, sc = self.conv1(x, stats=tr), x
+            y, sc = self.conv1(x, stats=self.bn1.training), x
         y = self.bn1(y, relu=True)
-        y = self.bn2(self.conv2(y, stats=tr), relu=True)
-        y = self.conv3(y, stats=tr)
+        y = self.bn2(self.conv2(y, stats=self.bn2.training), relu=True)
+        y = self.conv3(y, stats=self.bn3.training)
         if self.downsample is not None:
-            sc = self.downsample[1](self.downsample[0](sc, stats=tr))
+            sc = self.downsample[1](self.downsample[0](sc, stats=self.downsample[1].training))
         return self.bn3(y, relu=True, res=sc)          # relu(bn3(y) + shortcut) in one pass
 
 
@@ -131,12 +132,11 @@ class PointNet_Plus(nn.Module):
         """Rest of a set-abstraction MLP after its first 1x1 convolution (:48-65,67-103): BN -> ReLU, 2 x (conv -> BN -> ReLU),
         MaxPool over the K neighbours.  y1: rows [cloud*centroid*neighbour, channel].  The last BatchNorm, its ReLU and the
         pooling are one pass over the last convolution's output (F.bn_relu_max_over_k)."""
-        tr = seq[1].training
         # (lazy: the two inner BatchNorm + ReLU are applied by the linear layer that consumes them -- no pass over the rows, no
         # normalised tensor; F.batch_norm)
         x = seq[1](F.carry_stats(y1, y1.reshape(-1, y1.shape[-1])), relu=True, lazy=LAZY_SA_BN)
-        x = seq[4](seq[3](x, stats=tr), relu=True, lazy=LAZY_SA_BN)
-        return seq[7].relu_max_over_k(seq[6](x, stats=tr), K)
+        x = seq[4](seq[3](x, stats=seq[4].training), relu=True, lazy=LAZY_SA_BN)
+        return seq[7].relu_max_over_k(seq[6](x, stats=seq[7].training), K)
 
     @staticmethod
     def _group_conv(conv, rows, S, K, r2):
@@ -188,7 +188,7 @@ class PointNet_Plus(nn.Module):
             e2, emb2 = e2
         y = torch.cat((x[:, :S2, :3], y.view(B, S2, 256), y.new_zeros(B, S2, _pad16(259) - 259)), 2)   # [B,S2,259 | 0]
         y = self.sft2(y, e2)                                                               #              (:147)
-        y = self._mlp_max(self.netR_3, self.netR_3[0](y, stats=self.training), S2)           # [B,1024]     (:152)
+        y = self._mlp_max(self.netR_3, self.netR_3[0](y, stats=self.netR_3[1].training), S2)           # [B,1024]     (:152)
         return (y.view(B, 1, 1024), emb2) if chain else y.view(B, 1, 1024)
 
 
@@ -209,11 +209,10 @@ class ResNetSimple_decoder(nn.Module):
 
     def forward(self, x):
         fmaps = []
-        tr = self.training
-        x = self.models[0][2](self.models[0][0](x, F.ACT_RELU, stats=tr))
+        x = self.models[0][2](self.models[0][0](x, F.ACT_RELU, stats=self.models[0][2].training))
         fmaps.append(x)
         for m in list(self.models)[1:]:
-            x = m[3](m[1](F.upsample2x(x), F.ACT_RELU, stats=tr))
+            x = m[3](m[1](F.upsample2x(x), F.ACT_RELU, stats=m[3].training))
             fmaps.append(x)
         if self.up_scale:
             x = F.upsample2x(self.final_layer[1](F.upsample2x(x)))
@@ -305,7 +304,7 @@ class ResNetSimple(nn.Module):
         x1 = r.layer4(x2)
         pyr = F.l2norm_cat([self.p2(x4), self.p3(x3), self.p4(x2), self.p5(x1)],         # NHWC channel concat, written in place
                            [self.p2_l2.weight, self.p3_l2.weight, self.p4_l2.weight, self.p5_l2.weight])
-        return self.feat_bn(self.feat(pyr, stats=self.training), relu=True), emb0, x1     # :740-744
+        return self.feat_bn(self.feat(pyr, stats=self.feat_bn.training), relu=True), emb0, x1     # :740-744
 
     def trunk(self, img, ind, choose, cloud, depth=None, K_new=None, valid=None):
         """Everything the mesh decoder waits on: ResNet, pyramid, `feat`, the centre heat-map head, centre features,
@@ -345,7 +344,7 @@ class ResNetSimple(nn.Module):
         st = {'x1': x1, 'ret': {}}
         pyr = F.l2norm_cat([self.p2(x4), self.p3(x3), self.p4(x2), self.p5(x1)],         # NHWC channel concat, written in place
                            [self.p2_l2.weight, self.p3_l2.weight, self.p4_l2.weight, self.p5_l2.weight])
-        x0 = self.feat_bn(self.feat(pyr, stats=self.training), relu=True)                 # :740-744
+        x0 = self.feat_bn(self.feat(pyr, stats=self.feat_bn.training), relu=True)                 # :740-744
         st['x0'] = x0
         hm_fc = self.hm
         st['ret']['hm'] = hm_fc[2](hm_fc[0](x0, F.ACT_RELU))                               # 'hm' is first in opt.heads (:291)
@@ -438,7 +437,7 @@ class resnet_mid(nn.Module):
         fmaps = []
         for i, conv in enumerate(self.convs):
             parts = [hms_f[i], dp_f[i]] + ([img_f[i]] if i > 0 else [])
-            fmaps.append(conv[2](conv[0](torch.cat(parts, 1), F.ACT_RELU, stats=self.training)))
+            fmaps.append(conv[2](conv[0](torch.cat(parts, 1), F.ACT_RELU, stats=conv[2].training)))
         return img_f[0][:, 0], img_f[0][:, 1], fmaps
 
 

@@ -42,7 +42,7 @@ def load(d, counter, by_tile=False):
         if by_tile:
             fam = tile_name(k)
         else:
-            fam = ("igemm_nt" if ("igemm_nt" in k or "igemm_halo3x3" in k or "small_k_gemm" in k) else "wgemm_tn" if "wgemm_tn" in k else
+            fam = ("igemm_nt" if ("igemm_nt" in k or "igemm_halo3x3" in k or "small_k_gemm" in k or "igemm_dma" in k) else "wgemm_tn" if "wgemm_tn" in k else
                    "reduce_slabs" if ("reduce_slabs" in k or "splitk_finish" in k) else None)
         if fam is None:
             continue
@@ -91,7 +91,42 @@ def hbm_family(fdir, wdir, steps):
     return out
 
 
+def bf16_symbols(fdir, wdir, steps, out):
+    """`--bf16 <fetch_dir> <write_dir> <steps> <out.json>`: merge the per-symbol HBM bytes of a bf16 run (bench.py --dtype bf16 --batch 64)
+    into an existing profile as `bf16_symbols`, tied to the bf16 kernel sources by `bf16_src_sha256`."""
+    def by_symbol(d, counter):
+        f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter or not re.search(r"gemm|reduce_slabs|splitk", r["Kernel_Name"]):
+                continue
+            k = re.sub(r"^void |\(.*$", "", r["Kernel_Name"])
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+        return agg
+    fs, ws = by_symbol(fdir, "FETCH_SIZE"), by_symbol(wdir, "WRITE_SIZE")
+    res = json.load(open(out))
+    res["bf16_symbols"] = {}
+    for k in sorted(set(fs) | set(ws)):
+        n = fs[k][0] or ws[k][0]
+        rb, wb = fs[k][1] * 1024 * 2, ws[k][1] * 1024
+        res["bf16_symbols"][k] = {"launches_per_step": n / steps, "read_MB_per_launch": rb / max(n, 1) / 1e6, "write_MB_per_launch": wb / max(n, 1) / 1e6,
+                                  "bytes_per_launch": (rb + wb) / max(n, 1)}
+    res["bf16_run"] = "bench.py --dtype bf16 --batch 64 (separate --pmc FETCH_SIZE / WRITE_SIZE passes, side streams off)"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("gemm_bf16.hip", "gemm_dma.hip"):
+        h.update(open(os.path.join(root, "pdfnet_amd", "csrc", f), "rb").read())
+    res["bf16_src_sha256"] = h.hexdigest()
+    json.dump(res, open(out, "w"), indent=1)
+    top = sorted(res["bf16_symbols"].items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches_per_step"])[:8]
+    for k, v in top:
+        print("bf16 %-60s %5.1f launches/step  read %8.1f MB  write %8.1f MB per launch" % (k[:60], v["launches_per_step"], v["read_MB_per_launch"], v["write_MB_per_launch"]))
+
+
 def main():
+    if sys.argv[1] == "--bf16":
+        return bf16_symbols(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
     fdir, wdir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     fe, wr = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py (separate passes)",

@@ -18,5 +18,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/$tag.fps.$c -o p -- python3 $root/tools/hbm_bench.py fps > /tmp/$tag.fps.$c.log 2>&1 < /dev/null
 done
 timeout 120 python3 $root/tools/pmc_traffic.py /tmp/$tag.FETCH_SIZE /tmp/$tag.WRITE_SIZE 3 $root/gpurun_out/${tag}_pmc_traffic.json $tag < /dev/null | cut -c1-400
+# the bf16 kernels (BASELINE configs[4] per rank: --dtype bf16 --batch 64): their own two PMC passes, merged into the same file
+for c in FETCH_SIZE WRITE_SIZE; do
+  PDFNET_SIDE_STREAMS=0 timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/$tag.bf16.$c -o p -- python3 $root/bench.py --dtype bf16 --batch 64 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-mpjpe > /tmp/$tag.bf16.$c.log 2>&1 < /dev/null
+done
+timeout 120 python3 $root/tools/pmc_traffic.py --bf16 /tmp/$tag.bf16.FETCH_SIZE /tmp/$tag.bf16.WRITE_SIZE 3 $root/gpurun_out/${tag}_pmc_traffic.json < /dev/null | cut -c1-300
+PDFNET_SIDE_STREAMS=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/$tag.kxb -o p -- python3 $root/bench.py --dtype bf16 --batch 64 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-mpjpe > /tmp/$tag.kxb.log 2>&1 < /dev/null
+cp /tmp/$tag.kxb/p_kernel_stats.csv $root/gpurun_out/${tag}_kernel_stats_exclusive_bf16_B64.csv
 timeout 120 python3 $root/tools/pmc_traffic.py /tmp/$tag.fps.FETCH_SIZE /tmp/$tag.fps.WRITE_SIZE 1 $root/gpurun_out/${tag}_pmc_fps.json $tag < /dev/null | grep fps_kernel
 ls -la $root/gpurun_out/${tag}_*
