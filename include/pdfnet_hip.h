@@ -407,7 +407,9 @@ int pdf_mano_split_coeff_bwd(const float* params, float* dparams, int ldp, long 
  *   tile_stats, tile_n, tile_rows   pdf_bn_train_fwd / pdf_bn_relu_maxk_fwd: such partials; the call skips its statistics pass.
  *   in_scale, in_shift   pdf_linear_fwd / pdf_linear_bwd_weight: x is read as relu(x * in_scale[k] + in_shift[k]).
  *   op1_bf16_t           pdf_conv2d_bwd_data(_add) / pdf_linear_bwd_data (bf16 mode): the weight's transposed bf16 shadow,
- *                        wt[c][tap][r] for w[r][tap][c] (pdf_cast_bf16_transposed); lets the LDS-DMA kernel take the launch. */
+ *                        wt[c][tap][r] for w[r][tap][c] (pdf_cast_bf16_transposed); lets the LDS-DMA kernel take the launch.
+ *   ws, ws_floats        pdf_conv2d_fwd / pdf_conv2d_bwd_data(_add), fp32 mode: a workspace of pdf_conv2d_winograd_workspace_floats floats;
+ *                        a stride-1 3x3 layer that qualifies is then computed as Winograd F(2x2, 3x3) (csrc/winograd.hip). */
 typedef struct PdfCallOpts {
     const void* op0_bf16; const void* op1_bf16;
     void* out_bf16;
@@ -417,6 +419,7 @@ typedef struct PdfCallOpts {
     const float* tile_stats; long tile_n; long tile_rows;
     const float* in_scale; const float* in_shift;
     const void* op1_bf16_t;
+    float* ws; long ws_floats;
 } PdfCallOpts;
 int pdf_linear_fwd_x(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream, PdfCallOpts* opts);
 int pdf_linear_fwd_pair_x(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream, PdfCallOpts* opts);
@@ -437,6 +440,9 @@ int pdf_bn_relu_maxk_fwd_x(const float* y, int ldy, int C, long R, int K, const 
 int pdf_l2norm_cat_fwd_x(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R, float* y, int ldy, float* const* norm, void* stream, PdfCallOpts* opts);
 /* number of hand-over slots currently armed on the calling thread (0 after every entry-point call), and sizeof(PdfCallOpts) as the
  * library was built (a binding checks its own layout against it) */
+/* Winograd F(2x2, 3x3) for stride-1 3x3 convolutions with >= 256 input channels (nn.Conv2d sites intaghand_encoder.py:602,617,675-693):
+ * floats of workspace the layer wants (PdfCallOpts::ws), 0 when it does not qualify.  Backward-data: swap Cin and Cout. */
+long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int pdf_debug_armed_slots(void);
 int pdf_debug_callopts_size(void);
 

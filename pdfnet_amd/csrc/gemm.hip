@@ -13,6 +13,17 @@
 
 #include "gemm_common.h"
 
+// winograd.hip
+long pdf_internal_wino_workspace(int N, int H, int W, int Ck, int Cn);
+int pdf_internal_wino_eligible(int N, int H, int W, int Ck, int Cn, int KH, int KW, int stride, int pad);
+int pdf_internal_conv3x3_winograd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* ws,
+                                  int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, hipStream_t s);
+// Workspace (floats) a stride-1 3x3 convolution of this shape wants for its Winograd path -- forward: (Cin, Cout) as given;
+// backward-data: call it with the channel counts swapped -- or 0 when the layer does not qualify (then no workspace is needed)
+PDF_API long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    return pdf_internal_wino_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad) ? pdf_internal_wino_workspace(N, H, W, Cin, Cout) : 0;
+}
+
 // Read the LDS fragments of the next k-pair while the MFMAs of the current one run (see igemm_nt).  Compile-time switch for A/B runs.
 #ifndef PDF_FRAG_PIPE
 #define PDF_FRAG_PIPE 0
@@ -49,7 +60,8 @@ __device__ __forceinline__ void igemm_nt_body(const IGemm& g) {    // (128x128: 
     const int wm = wave / WN, wn = wave % WN;
     const float* __restrict__ Ap = g.A; const float* __restrict__ Bp = g.B; const float* __restrict__ biasp = g.bias;
     float* __restrict__ Cp = g.C;
-    if (blockIdx.y) { Ap += g.gsA; Cp += g.gsC; Bp = g.B1; biasp = g.bias1; }
+    if (g.batch > 0) { Ap += (long)blockIdx.y * g.gsA; Bp += (long)blockIdx.y * g.gsB; Cp += (long)blockIdx.y * g.gsC; }
+    else if (blockIdx.y) { Ap += g.gsA; Cp += g.gsC; Bp = g.B1; biasp = g.bias1; }
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     int tmi, tni;
     xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
@@ -1400,7 +1412,8 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     // 1x1 layers with a short reduction (2-16 K-steps per tile) are all prologue and epilogue: the 64x64 kernel's 4x block count hides
     // them better (r02: ResNet 128->512 @32x32 49.7 -> 70.5 TFLOP/s, 64->256 @64x64 45.4 -> 53.5, 512->256 backward-data 61.6 -> 88.7);
     // the million-row PointNet++ linears keep the wide tile (54.5 vs 50.5)
-    const bool short_k = g.T == 1 && ((g.K <= 256 && g.M <= 262144) || (g.K <= 512 && g.M <= 32768)) && env_int(ENV_IG_SHORTK, 1);
+    // (a batched launch -- the 16 transform-domain products of winograd.hip -- has its tile count multiplied by the batch: wide tiles)
+    const bool short_k = g.T == 1 && g.batch == 0 && ((g.K <= 256 && g.M <= 262144) || (g.K <= 512 && g.M <= 32768)) && env_int(ENV_IG_SHORTK, 1);
     bool halo = fast && groups == 1 && g.T == 9 && !g.plain_in && g.plain_out && g.ps_cout == 0 && g.sy == 1 && g.sx == 1 && g.QW == g.W && g.QH == g.H &&
                 (g.W == 64 || g.W == 32 || g.W == 16) && (g.H * g.W) % 128 == 0 && g.M % 128 == 0 && g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) &&
                 g.Cin >= env_int(ENV_IG_HALO_MINC, 256) &&      // measured: 128-channel layers lose (94 vs 107 TFLOP/s forward), 256+ gain 2-3 %
@@ -1422,7 +1435,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     else if (g.N > 64 && t128 >= env_int(ENV_IG_T128, 600) && !short_k) {
         stat_plan(g, stat_cap, 128);
         const int dma = env_int(ENV_IG_DMA128, 0);
-        if (!(dma > 0 && fast && launch_igemm_dma(g, 128, dma - 1, groups, 0, s)))
+        if (!(dma > 0 && fast && g.batch == 0 && launch_igemm_dma(g, 128, dma - 1, groups, 0, s)))
             launch_igemm_tile<128, 128, 2, 2>(g, fast, dim3(cdiv(g.M, 128) * cdiv(g.N, 128), groups), s);
         g_last_tile = 128128;
     }
@@ -1447,6 +1460,22 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     }
     PDF_LAUNCH_CHECK();
     return 0;
+}
+
+// `batch` independent plain GEMMs C_b[M][N] = A_b[M][K] B_b[N][K]^T in ONE launch (fp32 MFMA kernels only): operand b at base + b * gs*.
+// Used by the Winograd path (winograd.hip), whose 16 transform-domain products would each fill the chip only two thirds on their own.
+int pdf_internal_batched_gemm(const float* A, const float* B, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, hipStream_t s) {
+    IGemm g = {};
+    g.A = A; g.B = B; g.C = C; g.bias = nullptr;
+    g.M = M; g.N = N; g.K = K; g.Cin = K; g.lda = K; g.ldb = K; g.ldc = N;
+    g.T = 1; g.plain_in = 1; g.plain_out = 1; g.act = 0;
+    g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
+    g.batch = batch; g.gsA = gsA; g.gsB = gsB; g.gsC = gsC;
+    const int saved = g_gemm_bf16;                          // (transform-domain products stay fp32)
+    g_gemm_bf16 = 0;
+    const int rc = launch_igemm(g, s, batch);
+    g_gemm_bf16 = saved;
+    return rc;
 }
 
 static void conv_taps(IGemm& g, int KH, int KW, int pad, int dil) {
@@ -1775,6 +1804,12 @@ static int pdf_conv2d_fwd_impl(const float* x, const float* w, const float* bias
         PDF_LAUNCH_CHECK();
         return 0;
     }
+    // Winograd F(2x2, 3x3) (winograd.hip): fp32 mode, the caller handed a workspace (PdfCallOpts::ws), the layer qualifies
+    if (!g_gemm_bf16 && co.ws != nullptr && y16 == nullptr && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(co.ws) &&
+        pdf_internal_wino_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad) && co.ws_floats >= pdf_internal_wino_workspace(N, H, W, Cin, Cout)) {
+        g_last_tile = 128128;
+        return pdf_internal_conv3x3_winograd(x, ldx, w, bias, y, ldy, co.ws, N, H, W, Cin, Cout, act, 0, 0, s);
+    }
     IGemm g = {};
     g.A = x; g.B = w; g.C = y; g.bias = bias;
     g.M = N * OH * OW; g.N = Cout; g.K = KH * KW * Cin; g.Cin = Cin; g.lda = ldx; g.ldb = KH * KW * Cin; g.ldc = ldy;
@@ -1804,6 +1839,12 @@ static int conv2d_bwd_data(const float* dy, const float* w, float* dx,
     const Shadows sh = {co.op0_bf16, co.op1_bf16};
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
     if (accumulate && stride > 1) return PDF_E_BADARG;       // (every dx element must be written by exactly one launch)
+    // Winograd: dx = the 3x3 convolution of dy (Cout channels) with the mirrored taps, Cin output channels
+    if (!g_gemm_bf16 && co.ws != nullptr && lddx % 4 == 0 && lddy % 4 == 0 && aligned16(dy) && aligned16(dx) && aligned16(co.ws) && OH == H && OW == W &&
+        pdf_internal_wino_eligible(N, H, W, Cout, Cin, KH, KW, stride, pad) && co.ws_floats >= pdf_internal_wino_workspace(N, H, W, Cout, Cin)) {
+        g_last_tile = 128128;
+        return pdf_internal_conv3x3_winograd(dy, lddy, w, nullptr, dx, lddx, co.ws, N, H, W, Cout, Cin, 0, accumulate, 1, s);
+    }
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {
             IGemm g = {};

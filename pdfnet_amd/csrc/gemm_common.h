@@ -45,6 +45,9 @@ struct IGemm {
     // b_kn launches in bf16 mode: the same B as a [N][K] ROW operand -- the weight's transposed bf16 shadow, element (n, tap, c) at
     // n * ldbT + wt[tap] * Cin + c (PdfCallOpts::op1_bf16_t) -- so that the LDS-DMA kernel can take a backward-data launch
     const void* B16T; int ldbT;
+    // batched plain GEMMs in one launch (winograd.hip: the 16 transform-domain products): blockIdx.y = batch index b, operands
+    // advanced by b * gsA / gsB / gsC floats (batch > 0 replaces the two-group meaning of blockIdx.y)
+    int batch; long gsB;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 

@@ -207,6 +207,26 @@ def _O(**kw):
     return o, _byref(o)
 
 
+# Winograd F(2x2, 3x3) (csrc/winograd.hip, fp32 mode): a stride-1 3x3 convolution with many channels is handed a workspace and the
+# library computes it in the transform domain -- 2.25x fewer MFMA instructions (forward and backward-data).
+WINOGRAD = _os.environ.get("PDFNET_WINOGRAD", "1") != "0"
+_wino_cache = {}
+
+
+def _wino_ws(N, H, W, Ck, Cn, KH, KW, stride, pad, dev):
+    """-> (workspace tensor, floats) for the Winograd path of this convolution, or (None, None).  Ck: channels of the tensor that is
+    transformed (forward: Cin; backward-data: Cout), Cn: channels produced."""
+    if not WINOGRAD or _GEMM_BF16 or KH != 3 or KW != 3 or stride != 1 or pad != 1 or Ck < 128:
+        return None, None
+    key = (N, H, W, Ck, Cn)
+    n = _wino_cache.get(key)
+    if n is None:
+        n = _wino_cache[key] = _L().pdf_conv2d_winograd_workspace_floats(N, H, W, Ck, Cn, KH, KW, stride, pad)
+    if n <= 0:
+        return None, None
+    return torch.empty(n, dtype=torch.float32, device=dev), n
+
+
 def _O2(a, b):
     """_O2(a, b) for the most frequent call shape: the two operand shadows of a GEMM-family launch."""
     if a is None and b is None:
@@ -466,7 +486,9 @@ class _Conv2d(Function):
         if (stats and storage_on() and b is None and act == ACT_NONE and Cin % 16 == 0 and Cout % 16 == 0
                 and (N * OH * OW) % 128 == 0):
             y16 = torch.empty_like(y, dtype=torch.bfloat16)  # the output: y itself stays unwritten (see BF16_STORAGE)
-        o, oa = _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16), out_bf16=ptr(y16), stats_out=ptr(part), stats_cap=part.numel() if part is not None else None)
+        ws, nws = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, x.device)
+        o, oa = _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16), out_bf16=ptr(y16), stats_out=ptr(part), stats_cap=part.numel() if part is not None else None,
+                   ws=ptr(ws), ws_floats=nws)
         _L().pdf_conv2d_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream(), oa)
         _stats_attach(y, part, o)
         if y16 is not None:
@@ -501,7 +523,8 @@ class _Conv2d(Function):
         dx = dw = db = None
         L = _L()
         if ctx.needs_input_grad[0]:
-            _, oa = _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16), op1_bf16_t=ptr(ctx.w16t) if g16 is not None else None)
+            ws, nws = _wino_ws(N, H, W, Cout, Cin, KH, KW, stride, pad, x.device) if (OH == H and OW == W and gp is not None) else (None, None)
+            _, oa = _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16), op1_bf16_t=ptr(ctx.w16t) if g16 is not None else None, ws=ptr(ws), ws_floats=nws)
             if dskip is not None and stride == 1 and dskip.shape == x.shape and dskip.is_contiguous(memory_format=CL):
                 dx = dskip                                  # the shortcut's gradient (sole consumer: this node); += in the epilogue
                 L.pdf_conv2d_bwd_data_add_x(gp, ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(), oa)

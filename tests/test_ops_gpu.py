@@ -914,13 +914,13 @@ def test_fps_single_wave_kernel_and_the_reorder_option(F):
     gen = torch.Generator().manual_seed(11)
     for N, S in ((1024, 512), (1000, 128), (65, 64), (300, 300), (64, 7)):
         pts = torch.rand(5, N, 3, generator=gen)
-        pts[1, N // 2:] = pts[1, :N - N // 2]                     # duplicates: their distances freeze at <= 1e-8
+        pts[1, N // 2:] = pts[1, :N - N // 2].clone()             # duplicates: their distances freeze at <= 1e-8
         start = torch.randint(0, N, (5,), generator=gen, dtype=torch.int32)
         got = F.fps(dev(pts), S, dev(start)).cpu().numpy()
         for b in range(5):
             assert np.array_equal(got[b].astype(np.int64), O.fps_order(pts[b].numpy(), S, int(start[b]))), (N, S, b)
     pts = torch.rand(6, 1024, 3, generator=gen)
-    pts[2, 700:] = pts[2, :324]
+    pts[2, 700:] = pts[2, :324].clone()
     choose = torch.randint(0, 65536, (6, 1024), generator=gen)
     s1 = torch.randint(0, 1024, (6,), generator=gen, dtype=torch.int32)
     s2 = torch.randint(0, 512, (6,), generator=gen, dtype=torch.int32)
