@@ -408,7 +408,7 @@ int pdf_mano_split_coeff_bwd(const float* params, float* dparams, int ldp, long 
  *   in_scale, in_shift   pdf_linear_fwd / pdf_linear_bwd_weight: x is read as relu(x * in_scale[k] + in_shift[k]).
  *   op1_bf16_t           pdf_conv2d_bwd_data(_add) / pdf_linear_bwd_data (bf16 mode): the weight's transposed bf16 shadow,
  *                        wt[c][tap][r] for w[r][tap][c] (pdf_cast_bf16_transposed); lets the LDS-DMA kernel take the launch.
- *   ws, ws_floats        pdf_conv2d_fwd / pdf_conv2d_bwd_data(_add), fp32 mode: a workspace of pdf_conv2d_winograd_workspace_floats floats;
+ *   ws, ws_floats        pdf_conv2d_fwd / pdf_conv2d_bwd_data(_add) / pdf_conv2d_bwd_weight, fp32 mode: a workspace of pdf_conv2d_winograd_workspace_floats floats;
  *                        a stride-1 3x3 layer that qualifies is then computed as Winograd F(2x2, 3x3) (csrc/winograd.hip). */
 typedef struct PdfCallOpts {
     const void* op0_bf16; const void* op1_bf16;
@@ -441,8 +441,9 @@ int pdf_l2norm_cat_fwd_x(int nparts, const float* const* x, const int* C, const 
 /* number of hand-over slots currently armed on the calling thread (0 after every entry-point call), and sizeof(PdfCallOpts) as the
  * library was built (a binding checks its own layout against it) */
 /* Winograd F(2x2, 3x3) for stride-1 3x3 convolutions with >= 256 input channels (nn.Conv2d sites intaghand_encoder.py:602,617,675-693):
- * floats of workspace the layer wants (PdfCallOpts::ws), 0 when it does not qualify.  Backward-data: swap Cin and Cout. */
-long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+ * floats of workspace the layer wants (PdfCallOpts::ws) for its forward (backward = 0), backward-data (1) or weight-gradient (2) pass,
+ * 0 when it does not qualify. */
+long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward);
 int pdf_debug_armed_slots(void);
 int pdf_debug_callopts_size(void);
 

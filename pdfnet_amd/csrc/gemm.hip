@@ -14,14 +14,20 @@
 #include "gemm_common.h"
 
 // winograd.hip
-long pdf_internal_wino_workspace(int N, int H, int W, int Ck, int Cn);
-int pdf_internal_wino_eligible(int N, int H, int W, int Ck, int Cn, int KH, int KW, int stride, int pad);
+long pdf_internal_wino_workspace(int N, int H, int W, int Ck, int Cn, int flip);
+int pdf_internal_wino_eligible(int N, int H, int W, int Ck, int Cn, int KH, int KW, int stride, int pad, int flip);
 int pdf_internal_conv3x3_winograd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* ws,
                                   int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, hipStream_t s);
-// Workspace (floats) a stride-1 3x3 convolution of this shape wants for its Winograd path -- forward: (Cin, Cout) as given;
-// backward-data: call it with the channel counts swapped -- or 0 when the layer does not qualify (then no workspace is needed)
-PDF_API long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    return pdf_internal_wino_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad) ? pdf_internal_wino_workspace(N, H, W, Cin, Cout) : 0;
+int pdf_internal_wino_wgrad_eligible(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+long pdf_internal_wino_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
+int pdf_internal_conv3x3_winograd_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* db, float* ws,
+                                        int N, int H, int W, int Cin, int Cout, int accumulate, hipStream_t s);
+// Workspace (floats) a stride-1 3x3 convolution [Cout][3][3][Cin] on N x H x W maps wants for its Winograd path -- backward = 0: the
+// forward pass, 1: backward-data, 2: the weight gradient -- or 0 when the layer does not qualify (then no workspace is needed)
+PDF_API long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward) {
+    if (backward == 2) return pdf_internal_wino_wgrad_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad) ? pdf_internal_wino_wgrad_workspace(N, H, W, Cin, Cout) : 0;
+    const int Ck = backward ? Cout : Cin, Cn = backward ? Cin : Cout;
+    return pdf_internal_wino_eligible(N, H, W, Ck, Cn, KH, KW, stride, pad, backward) ? pdf_internal_wino_workspace(N, H, W, Ck, Cn, backward) : 0;
 }
 
 // Read the LDS fragments of the next k-pair while the MFMAs of the current one run (see igemm_nt).  Compile-time switch for A/B runs.
@@ -830,7 +836,8 @@ __device__ __forceinline__ void wgemm_tn_dma_body(const WGemm& g) {
     __shared__ __attribute__((aligned(16))) float smem[ST * 2 * BK * 128];     // [stage][P|Q][k][128]  (48 KB, ONE array)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab; float* bslabp = g.bslab;
-    if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; bslabp = g.bslab1; }
+    if (g.batch > 0) { Pp += (long)blockIdx.z * g.gsP; Qp += (long)blockIdx.z * g.gsQ; bslabp = nullptr; }
+    else if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; bslabp = g.bslab1; }
     const int wm = wave / WN, wn = wave % WN;
     const int NJ = g.T * g.Cq;
     const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
@@ -1462,6 +1469,28 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     return 0;
 }
 
+// `batch` independent weight-gradient-shaped products in ONE launch of the LDS-DMA kernel: slab[b][y] [NI][NJ] = sum over rows m of split y
+// of P_b[m][:]^T Q_b[m][:]  (P_b [M][NI], Q_b [M][NJ] plain rows; M % 16 == 0, rows_per_split % 16 == 0).  The caller sums the splits.
+int pdf_internal_batched_wgemm(const float* P, const float* Q, float* slab, int batch, long gsP, long gsQ, int M, int NI, int NJ, int splits, hipStream_t s) {
+    if (M % 16 != 0 || NI % 4 != 0 || NJ % 4 != 0 || splits < 1) return PDF_E_BADARG;
+    WGemm g = {};
+    g.P = P; g.Q = Q; g.M = M; g.NI = NI; g.Cq = NJ; g.T = 1; g.ldp = NI; g.ldq = NJ; g.ldw = NJ;
+    g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1; g.plain_q = 1;
+    g.dy[0] = 0; g.dx[0] = 0; g.wt[0] = 0;
+    const int rps = cdiv(cdiv(M, splits), 16) * 16;
+    splits = cdiv(M, rps);
+    g.rows_per_split = rps;
+    g.slab = slab; g.batch = batch; g.gsP = gsP; g.gsQ = gsQ; g.gsW = (long)splits * NI * NJ;
+    g.beta = 0; g.wbytes = (unsigned)(4.0 * NI * NJ);
+    g.pbytes = (unsigned)(4.0 * M * NI); g.qbytes = (unsigned)(4.0 * M * NJ);
+    g.uniform = 2;
+    const dim3 grid((unsigned)(cdiv(NI, 128) * cdiv(NJ, 128)), (unsigned)splits, (unsigned)batch);
+    KTimer kt("wgemm_tn_dma<3, true>", 2.0 * batch * M * NI * NJ, 4.0 * batch * ((double)M * (NI + NJ) + (double)splits * NI * NJ), s);
+    hipLaunchKernelGGL((wgemm_tn_dma<3, true>), grid, dim3(256), 0, s, g);
+    PDF_LAUNCH_CHECK();
+    return splits;                                           // (> 0: the split count actually used)
+}
+
 // `batch` independent plain GEMMs C_b[M][N] = A_b[M][K] B_b[N][K]^T in ONE launch (fp32 MFMA kernels only): operand b at base + b * gs*.
 // Used by the Winograd path (winograd.hip), whose 16 transform-domain products would each fill the chip only two thirds on their own.
 int pdf_internal_batched_gemm(const float* A, const float* B, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, hipStream_t s) {
@@ -1806,7 +1835,7 @@ static int pdf_conv2d_fwd_impl(const float* x, const float* w, const float* bias
     }
     // Winograd F(2x2, 3x3) (winograd.hip): fp32 mode, the caller handed a workspace (PdfCallOpts::ws), the layer qualifies
     if (!g_gemm_bf16 && co.ws != nullptr && y16 == nullptr && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(co.ws) &&
-        pdf_internal_wino_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad) && co.ws_floats >= pdf_internal_wino_workspace(N, H, W, Cin, Cout)) {
+        pdf_internal_wino_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad, 0) && co.ws_floats >= pdf_internal_wino_workspace(N, H, W, Cin, Cout, 0)) {
         g_last_tile = 128128;
         return pdf_internal_conv3x3_winograd(x, ldx, w, bias, y, ldy, co.ws, N, H, W, Cin, Cout, act, 0, 0, s);
     }
@@ -1841,7 +1870,7 @@ static int conv2d_bwd_data(const float* dy, const float* w, float* dx,
     if (accumulate && stride > 1) return PDF_E_BADARG;       // (every dx element must be written by exactly one launch)
     // Winograd: dx = the 3x3 convolution of dy (Cout channels) with the mirrored taps, Cin output channels
     if (!g_gemm_bf16 && co.ws != nullptr && lddx % 4 == 0 && lddy % 4 == 0 && aligned16(dy) && aligned16(dx) && aligned16(co.ws) && OH == H && OW == W &&
-        pdf_internal_wino_eligible(N, H, W, Cout, Cin, KH, KW, stride, pad) && co.ws_floats >= pdf_internal_wino_workspace(N, H, W, Cout, Cin)) {
+        pdf_internal_wino_eligible(N, H, W, Cout, Cin, KH, KW, stride, pad, 1) && co.ws_floats >= pdf_internal_wino_workspace(N, H, W, Cout, Cin, 1)) {
         g_last_tile = 128128;
         return pdf_internal_conv3x3_winograd(dy, lddy, w, nullptr, dx, lddx, co.ws, N, H, W, Cout, Cin, 0, accumulate, 1, s);
     }
@@ -2228,6 +2257,11 @@ static int pdf_conv2d_bwd_weight_impl(const float* x, const float* dy, float* dw
                                   int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s, PdfCallOpts& co) {
     const Shadows sh = {co.op0_bf16, co.op1_bf16};                       // op0: x, op1: dy
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    // Winograd F(4x4, 3x3) weight gradient (winograd.hip): fp32 mode, the caller handed a workspace (PdfCallOpts::ws), the layer qualifies
+    if (!g_gemm_bf16 && co.ws != nullptr && dy != nullptr && OH == H && OW == W && ldx % 4 == 0 && lddy % 4 == 0 && aligned16(x) && aligned16(dy) &&
+        aligned16(co.ws) && pdf_internal_wino_wgrad_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad) &&
+        co.ws_floats >= pdf_internal_wino_wgrad_workspace(N, H, W, Cin, Cout))
+        return pdf_internal_conv3x3_winograd_wgrad(x, ldx, dy, lddy, dw, db, co.ws, N, H, W, Cin, Cout, accumulate, s);
     // bf16 storage mode: dy exists only as bf16 (dy == NULL) -- the launch must be one the bf16 kernel takes with a shadow operand
     if (dy == nullptr && (sh.op1 == nullptr || db != nullptr || !g_gemm_bf16 || Cin % 16 != 0 || Cout % 16 != 0 || lddy % 8 != 0)) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && db == nullptr && (long)N * OH * OW >= (1L << 16) && ws_floats >= 81L * 64) {

@@ -209,6 +209,9 @@ struct WGemm {
     // and the tile's 128 columns belong to one tap (Cq % 128 == 0), or Q is plain rows: the pixel position, the tap and all
     // offsets except a per-thread constant are block-uniform, i.e. scalar-unit work
     int uniform;
+    // batched launch (winograd.hip weight gradients: one transform-domain plane per blockIdx.z): P, Q advanced by z * gsP / gsQ floats,
+    // the slabs of plane z start at slab + z * gsW (batch > 0 replaces the two-group meaning of blockIdx.z; no bias partials)
+    int batch; long gsW;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
@@ -219,8 +222,8 @@ struct WGemm {
 template <int TM, int TN>
 __device__ __forceinline__ void wgemm_finish(const WGemm& g, const f32x16 (&acc)[TM][TN], int i0, int j0, int wm, int wn, int lane,
                                              bool bias_thread, float bval, int tile_id, int ntiles, int* lds_flag, bool rows_whole = false) {
-    const int grp = blockIdx.z, split = blockIdx.y, splits = gridDim.y;
-    float* slabp = grp ? g.slab1 : g.slab;
+    const int grp = g.batch > 0 ? 0 : blockIdx.z, split = blockIdx.y, splits = gridDim.y;
+    float* slabp = g.batch > 0 ? g.slab + (long)blockIdx.z * g.gsW : (grp ? g.slab1 : g.slab);
     float* bslabp = grp ? g.bslab1 : g.bslab;
     const int NJ = g.T * g.Cq;
     if (g.atomic) {

@@ -865,6 +865,10 @@ static int colsum_launch(const float* g, int ldg, int C, long R, float* out, flo
     PDF_LAUNCH_CHECK();
     return 0;
 }
+int pdf_internal_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s) {
+    return colsum_launch(g, ldg, C, R, out, nullptr, accumulate, ws, s);
+}
+long pdf_internal_colsum_ws(int C, long R) { return pdf_bn_workspace_floats(C, R); }
 PDF_API int pdf_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s) {
     return colsum_launch(g, ldg, C, R, out, nullptr, accumulate, ws, s);
 }

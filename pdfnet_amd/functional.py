@@ -213,15 +213,14 @@ WINOGRAD = _os.environ.get("PDFNET_WINOGRAD", "1") != "0"
 _wino_cache = {}
 
 
-def _wino_ws(N, H, W, Ck, Cn, KH, KW, stride, pad, dev):
-    """-> (workspace tensor, floats) for the Winograd path of this convolution, or (None, None).  Ck: channels of the tensor that is
-    transformed (forward: Cin; backward-data: Cout), Cn: channels produced."""
-    if not WINOGRAD or _GEMM_BF16 or KH != 3 or KW != 3 or stride != 1 or pad != 1 or Ck < 128:
+def _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, backward, dev):
+    """-> (workspace tensor, floats) for the Winograd path of this convolution's forward (backward = 0) or backward-data pass, or (None, None)."""
+    if not WINOGRAD or _GEMM_BF16 or KH != 3 or KW != 3 or stride != 1 or pad != 1 or Cin < 64 or Cout < 64:
         return None, None
-    key = (N, H, W, Ck, Cn)
+    key = (N, H, W, Cin, Cout, backward)
     n = _wino_cache.get(key)
     if n is None:
-        n = _wino_cache[key] = _L().pdf_conv2d_winograd_workspace_floats(N, H, W, Ck, Cn, KH, KW, stride, pad)
+        n = _wino_cache[key] = _L().pdf_conv2d_winograd_workspace_floats(N, H, W, Cin, Cout, KH, KW, stride, pad, backward)
     if n <= 0:
         return None, None
     return torch.empty(n, dtype=torch.float32, device=dev), n
@@ -486,7 +485,7 @@ class _Conv2d(Function):
         if (stats and storage_on() and b is None and act == ACT_NONE and Cin % 16 == 0 and Cout % 16 == 0
                 and (N * OH * OW) % 128 == 0):
             y16 = torch.empty_like(y, dtype=torch.bfloat16)  # the output: y itself stays unwritten (see BF16_STORAGE)
-        ws, nws = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, x.device)
+        ws, nws = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 0, x.device)
         o, oa = _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16), out_bf16=ptr(y16), stats_out=ptr(part), stats_cap=part.numel() if part is not None else None,
                    ws=ptr(ws), ws_floats=nws)
         _L().pdf_conv2d_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream(), oa)
@@ -523,7 +522,7 @@ class _Conv2d(Function):
         dx = dw = db = None
         L = _L()
         if ctx.needs_input_grad[0]:
-            ws, nws = _wino_ws(N, H, W, Cout, Cin, KH, KW, stride, pad, x.device) if (OH == H and OW == W and gp is not None) else (None, None)
+            ws, nws = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 1, x.device) if (OH == H and OW == W and gp is not None) else (None, None)
             _, oa = _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16), op1_bf16_t=ptr(ctx.w16t) if g16 is not None else None, ws=ptr(ws), ws_floats=nws)
             if dskip is not None and stride == 1 and dskip.shape == x.shape and dskip.is_contiguous(memory_format=CL):
                 dx = dskip                                  # the shortcut's gradient (sole consumer: this node); += in the epilogue
@@ -538,8 +537,9 @@ class _Conv2d(Function):
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(R, Cout, KH * KW * Cin, x.device)
+            wws, nww = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 2, x.device) if (OH == H and OW == W and gp is not None) else (None, None)
             L.pdf_conv2d_bwd_weight_x(ptr(x), gp, ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                      stride, pad, OH, OW, Cout, acc, stream(), _O2(x16, g16))
+                                      stride, pad, OH, OW, Cout, acc, stream(), _O(op0_bf16=ptr(x16), op1_bf16=ptr(g16), ws=ptr(wws), ws_floats=nww)[1])
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True, shadows=(x16, g16))
         return dx, dw, db, None, None, None, None, None
 

@@ -138,7 +138,7 @@ def test_train_step_at_the_headline_batch_matches_the_fp64_oracle(headline):
     torch.cuda.synchronize()
     assert abs(loss_g - loss_o) <= 1e-4 * abs(loss_o), (loss_g, loss_o)
     named = dict(m.named_parameters())
-    bad, checked, none_o = [], 0, 0
+    bad, checked, none_o, worst = [], 0, 0, []
     for n, g64 in go.items():
         p = named[n]
         if g64 is None:
@@ -153,6 +153,9 @@ def test_train_step_at_the_headline_batch_matches_the_fp64_oracle(headline):
             continue
         cos = float((g64 * g).sum()) / (na * nb + 1e-300)
         tol = 5e-3 if 'pointnet_plus.sft0' in n else 1.5e-3  # (the cancelling 3-channel layer, see test_full_gradient_gpu.py)
+        wn0 = n[:-4] + 'weight'
+        if not (n.endswith('.bias') and wn0 in go and go[wn0] is not None and na <= 1e-6 * float(go[wn0].norm())):     # (exempt below)
+            worst.append((abs(na - nb) / (tol * na + 1e-12), 1.0 - cos, n))
         if abs(na - nb) <= tol * na + 1e-12 and cos >= 0.9999:
             checked += 1
             continue
@@ -161,6 +164,8 @@ def test_train_step_at_the_headline_batch_matches_the_fp64_oracle(headline):
             checked += 1
             continue
         bad.append((n, tuple(g.shape), na, nb, cos))
+    worst.sort(reverse=True)
+    print("gradient norm error / bar, worst five: " + "; ".join("%s %.2f (1-cos %.1e)" % (n, r, c) for r, c, n in worst[:5]))
     assert not bad, "%d gradients off:\n" % len(bad) + "\n".join("%s %s |g64|=%.4e |g32|=%.4e cos=%.6f" % b for b in bad[:40])
     assert none_o == 332 and checked == len(go) - 332         # 324 unreachable tensors + the wh / params heads (no loss term)
     sg = m.state_dict()
@@ -215,8 +220,12 @@ HEAVY_CONVS = [  # N, Cin, H, W, Cout, k, stride, pad, bias      (layer; entry o
 @pytest.mark.parametrize("winograd", [True, False])
 @pytest.mark.parametrize("cfg", HEAVY_CONVS)
 def test_heaviest_convolutions_of_the_step_at_their_real_size(cfg, winograd, monkeypatch):
-    """winograd: the stride-1 3x3 layers with >= 128 channels go through Winograd F(2x2, 3x3) (csrc/winograd.hip) by default; False
-    keeps the direct implicit-GEMM kernels (LDS-halo 128x128 tile, 64x64 tile) value-checked at the same sizes."""
+    """winograd: the stride-1 3x3 layers with >= 128 channels go through the Winograd path (csrc/winograd.hip: F(4x4, 3x3), F(2x2, 3x3)
+    for the forward of `feat`) by default; False keeps the direct implicit-GEMM kernels (LDS-halo 128x128 tile, 64x64 tile) value-checked
+    at the same sizes.  F(4x4) arithmetic itself carries ~4e-5 absolute error on values of a few units in fp32 (its transform matrices
+    hold 4, 5, 8, 1/6, 1/24; measured with a float32 emulation of the algorithm against float64, tools/experiments/r04/wino_error.py):
+    the forward / input-gradient bars of a Winograd run are widened by that much -- the model-level parity bars are NOT (the B=32
+    train step keeps every gradient inside its bar against the float64 oracle with this path on)."""
     from pdfnet_amd import functional as F
     N, Cin, H, W, Cout, k, s, p, bias = cfg
     if not winograd and not (k == 3 and s == 1 and Cin >= 128):
@@ -238,13 +247,14 @@ def test_heaviest_convolutions_of_the_step_at_their_real_size(cfg, winograd, mon
     out.backward(gy.cuda())
     F.join_wgrad()
     K, M = Cin * k * k, N * ref.shape[2] * ref.shape[3]
-    _close(out, ref, 3e-5 * max(1, K ** 0.5 / 16), 1e-5, "conv fwd")
-    _close(xd.grad, xr.grad, 1e-4, 2e-5, "conv dx")
+    f4 = 2e-4 if (winograd and k == 3 and s == 1 and Cin >= 128) else 0.0
+    _close(out, ref, 3e-5 * max(1, K ** 0.5 / 16) + f4, 1e-5, "conv fwd")
+    _close(xd.grad, xr.grad, 1e-4 + f4, 2e-5, "conv dx")
     _close(wd.grad, wr.grad, 5e-5 * max(1, M ** 0.5 / 16), 5e-5, "conv dw")
     if bias:
         _close(bd.grad, br.grad, 1e-4 * max(1, M ** 0.5 / 64), 5e-5, "conv db")
     with torch.no_grad():                                      # the fused ReLU epilogue at the same size (forward only: the mask of
-        _close(F.conv2d(xd, wd, bd, s, p, 1), TF.relu(ref), 3e-5 * max(1, K ** 0.5 / 16), 1e-5, "conv + relu fwd")   # ~0 values may flip)
+        _close(F.conv2d(xd, wd, bd, s, p, 1), TF.relu(ref), 3e-5 * max(1, K ** 0.5 / 16) + f4, 1e-5, "conv + relu fwd")   # ~0 values may flip)
 
 
 @pytest.mark.parametrize("cfg", [(32, 512, 32, 32, 256, 4, 2, 1), (32, 1024, 16, 16, 256, 4, 4, 0), (32, 2048, 8, 8, 256, 8, 8, 0)])

@@ -1075,10 +1075,12 @@ STAT_CONVS = [(10, 256, 64, 64, 256, 3, 1, 1, 0, True), (10, 128, 64, 64, 256, 3
 
 
 @pytest.mark.parametrize("cfg", STAT_CONVS)
-def test_batchnorm_statistics_from_the_gemm_epilogue(F, cfg):
+def test_batchnorm_statistics_from_the_gemm_epilogue(F, cfg, monkeypatch):
     """conv -> training BatchNorm with the statistics taken out of the GEMM accumulators (IGemm::stat, per-row-block Chan
     partials, fp64 combination in pdf_bn_train_fwd): same output, saved statistics, running statistics and gradients as the
-    BatchNorm's own statistics pass over the stored tensor, and both agree with a float64 evaluation."""
+    BatchNorm's own statistics pass over the stored tensor, and both agree with a float64 evaluation.  (The subject is the direct
+    kernels' epilogue: the Winograd path, which has none -- its BatchNorm runs its own statistics pass -- is switched off here.)"""
+    monkeypatch.setattr(F, "WINOGRAD", False)
     N, Cin, H, W, Cout, k, st, pad, act, has_epilogue = cfg
     x = (rnd(N, Cin, H, W, seed=3) * 1.5 + 0.4)
     w = rnd(Cout, Cin, k, k, seed=4) / (Cin * k * k) ** 0.5
@@ -1109,6 +1111,35 @@ def test_batchnorm_statistics_from_the_gemm_epilogue(F, cfg):
     mean, var = y64.mean(0), y64.var(0, unbiased=True)
     close(res['epilogue'][1], (0.9 * rm0.double() + 0.1 * mean).float(), 1e-5, rtol=1e-5, what="running_mean vs float64")
     close(res['epilogue'][2], (0.9 * rv0.double() + 0.1 * var).float(), 1e-5, rtol=2e-5, what="running_var vs float64")
+
+
+def test_winograd_layers_equal_the_direct_kernels_through_a_batchnorm(F, monkeypatch):
+    """A stride-1 3x3 convolution with >= 128 channels takes the Winograd path (csrc/winograd.hip: forward, backward-data, weight gradient);
+    it has no statistics epilogue, so the BatchNorm behind it runs its own pass.  Output, running statistics and all gradients against the
+    direct kernels (bars: F(4x4) carries ~1e-5 relative error, see tests/test_headline_gpu.py)."""
+    N, Cin, H, W, Cout = 10, 256, 64, 64, 256
+    x = (rnd(N, Cin, H, W, seed=3) * 1.5 + 0.4)
+    w = rnd(Cout, Cin, 3, 3, seed=4) / (Cin * 9) ** 0.5
+    bconv = rnd(Cout, seed=8)
+    g, b = torch.rand(Cout) + 0.5, rnd(Cout, seed=2)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(F, "WINOGRAD", mode)
+        xd = dev(x).contiguous(memory_format=torch.channels_last).requires_grad_()
+        wd = dev(w).contiguous(memory_format=torch.channels_last).requires_grad_()
+        cb = dev(bconv).requires_grad_()
+        gd, bd = dev(g).requires_grad_(), dev(b).requires_grad_()
+        rm, rv = dev(torch.zeros(Cout)), dev(torch.ones(Cout))
+        y = F.conv2d(xd, wd, cb, 1, 1, 0, stats=True)
+        if mode:
+            assert F.tile_stats_of(y) is None                 # (the Winograd path reports no statistics: stats_tiles == 0)
+        out = F.batch_norm(y, gd, bd, rm, rv, True, 0.1, 1e-5, False)
+        out.backward(dev(rnd(*out.shape, seed=6)).contiguous(memory_format=torch.channels_last))
+        F.join_wgrad()
+        torch.cuda.synchronize()
+        res[mode] = (out.detach(), rm, rv, xd.grad, wd.grad, cb.grad, gd.grad, bd.grad)
+    for a, c, what in zip(res[True], res[False], ('out', 'running_mean', 'running_var', 'dx', 'dw', 'dbias', 'dgamma', 'dbeta')):
+        close(a, c.cpu(), 3e-4, rtol=5e-5, what=what)
 
 
 def test_statistics_epilogue_survives_a_large_common_offset(F):

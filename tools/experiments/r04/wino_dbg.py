@@ -12,7 +12,7 @@ for (N, Cin, H, Cout) in ((8, 256, 64, 256), (16, 256, 64, 256), (32, 256, 64, 2
     outs = []
     for use in (0, 1, 1):
         dx = torch.full((N, Cin, H, H), 7.0, device='cuda').contiguous(memory_format=CL)
-        n = L.pdf_conv2d_winograd_workspace_floats(N, H, H, Cout, Cin, 3, 3, 1, 1)
+        n = L.pdf_conv2d_winograd_workspace_floats(N, H, H, Cin, Cout, 3, 3, 1, 1, 1)
         ws = torch.empty(n, device='cuda')
         o = hip.CallOpts(ws=ptr(ws) if use else None, ws_floats=n if use else 0)
         L.pdf_conv2d_bwd_data_x(ptr(dy), ptr(w), ptr(dx), N, H, H, Cin, Cin, Cout, 3, 3, 1, 1, H, H, Cout, stream(), ctypes.byref(o))
