@@ -341,18 +341,27 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
         }
     }
 }
-// slabs [36][splits][Co][Ci] -> dw [Co][3][3][Ci] (+)= G^T (sum over splits) G      (one thread per (co, ci))
+// slabs [36][splits][Co][Ci]: the splits of every plane summed into its split 0, in split order (a small layer has one 128x128 tile per
+// plane and 32 splits: with one thread per weight element summing 36 x 32 values in turn the pass was latency-bound -- 0.16 ms per call
+// for 75 MB -- so the sum runs over all 36 Co Ci elements in parallel, four values per thread)
+__global__ __launch_bounds__(256) void wino4_slab_sum_kernel(float* __restrict__ slab, int splits, long total4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < 36 * total4; i += (long)gridDim.x * 256) {
+        const long p = i / total4, e = i - p * total4;
+        float4* base = reinterpret_cast<float4*>(slab) + p * splits * total4 + e;
+        float4 v = base[0];
+        for (int y = 1; y < splits; ++y) { const float4 w = base[(long)y * total4]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        base[0] = v;
+    }
+}
+// summed slabs (split 0 of each plane) -> dw [Co][3][3][Ci] (+)= G^T u G      (one thread per (co, ci))
 __global__ __launch_bounds__(256) void wino4_wgrad_out_kernel(const float* __restrict__ slab, int splits, float* __restrict__ dw, int Co, int Ci, int accumulate) {
     const long total = (long)Co * Ci;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int n = (int)(i / Ci), c = (int)(i - (long)n * Ci);
         float u[6][6];
 #pragma unroll
-        for (int p = 0; p < 36; ++p) {
-            float v = 0.f;
-            for (int y = 0; y < splits; ++y) v += slab[((long)p * splits + y) * total + i];
-            u[p / 6][p % 6] = v;
-        }
+        for (int p = 0; p < 36; ++p) u[p / 6][p % 6] = slab[(long)p * splits * total + i];
+        {
         float t[3][6];                                       // G^T u: rows G[:,a]
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(256) void wino4_wgrad_out_kernel(const float* __res
             float* o = dw + (((long)n * 3 + a) * 3) * Ci + c;
             if (accumulate) { o[0] += g0; o[Ci] += g1; o[2 * (long)Ci] += g2; }
             else { o[0] = g0; o[Ci] = g1; o[2 * (long)Ci] = g2; }
+        }
         }
     }
 }
@@ -388,7 +398,8 @@ int pdf_internal_wino_wgrad_eligible(int N, int H, int W, int Cin, int Cout, int
     if (KH != 3 || KW != 3 || stride != 1 || pad != 1 || H % 4 || W % 4) return 0;
     if (Cin % 16 || Cout % 16 || Cin < minc || Cout < 64) return 0;
     const long T = (long)N * (H / 4) * (W / 4);
-    if (T % 16 != 0 || T < 2048) return 0;
+    static const long minpt = getenv("PDF_WINOGRAD_MINPT") ? atol(getenv("PDF_WINOGRAD_MINPT")) : 65536;
+    if (T % 16 != 0 || 36 * T < minpt) return 0;
     if ((double)T * (Cin > Cout ? Cin : Cout) * 4.0 > 4.0e9) return 0;
     return 1;
 }
@@ -410,6 +421,7 @@ int pdf_internal_conv3x3_winograd_wgrad(const float* x, int ldx, const float* dy
     PDF_LAUNCH_CHECK();
     const int used = pdf_internal_batched_wgemm(Yh, V, slab, 36, T * Cout, T * Cin, (int)T, Cout, Cin, splits, s);
     if (used <= 0) return used < 0 ? used : PDF_E_BADARG;
+    if (used > 1) hipLaunchKernelGGL(wino4_slab_sum_kernel, dim3(grid_for(36L * Cout * Cin / 4)), dim3(256), 0, s, slab, used, (long)Cout * Cin / 4);
     hipLaunchKernelGGL(wino4_wgrad_out_kernel, dim3(grid_for((long)Cout * Cin)), dim3(256), 0, s, slab, used, dw, Cout, Cin, accumulate);
     PDF_LAUNCH_CHECK();
     if (db != nullptr) return pdf_internal_colsum(dy, lddy, Cout, (long)N * H * W, db, accumulate, cws, s);
@@ -447,7 +459,8 @@ int pdf_internal_wino_eligible(int N, int H, int W, int Ck, int Cn, int KH, int 
     if (m == 0 || KH != 3 || KW != 3 || stride != 1 || pad != 1) return 0;
     if (Ck % 16 != 0 || Cn % 16 != 0 || Ck < minc || Cn < 64) return 0;
     const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
-    if (P * T < 65536) return 0;                             // (the batched GEMM must fill the chip: >= 512 row blocks of 128)
+    static const long minpt = getenv("PDF_WINOGRAD_MINPT") ? atol(getenv("PDF_WINOGRAD_MINPT")) : 65536;
+    if (P * T < minpt) return 0;                             // (the batched GEMM must fill the chip: >= 512 row blocks of 128)
     if ((double)T * (Ck > Cn ? Ck : Cn) * 4.0 > 4.0e9) return 0;      // one transform-domain plane beyond 4 GB: leave it to the direct kernel
     return 1;
 }

@@ -1139,6 +1139,10 @@ def test_winograd_layers_equal_the_direct_kernels_through_a_batchnorm(F, monkeyp
         torch.cuda.synchronize()
         res[mode] = (out.detach(), rm, rv, xd.grad, wd.grad, cb.grad, gd.grad, bd.grad)
     for a, c, what in zip(res[True], res[False], ('out', 'running_mean', 'running_var', 'dx', 'dw', 'dbias', 'dgamma', 'dbeta')):
+        if what == 'dbias':                                   # a bias in front of a training BatchNorm: exactly zero in exact arithmetic --
+            for t in (a, c):                                  # both paths leave rounding noise of the sum over 40,960 pixels
+                assert float(t.abs().max()) <= 1e-5 * float(res[False][4].abs().max()), what
+            continue
         close(a, c.cpu(), 3e-4, rtol=5e-5, what=what)
 
 
