@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void wino4_wgrad_out_kernel(const float* __res
 int pdf_internal_batched_wgemm(const float* P, const float* Q, float* slab, int batch, long gsP, long gsQ, int M, int NI, int NJ, int splits, hipStream_t s);
 int pdf_internal_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s);
 long pdf_internal_colsum_ws(int C, long R);
+static long wino_minpt();
 static int wino_wgrad_splits(long T, int Co, int Ci) {
     const long tiles = 36L * cdiv(Co, 128) * cdiv(Ci, 128);
     long sp = (2304 + tiles - 1) / tiles;                    // ~3 full rounds of 768 co-resident blocks
@@ -398,8 +399,7 @@ int pdf_internal_wino_wgrad_eligible(int N, int H, int W, int Cin, int Cout, int
     if (KH != 3 || KW != 3 || stride != 1 || pad != 1 || H % 4 || W % 4) return 0;
     if (Cin % 16 || Cout % 16 || Cin < minc || Cout < 64) return 0;
     const long T = (long)N * (H / 4) * (W / 4);
-    static const long minpt = getenv("PDF_WINOGRAD_MINPT") ? atol(getenv("PDF_WINOGRAD_MINPT")) : 65536;
-    if (T % 16 != 0 || 36 * T < minpt) return 0;
+    if (T % 16 != 0 || 36 * T < wino_minpt()) return 0;
     if ((double)T * (Cin > Cout ? Cin : Cout) * 4.0 > 4.0e9) return 0;
     return 1;
 }
@@ -437,16 +437,29 @@ static int wino_mode() {
 // the rest.  Default 11 = everything but the forward of `feat`: with F(4x4) THERE one of the 705 gradients of the B=32 step misses its
 // bar against the float64 oracle (pointnet_plus.sft1.SFT_shift_conv1.bias: 2.1e-3 of its norm, bar 1.5e-3; tools/experiments/r04/
 // wino_parity.sh), every other combination keeps all of them.
-int pdf_internal_wino_tile(int H, int W, int Ck, int Cn, int flip) {
+static long wino_minpt() {
+    static const long v = getenv("PDF_WINOGRAD_MINPT") ? atol(getenv("PDF_WINOGRAD_MINPT")) : 65536;
+    return v;
+}
+// the output tile edge for this launch: 4, 2, or 0 (not a Winograd launch).  A size only qualifies when its planes x tiles fill the chip
+// (the batched GEMM wants >= 512 row blocks of 128) and one transform-domain plane stays below 4 GB.
+int pdf_internal_wino_tile(int N, int H, int W, int Ck, int Cn, int flip) {
     static const int f4 = getenv("PDF_WINOGRAD_F4") ? atoi(getenv("PDF_WINOGRAD_F4")) : 11;
     const int mode = wino_mode();
+    if (mode == 0) return 0;
     const int bit = ((Ck > 256 || Cn > 256) ? 4 : 1) << (flip ? 1 : 0);
-    if (mode == 4 && H % 4 == 0 && W % 4 == 0 && (f4 & bit)) return 4;
-    return (mode != 0 && H % 2 == 0 && W % 2 == 0) ? 2 : 0;
+    for (int m = (mode == 4 && (f4 & bit)) ? 4 : 2; m >= 2; m -= 2) {
+        if (H % m || W % m) continue;
+        const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
+        if (P * T < wino_minpt()) continue;
+        if ((double)T * (Ck > Cn ? Ck : Cn) * 4.0 > 4.0e9) continue;
+        return m;
+    }
+    return 0;
 }
 // floats of workspace a call needs: U + V + M
 long pdf_internal_wino_workspace(int N, int H, int W, int Ck, int Cn, int flip) {
-    const int m = pdf_internal_wino_tile(H, W, Ck, Cn, flip);
+    const int m = pdf_internal_wino_tile(N, H, W, Ck, Cn, flip);
     if (m == 0) return 0;
     const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
     return P * Cn * Ck + P * T * Ck + P * T * Cn;
@@ -455,20 +468,15 @@ long pdf_internal_wino_workspace(int N, int H, int W, int Ck, int Cn, int flip) 
 // tiles like, enough work)
 int pdf_internal_wino_eligible(int N, int H, int W, int Ck, int Cn, int KH, int KW, int stride, int pad, int flip) {
     static const int minc = getenv("PDF_WINOGRAD_MINC") ? atoi(getenv("PDF_WINOGRAD_MINC")) : 128;
-    const int m = pdf_internal_wino_tile(H, W, Ck, Cn, flip);
-    if (m == 0 || KH != 3 || KW != 3 || stride != 1 || pad != 1) return 0;
+    if (KH != 3 || KW != 3 || stride != 1 || pad != 1) return 0;
     if (Ck % 16 != 0 || Cn % 16 != 0 || Ck < minc || Cn < 64) return 0;
-    const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
-    static const long minpt = getenv("PDF_WINOGRAD_MINPT") ? atol(getenv("PDF_WINOGRAD_MINPT")) : 65536;
-    if (P * T < minpt) return 0;                             // (the batched GEMM must fill the chip: >= 512 row blocks of 128)
-    if ((double)T * (Ck > Cn ? Ck : Cn) * 4.0 > 4.0e9) return 0;      // one transform-domain plane beyond 4 GB: leave it to the direct kernel
-    return 1;
+    return pdf_internal_wino_tile(N, H, W, Ck, Cn, flip) != 0;
 }
 // x [N][H][W][Ck] (ldx) * w -> y [N][H][W][Cn] (ldy).  flip = 0: forward, w = [Cn][3][3][Ck]; flip = 1: backward-data, w = [Ck][3][3][Cn]
 // (x = dy, y = dx).  ws: pdf_internal_wino_workspace(N, H, W, Ck, Cn) floats.
 int pdf_internal_conv3x3_winograd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* ws,
                                   int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, hipStream_t s) {
-    const int m = pdf_internal_wino_tile(H, W, Ck, Cn, flip);
+    const int m = pdf_internal_wino_tile(N, H, W, Ck, Cn, flip);
     const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
     float* U = ws;
     float* V = U + P * Cn * Ck;
