@@ -765,8 +765,10 @@ def main():
                 "traffic": traffic_all,
                 "per_entry_point": {k: {"calls": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 2),
                                         "tflops": round(v[1] / max(v[2], 1e-9) / 1e12, 1)} for k, v in sorted(per.items())}},
-            "formulation": "executed contraction = exact sparse centre features (SURVEY 8a6): %.0f GFLOP/img/step (measured, this line); " % (flops / 1e9 / B) +
-                           "reference formulation (dense centre convs) = 358 GFLOP/img/step",
+            "formulation": "all_gemm_kernels / step_level count ALGORITHMIC contraction FLOPs from the entry points' arguments (2 M N K of the direct "
+                           "sum, exact sparse centre features, SURVEY 8a6): %.0f GFLOP/img/step; reference formulation (dense centre convs) = 358.  " % (flops / 1e9 / B) +
+                           "The stride-1 3x3 layers with >= 128 channels EXECUTE 4x / 2.25x fewer multiplications (Winograd F(4x4,3x3) / F(2x2,3x3), "
+                           "csrc/winograd.hip, fp32): per_symbol and the dominant-kernel figures count what each kernel executes",
             "step_level": {"gflop_per_img_step_reference_formulation": ALGO_GFLOP_PER_IMG_STEP_DENSE,
                            "tflops_reference_formulation": round(ALGO_GFLOP_PER_IMG_STEP_DENSE * out["value"] / world / 1e3, 2),
                            "gflop_per_img_step_executed": round(flops / 1e9 / B, 1),
