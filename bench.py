@@ -524,9 +524,9 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
             # the collection above destroys what the launch-mode trial left behind (the losing mode's hipGraph and its private memory
             # pool: tens of GB of hipFree), and the first steps after it re-grow the allocator's cache -- r04: a 1.6 s stall INSIDE the
             # timed loop of the B=64 leg (226 ms/step at a median of 62.7), r03: 75 vs 60 ms.  Settle before the clock starts.
-            for _ in range(3):
+            for _ in range(8):
                 tr.train_step(batch)
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
             t0 = time.time()
             marks[0].record()
             for i in range(steps):
