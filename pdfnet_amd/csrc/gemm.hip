@@ -1500,11 +1500,8 @@ int pdf_internal_batched_gemm(const float* A, const float* B, float* C, int batc
     g.T = 1; g.plain_in = 1; g.plain_out = 1; g.act = 0;
     g.H = 1; g.W = M; g.QH = 1; g.QW = M; g.sy = 1; g.sx = 1;
     g.batch = batch; g.gsA = gsA; g.gsB = gsB; g.gsC = gsC;
-    const int saved = g_gemm_bf16;                          // (transform-domain products stay fp32)
-    g_gemm_bf16 = 0;
-    const int rc = launch_igemm(g, s, batch);
-    g_gemm_bf16 = saved;
-    return rc;
+    if (g_gemm_bf16) return PDF_E_BADARG;                   // (transform-domain products are fp32 only: the callers check the precision mode)
+    return launch_igemm(g, s, batch);
 }
 
 static void conv_taps(IGemm& g, int KH, int KW, int pad, int dil) {
