@@ -250,7 +250,7 @@ class HbmProfiler:
                     e0.record()
                     r = _fn(*a)
                     e1.record()
-                    self.records.append((_n, float(self.nbytes(_n, a)), e0, e1))
+                    self.records.append((_n, float(self.nbytes(_n, a)), e0, e1, tuple(v for v in a if isinstance(v, int) and 0 < v < (1 << 32))))
                     return r
                 setattr(self.lib, n, wrapped)
         return self
@@ -262,12 +262,22 @@ class HbmProfiler:
     def summary(self):
         torch.cuda.synchronize()
         per = {}
-        for n, b, e0, e1 in self.records:
+        for n, b, e0, e1, _ in self.records:
             d = per.setdefault(n, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += b
             d[2] += e0.elapsed_time(e1) * 1e-3
         return per
+
+    def by_shape(self):
+        torch.cuda.synchronize()
+        per = {}
+        for n, b, e0, e1, ints in self.records:
+            d = per.setdefault((n, ints), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += b
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        return sorted(per.items(), key=lambda kv: -kv[1][2])
 
 
 def fps_hbm(dev, Bc=64, N=4096, S=1024):
@@ -648,6 +658,7 @@ def main():
     ap.add_argument('--no-check-grads', action='store_true')
     ap.add_argument('--no-bf16-legs', action='store_true', help='skip the bf16 B=32 / B=64 per-GPU legs (bf16_per_gpu) of the default fp32 run')
     ap.add_argument('--gemm-shapes', default=None, help='write the per-shape table of the instrumented step to this file')
+    ap.add_argument('--hbm-shapes', default=None, help='the same for the HBM-bound entry points (integer arguments, algorithmic MB, ms, GB/s)')
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 8 if args.config == 'rgb-encoder' else 32
@@ -744,6 +755,10 @@ def main():
             with open(args.gemm_shapes, 'w') as f:
                 for (n, ints), (c, fl, sec) in prof.by_shape():
                     f.write("%-26s %-60s calls %3d  %8.3f ms  %6.1f TF\n" % (n, ' '.join(map(str, ints)), c, sec * 1e3, fl / max(sec, 1e-9) / 1e12))
+        if args.hbm_shapes:
+            with open(args.hbm_shapes, 'w') as f:
+                for (n, ints), (c, nb, sec) in hprof.by_shape():
+                    f.write("%-26s %-48s calls %3d  %9.1f MB  %8.3f ms  %7.1f GB/s\n" % (n, ' '.join(map(str, ints)), c, nb / 1e6, sec * 1e3, nb / max(sec, 1e-9) / 1e9))
         calls = sum(v[0] for v in per.values())
         flops = sum(v[1] for v in per.values())
         secs = sum(v[2] for v in per.values())

@@ -144,7 +144,7 @@ int pdf_gather_sub_bwd(const float* dy, int lddy, const int* idx, float* du, int
 /* Deterministic form of the same backward (no float atomics; du needs no zero fill): pdf_invert_index turns idx [Bc][E = S*K]
  * (values in [0, N)) into per-point slot lists -- start [Bc][N + 1], list [Bc][E] ascending within a point's segment, tmp [Bc][E]
  * unused (kept for ABI stability) -- once per forward; pdf_gather_sub_bwd_sorted sums each point's rows of dy in list order.
- * E <= 65536 and (2 N + 1) * 4 + 2 E <= 160 KiB (the cloud's lists are built in LDS). */
+ * A stable counting sort in LDS, one block per cloud: (2 N + 1) * 4 <= 160 KiB, i.e. N <= 20,479; any E. */
 int pdf_invert_index(const int* idx, int Bc, int N, int E, int* start, int* list, int* tmp, void* stream);
 int pdf_gather_sub_bwd_sorted(const float* dy, int lddy, const int* start, const int* list, float* du, int ldu, float* dv, int ldv,
                               int Bc, int N, int S, int K, int C, void* stream);

@@ -1460,6 +1460,9 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
         const dim3 grid(cdiv(g.M, 64) * cdiv(g.N, 64), groups);
         const int dma = env_int(ENV_IG_DMA, 0);
         // K-step 32 for the small tile: its 8 MFMAs per wave and 16-wide step leave the barrier exposed (l4 3x3: 62 -> 72 TFLOP/s)
+        // (a deep-ring form for the mesh decoder's latency-bound products -- the whole reduction in flight before the first MFMA, 4-8 stages
+        // of the LDS-DMA kernel on <= 512 / 1024 tiles -- was measured: the pair entry points unchanged, the step 0.5-3 % slower;
+        // profiles/r04_igemm_dma_ab.txt)
         if (dma > 0 && fast && launch_igemm_dma(g, 64, dma - 1, groups, 0, s)) {}
         else if (fast && g.Cin % 32 == 0 && env_int(ENV_IG_BK32, 1)) launch_igemm_tile<64, 64, 2, 2, 32>(g, fast, grid, s);
         else launch_igemm_tile<64, 64, 2, 2>(g, fast, grid, s);

@@ -227,6 +227,15 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
 // flight per thread.  The scalar forms above moved 1.1-1.6 TB/s (one 4-byte load in flight per thread).
 #define V4_TX 16
 #define V4_TY 16
+// rows a block of the float4 kernels walks: rows_per_chunk > 0: its own contiguous chunk [blockIdx.y * rpc, ...); < 0: the chunks taken
+// from the END of the tensor (bn_second_pass_reverse); == 0: INTERLEAVED -- block y takes the 16-row groups y, y + gridDim.y, ... so the
+// whole grid reads one moving window of the tensor instead of gridDim.y separate streams (bn_interleave)
+__device__ __forceinline__ void v4_rows(long rows_per_chunk, long R, int ty, long& rs, long& re, long& rstep) {
+    if (rows_per_chunk == 0) { rs = (long)blockIdx.y * V4_TY + ty; re = R; rstep = (long)gridDim.y * V4_TY; return; }
+    const long rpc = rows_per_chunk < 0 ? -rows_per_chunk : rows_per_chunk;
+    const long r0 = (rows_per_chunk < 0 ? (long)(gridDim.y - 1 - blockIdx.y) : (long)blockIdx.y) * rpc;
+    rs = r0 + ty; re = min(R, r0 + rpc); rstep = V4_TY;
+}
 __device__ __forceinline__ void v4_block_reduce(float4 a, float4 b, float4 (&sa)[V4_TY][V4_TX], float4 (&sb)[V4_TY][V4_TX],
                                                 float* __restrict__ part, int C, int c0, bool two, bool wt = false) {
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
@@ -269,13 +278,14 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
     __shared__ float4 sa[V4_TY][V4_TX], sb[V4_TY][V4_TX];
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
-    const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    long rs, re, rstep;
+    v4_rows(rows_per_chunk, R, ty, rs, re, rstep);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (c0 < C) {
         const float4 sh = ld_x4<X16>(x, c0);
         if (X16 && blockIdx.y == 0 && ty == 0) *reinterpret_cast<float4*>(fin.shift0 + c0) = sh;      // (the finaliser's `x[c]`: row 0 as floats)
 #pragma unroll 4
-        for (long r = r0 + ty; r < r1; r += V4_TY) {
+        for (long r = rs; r < re; r += rstep) {
             float4 v = ld_x4<X16>(x, r * ldx + c0);
             v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
@@ -302,14 +312,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
     const long RT = R;
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
-    const long r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    long row_s, row_e, row_step;
+    v4_rows(rows_per_chunk, R, ty, row_s, row_e, row_step);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (c0 < C) {
         const float4 m = *reinterpret_cast<const float4*>(mean + c0), rs = *reinterpret_cast<const float4*>(rstd + c0);
         float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
         if (relu == 2) { sc = *reinterpret_cast<const float4*>(scale + c0); sh = *reinterpret_cast<const float4*>(shift + c0); }
 #pragma unroll 4
-        for (long r = r0 + ty; r < r1; r += V4_TY) {
+        for (long r = row_s; r < row_e; r += row_step) {
             float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c0);
             const float4 xv = ld_x4<X16>(x, r * ldx + c0);
             if (relu) {
@@ -363,12 +374,11 @@ __global__ __launch_bounds__(256) void affine_apply_v4_kernel(const float* __res
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
     if (c0 >= C) return;
-    const long r0 = (rows_per_chunk < 0 ? (long)(gridDim.y - 1 - blockIdx.y) : (long)blockIdx.y) * (rows_per_chunk < 0 ? -rows_per_chunk : rows_per_chunk);
-    rows_per_chunk = rows_per_chunk < 0 ? -rows_per_chunk : rows_per_chunk;        // (negative: chunks walked from the END of the tensor, see bn_second_pass_order)
-    const long r1 = min(R, r0 + rows_per_chunk);
+    long row_s, row_e, row_step;
+    v4_rows(rows_per_chunk, R, ty, row_s, row_e, row_step);
     const float4 sc = *reinterpret_cast<const float4*>(scale + c0), sh = *reinterpret_cast<const float4*>(shift + c0);
 #pragma unroll 4
-    for (long r = r0 + ty; r < r1; r += V4_TY) {
+    for (long r = row_s; r < row_e; r += row_step) {
         const float4 xv = ld_x4<X16>(x, r * ldx + c0);
         float4 v = make_float4(fmaf(xv.x, sc.x, sh.x), fmaf(xv.y, sc.y, sh.y), fmaf(xv.z, sc.z, sh.z), fmaf(xv.w, sc.w, sh.w));
         if (res != nullptr) {
@@ -391,16 +401,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
     const int tx = threadIdx.x & (V4_TX - 1), ty = threadIdx.x / V4_TX;
     const int c0 = blockIdx.x * BN_CT + tx * 4;
     if (c0 >= C) return;
-    const long r0 = (rows_per_chunk < 0 ? (long)(gridDim.y - 1 - blockIdx.y) : (long)blockIdx.y) * (rows_per_chunk < 0 ? -rows_per_chunk : rows_per_chunk);
-    rows_per_chunk = rows_per_chunk < 0 ? -rows_per_chunk : rows_per_chunk;
-    const long r1 = min(R, r0 + rows_per_chunk);
+    long row_s, row_e, row_step;
+    v4_rows(rows_per_chunk, R, ty, row_s, row_e, row_step);
     const float4 m = *reinterpret_cast<const float4*>(mean + c0), rs = *reinterpret_cast<const float4*>(rstd + c0);
     const float4 ka = *reinterpret_cast<const float4*>(coef + c0), k1 = *reinterpret_cast<const float4*>(coef + C + c0),
                  k2 = *reinterpret_cast<const float4*>(coef + 2 * C + c0);
     float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
     if (relu == 2) { sc = *reinterpret_cast<const float4*>(scale + c0); sh = *reinterpret_cast<const float4*>(shift + c0); }
 #pragma unroll 4
-    for (long r = r0 + ty; r < r1; r += V4_TY) {
+    for (long r = row_s; r < row_e; r += row_step) {
         float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c0);
         const float4 xv = ld_x4<X16>(x, r * ldx + c0);
         if (relu) {
@@ -424,7 +433,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
 
 // row chunks for the streaming passes: ~4096 blocks, >= 64 rows each
 static long apply_rows_per_chunk(int C, long R) {
-    long want = 4096 / ((C + BN_CT - 1) / BN_CT);
+    static const long blocks = getenv("PDF_BN_APPLY_BLOCKS") ? atol(getenv("PDF_BN_APPLY_BLOCKS")) : 4096;
+    long want = blocks / ((C + BN_CT - 1) / BN_CT);
     if (want < 1) want = 1;
     long rpc = (R + want - 1) / want;
     if (rpc < 64) rpc = 64;
@@ -435,6 +445,10 @@ static long apply_rows_per_chunk(int C, long R) {
 // pass has just streamed.  The 256 MiB Infinity Cache is memory-side and keeps what was touched most recently (MI355X_MICROARCH.md
 // "Infinity Cache"): walking the tensor in the SAME order evicts a line just before it is wanted again once the operands exceed the
 // cache; walking it BACKWARDS meets the most recently read rows first.  sign(rows_per_chunk) carries the order into the kernels.
+static int bn_interleave() {                                  // 1: partial passes, 2: apply passes, 3: both (PDF_BN_INTERLEAVE)
+    static const int v = getenv("PDF_BN_INTERLEAVE") ? atoi(getenv("PDF_BN_INTERLEAVE")) : 0;
+    return v;
+}
 static int bn_second_pass_reverse() {
     static const int v = getenv("PDF_BN_REVERSE") ? atoi(getenv("PDF_BN_REVERSE")) : 0;
     return v;
@@ -451,11 +465,11 @@ static void launch_affine_apply(const float* x, int ldx, const float* scale, con
     if (x16 != nullptr) {                                    // (the caller checked v4_ok)
         const long rpc = apply_rows_per_chunk(C, R);
         hipLaunchKernelGGL((affine_apply_v4_kernel<true>), dim3(cdiv(C, BN_CT), (unsigned)((R + rpc - 1) / rpc)), dim3(256), 0, s,
-                           reinterpret_cast<const float*>(x16), ldx, scale, shift, res, ldr, y, ldy, C, R, bn_second_pass_reverse() ? -rpc : rpc, relu, reinterpret_cast<unsigned short*>(y16));
+                           reinterpret_cast<const float*>(x16), ldx, scale, shift, res, ldr, y, ldy, C, R, (bn_interleave() & 2) ? 0 : bn_second_pass_reverse() ? -rpc : rpc, relu, reinterpret_cast<unsigned short*>(y16));
     } else if (v4_ok(C, {ldx, ldy, res ? ldr : 0}, {x, y, res, scale, shift})) {
         const long rpc = apply_rows_per_chunk(C, R);
         hipLaunchKernelGGL((affine_apply_v4_kernel<false>), dim3(cdiv(C, BN_CT), (unsigned)((R + rpc - 1) / rpc)), dim3(256), 0, s,
-                           x, ldx, scale, shift, res, ldr, y, ldy, C, R, bn_second_pass_reverse() ? -rpc : rpc, relu, reinterpret_cast<unsigned short*>(y16));
+                           x, ldx, scale, shift, res, ldr, y, ldy, C, R, (bn_interleave() & 2) ? 0 : bn_second_pass_reverse() ? -rpc : rpc, relu, reinterpret_cast<unsigned short*>(y16));
     } else
         hipLaunchKernelGGL(affine_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, ldx, scale, shift, res, ldr, y, ldy, C, R * C, relu);
 }
@@ -463,8 +477,14 @@ static void launch_affine_apply(const float* x, int ldx, const float* scale, con
 // Training forward.  ws: >= pdf_bn_workspace_floats(C, R) floats.  scale/shift [C] are outputs the
 // caller keeps for backward-free reuse; save_mean/save_rstd [C] feed the backward.
 static long bn_chunks(int C, long R) {
-    long want = 1024 / ((C + BN_CT - 1) / BN_CT);          // ~1024 blocks over (channel tiles x chunks)
-    if (want > 256) want = 256;
+    static const long blocks = getenv("PDF_BN_PARTIAL_BLOCKS") ? atol(getenv("PDF_BN_PARTIAL_BLOCKS")) : 1024;
+    static const long cap_env = getenv("PDF_BN_PARTIAL_CAP") ? atol(getenv("PDF_BN_PARTIAL_CAP")) : 0;
+    const long ctiles = (C + BN_CT - 1) / BN_CT;
+    long want = blocks / ctiles;                            // ~1024 blocks over (channel tiles x chunks)
+    // at most 256 chunks -- but at least 512 blocks: a 64-channel tensor (one channel tile: the stem's 1M-row BatchNorm) ran its
+    // statistics passes on 256 blocks, one per CU, at 4.3 TB/s; 512 chunks: 5.2 (tools/experiments/r04/bn_ab3.sh; 1024+ lose again)
+    const long cap = cap_env > 0 ? cap_env : (512 / ctiles > 256 ? 512 / ctiles : 256);
+    if (want > cap) want = cap;
     long by_rows = (R + 63) / 64;                           // at least 64 rows per chunk
     if (want > by_rows) want = by_rows;
     if (want < 1) want = 1;
@@ -497,10 +517,10 @@ static int pdf_bn_train_fwd_impl(const float* x, int ldx, int C, long R, const f
         fin.counters = reinterpret_cast<int*>(1);            // (marks "finalised" for the branch below)
     } else if (x16 != nullptr) {
         fin.counters = bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr;
-        hipLaunchKernelGGL((bn_partial_v4_kernel<true>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, reinterpret_cast<const float*>(x16), ldx, C, R, rpc, ws, fin);
+        hipLaunchKernelGGL((bn_partial_v4_kernel<true>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, reinterpret_cast<const float*>(x16), ldx, C, R, (bn_interleave() & 1) ? 0 : rpc, ws, fin);
     } else if (v4_ok(C, {ldx}, {x})) {
         fin.counters = bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr;          // finalize in the last block of each channel tile
-        hipLaunchKernelGGL((bn_partial_v4_kernel<false>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws, fin);
+        hipLaunchKernelGGL((bn_partial_v4_kernel<false>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, (bn_interleave() & 1) ? 0 : rpc, ws, fin);
     } else
         hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, x, ldx, C, R, rpc, ws);
     PDF_LAUNCH_CHECK();
@@ -622,10 +642,10 @@ static int pdf_bn_train_bwd_impl(const float* dy, int lddy, const float* y, int 
         fin.counters = bn_inlaunch(C, R) ? pdf_ticket_counters(cdiv(C, BN_CT)) : nullptr;
         if (x16 != nullptr)
             hipLaunchKernelGGL((bn_bwd_partial_v4_kernel<true>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, xin, ldx,
-                               save_mean, save_rstd, scale, shift, C, R, rpc, ws, fin);
+                               save_mean, save_rstd, scale, shift, C, R, (bn_interleave() & 1) ? 0 : rpc, ws, fin);
         else
             hipLaunchKernelGGL((bn_bwd_partial_v4_kernel<false>), dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
-                               save_mean, save_rstd, scale, shift, C, R, rpc, ws, fin);
+                               save_mean, save_rstd, scale, shift, C, R, (bn_interleave() & 1) ? 0 : rpc, ws, fin);
     } else
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(C, BN_CT), (unsigned)chunks), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx,
                            save_mean, save_rstd, scale, shift, C, R, rpc, ws);
@@ -639,10 +659,10 @@ static int pdf_bn_train_bwd_impl(const float* dy, int lddy, const float* y, int 
         const dim3 grid(cdiv(C, BN_CT), (unsigned)((R + arpc - 1) / arpc));
         if (x16 != nullptr)
             hipLaunchKernelGGL((bn_bwd_apply_v4_kernel<true>), grid, dim3(256), 0, s, dy, lddy, y, ldy, relu,
-                               xin, ldx, save_mean, save_rstd, coef, scale, shift, C, R, bn_second_pass_reverse() ? -arpc : arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
+                               xin, ldx, save_mean, save_rstd, coef, scale, shift, C, R, (bn_interleave() & 2) ? 0 : bn_second_pass_reverse() ? -arpc : arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
         else
             hipLaunchKernelGGL((bn_bwd_apply_v4_kernel<false>), grid, dim3(256), 0, s, dy, lddy, y, ldy, relu,
-                               x, ldx, save_mean, save_rstd, coef, scale, shift, C, R, bn_second_pass_reverse() ? -arpc : arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
+                               x, ldx, save_mean, save_rstd, coef, scale, shift, C, R, (bn_interleave() & 2) ? 0 : bn_second_pass_reverse() ? -arpc : arpc, dx, lddx, dres, lddr, reinterpret_cast<unsigned short*>(dx16));
     } else if (dx16 != nullptr) return PDF_E_BADARG;
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, dy, lddy, y, ldy, relu, x, ldx, save_mean, save_rstd, coef,

@@ -226,28 +226,41 @@ __global__ __launch_bounds__(256) void gather_sub_bwd_kernel(const float* __rest
 // (centroid, neighbour) slots e = s*K + k that picked it, ascending), and the backward sums each point's rows of dy in list order
 // -- no float atomics, bit-reproducible, every du row written exactly once (no zero fill).
 //   start [Bc][N + 1] : list segment of point n = [start[n], start[n + 1])      list [Bc][E] : slots, ascending within a segment
-// One block per cloud.  Counting sort: histogram (LDS atomics: integer, order-free), exclusive scan, fill through LDS cursors in
-// arbitrary order into `tmp`, then every segment is rank-sorted into `list` (segments are short: E / N = 16-32 on average).
+// One block per cloud, a STABLE counting sort with no sorting pass: the slots are cut into one contiguous range per wave; every wave
+// histograms its range (LDS integer atomics: order-free), a scan turns the [wave][point] counts into cursors
+// (segment start + what the earlier waves hold of that point), and every wave then walks its range IN ORDER, 64 slots per round:
+// a lane's position is its cursor plus the number of LOWER lanes of the round with the same point (64 v_readlane compares), so the
+// segments come out ascending without atomics in the fill and without the rank sort this kernel used to end with -- that sort was
+// O(L^2) per segment and, on clouds where a few points own hundreds of slots (an invalid hand's all-zero cloud, ball-query padding),
+// made the launch 110-175 us for 2 MB of indices (profiles/r03, r04_kernel_stats_exclusive.csv).  Same output, bit for bit.
 #define INV_NT 1024
-__global__ __launch_bounds__(INV_NT) void invert_index_kernel(const int* __restrict__ idx, int N, int E, int* __restrict__ start,
+__global__ __launch_bounds__(INV_NT) void invert_index_kernel(const int* __restrict__ idx, int N, int E, int nw, int* __restrict__ start,
                                                               int* __restrict__ list) {
-    extern __shared__ int sm[];                              // [N] counts / cursors, [N + 1] starts, [E] unsorted slots (u16 pairs when E <= 65536)
+    extern __shared__ int sm[];                              // [nw][N] counts -> cursors, [N + 1] starts
     int* cnt = sm;
-    int* st = sm + N;
-    unsigned short* tm = reinterpret_cast<unsigned short*>(sm + 2 * N + 1);
+    int* st = sm + (long)nw * N;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* id = idx + (long)b * E;
     int* lst = list + (long)b * E;
-    for (int n = tid; n < N; n += INV_NT) cnt[n] = 0;
+    for (int i = tid; i < nw * N; i += INV_NT) cnt[i] = 0;
     __syncthreads();
+    const int per = ((E + nw - 1) / nw + 63) & ~63;          // slots per wave (whole rounds)
+    const int e0 = wave * per, e1 = min(E, e0 + per);
     // (indices are clamped into [0, N): an index outside the cloud must not reach past the LDS arrays -- ADVICE r3)
-    for (int e = tid; e < E; e += INV_NT) atomicAdd(&cnt[min(max(id[e], 0), N - 1)], 1);
+    if (wave < nw)
+        for (int e = e0 + lane; e < e1; e += 64) atomicAdd(&cnt[wave * N + min(max(id[e], 0), N - 1)], 1);
     __syncthreads();
-    if (wave == 0) {                                         // exclusive scan of the counts by one wave, 64 points per round
+    for (int n = tid; n < N; n += INV_NT) {                  // per point: counts of the waves -> offsets inside the segment; total -> st (scanned below)
+        int run = 0;
+        for (int w = 0; w < nw; ++w) { const int c = cnt[w * N + n]; cnt[w * N + n] = run; run += c; }
+        st[n] = run;
+    }
+    __syncthreads();
+    if (wave == 0) {                                         // exclusive scan of the totals by one wave, 64 points per round
         int run = 0;
         for (int n0 = 0; n0 < N; n0 += 64) {
             const int n = n0 + lane;
-            const int c = n < N ? cnt[n] : 0;
+            const int c = n < N ? st[n] : 0;
             int inc = c;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
@@ -258,49 +271,38 @@ __global__ __launch_bounds__(INV_NT) void invert_index_kernel(const int* __restr
     }
     __syncthreads();
     for (int n = tid; n <= N; n += INV_NT) start[(long)b * (N + 1) + n] = st[n];
-    for (int n = tid; n < N; n += INV_NT) cnt[n] = st[n];  // cursors
-    __syncthreads();
-    for (int e = tid; e < E; e += INV_NT) tm[atomicAdd(&cnt[min(max(id[e], 0), N - 1)], 1)] = (unsigned short)e;      // arbitrary order inside a segment ...
-    __syncthreads();
-    // ... then every segment is rank-sorted (slots are distinct), all in LDS: O(L^2) compares per segment.  Typical segments hold
-    // E / N = 16-32 slots and one wave sorts one; a degenerate cloud (an invalid hand's all-zero cloud: every centroid picks the same 64
-    // points, 512 slots each; ball-query padding that repeats one neighbour) makes a few segments long, and one wave grinding through
-    // L^2 / 64 compares while the block idles was a multi-millisecond cliff.  Segments above INV_LONG are therefore sorted
-    // by the WHOLE block (L^2 / 1024 per thread), and above INV_NOSORT -- one point owning a sixth of a 64k-slot cloud -- left in cursor
-    // order: the sums stay correct, only their order (bit-reproducibility of that one row) is given up for such an input.
-    constexpr int INV_LONG = 128, INV_NOSORT = 8192;
-    for (int n = wave; n < N; n += INV_NT / 64) {
-        const int s0 = st[n], L = st[n + 1] - s0;
-        if (L > INV_LONG) continue;
-        for (int i = lane; i < L; i += 64) {
-            const int v = tm[s0 + i];
-            int r = 0;
-            for (int j = 0; j < L; ++j) r += tm[s0 + j] < v;
-            lst[s0 + r] = v;
+    if (wave >= nw) return;
+    int* cur = cnt + wave * N;                               // this wave's cursors, relative to the segment starts
+    for (int eb = e0; eb < e1; eb += 64) {
+        const int e = eb + lane;
+        const int key = e < e1 ? min(max(id[e], 0), N - 1) : -1;
+        int below = 0, same = 0;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            const int kj = __builtin_amdgcn_readlane(key, j);
+            const int eq = kj == key;
+            same += eq;
+            below += eq & (j < lane);
         }
-    }
-    for (int n = 0; n < N; ++n) {                            // (uniform: every thread sees the same st[])
-        const int s0 = st[n], L = st[n + 1] - s0;
-        if (L <= INV_LONG) continue;
-        for (int i = tid; i < L; i += INV_NT) {
-            const int v = tm[s0 + i];
-            int r = i;
-            if (L <= INV_NOSORT) {
-                r = 0;
-                for (int j = 0; j < L; ++j) r += tm[s0 + j] < v;
-            }
-            lst[s0 + r] = v;
+        if (key >= 0) {
+            const int pos = st[key] + cur[key] + below;
+            lst[pos] = e;
+            if (below == 0) cur[key] += same;                // (one lane per point of the round; the wave's LDS accesses execute in order)
         }
     }
 }
 PDF_API int pdf_invert_index(const int* idx, int Bc, int N, int E, int* start, int* list, int* tmp, hipStream_t s) {
-    (void)tmp;                                               // (the unsorted slots live in LDS)
+    (void)tmp;
     if (Bc <= 0 || E <= 0) return 0;
-    const size_t lds = (2 * (size_t)N + 1) * 4 + (size_t)E * 2;
-    if (N <= 0 || E > 65536 || lds > 160 * 1024) return PDF_E_BADARG;
+    if (N <= 0) return PDF_E_BADARG;
+    const long room = 160 * 1024 / 4 - (N + 1);              // LDS words left for the per-wave histograms
+    int nw = (int)(room / N);
+    if (nw > INV_NT / 64) nw = INV_NT / 64;
+    if (nw < 1) return PDF_E_BADARG;
+    const size_t lds = ((size_t)nw * N + N + 1) * 4;
     static std::once_flag once;
     std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(invert_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    hipLaunchKernelGGL(invert_index_kernel, dim3(Bc), dim3(INV_NT), lds, s, idx, N, E, start, list);
+    hipLaunchKernelGGL(invert_index_kernel, dim3(Bc), dim3(INV_NT), lds, s, idx, N, E, nw, start, list);
     PDF_LAUNCH_CHECK();
     return 0;
 }

@@ -1466,7 +1466,7 @@ class _GatherSub(Function):
         L = _L()
         L.pdf_gather_sub_fwd(ptr(u), C, ptr(v), C, ptr(idx), Bc, N, S, K, C, ptr(y), C, stream())
         inv = None
-        if GATHER_SORTED and (u.requires_grad or v.requires_grad) and S * K <= 65536 and (2 * N + 1) * 4 + 2 * S * K <= 160 * 1024:
+        if GATHER_SORTED and (u.requires_grad or v.requires_grad) and (2 * N + 1) * 4 <= 160 * 1024:
             # the index inverted now, beside the forward (it is launch-bound filler there), for a backward without float atomics
             start = torch.empty((Bc, N + 1), dtype=torch.int32, device=u.device)
             lst = torch.empty((Bc, S * K), dtype=torch.int32, device=u.device)

@@ -251,6 +251,18 @@ def test_gather_sub_backward_is_deterministic_and_needs_no_atomics(F):
         order = torch.sort(flat[b], stable=True)[1].int()      # slots grouped by point, ascending inside a group
         assert torch.equal(lst[b].cpu(), order)
         assert torch.equal(start[b].cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(flat[b], minlength=N).cumsum(0)]))
+    # degenerate clouds (an invalid hand's all-zero cloud: every centroid picks the same few points) and shapes that do not divide into
+    # whole 64-slot rounds per wave, incl. a point count that leaves LDS room for fewer than 16 per-wave histograms
+    for (B2, N2, E2, hot) in ((2, 1024, 512 * 64, 64), (2, 37, 1000, 3), (1, 4000, 5000, 4000), (1, 1, 130, 1)):
+        i2 = torch.randint(0, hot, (B2, E2), generator=g, dtype=torch.int32)
+        i2[0, ::7] = N2 - 1
+        s2 = torch.empty((B2, N2 + 1), dtype=torch.int32, device='cuda')
+        l2 = torch.empty((B2, E2), dtype=torch.int32, device='cuda')
+        L.pdf_invert_index(dev(i2).data_ptr(), B2, N2, E2, s2.data_ptr(), l2.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        for b in range(B2):
+            assert torch.equal(l2[b].cpu(), torch.sort(i2[b].long(), stable=True)[1].int()), (N2, E2, hot)
+            assert torch.equal(s2[b].cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(i2[b].long(), minlength=N2).cumsum(0)]))
     outs = []
     for mode in (True, True, False):
         F.GATHER_SORTED = mode
@@ -290,6 +302,17 @@ def test_pool_upsample_relu(F):
     out.backward(dev(gy))
     close(out, ref, 2e-6, what="upsample")
     close(xd.grad, xr.grad, 1e-5, what="upsample dx")
+    for shape in ((3, 2, 16, 16), (2, 3, 5, 7)):            # channel counts the float4 kernels decline (the 2-channel mask head): gather form
+        x2 = rnd(*shape, seed=4)
+        xr = x2.clone().requires_grad_()
+        ref = TF.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=True)
+        gy2 = rnd(*ref.shape, seed=5)
+        ref.backward(gy2)
+        xd = dev(x2).requires_grad_()
+        out = F.upsample2x(xd)
+        out.backward(dev(gy2))
+        close(out, ref, 2e-6, what="upsample C=%d" % shape[1])
+        close(xd.grad, xr.grad, 1e-5, what="upsample dx C=%d" % shape[1])
     xd = dev(x).requires_grad_()
     out = F.relu(xd)
     out.backward(dev(gy[:, :, :13, :14].contiguous()))

@@ -38,6 +38,21 @@ def timeit(fn, iters=10):
 
 
 BF16 = os.environ.get("PDF_BENCH_BF16", "0") != "0"      # bf16 kernels with bf16 shadows of every operand
+WINO = os.environ.get("PDF_BENCH_WINOGRAD", "0") != "0"  # fp32: the `_x` forms with a Winograd workspace (what the train step calls)
+
+
+def wino_opts(N, H, Cin, Cout, k, s, p, backward, dev):
+    """(keep-alive tuple, byref(PdfCallOpts)) with the Winograd workspace of this pass, or (None, None) when the layer is not eligible."""
+    import ctypes
+    if not WINO or BF16:
+        return None, None
+    n = L.pdf_conv2d_winograd_workspace_floats(N, H, H, Cin, Cout, k, k, s, p, backward)
+    if n <= 0:
+        return None, None
+    ws = torch.empty(n, device=dev)
+    o = hip.CallOpts()
+    o.ws, o.ws_floats = ws.data_ptr(), n
+    return (ws, o), ctypes.byref(o)
 
 
 def sh(*ts):
@@ -66,9 +81,18 @@ def main():
         ws = torch.empty(max(n, 1), device=dev)
         fl = 2.0 * B * OH * OH * Cout * Cin * k * k
         x16, w16, dy16 = (t.to(torch.bfloat16) for t in (x, w, dy))
-        t_f = timeit(lambda: (sh(x16, w16), L.pdf_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream())))
-        t_d = timeit(lambda: (sh(dy16, w16), L.pdf_conv2d_bwd_data(ptr(dy), ptr(w), ptr(dx), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, stream())))
-        t_w = timeit(lambda: (sh(x16, dy16), L.pdf_conv2d_bwd_weight(ptr(x), ptr(dy), ptr(dw), None, ptr(ws), n, B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream())))
+        k0, o0 = wino_opts(B, H, Cin, Cout, k, s, p, 0, dev)
+        k1, o1 = wino_opts(B, H, Cin, Cout, k, s, p, 1, dev)
+        k2, o2 = wino_opts(B, H, Cin, Cout, k, s, p, 2, dev)
+        if WINO and not BF16:
+            t_f = timeit(lambda: L.pdf_conv2d_fwd_x(ptr(x), ptr(w), None, ptr(y), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream(), o0))
+            t_d = timeit(lambda: L.pdf_conv2d_bwd_data_x(ptr(dy), ptr(w), ptr(dx), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, stream(), o1))
+            t_w = timeit(lambda: L.pdf_conv2d_bwd_weight_x(ptr(x), ptr(dy), ptr(dw), None, ptr(ws), n, B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream(), o2))
+            name = name + ("*" if o0 is not None else "")                 # * = Winograd path taken
+        else:
+            t_f = timeit(lambda: (sh(x16, w16), L.pdf_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream())))
+            t_d = timeit(lambda: (sh(dy16, w16), L.pdf_conv2d_bwd_data(ptr(dy), ptr(w), ptr(dx), B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, stream())))
+            t_w = timeit(lambda: (sh(x16, dy16), L.pdf_conv2d_bwd_weight(ptr(x), ptr(dy), ptr(dw), None, ptr(ws), n, B, H, H, Cin, Cin, Cout, k, k, s, p, OH, OH, Cout, 0, stream())))
         print("%-16s M=%7d N=%5d K=%5d  %7.1f GF | fwd %6.3f ms %6.1f TF | bwd_data %6.3f ms %6.1f TF | bwd_w %6.3f ms %6.1f TF" %
               (name, B * OH * OH, Cout, Cin * k * k, fl / 1e9, t_f * 1e3, fl / t_f / 1e12, t_d * 1e3, fl / t_d / 1e12, t_w * 1e3, fl / t_w / 1e12), flush=True)
     for name, M, K, N in LINS:

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(sys.argv[1])):
         n[k] += 1
         dur[k] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
 for k, c in sorted(agg.items()):
-    if 'gemm' not in k:
+    if 'gemm' not in k and 'wino' not in k:
         continue
     wc = c['SQ_WAVE_CYCLES'] or 1
     print("%-56s x%-3d WAIT_ANY %.2f  WAIT_INST_ANY %.2f  ACTIVE_INST %.2f  WAIT_INST_LDS %.2f | MFMA_BUSY/BUSY %.3f" % (
