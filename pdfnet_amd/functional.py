@@ -161,11 +161,21 @@ def new_shadow(t):
 # bf16 shadow of it for the backward GEMMs; now it writes nothing else).  Autograd still sees fp32 tensors of the right shape --
 # allocated, never written ("phantoms"), carrying the bf16 tensor as an attribute; the library gets a NULL fp32 pointer for them
 # and refuses (PDF_E_BADARG) any launch that would have to read it.
-BF16_STORAGE = _os.environ.get("PDFNET_BF16_STORAGE", "0") != "0"
+# Default 'auto': on for convolutions over >= BF16_STORAGE_MIN_BATCH images -- measured per GPU: B=64 1,046-1,050 -> 1,063-1,076 img/s (the
+# covered BatchNorm sites 9.5 -> 5.5 ms), while at B=32 the step is bound by the host's issue time and the extra allocations and calls
+# cost more than the kernels gain (868 -> 799).  PDFNET_BF16_STORAGE=1 / 0 forces it on / off.
+_bs = _os.environ.get("PDFNET_BF16_STORAGE", "auto")
+BF16_STORAGE = 'auto' if _bs == "auto" else _bs != "0"
+BF16_STORAGE_MIN_BATCH = int(_os.environ.get("PDFNET_BF16_STORAGE_MIN_BATCH", "48"))
 
 
-def storage_on():
-    return BF16_STORAGE and BF16_SHADOWS and _GEMM_BF16
+def storage_on(batch=None):
+    """bf16 storage for a convolution over `batch` images (None: only when forced on)."""
+    if not (BF16_SHADOWS and _GEMM_BF16):
+        return False
+    if BF16_STORAGE == 'auto':
+        return batch is not None and batch >= BF16_STORAGE_MIN_BATCH
+    return bool(BF16_STORAGE)
 
 
 def _lazy_bn(t):
@@ -482,7 +492,7 @@ class _Conv2d(Function):
         x16, w16 = shadow_of(x), shadow_of(w)
         part = _stats_request(stats, N * OH * OW, Cout, x.device)
         y16 = None
-        if (stats and storage_on() and b is None and act == ACT_NONE and Cin % 16 == 0 and Cout % 16 == 0
+        if (stats and storage_on(N) and b is None and act == ACT_NONE and Cin % 16 == 0 and Cout % 16 == 0
                 and (N * OH * OW) % 128 == 0):
             y16 = torch.empty_like(y, dtype=torch.bfloat16)  # the output: y itself stays unwritten (see BF16_STORAGE)
         ws, nws = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 0, x.device)

@@ -281,3 +281,20 @@ def test_rejected_call_leaves_no_armed_slot():
     assert rc == -1 and o.stats_tiles == 0 and L.pdf_debug_armed_slots() == 8      # (an `_x` call does not touch the compat slots)
     c.pdf_linear_fwd_pair(None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, None)                 # any plain GEMM-family call clears them
     assert L.pdf_debug_armed_slots() == 0
+
+
+def test_bf16_storage_defaults_to_the_batches_where_it_wins(monkeypatch):
+    """PDFNET_BF16_STORAGE unset = 'auto': bf16 storage of the conv -> BatchNorm tensors for convolutions over >= 48 images (B=64 per GPU:
+    +2 %; at B=32 the step is host-bound and the mode loses), never outside bf16 mode; 1 / 0 force it."""
+    from pdfnet_amd import functional as F
+    monkeypatch.setattr(F, '_GEMM_BF16', True)
+    monkeypatch.setattr(F, 'BF16_SHADOWS', True)
+    monkeypatch.setattr(F, 'BF16_STORAGE', 'auto')
+    assert not F.storage_on(32) and F.storage_on(64) and not F.storage_on()
+    monkeypatch.setattr(F, 'BF16_STORAGE', True)
+    assert F.storage_on(2) and F.storage_on()
+    monkeypatch.setattr(F, 'BF16_STORAGE', False)
+    assert not F.storage_on(64)
+    monkeypatch.setattr(F, 'BF16_STORAGE', 'auto')
+    monkeypatch.setattr(F, '_GEMM_BF16', False)
+    assert not F.storage_on(64)
