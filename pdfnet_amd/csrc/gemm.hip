@@ -836,13 +836,23 @@ __device__ __forceinline__ void wgemm_tn_dma_body(const WGemm& g) {
     __shared__ __attribute__((aligned(16))) float smem[ST * 2 * BK * 128];     // [stage][P|Q][k][128]  (48 KB, ONE array)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ Pp = g.P; const float* __restrict__ Qp = g.Q; float* slabp = g.slab; float* bslabp = g.bslab;
-    if (g.batch > 0) { Pp += (long)blockIdx.z * g.gsP; Qp += (long)blockIdx.z * g.gsQ; bslabp = nullptr; }
-    else if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; bslabp = g.bslab1; }
     const int wm = wave / WN, wn = wave % WN;
     const int NJ = g.T * g.Cq;
     const int nti = (g.NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ;
+    int split = blockIdx.y, plane = blockIdx.z, lin_tile = -1;
+    if (g.batch > 0 && g.bsplits > 0) {                     // linear grid: see WGemm::bsplits
+        const int tiles = nti * ntj, slot = blockIdx.x >> 3;
+        const int grp = (slot / tiles) * 8 + (blockIdx.x & 7);
+        if (grp >= g.bsplits * g.batch) return;             // (grid padded to whole rounds of 8 groups)
+        lin_tile = slot - (slot / tiles) * tiles;
+        plane = grp / g.bsplits;
+        split = grp - plane * g.bsplits;
+    }
+    if (g.batch > 0) { Pp += (long)plane * g.gsP; Qp += (long)plane * g.gsQ; bslabp = nullptr; }
+    else if (blockIdx.z) { Pp += g.gsP; Qp += g.gsQ; slabp = g.slab1; bslabp = g.bslab1; }
     int ti, tj;
-    if (g.tap_major) {
+    if (lin_tile >= 0) { ti = lin_tile / ntj; tj = lin_tile - ti * ntj; }
+    else if (g.tap_major) {
         const int nblk = nti * ntj, q = nblk >> 3, r = nblk & 7, x = blockIdx.x & 7;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
         const int nb = g.Cq / BJ, per_cb = g.T * nti;
@@ -856,7 +866,7 @@ __device__ __forceinline__ void wgemm_tn_dma_body(const WGemm& g) {
     const int i0 = ti * BI, j0 = tj * BJ;
     const bool do_bias = bslabp != nullptr && tj == 0 && tid < BI;
     float bsum = 0.f;
-    const int ms = blockIdx.y * g.rows_per_split;
+    const int ms = split * g.rows_per_split;
     const int me = min(g.M, ms + g.rows_per_split);
     const int nt = (me - ms + BK - 1) / BK;
 
@@ -1090,7 +1100,8 @@ __device__ __forceinline__ void wgemm_tn_dma_body(const WGemm& g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup
 
-    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && i0 + tid < g.NI, bsum, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(smem), i0 + 128 <= g.NI);
+    wgemm_finish<TM, TN>(g, acc, i0, j0, wm, wn, lane, do_bias && i0 + tid < g.NI, bsum, ti * ntj + tj, nti * ntj, reinterpret_cast<int*>(smem), i0 + 128 <= g.NI,
+                         lin_tile >= 0 ? split : -1, plane);
 }
 
 template <int ST, bool BUF>
@@ -1149,10 +1160,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_IG_BUFSTORE, ENV_IG_BF16_STATS, ENV_IG_DMA, ENV_IG_DMA128, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_IG_BUFSTORE, ENV_IG_BF16_STATS, ENV_IG_DMA, ENV_IG_DMA128, ENV_WG_BATCH_XCD, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM", "PDF_IG_BUFSTORE", "PDF_IG_BF16_STATS", "PDF_IG_DMA", "PDF_IG_DMA128"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM", "PDF_IG_BUFSTORE", "PDF_IG_BF16_STATS", "PDF_IG_DMA", "PDF_IG_DMA128", "PDF_WG_BATCH_XCD"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1487,7 +1498,11 @@ int pdf_internal_batched_wgemm(const float* P, const float* Q, float* slab, int 
     g.beta = 0; g.wbytes = (unsigned)(4.0 * NI * NJ);
     g.pbytes = (unsigned)(4.0 * M * NI); g.qbytes = (unsigned)(4.0 * M * NJ);
     g.uniform = 2;
-    const dim3 grid((unsigned)(cdiv(NI, 128) * cdiv(NJ, 128)), (unsigned)splits, (unsigned)batch);
+    dim3 grid((unsigned)(cdiv(NI, 128) * cdiv(NJ, 128)), (unsigned)splits, (unsigned)batch);
+    if (env_int(ENV_WG_BATCH_XCD, 1)) {                     // the tiles of one (split, plane) on one XCD (WGemm::bsplits)
+        g.bsplits = splits;
+        grid = dim3((unsigned)(grid.x * 8 * cdiv(splits * batch, 8)));
+    }
     KTimer kt("wgemm_tn_dma<3, true>", 2.0 * batch * M * NI * NJ, 4.0 * batch * ((double)M * (NI + NJ) + (double)splits * NI * NJ), s);
     hipLaunchKernelGGL((wgemm_tn_dma<3, true>), grid, dim3(256), 0, s, g);
     PDF_LAUNCH_CHECK();

@@ -212,6 +212,10 @@ struct WGemm {
     // batched launch (winograd.hip weight gradients: one transform-domain plane per blockIdx.z): P, Q advanced by z * gsP / gsQ floats,
     // the slabs of plane z start at slab + z * gsW (batch > 0 replaces the two-group meaning of blockIdx.z; no bias partials)
     int batch; long gsW;
+    // bsplits > 0 (batched launch only): a ONE-dimensional grid whose linear id carries (tile, split, plane) so that the tiles of one
+    // (split, plane) -- the blocks that read the same rows of P_b and Q_b -- are consecutive dispatches of ONE XCD and share its L2:
+    // id & 7 = XCD, (id >> 3) = slot; group = (slot / tiles) * 8 + XCD = plane * bsplits + split, tile = slot % tiles
+    int bsplits;
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
@@ -221,9 +225,11 @@ struct WGemm {
 // bias_thread: this thread carries the bias partial `bval` of output row i0 + threadIdx.x.
 template <int TM, int TN>
 __device__ __forceinline__ void wgemm_finish(const WGemm& g, const f32x16 (&acc)[TM][TN], int i0, int j0, int wm, int wn, int lane,
-                                             bool bias_thread, float bval, int tile_id, int ntiles, int* lds_flag, bool rows_whole = false) {
-    const int grp = g.batch > 0 ? 0 : blockIdx.z, split = blockIdx.y, splits = gridDim.y;
-    float* slabp = g.batch > 0 ? g.slab + (long)blockIdx.z * g.gsW : (grp ? g.slab1 : g.slab);
+                                             bool bias_thread, float bval, int tile_id, int ntiles, int* lds_flag, bool rows_whole = false,
+                                             int split_ = -1, int plane_ = 0) {
+    // (split_ >= 0: the caller decoded split / plane from a linear grid, WGemm::bsplits)
+    const int grp = g.batch > 0 ? 0 : blockIdx.z, split = split_ >= 0 ? split_ : (int)blockIdx.y, splits = split_ >= 0 ? g.bsplits : (int)gridDim.y;
+    float* slabp = g.batch > 0 ? g.slab + (long)(split_ >= 0 ? plane_ : (int)blockIdx.z) * g.gsW : (grp ? g.slab1 : g.slab);
     float* bslabp = grp ? g.bslab1 : g.bslab;
     const int NJ = g.T * g.Cq;
     if (g.atomic) {
