@@ -4,7 +4,9 @@ tag=${1:-r03}
 mkdir -p gpurun_out
 bash tools/profile_step.sh $tag > gpurun_out/${tag}_profile.log 2>&1
 cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py --gemm-shapes gpurun_out/${tag}_gemm_shapes.txt > gpurun_out/${tag}_bench_B32_1gpu.json 2> gpurun_out/${tag}_bench_err.txt
+# the bench line looks its `traffic` up in the newest profiles/*_pmc_traffic.json taken from the SAME kernel sources: the one just made
+cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
+timeout 900 python bench.py --gemm-shapes gpurun_out/${tag}_gemm_shapes.txt --hbm-shapes gpurun_out/${tag}_hbm_shapes.txt > gpurun_out/${tag}_bench_B32_1gpu.json 2> gpurun_out/${tag}_bench_err.txt
 timeout 300 python tools/probe/phase_events.py 32 > gpurun_out/${tag}_phase_events.txt 2>&1
 timeout 300 python bench.py --config rgb-encoder --no-cpu-baseline > gpurun_out/${tag}_bench_rgb_encoder_B8.json 2>/dev/null
 timeout 300 python bench.py --batch 8 --no-cpu-baseline --no-mpjpe > gpurun_out/${tag}_bench_B8_1gpu.json 2>/dev/null
