@@ -434,17 +434,20 @@ static int wino_mode() {
 }
 // PDF_WINOGRAD=4 uses F(4x4) for the launches PDF_WINOGRAD_F4 allows -- bit 0: forward of the layers with at most 256 channels on
 // either side, bit 1: their backward-data, bit 2: forward of the wider layers (`feat`), bit 3: their backward-data -- and F(2x2) for
-// the rest.  Default 11 = everything but the forward of `feat`: with F(4x4) THERE one of the 705 gradients of the B=32 step misses its
-// bar against the float64 oracle (pointnet_plus.sft1.SFT_shift_conv1.bias: 2.1e-3 of its norm, bar 1.5e-3; tools/experiments/r04/
-// wino_parity.sh), every other combination keeps all of them.
-static long wino_minpt() {
-    static const long v = getenv("PDF_WINOGRAD_MINPT") ? atol(getenv("PDF_WINOGRAD_MINPT")) : 65536;
+// the rest.  Default 15 = all of them.  (Until late in round 4 the default was 11, everything but the forward of `feat`: with F(4x4)
+// THERE pointnet_plus.sft1.SFT_shift_conv1.bias -- one of the 705 gradients of the B=32 step -- deviates by 2.2e-3 of its norm from the
+// float64 oracle, over the fixed 1.5e-3 bar; the oracle's own float32 run deviates by 3.8e-2 on that tensor, a sum of +- terms
+// that nearly cancel, so the bar of tests/test_headline_gpu.py is now the fixed one plus twice the fp32 oracle's own deviation and the
+// launch is no exception any more: worst tensor 0.48 of its bar, every tensor that is not noise in fp32 below its FIXED bar;
+// profiles/r04_winograd_ab.txt, tools/experiments/r04/wino_parity.sh, f4_ab.sh.)
+static long wino_minpt() {                                   // planes x tiles a launch must have: 16384 takes ResNet layer 3 (36 x 512) in
+    static const long v = getenv("PDF_WINOGRAD_MINPT") ? atol(getenv("PDF_WINOGRAD_MINPT")) : 16384;
     return v;
 }
 // the output tile edge for this launch: 4, 2, or 0 (not a Winograd launch).  A size only qualifies when its planes x tiles fill the chip
 // (the batched GEMM wants >= 512 row blocks of 128) and one transform-domain plane stays below 4 GB.
 int pdf_internal_wino_tile(int N, int H, int W, int Ck, int Cn, int flip) {
-    static const int f4 = getenv("PDF_WINOGRAD_F4") ? atoi(getenv("PDF_WINOGRAD_F4")) : 11;
+    static const int f4 = getenv("PDF_WINOGRAD_F4") ? atoi(getenv("PDF_WINOGRAD_F4")) : 15;
     const int mode = wino_mode();
     if (mode == 0) return 0;
     const int bit = ((Ck > 256 || Cn > 256) ? 4 : 1) << (flip ? 1 : 0);
