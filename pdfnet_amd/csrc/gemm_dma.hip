@@ -468,7 +468,8 @@ static void launch_bf16_one(const IGemm& g, dim3 grid, hipStream_t s) {
 }
 // bf16 shadows of BOTH operands, [N][K] weights.  tile: 128 (128x128) | 64 (64x64) | 12864 (128x64).  -> 1 launched, 0 not taken
 int launch_igemm_bf16_dma(const IGemm& g, int tile, int variant, int groups, hipStream_t s) {
-    if (g.A16 == nullptr || g.B16 == nullptr || g.b_kn || g.abytes == 0 || g.bbytes == 0 || g.Cin % 8 != 0 || g.lda % 8 != 0 || g.ldb % 8 != 0 || g.C16 != nullptr) return 0;
+    if (g.A16 == nullptr || g.B16 == nullptr || g.b_kn || g.abytes == 0 || g.bbytes == 0 || g.Cin % 8 != 0 || g.lda % 8 != 0 || g.ldb % 8 != 0) return 0;
+    // (a bf16 output -- IGemm::C16, storage mode -- is written by lean_epilogue: the caller has checked whole tiles for the tile height this launcher uses too)
     if (groups > 1 && (g.B116 == nullptr || g.gsA % 8 != 0)) return 0;
     const int bm = tile == 64 ? 64 : 128, bn = tile == 128 ? 128 : 64;
     const dim3 grid((unsigned)(cdiv(g.M, bm) * cdiv(g.N, bn)), (unsigned)groups);

@@ -66,8 +66,12 @@ def test_train_forward_and_grads_match_reference_golden(setup):
         head = gr.contiguous().flatten()[:64].cpu().double().numpy()     # logical (OIHW) order
         # (1) tight, against the fp64 oracle: fp32 kernels vs exact arithmetic
         n64, h64 = float(g64[k][0]), g64["gradhead::" + name]
-        if abs(n - n64) > 1.5e-3 * n64:
-            bad.append((name, "norm64", n, n64))
+        # bar: 1.5e-3, plus twice what the REFERENCE's own fp32 gradient (the golden) deviates from the fp64 evaluation on this tensor
+        # (capped at 1e-2): 6 of the 34 golden tensors are past 1.5e-3 in the reference itself (e_conv1.weight 9.2e-3, the PointNet++ /
+        # SFT layers on the raw cloud 2.1-2.6e-3) -- there the fixed bar measures summation order, not correctness
+        tol64 = min(1.5e-3 + 2.0 * abs(float(v[0]) - n64) / n64, 1e-2)
+        if abs(n - n64) > tol64 * n64:
+            bad.append((name, "norm64", n, n64, tol64))
         if np.abs(head - h64).max() > 1.5e-2 * np.abs(h64).max() + 1e-9:
             bad.append((name, "head64", float(np.abs(head - h64).max()), float(np.abs(h64).max())))
         # (2) against the reference's own fp32 gradients, whose train-mode (B=2 batch statistics) noise is
