@@ -15,7 +15,8 @@ if d:
     print("dominant:", {k: r[k] for k in ('kernel', 'achieved', 'frac', 'launches_per_step', 'ms_per_step', 'algorithmic_gflop_per_launch', 'algorithmic_bytes_per_launch', 'traffic', 'traffic_source')})
     print("all_gemm:", {k: v for k, v in r['all_gemm_kernels'].items() if k != 'per_entry_point'})
     print("step_level:", r['step_level'])
-    for row in r['per_symbol'][:10]:
+    ps = r['per_symbol']
+    for row in (list(ps.items()) if isinstance(ps, dict) else ps)[:10]:
         print("   ", row)
     h = d['roofline_hbm']
     print("hbm pointnet:", h['achieved'], h['frac'], h['ms_per_step'], h['traffic'])
