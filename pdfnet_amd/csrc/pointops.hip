@@ -229,11 +229,12 @@ __global__ __launch_bounds__(256) void gather_sub_bwd_kernel(const float* __rest
 // One block per cloud, a STABLE counting sort with no sorting pass: the slots are cut into one contiguous range per wave; every wave
 // histograms its range (LDS integer atomics: order-free), a scan turns the [wave][point] counts into cursors
 // (segment start + what the earlier waves hold of that point), and every wave then walks its range IN ORDER, 64 slots per round:
-// a lane's position is its cursor plus the number of LOWER lanes of the round with the same point (64 v_readlane compares), so the
+// a lane's position is its cursor plus the number of LOWER lanes of the round with the same point (ballots over the key's bits), so the
 // segments come out ascending without atomics in the fill and without the rank sort this kernel used to end with -- that sort was
 // O(L^2) per segment and, on clouds where a few points own hundreds of slots (an invalid hand's all-zero cloud, ball-query padding),
 // made the launch 110-175 us for 2 MB of indices (profiles/r03, r04_kernel_stats_exclusive.csv).  Same output, bit for bit.
 #define INV_NT 1024
+#define INV_KR 32                                            // rounds of 64 slots whose keys a lane keeps in registers (16 waves x 32 x 64 = 32,768 slots: level 1's S * K)
 __global__ __launch_bounds__(INV_NT) void invert_index_kernel(const int* __restrict__ idx, int N, int E, int nw, int* __restrict__ start,
                                                               int* __restrict__ list) {
     extern __shared__ int sm[];                              // [nw][N] counts -> cursors, [N + 1] starts
@@ -246,9 +247,20 @@ __global__ __launch_bounds__(INV_NT) void invert_index_kernel(const int* __restr
     __syncthreads();
     const int per = ((E + nw - 1) / nw + 63) & ~63;          // slots per wave (whole rounds)
     const int e0 = wave * per, e1 = min(E, e0 + per);
+    // this lane's keys of the wave's first INV_KR rounds, loaded ONCE (one memory latency for both passes instead of one per round);
     // (indices are clamped into [0, N): an index outside the cloud must not reach past the LDS arrays -- ADVICE r3)
-    if (wave < nw)
-        for (int e = e0 + lane; e < e1; e += 64) atomicAdd(&cnt[wave * N + min(max(id[e], 0), N - 1)], 1);
+    int keys[INV_KR];
+#pragma unroll
+    for (int r = 0; r < INV_KR; ++r) {
+        const int e = e0 + r * 64 + lane;
+        keys[r] = (wave < nw && e < e1) ? min(max(id[e], 0), N - 1) : -1;
+    }
+    auto key_of = [&](int r, int e) { return e < e1 ? min(max(id[e], 0), N - 1) : -1; };      // rounds past INV_KR (E > nw * 64 * INV_KR)
+    if (wave < nw) {
+#pragma unroll
+        for (int r = 0; r < INV_KR; ++r) if (keys[r] >= 0) atomicAdd(&cnt[wave * N + keys[r]], 1);
+        for (int eb = e0 + INV_KR * 64; eb < e1; eb += 64) { const int k = key_of(0, eb + lane); if (k >= 0) atomicAdd(&cnt[wave * N + k], 1); }
+    }
     __syncthreads();
     for (int n = tid; n < N; n += INV_NT) {                  // per point: counts of the waves -> offsets inside the segment; total -> st (scanned below)
         int run = 0;
@@ -273,23 +285,29 @@ __global__ __launch_bounds__(INV_NT) void invert_index_kernel(const int* __restr
     for (int n = tid; n <= N; n += INV_NT) start[(long)b * (N + 1) + n] = st[n];
     if (wave >= nw) return;
     int* cur = cnt + wave * N;                               // this wave's cursors, relative to the segment starts
-    for (int eb = e0; eb < e1; eb += 64) {
-        const int e = eb + lane;
-        const int key = e < e1 ? min(max(id[e], 0), N - 1) : -1;
-        int below = 0, same = 0;
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            const int kj = __builtin_amdgcn_readlane(key, j);
-            const int eq = kj == key;
-            same += eq;
-            below += eq & (j < lane);
+    const unsigned long long lt = (1ull << lane) - 1ull;    // lanes below this one
+    const int kbits = 32 - __clz(max(N - 1, 1));
+    auto place = [&](int key, int e) {
+        // the lanes of the round holding the same point: intersect, bit by bit of the key, the ballots of "my bit" (<= 15 steps instead of
+        // 64 v_readlane compares); a lane's position = cursor + the number of LOWER such lanes; the lowest of them advances the cursor
+        unsigned long long same = __ballot(key >= 0);
+        for (int i = 0; i < kbits; ++i) {
+            const bool bit = (key >> i) & 1;
+            const unsigned long long m = __ballot(bit);
+            same &= bit ? m : ~m;
         }
         if (key >= 0) {
-            const int pos = st[key] + cur[key] + below;
-            lst[pos] = e;
-            if (below == 0) cur[key] += same;                // (one lane per point of the round; the wave's LDS accesses execute in order)
+            const int below = __popcll(same & lt);
+            lst[st[key] + cur[key] + below] = e;
+            if (below == 0) cur[key] += __popcll(same);      // (one lane per point of the round; the wave's LDS accesses execute in order)
         }
+    };
+#pragma unroll
+    for (int r = 0; r < INV_KR; ++r) {
+        if (e0 + r * 64 >= e1) break;                        // (wave-uniform)
+        place(keys[r], e0 + r * 64 + lane);
     }
+    for (int eb = e0 + INV_KR * 64; eb < e1; eb += 64) place(key_of(0, eb + lane), eb + lane);
 }
 PDF_API int pdf_invert_index(const int* idx, int Bc, int N, int E, int* start, int* list, int* tmp, hipStream_t s) {
     (void)tmp;
