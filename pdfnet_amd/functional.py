@@ -252,15 +252,22 @@ def _O2(a, b):
 # asks the library for per-row-block (mean, M2) pairs of its output columns (PdfCallOpts::stats_out); they travel as an attribute
 # of the output tensor and the BatchNorm that consumes it skips its own statistics pass over the tensor (PdfCallOpts::tile_stats).
 BN_EPILOGUE_STATS = _os.environ.get("PDFNET_BN_EPILOGUE_STATS", "1") != "0"
-# bf16 mode: the kernels can do it too (whole tiles), but their MFMA time is so short that the epilogue work costs what the saved
-# pass gains -- measured B=32 850 -> 868 img/s, B=64 1,038 -> 1,013 -- so it is opt-in there
-BN_EPILOGUE_STATS_BF16 = _os.environ.get("PDFNET_BN_EPILOGUE_STATS_BF16", "0") != "0"
+# bf16 mode: the kernels can do it too (whole tiles).  Round 3 (register-staged bf16 kernels): B=32 850 -> 868 img/s, B=64 1,038 -> 1,013, so it
+# was opt-in.  Round 4 (LDS-DMA kernels): B=64 1,098 -> 1,120, B=32 (bound by the host's issue time) 818 -> 717 on a slow host
+# (tools/experiments/r04/bf16_stats_ab.sh).  Default 'auto': convolutions over >= BF16_STORAGE_MIN_BATCH images, like the bf16 storage; 1 / 0 force it.
+_be = _os.environ.get("PDFNET_BN_EPILOGUE_STATS_BF16", "auto")
+BN_EPILOGUE_STATS_BF16 = 'auto' if _be == "auto" else _be != "0"
 
 
-def _stats_request(stats, rows, cols, dev):
-    """-> the partials buffer for a conv / linear forward launch (PdfCallOpts::stats_out, cap = numel), or None."""
-    if not (stats and BN_EPILOGUE_STATS) or (_GEMM_BF16 and not BN_EPILOGUE_STATS_BF16):
+def _stats_request(stats, rows, cols, dev, batch=None):
+    """-> the partials buffer for a conv / linear forward launch (PdfCallOpts::stats_out, cap = numel), or None.
+    batch: images the launch covers (convolutions), for the bf16 'auto' rule."""
+    if not (stats and BN_EPILOGUE_STATS):
         return None
+    if _GEMM_BF16:
+        on = (batch is not None and batch >= BF16_STORAGE_MIN_BATCH) if BN_EPILOGUE_STATS_BF16 == 'auto' else bool(BN_EPILOGUE_STATS_BF16)
+        if not on:
+            return None
     cap = ((rows + 31) // 32) * cols * 2
     return torch.empty(cap, dtype=torch.float32, device=dev)
 
@@ -490,7 +497,7 @@ class _Conv2d(Function):
         OW = (W + 2 * pad - KW) // stride + 1
         y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
         x16, w16 = shadow_of(x), shadow_of(w)
-        part = _stats_request(stats, N * OH * OW, Cout, x.device)
+        part = _stats_request(stats, N * OH * OW, Cout, x.device, batch=N)
         y16 = None
         if (stats and storage_on(N) and b is None and act == ACT_NONE and Cin % 16 == 0 and Cout % 16 == 0
                 and (N * OH * OW) % 128 == 0):

@@ -295,6 +295,14 @@ def test_bf16_storage_defaults_to_the_batches_where_it_wins(monkeypatch):
     assert F.storage_on(2) and F.storage_on()
     monkeypatch.setattr(F, 'BF16_STORAGE', False)
     assert not F.storage_on(64)
+    # the same rule for the BatchNorm statistics out of the bf16 GEMM epilogue (fp32 mode: always, it is a pure gain there)
+    monkeypatch.setattr(F, 'BN_EPILOGUE_STATS_BF16', 'auto')
+    assert F._stats_request(True, 1024, 64, 'cpu', batch=32) is None and F._stats_request(True, 1024, 64, 'cpu') is None
+    assert F._stats_request(True, 1024, 64, 'cpu', batch=64) is not None
+    monkeypatch.setattr(F, 'BN_EPILOGUE_STATS_BF16', True)
+    assert F._stats_request(True, 1024, 64, 'cpu', batch=2) is not None
     monkeypatch.setattr(F, 'BF16_STORAGE', 'auto')
+    monkeypatch.setattr(F, 'BN_EPILOGUE_STATS_BF16', 'auto')
     monkeypatch.setattr(F, '_GEMM_BF16', False)
     assert not F.storage_on(64)
+    assert F._stats_request(True, 1024, 64, 'cpu', batch=2) is not None
