@@ -1,3 +1,4 @@
+# (historical: the PDF_IG_DEEP variants this script drives were removed after the measurement -- profiles/r04_igemm_dma_ab.txt)
 # deep-ring LDS-DMA kernel on the latency-bound small products (mesh decoder, centre windows): step time and the pair entry points
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
