@@ -1,5 +1,8 @@
-// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions with many channels (fp32 mode): `feat` (1024 -> 256 at 64x64, a fifth of the
-// step's multiply-adds), p2 and the first convolution of the hm / wh / params heads (256 -> 256) -- forward and backward-data.
+// Winograd F(4x4, 3x3) (default) and F(2x2, 3x3) for the stride-1 3x3 convolutions with >= 128 channels (fp32 mode): `feat` (1024 -> 256 at
+// 64x64, a fifth of the step's multiply-adds), p2, the first convolution of the hm / wh / params heads (256 -> 256), the up-sampling decoders,
+// ResNet layers 2-3 -- forward, backward-data and (F(4x4) only, further down) the weight gradient.  The F(2x2) form is described first; F(4x4)
+// is the same scheme with 6x6 patches, 36 planes and 4x instead of 2.25x fewer multiplications (matrices and accuracy: see wino4_* below and
+// DESIGN section 4).
 //
 // Why.  Every dense contraction of the step already runs on the matrix pipe at 75-83 % of its fp32 peak; what is left
 // is to do fewer multiplications.  A 2x2 output tile of a 3x3 convolution costs 36 multiply-adds per (input, output) channel pair
