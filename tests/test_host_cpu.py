@@ -306,3 +306,17 @@ def test_bf16_storage_defaults_to_the_batches_where_it_wins(monkeypatch):
     monkeypatch.setattr(F, '_GEMM_BF16', False)
     assert not F.storage_on(64)
     assert F._stats_request(True, 1024, 64, 'cpu', batch=2) is not None
+
+
+def test_committed_pmc_profile_matches_the_committed_kernel_sources():
+    """bench.py looks `roofline.traffic` (HBM bytes per launch from the rocprofv3 --pmc passes) up in the newest profiles/*_pmc_traffic.json
+    and WITHHOLDS it when the kernel sources have changed since the profile was taken (sha256 recorded in the profile).  A kernel edit
+    without a re-profile (tools/run_final.sh) would therefore ship a bench line whose `traffic` is null: caught here, without a GPU."""
+    import bench
+    per_symbol, family, src = bench.pmc_traffic()
+    assert per_symbol is not None and family, src
+    assert any(k.startswith('wgemm_tn_dma') for k in per_symbol), sorted(per_symbol)[:5]
+    hbm, hsrc = bench.pmc_traffic_hbm()
+    assert hbm, hsrc
+    b16, bsrc = bench.pmc_traffic_bf16()
+    assert b16 and any(k.startswith('igemm_bf16_dma') for k in b16), bsrc
