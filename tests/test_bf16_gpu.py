@@ -36,7 +36,8 @@ CONVS = [  # N, Cin, H, W, Cout, k, stride, pad
     (2, 72, 9, 9, 40, 3, 1, 1), (3, 256, 8, 8, 256, 3, 1, 1), (2, 64, 16, 16, 128, 1, 2, 0), (2, 192, 6, 6, 200, 3, 1, 1)]
 
 
-@pytest.mark.parametrize("cfg", [(8, 64, 32, 32, 128, 3, 1, 1), (16, 128, 16, 16, 64, 1, 1, 0), (4, 64, 64, 64, 256, 1, 1, 0)])
+@pytest.mark.parametrize("cfg", [(8, 64, 32, 32, 128, 3, 1, 1), (16, 128, 16, 16, 64, 1, 1, 0), (4, 64, 64, 64, 256, 1, 1, 0),
+                                 (32, 256, 64, 64, 256, 3, 1, 1)])       # (the last: statistics over 256-row blocks, the 256x256 tile)
 def test_batchnorm_statistics_from_the_bf16_gemm_epilogue(bf16_mode, cfg, monkeypatch):
     """Opt-in in bf16 mode (PDFNET_BN_EPILOGUE_STATS_BF16): the bf16 kernels' whole-tile epilogue takes the BatchNorm statistics
     of the stored fp32 output out of the accumulators; the BatchNorm then produces the same output, saved / running statistics
@@ -355,7 +356,8 @@ def test_bf16_train_step_against_the_fp32_oracle(bf16_mode):
 
 SHADOW_CONVS = [  # N, Cin, H, W, Cout, k, stride, pad
     (2, 64, 16, 16, 128, 3, 1, 1), (2, 128, 8, 8, 64, 1, 1, 0), (1, 64, 17, 15, 96, 3, 2, 1), (4, 256, 16, 16, 256, 3, 1, 1),
-    (2, 72, 9, 9, 40, 3, 1, 1), (2, 64, 16, 16, 128, 1, 2, 0), (8, 128, 32, 32, 128, 3, 1, 1)]
+    (2, 72, 9, 9, 40, 3, 1, 1), (2, 64, 16, 16, 128, 1, 2, 0), (8, 128, 32, 32, 128, 3, 1, 1),
+    (32, 256, 64, 64, 256, 3, 1, 1)]                      # 512 whole 256x256 tiles: the 8-wave LDS-DMA tile (forward and backward-data)
 
 
 @pytest.mark.parametrize("cfg", SHADOW_CONVS)
