@@ -301,6 +301,10 @@ int pdf_maxpool3s2_bwd_add(const float* dy, const unsigned char* arg, int N, int
 /* nn.Upsample(scale_factor=2, bilinear, align_corners=True) (intaghand_encoder.py:287-302) */
 int pdf_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);
 int pdf_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream);
+/* dst [R2][C2] (ldd) = src [R][C] (lds) in its top-left corner, zeros elsewhere; R2 <= R / C2 <= C crops.  Replaces the reference's
+ * zero-padding of the PointNet++ 1x1 layers' matrices to aligned widths (torch.nn.functional.pad = fill + strided copy per pad), forward and
+ * (as the crop of the gradient) backward: `intaghand_encoder.py:48-103` layers with 3 / 131 / 259 input channels. */
+int pdf_pad2d(const float* src, int lds, long R, int C, float* dst, int ldd, long R2, int C2, void* stream);
 /* torch.optim.Adam step (main.py:63) over one flat buffer; corr = device [1-b1^t, 1-b2^t] */
 int pdf_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   const float* corr, float grad_scale, void* stream);

@@ -502,6 +502,27 @@ PDF_API int pdf_upsample2x_bwd(const float* dy, int N, int H, int W, int C, floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// dst [R2][C2] (ldd) = src [R][C] (lds) in its top-left corner, zeros elsewhere -- and the same launch CROPS when R2 <= R, C2 <= C.  The
+// PointNet++ 1x1 layers keep the reference's parameter shapes (131 / 259 input channels, `intaghand_encoder.py:48-103`) and hand the GEMMs
+// matrices padded to 16-float rows: torch's constant_pad_nd is a fill plus a strided copy per pad and direction (56 pads = 112 launches per
+// step); here a padded matrix is one launch forward and one (the crop of the gradient) backward.
+__global__ void pad2d_kernel(const float* __restrict__ src, int lds, long R, int C, float* __restrict__ dst, int ldd, long R2, int C2) {
+    const long total = R2 * C2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C2;
+        const int c = (int)(i - r * C2);
+        dst[r * ldd + c] = (r < R && c < C) ? src[r * lds + c] : 0.f;
+    }
+}
+PDF_API int pdf_pad2d(const float* src, int lds, long R, int C, float* dst, int ldd, long R2, int C2, hipStream_t s) {
+    if (R < 0 || C < 0 || R2 < 0 || C2 < 0 || lds < C || ldd < C2) return PDF_E_BADARG;
+    if (R2 == 0 || C2 == 0) return 0;
+    hipLaunchKernelGGL(pad2d_kernel, dim3(grid_for(R2 * C2)), dim3(256), 0, s, src, lds, R, C, dst, ldd, R2, C2);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam semantics, main.py:63) over one flat fp32 buffer.
 // step_size / bias corrections are read from a 2-float device buffer so the launch is graph-replayable.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,

@@ -888,6 +888,35 @@ def batch_norm(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, re
     return _BatchNorm.apply(x, gamma, beta, rmean, rvar, res, training, momentum, eps, relu, lazy)
 
 
+class _Pad2d(Function):
+    """y [R2, C2] = x [R, C] in the top-left corner, zeros elsewhere (one launch; backward: the crop of dy, one launch)."""
+
+    @staticmethod
+    def forward(ctx, x, R2, C2):
+        hip.require_gpu(x)
+        x = x.contiguous()
+        R, C = x.shape
+        y = torch.empty((R2, C2), dtype=torch.float32, device=x.device)
+        _L().pdf_pad2d(ptr(x), C, R, C, ptr(y), C2, R2, C2, stream())
+        ctx.shape = (R, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        R, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((R, C), dtype=torch.float32, device=dy.device)
+        _L().pdf_pad2d(ptr(dy), dy.shape[1], dy.shape[0], dy.shape[1], ptr(dx), C, R, C, stream())
+        return dx, None, None
+
+
+def pad2d(x, rows, cols):
+    """Zero-pad a 2-D fp32 tensor to [rows, cols] (no-op when it already has that shape)."""
+    if x.shape[0] == rows and x.shape[1] == cols:
+        return x
+    return _Pad2d.apply(x, rows, cols)
+
+
 class _Act(Function):
     @staticmethod
     def forward(ctx, x, act):

@@ -167,7 +167,7 @@ class PointNet_Plus(nn.Module):
         if chain:
             e0, emb0 = e0
         pts = self.sft0(cloud, e0)                                                         # [B,1024,3]   (:120-122)
-        y1 = self._group_conv(self.netR_1[0], torch.nn.functional.pad(pts, (0, _pad16(3) - 3)), S1, K, o.ball_radius)   # (:123,:49)
+        y1 = self._group_conv(self.netR_1[0], F.pad2d(pts.reshape(-1, 3), pts.shape[0] * pts.shape[1], _pad16(3)).view(pts.shape[0], pts.shape[1], _pad16(3)), S1, K, o.ball_radius)   # (:123,:49)
         x = self._mlp_max(self.netR_1, y1, K)                                               # [B*S1,128]   (:132)
         e1 = F.gather_rows(emb1, choose[:, :S1], R, 1, chain=chain)                        # [B,S1,64]    (:125-127)
         if chain:

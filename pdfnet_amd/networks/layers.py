@@ -74,21 +74,19 @@ class PointConv(nn.Module):
         bound = 1.0 / math.sqrt(cin)
         self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
 
-    def matrix(self, kpad):
-        """[Cout, kpad] weight matrix (zero columns for the padded channels)."""
+    def matrix(self, kpad, npad=None):
+        """[npad or Cout, kpad] weight matrix (zero columns for the padded input channels, zero rows for padded outputs): one launch
+        (F.pad2d) instead of a fill and a strided copy per padded side."""
         w = self.weight.flatten(1)
-        if kpad != w.shape[1]:
-            w = torch.nn.functional.pad(w, (0, kpad - w.shape[1]))
-        return w
+        return F.pad2d(w, npad if npad is not None else w.shape[0], kpad)
 
     def forward(self, x, act=F.ACT_NONE, npad=None, stats=False):
         """npad: also pad the OUTPUT channels (zero weight rows, zero bias) -- a 131- / 259-wide output has rows that are not
         16-byte aligned, which sends its backward-data and weight-gradient GEMMs down the per-element path.
         stats: the output goes straight into a training-mode BatchNorm (F.linear)."""
-        w, b = self.matrix(x.shape[-1]), self.bias
-        if npad is not None and npad != w.shape[0]:
-            w = torch.nn.functional.pad(w, (0, 0, 0, npad - w.shape[0]))
-            b = torch.nn.functional.pad(b, (0, npad - b.shape[0]))
+        w, b = self.matrix(x.shape[-1], npad), self.bias
+        if npad is not None and npad != b.shape[0]:
+            b = F.pad2d(b.view(1, -1), 1, npad).view(-1)
         return F.linear(x, w, b, act, stats=stats)
 
 

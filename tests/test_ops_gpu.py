@@ -320,6 +320,22 @@ def test_pool_upsample_relu(F):
     close(xd.grad, gy[:, :, :13, :14] * (x > 0), 0, what="relu dx")
 
 
+def test_pad2d_pads_and_crops_in_one_launch(F):
+    """F.pad2d (pdf_pad2d): zero-padding of a matrix to [rows, cols] and, as its backward, the crop of the gradient -- against
+    torch.nn.functional.pad; incl. a single row (a bias), a 3-column cloud and the no-op."""
+    for (R, C, R2, C2) in ((131, 259, 144, 272), (1, 131, 1, 144), (2048, 3, 2048, 16), (64, 64, 64, 64), (5, 7, 9, 7)):
+        x = rnd(R, C, seed=R + C)
+        xr = x.clone().requires_grad_()
+        ref = TF.pad(xr, (0, C2 - C, 0, R2 - R))
+        g = rnd(R2, C2, seed=3)
+        ref.backward(g)
+        xd = dev(x).requires_grad_()
+        out = F.pad2d(xd, R2, C2)
+        out.backward(dev(g))
+        close(out, ref, 0, what="pad2d %s" % ((R, C, R2, C2),))
+        close(xd.grad, xr.grad, 0, what="pad2d dx")
+
+
 def test_l2norm_layernorm(F):
     x = rnd(2, 256, 7, 9, seed=1)
     w = torch.rand(256) * 10 + 5
