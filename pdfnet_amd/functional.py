@@ -349,6 +349,11 @@ _wg_streams = {}
 _wg_used = set()
 
 
+# queue priority of the weight-gradient side streams (torch: 0 = normal, -1 = high; the default stream the step is issued on outranks a
+# normal-priority stream in practice -- tools/experiments/r04/stream_priority.py)
+WGRAD_STREAM_PRIORITY = int(_os.environ.get("PDFNET_WGRAD_STREAM_PRIORITY", "0"))
+
+
 class wgrad_stream:
     """Context for weight-gradient kernels that accumulate straight into the trainer's flat gradient buffer: nothing
     in the backward chain consumes them, so they run on a side HIP stream and overlap the data-gradient chain (whose
@@ -375,7 +380,7 @@ class wgrad_stream:
         key = (dev, cur_raw)
         ent = _wg_streams.get(key)
         if ent is None:
-            s = torch.cuda.Stream()
+            s = torch.cuda.Stream(priority=WGRAD_STREAM_PRIORITY)
             ent = _wg_streams[key] = (s, s.cuda_stream, s.stream_id, s.device_index, s.device_type)
         side, side_raw = ent[0], ent[1]
         wait = _L().pdf_stream_wait
