@@ -409,12 +409,14 @@ class wgrad_stream:
         return False
 
 
-def join_wgrad():
-    """Make the current stream wait for every outstanding side-stream weight-gradient kernel."""
+def join_wgrad(keep=False):
+    """Make the current stream wait for every outstanding side-stream weight-gradient kernel.  keep: the streams stay listed
+    (a later join -- another stream's, or the one after the backward -- still waits for them)."""
     cur = hip.stream()
     for key in list(_wg_used):
         _L().pdf_stream_wait(cur, _wg_streams[key][1])
-    _wg_used.clear()
+    if not keep:
+        _wg_used.clear()
 
 
 def _main_grad(param, like):

@@ -400,6 +400,7 @@ class Trainer:
         # BatchNorm / GEMM kernels; off by default)
         self.overlap_adam = os.environ.get('PDFNET_OVERLAP_ADAM', '0') != '0'
         self._adam_stream, self._adam_done, self._in_train_step = None, 0, False
+        self._comm_stream = None                               # the early gradient all-reduce is issued from here (_early_grads_ready)
         hip.check_device(self.optimizer.flat_p.device)
         model.register_load_state_dict_post_hook(lambda *_: self.optimizer.params_changed())
         if self.world > 1:
@@ -439,11 +440,32 @@ class Trainer:
         if self.use_graph or self.reducer.early is not None or not self.collectives or \
                 (self.world == 1 and self.early_probe is None and not self.force_collectives):
             return
-        F.join_wgrad()                                         # the side-stream kernels issued so far wrote into this part
-        if self.early_probe is not None:
+        if self.early_probe is not None:                       # (test hook: it reads the slice on THIS stream, so this stream joins)
+            F.join_wgrad(keep=True)
             self.early_probe(self.optimizer.flat_g[:self.n_early])
         self.reducer.force = self.force_collectives
-        self.reducer.early_ready()
+        if not self.optimizer.flat_g.is_cuda:
+            self.reducer.early_ready()
+            return
+        # The early slice was written by the weight-gradient side streams (and by a few bias gradients on this stream).  Round 4
+        # joined those streams into THIS stream here, which parked the trunk's backward -- the third of the step the all-reduce is
+        # supposed to hide under -- behind everything they still held.  Now a dedicated communication stream
+        # waits for them; ProcessGroupNCCL orders its own stream after the stream that is current when the collective is issued,
+        # so the all-reduce (and the bf16 cast in front of it) starts when the gradients are complete and this stream never waits.
+        dev = hip._raw_device()
+        cur = hip._raw_stream(dev)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        comm = self._comm_stream.cuda_stream
+        wait = hip.lib().pdf_stream_wait
+        wait(comm, cur)
+        for key in list(F._wg_used):
+            wait(comm, F._wg_streams[key][1])
+        with torch.cuda.stream(self._comm_stream):
+            self.reducer.early_ready()
+        for r in self.reducer.early or ():                     # staged on the communication stream, finished (copied back) on this one
+            if r.buf is not None:
+                r.buf.record_stream(torch.cuda.current_stream())
 
     def _fwd_bwd(self, batch, epoch):
         self.reducer.reset()

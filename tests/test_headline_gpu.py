@@ -158,7 +158,7 @@ def test_train_step_at_the_headline_batch_matches_the_fp64_oracle(headline):
     torch.cuda.synchronize()
     assert abs(loss_g - loss_o) <= 1e-4 * abs(loss_o), (loss_g, loss_o)
     named = dict(m.named_parameters())
-    bad, checked, none_o, worst = [], 0, 0, []
+    bad, checked, none_o, worst, widened = [], 0, 0, [], []
     for n, g64 in go.items():
         p = named[n]
         if g64 is None:
@@ -180,6 +180,14 @@ def test_train_step_at_the_headline_batch_matches_the_fp64_oracle(headline):
             worst.append((abs(na - nb) / (tol * na + 1e-12), abs(na - nb) / (base * na + 1e-12), fn, 1.0 - cos, n))
         if abs(na - nb) <= tol * na + 1e-12 and cos >= 1.0 - tol_c:
             checked += 1
+            # ABSOLUTE guard (VERDICT r4 item 5 / ADVICE r4): the floor-relative bar above scales with somebody else's error, so every
+            # tensor that is well conditioned -- the fp32 oracle itself stays within 1e-3 of its fp64 run on it -- must ALSO meet the
+            # FIXED bar; only the remaining (noise) tensors may use the widened one, and their number is pinned below.
+            if fn < 1e-3:
+                if not (abs(na - nb) <= base * na + 1e-12 and cos >= 1.0 - 1e-4):
+                    bad.append((n + '  [fixed bar, fp32-oracle deviation %.1e]' % fn, tuple(g.shape), na, nb, cos))
+            elif abs(na - nb) > base * na + 1e-12 or cos < 1.0 - 1e-4:
+                widened.append((n, abs(na - nb) / (base * na + 1e-12), fn))
             continue
         wn = n[:-4] + 'weight'                                # a bias in front of a train-mode BatchNorm: exactly zero in exact arithmetic
         if n.endswith('.bias') and wn in go and go[wn] is not None and na <= 1e-6 * float(go[wn].norm()) and nb <= 1e-2 * float(go[wn].norm()):
@@ -189,6 +197,8 @@ def test_train_step_at_the_headline_batch_matches_the_fp64_oracle(headline):
     worst.sort(reverse=True)
     print("gradient norm error / bar (/ fixed bar; the fp32 oracle's own deviation), worst five: " +
           "; ".join("%s %.2f (%.2f; %.1e) 1-cos %.1e" % (n, r, rb, fn, c) for r, rb, fn, c, n in worst[:5]))
+    print("tensors that needed the widened (noise-floor) bar: %d of %d: %s" % (len(widened), len(go) - 332, "; ".join("%s %.2fx fixed (fp32 oracle off by %.1e)" % w for w in widened)))
+    assert len(widened) <= 6, widened                         # r04: 1 (pointnet_plus.sft1.SFT_shift_conv1.bias); a kernel change that makes noise of more tensors is a regression
     assert not bad, "%d gradients off:\n" % len(bad) + "\n".join("%s %s |g64|=%.4e |g32|=%.4e cos=%.6f" % b for b in bad[:40])
     assert none_o == 332 and checked == len(go) - 332         # 324 unreachable tensors + the wh / params heads (no loss term)
     sg = m.state_dict()
@@ -278,6 +288,32 @@ def test_heaviest_convolutions_of_the_step_at_their_real_size(cfg, winograd, mon
         _close(bd.grad, br.grad, 1e-4 * max(1, M ** 0.5 / 64), 5e-5, "conv db")
     with torch.no_grad():                                      # the fused ReLU epilogue at the same size (forward only: the mask of
         _close(F.conv2d(xd, wd, bd, s, p, 1), TF.relu(ref), 3e-5 * max(1, K ** 0.5 / 16) + f4, 1e-5, "conv + relu fwd")   # ~0 values may flip)
+
+
+def test_winograd_f4_weight_gradient_noise_on_the_feat_shape_is_pinned(monkeypatch):
+    """the transform-domain weight gradient of F(4x4, 3x3) is ~10x noisier than the direct kernel's (its transform matrices
+    hold 4, 5, 8, 1/6, 1/24).  Pin it on the heaviest layer (`feat`: 1024 -> 256 at 64x64, B = 32) against FLOAT64: max |dW - dW64| <= 1e-5 max|dW|
+    for the Winograd path (r04: 6.6e-6) and <= 2e-6 for the direct kernel (r04: 6.6e-7) -- a regression in either shows here, not in a model-level bar."""
+    from pdfnet_amd import functional as F
+    N, Cin, H, W, Cout = 32, 1024, 64, 64, 256
+    torch.set_num_threads(_threads())
+    x = _rnd(N, Cin, H, W, seed=11)
+    gy = _rnd(N, Cout, H, W, seed=12)
+    w = _rnd(Cout, Cin, 3, 3, seed=13, scale=(Cin * 9) ** -0.5)
+    ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), stride=1, padding=1)
+    top = float(ref.abs().max())
+    errs = {}
+    for wino in (True, False):
+        monkeypatch.setattr(F, "WINOGRAD", wino)
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        wd = w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        F.conv2d(xd, wd, None, 1, 1, 0).backward(gy.cuda())
+        F.join_wgrad()
+        torch.cuda.synchronize()
+        errs[wino] = float((wd.grad.detach().cpu().double() - ref).abs().max()) / top
+    print("feat weight gradient vs float64, max error / max|dW|: Winograd F(4x4) %.2e, direct %.2e" % (errs[True], errs[False]))
+    assert errs[True] <= 1e-5, errs
+    assert errs[False] <= 2e-6, errs
 
 
 @pytest.mark.parametrize("cfg", [(32, 512, 32, 32, 256, 4, 2, 1), (32, 1024, 16, 16, 256, 4, 4, 0), (32, 2048, 8, 8, 256, 8, 8, 0)])

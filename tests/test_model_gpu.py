@@ -359,6 +359,59 @@ def test_trainer_collectives_on_a_one_rank_rccl_group():
             dist.destroy_process_group()
 
 
+def test_early_slice_equals_an_all_gather_sum_on_a_one_rank_group():
+    """the early gradient slice the overlapped reduction leaves in the flat buffer -- all-reduced from the
+    communication stream, which waits for the weight-gradient streams while the main stream runs on into the trunk's backward -- is
+    BIT-IDENTICAL to the sum of an all_gather of what the slice held when the hook fired (fp32 transport), and to the widened bf16
+    cast of it (bf16 transport).  Also: nothing writes the early slice after the hook."""
+    import os
+    import torch.distributed as dist
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch, to_device
+    from pdfnet_amd.trains.base_trainer import Trainer
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    R, B = 128, 2
+    dev = torch.device('cuda')
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    batch = to_device(synthetic_train_batch(B, R, seed=5, consts=consts), dev)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29536')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        created = True
+    try:
+        for comm in (None, torch.bfloat16):
+            torch.manual_seed(12)
+            tr = Trainer(opt, load_model_intag(opt).to(dev), CtdetLoss(opt, consts).to(dev), lr=0.0, grad_comm_dtype=comm)
+            tr.force_collectives = True
+            seen = []
+            tr.early_probe = lambda g: seen.append(g.clone())
+            tr.train_step(batch, 0)
+            torch.cuda.synchronize()
+            assert len(seen) == 1 and tr.reducer.early is not None and len(tr.reducer.early) == 3
+            parts = [torch.empty_like(seen[0])]
+            dist.all_gather(parts, seen[0])
+            want = torch.stack(parts).sum(0)
+            if comm is not None:
+                want = want.to(comm).to(torch.float32)
+            got = tr.optimizer.flat_g[:tr.n_early]
+            assert float(want.abs().max()) > 0
+            assert torch.equal(got, want), float((got - want).abs().max())
+            # and without the probe (the production path: this stream never joins the side streams at the hook) the step gives the same
+            # gradient up to the LayerNorm parameter gradients' atomic summation order
+            tr.early_probe = None
+            tr.train_step(batch, 0)
+            torch.cuda.synchronize()
+            got2 = tr.optimizer.flat_g[:tr.n_early]
+            tol = 2e-3 if comm is None else 1e-2
+            assert float((got2 - want).abs().max()) <= tol * float(want.abs().max())
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_training_on_a_fixed_batch_reduces_the_loss():
     """30 steps of the MI355X train loop on one synthetic batch: the loss must fall by a large factor and stay finite
     (dropout on, default trainer settings) -- the end-to-end sanity check behind the throughput number."""

@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in 1 0; do
   export PDF_WG_BATCH_XCD=$v PDF_BENCH_WINOGRAD=1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/xcd_${v}_$c -o p -- python3 $GRAFT_REPO_ROOT/tools/gemm_bench.py head_3x3 > /tmp/xcd_$v_$c.log 2>&1 < /dev/null
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/xcd_${v}_$c -o p -- python3 $GRAFT_REPO_ROOT/tools/gemm_bench.py head_3x3 > /tmp/xcd_${v}_${c}.log 2>&1 < /dev/null
   done
   python3 - $v >> $GRAFT_REPO_ROOT/$o <<PY
 import csv, sys, collections
