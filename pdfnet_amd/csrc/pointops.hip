@@ -41,9 +41,12 @@ __global__ __launch_bounds__(256) void knn_ball_group_kernel(
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             int j = lane + 64 * i;
-            float dx = __fsub_rn(sx[j], cx), dy = __fsub_rn(sy[j], cy), dz = __fsub_rn(sz[j], cz);
+            const int jj = j < N ? j : 0;
+            float dx = __fsub_rn(sx[jj], cx), dy = __fsub_rn(sy[jj], cy), dz = __fsub_rn(sz[jj], cz);
             float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            key[i] = __float_as_uint(d);                    // d >= 0: uint order == float order
+            // d >= 0: uint order == float order.  Slots past the cloud's end (N not a multiple of 64 * NPL: the reference takes any
+            // N, lib/utils/utils.py:134-163) hold a key above every distance and every search candidate: never counted, never selected
+            key[i] = j < N ? __float_as_uint(d) : 0xFFFFFFFFu;
         }
         uint32_t thr = 0;
         for (int bit = 30; bit >= 0; --bit) {
@@ -115,11 +118,13 @@ __global__ __launch_bounds__(256) void knn_ball_group_kernel(
 
 PDF_API int pdf_knn_ball_group(const float* pts, int ldp, int C, int Bc, int N, int S, int K, float r2,
                                int* idx, float* grouped, int ldg, hipStream_t s) {
-    if (N % 64 != 0 || N > 1024 || K > N || K < 1 || S > N || C < 3 || ldp < C || (grouped && ldg < C)) return PDF_E_BADARG;
+    if (N < 1 || N > 1024 || K > N || K < 1 || S > N || C < 3 || ldp < C || (grouped && ldg < C)) return PDF_E_BADARG;
     dim3 grid(cdiv(S, 16), Bc);
     size_t smem = (size_t)3 * N * sizeof(float) + (size_t)4 * K * sizeof(int);
+    int npl = 1;                                                // points per lane: the power of two that covers N (padded slots: see the kernel)
+    while (npl * 64 < N) npl <<= 1;
 #define KNN_CASE(NPL_) case NPL_: hipLaunchKernelGGL(knn_ball_group_kernel<NPL_>, grid, dim3(256), smem, s, pts, ldp, C, N, S, K, r2, idx, grouped, ldg); break;
-    switch (N / 64) {
+    switch (npl) {
         KNN_CASE(1) KNN_CASE(2) KNN_CASE(4) KNN_CASE(8) KNN_CASE(16)
         default: return PDF_E_BADARG;
     }

@@ -409,6 +409,21 @@ def test_knn_ball_group_level1(F):
     close(pd.grad, pr.grad, 1e-4, what="group bwd")
 
 
+@pytest.mark.parametrize("N,S", [(700, 350), (100, 100), (1000, 512), (65, 17)])
+def test_knn_ball_group_takes_any_cloud_size(F, N, S):
+    """lib/utils/utils.py:134-163 has no restriction on opt.SAMPLE_NUM: N need not be 64 * 2^k.  Index sets against the
+    oracle on a cloud with far outliers (so the ball mask fires) for ragged N."""
+    from oracle import pdfnet_cpu as O
+    K, r2 = 64, 0.015
+    g = torch.Generator().manual_seed(N)
+    pts = torch.cat([(torch.rand(3, N, 2, generator=g) - 0.5) * 0.2, 0.4 + 0.1 * torch.rand(3, N, 1, generator=g)], -1)
+    far = torch.rand(3, N, generator=g) < 0.1
+    pts[..., :2] = torch.where(far.unsqueeze(-1), (torch.rand(3, N, 2, generator=g) - 0.5), pts[..., :2])
+    ref, _ = O.group_level1(pts, S, K, r2)
+    gold_idx = np.sort(O.knn_ball_indices(pts, S, K, r2).numpy(), -1)
+    _check_group(F, pts, 3, S, K, r2, 16, gold_idx, ref)
+
+
 def test_knn_ball_group_level2(F):
     from oracle import pdfnet_cpu as O
     gd = gold("op_group_points_l2")
