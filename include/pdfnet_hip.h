@@ -451,6 +451,52 @@ long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout
 int pdf_debug_armed_slots(void);
 int pdf_debug_callopts_size(void);
 
+/* ---- fused mesh decoder (round 5, csrc/meshdec.hip) ---------------------------------------------------------------------
+ * One DualGraphLayer of the dual-hand GCN / attention decoder (lib/models/networks/model_attn/DualGraph.py:62-92: 4 x GCN_ResBlock per hand,
+ * gcn.py:99-110 / 34-69; SelfAttn per hand, self_attn.py:63-85; cross-hand attention + MLP blocks, inter_attn.py:73-125) in two launches per
+ * direction: one 256-thread workgroup per (hand, sample) keeps that hand's [V][C] rows in LDS through the whole chain.
+ * V = 63 << level, C = 256 >> level; rows are stacked [2 (left, right)][B][V].  Index [0] / [1] of every parameter pair = left / right hand
+ * (the shared cross-hand projections pass the same pointer twice).  x already carries the position embedding (DualGraph.py:76-77).
+ * The forward writes what the backward and the weight-gradient GEMMs read into `tape` (pdf_mesh_tape_floats) and `qkv`
+ * ([3][2][B][V][C]); both buffers are needed in eval mode too (stage hand-offs).  The backward writes dx, ACCUMULATES every parameter
+ * gradient into the g* pointers (the LayerNorm ones with atomics from the data kernels on `stream`, the Linear ones with the library's
+ * weight-gradient GEMMs on `side_stream`, which first waits for `stream`), and uses `gtape` (pdf_mesh_gtape_floats) and `wg_ws`
+ * (>= 2 * pdf_wgrad_workspace_floats(B * V, C, 4 * C) floats) as scratch.  Dropout masks are the stateless hash of (seed, element index)
+ * the unfused kernels use, so the same seeds give the same masks. */
+typedef struct PdfMeshLin { const float* w[2]; const float* b[2]; } PdfMeshLin;
+typedef struct PdfMeshLN { const float* g[2]; const float* b[2]; } PdfMeshLN;
+typedef struct PdfMeshGcn { PdfMeshLin fc1, fc2, sc; PdfMeshLN n2, n3; unsigned long long seed; } PdfMeshGcn;
+typedef struct PdfMeshAttn {
+    PdfMeshLN ln; PdfMeshLin q, k, v, fc; PdfMeshLN ffln; PdfMeshLin f1, f2;
+    unsigned long long seed_att, seed_z, seed_t, seed_x;
+} PdfMeshAttn;
+typedef struct PdfMeshLinG { float* w[2]; float* b[2]; } PdfMeshLinG;
+typedef struct PdfMeshLNG { float* g[2]; float* b[2]; } PdfMeshLNG;
+typedef struct PdfMeshGcnG { PdfMeshLinG fc1, fc2, sc; PdfMeshLNG n2, n3; } PdfMeshGcnG;
+typedef struct PdfMeshAttnG { PdfMeshLNG ln; PdfMeshLinG q, k, v, fc; PdfMeshLNG ffln; PdfMeshLinG f1, f2; } PdfMeshAttnG;
+typedef struct PdfMeshLevel {
+    int level, B, training, cin0;
+    float p;
+    const unsigned long long* step;
+    const float* x;
+    float* out;
+    const int* ell_col[2]; const float* ell_val[2]; const int* ell_colT[2]; const float* ell_valT[2]; int ell_w;
+    PdfMeshGcn gcn[4];
+    PdfMeshAttn self_, cross;
+    float* tape;
+    float* qkv;
+    const float* dout;
+    float* dx;
+    float* gtape;
+    PdfMeshGcnG ggcn[4]; PdfMeshAttnG gself, gcross;
+    float* wg_ws; long wg_ws_floats;
+} PdfMeshLevel;
+long pdf_mesh_tape_floats(int level, int B);
+long pdf_mesh_gtape_floats(int level, int B);
+int pdf_mesh_level_fwd(const PdfMeshLevel* a, void* stream);
+int pdf_mesh_level_bwd(const PdfMeshLevel* a, void* stream, void* side_stream);
+int pdf_debug_mesh_level_size(void);
+
 #ifdef __cplusplus
 }
 #endif

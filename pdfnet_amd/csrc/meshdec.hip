@@ -1,0 +1,1239 @@
+// Fused mesh decoder for gfx950 (round 5): one DualGraphLayer of the IntagHand-style dual-hand GCN / attention decoder
+// (lib/models/networks/model_attn/DualGraph.py:62-92, gcn.py:34-69,99-110, self_attn.py:17-85, inter_attn.py:73-125) as
+// TWO launches per direction instead of ~50 dependent 5-20 us launches:
+//
+//   part 1  x -> 4 x GCN_ResBlock -> SelfAttn (LN, q/k/v, attention, fc, residual, MLP block) -> LN1/LN2 + shared q/k/v of the cross-hand step
+//   part 2  cross-hand attention (keys / values of the OTHER hand of the same sample: the only inter-block dependence) -> fc -> MLP block
+//
+// One 256-thread workgroup per (hand, sample) keeps that hand's [V][C] features of the sample on ONE CU for the whole chain:
+// V x C = 63 x 256 = 126 x 128 = 252 x 64 = 16,128 floats at every level, so two [V][C + 4] staging buffers (<= 139 KB) fit the
+// 160 KB LDS.  Every matrix product is "activation-stationary": the A operand (this hand's rows) is read from LDS by
+// ds_read_b128 -- lane l takes row l & 31 and the four k of chunk l >> 5, which feeds four v_mfma_f32_32x32x2_f32 (fp32 in, exact
+// fmaf chains) -- and the weights stream L2 -> registers once per workgroup, each lane one float4 of its output column (prefetched
+// four K-steps ahead).  No barrier inside a K loop; LayerNorm, the Chebyshev ELL product, softmax, dropout and the residuals run
+// on the LDS image between the products.  Attention runs on the matrix pipe too: S^T = K Q^T per (head, 32-query tile) stays in
+// accumulator registers (keys along rows), the softmax over keys is a register reduction plus ONE cross-half shuffle, and P goes
+// straight back into the MFMA as the B operand of O^T = V^T P.
+// Everything the backward (and the weight-gradient GEMMs, which stay ordinary side-stream launches) needs is written to a "tape"
+// in HBM as the chain passes; in eval mode nothing but the level output and q / k / v is written.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MD_THREADS 256
+
+// ---- argument block of one level (mirrors PdfMeshLevel of include/pdfnet_hip.h field for field) --------------------------------
+struct MdLin { const float* w[2]; const float* b[2]; };            // [hand]
+struct MdLN { const float* g[2]; const float* b[2]; };
+struct MdGcn { MdLin fc1, fc2, sc; MdLN n2, n3; unsigned long long seed; };
+struct MdAttn {
+    MdLN ln; MdLin q, k, v, fc; MdLN ffln; MdLin f1, f2;
+    unsigned long long seed_att, seed_z, seed_t, seed_x;
+};
+// gradient outputs (accumulated, += ): same shapes as the parameters
+struct MdLinG { float* w[2]; float* b[2]; };
+struct MdLNG { float* g[2]; float* b[2]; };
+struct MdGcnG { MdLinG fc1, fc2, sc; MdLNG n2, n3; };
+struct MdAttnG { MdLNG ln; MdLinG q, k, v, fc; MdLNG ffln; MdLinG f1, f2; };
+
+struct PdfMeshLevel {
+    int level, B, training, cin0;                 // level 0..2 (V = 63 << level, C = 256 >> level); cin0 = width of x (= 2 C)
+    float p;                                      // dropout probability (0 in eval mode)
+    const unsigned long long* step;               // device step counter mixed into every dropout seed (hipGraph replays draw fresh masks)
+    const float* x;                               // [2][B][V][cin0] level input (position embedding already added)
+    float* out;                                   // [2][B][V][C] level output
+    const int* ell_col[2]; const float* ell_val[2]; const int* ell_colT[2]; const float* ell_valT[2]; int ell_w;
+    MdGcn gcn[4];
+    MdAttn self_, cross;
+    float* tape;                                  // training: pdf_mesh_tape_floats(level, B) floats (forward writes, backward reads)
+    float* qkv;                                   // [3][2][B][V][C] cross-hand q / k / v (part 1 -> part 2; also part of the tape)
+    // backward
+    const float* dout;                            // [2][B][V][C]
+    float* dx;                                    // [2][B][V][cin0]
+    float* gtape;                                 // pdf_mesh_gtape_floats(level, B) floats: the dY operands of the weight-gradient GEMMs
+    MdGcnG ggcn[4]; MdAttnG gself, gcross;
+    float* wg_ws; long wg_ws_floats;              // workspace of the weight-gradient launches
+};
+
+template <int LV> struct Cfg {
+    static constexpr int V = 63 << LV, VP = 64 << LV, C = 256 >> LV, LD = C + 4, DH = C / 4, H = 4;
+    static constexpr int MT = VP / 32, NT = C / 32;
+    static constexpr int WMT = LV == 0 ? 2 : 4, WNT = LV == 0 ? 2 : 1;         // accumulator tiles per wave: always 4
+    static constexpr int BUF = VP * LD;                                        // floats per LDS staging buffer
+};
+
+// ---- tape layout (floats, per level; rows = 2 B V) ------------------------------------------------------------------------------
+// GCN block i: x_i [R][cin_i] (i = 0: the level input itself, not copied), cat1 [R][2 cin_i], y [R][C], st2 [R][2], cat2 [R][2C], z [R][C], st3 [R][2]
+// then out_i [R][C] = x_{i+1}.  Attention block a (0 = self, 1 = cross): h [R][C], st [R][2], q, k, v [R][C] (cross: in `qkv`), a [R][C],
+// stat [R][H][2], z [R][C], stz [R][2], hn [R][C], t [R][C], xo [R][C] (cross: the level output itself)
+struct TapeOff {
+    long R, C;
+    // GCN block i occupies R (2 cin + 5 C + 4) floats: [cat1 | y | st2 | cat2 | z | st3 | out]  (offsets by arithmetic: an indexed table of
+    // offsets would live in scratch memory once the block loop is not unrolled)
+    __host__ __device__ long gcn_base(int i) const { return i == 0 ? 0 : R * (9 * C + 4) + (long)(i - 1) * R * (7 * C + 4); }
+    __host__ __device__ long cat1(int i) const { return gcn_base(i); }
+    __host__ __device__ long y(int i) const { return gcn_base(i) + R * 2 * (i == 0 ? 2 * C : C); }
+    __host__ __device__ long st2(int i) const { return y(i) + R * C; }
+    __host__ __device__ long cat2(int i) const { return st2(i) + R * 2; }
+    __host__ __device__ long z(int i) const { return cat2(i) + R * 2 * C; }
+    __host__ __device__ long st3(int i) const { return z(i) + R * C; }
+    __host__ __device__ long out(int i) const { return st3(i) + R * 2; }
+    // attention block a (0 = self, 1 = cross) occupies R (10 C + 12) floats: [h | st | q | k | v | a | stat | z | stz | hn | t | xo]
+    __host__ __device__ long att_base(int a) const { return gcn_base(4) + (long)a * R * (10 * C + 12); }
+    __host__ __device__ long h(int a) const { return att_base(a); }
+    __host__ __device__ long st(int a) const { return h(a) + R * C; }
+    __host__ __device__ long q(int a) const { return st(a) + R * 2; }            // (a == 1: unused, the cross-hand q / k / v live in `qkv`)
+    __host__ __device__ long k(int a) const { return q(a) + R * C; }
+    __host__ __device__ long v(int a) const { return k(a) + R * C; }
+    __host__ __device__ long a_(int a) const { return v(a) + R * C; }
+    __host__ __device__ long stat(int a) const { return a_(a) + R * C; }
+    __host__ __device__ long az(int a) const { return stat(a) + R * 8; }
+    __host__ __device__ long stz(int a) const { return az(a) + R * C; }
+    __host__ __device__ long hn(int a) const { return stz(a) + R * 2; }
+    __host__ __device__ long t(int a) const { return hn(a) + R * C; }
+    __host__ __device__ long xo(int a) const { return t(a) + R * C; }            // (a == 1: unused, the level output is `out`)
+    __host__ __device__ long total() const { return att_base(2); }
+};
+__host__ __device__ inline TapeOff tape_offsets(int level, int B) {
+    TapeOff o;
+    o.C = 256L >> level;
+    o.R = 2L * B * (63L << level);
+    return o;
+}
+// gradient tape: the dY operands of the weight-gradient GEMMs
+struct GTapeOff {
+    long RC;
+    __host__ __device__ long dz(int i) const { return (3L * i) * RC; }
+    __host__ __device__ long dy2(int i) const { return (3L * i + 1) * RC; }
+    __host__ __device__ long dy(int i) const { return (3L * i + 2) * RC; }
+    // attention block a, slot k: 0 du, 1 dt_pre, 2 do, 3 dq, 4 dk, 5 dv, 6 dc (gradient of the attention output), 7 dxr (gradient reaching the
+    // residual stream at z), 8 dxin (gradient of the block's input: what the kernel in front of it starts from)
+    __host__ __device__ long att(int a, int k) const { return (12L + 9L * a + k) * RC; }
+    __host__ __device__ long scr() const { return 30L * RC; }                               // [R][C] scratch of GCN block 0's backward
+    __host__ __device__ long total() const { return 31L * RC; }
+};
+__host__ __device__ inline GTapeOff gtape_offsets(int level, int B) {
+    GTapeOff o;
+    o.RC = 2L * B * (63L << level) * (256L >> level);
+    return o;
+}
+PDF_API long pdf_mesh_tape_floats(int level, int B) { return level < 0 || level > 2 || B < 1 ? 0 : tape_offsets(level, B).total(); }
+PDF_API long pdf_mesh_gtape_floats(int level, int B) { return level < 0 || level > 2 || B < 1 ? 0 : gtape_offsets(level, B).total(); }
+
+// ---- wave / lane geometry ---------------------------------------------------------------------------------------------------------
+template <int LV> struct Geo {
+    using G = Cfg<LV>;
+    int lane, wave, half, l31;
+    int mt0, nt0;                                 // first M-tile / N-tile of this wave
+    __device__ Geo() {
+        lane = threadIdx.x & 63; wave = threadIdx.x >> 6; half = lane >> 5; l31 = lane & 31;
+        mt0 = LV == 2 ? 4 * (wave >> 1) : 0;
+        nt0 = LV == 0 ? 2 * wave : LV == 1 ? wave : (wave & 1);
+    }
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// acc[i][j] += A[rows of M-tile mt0 + i][0 .. K) . W[columns of N-tile nt0 + j][koff .. koff + K)^T
+// A: LDS image [VP][LD]; W: global, row n at W + n * ldw (nn.Linear storage [out][in]).  CHEBY: two A images (x, L x) against the
+// interleaved columns of a graph_conv_cheby weight (feature index fin * 2 + k, gcn.py:61-63): W[n][koff2 + 2 kk + {0, 1}].
+template <int LV, bool CHEBY>
+__device__ __forceinline__ void gemm_nt(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT], const Geo<LV>& g, const float* __restrict__ A0,
+                                        const float* __restrict__ A1, const float* __restrict__ W, int ldw, int koff, int K) {
+    using G = Cfg<LV>;
+    constexpr int WMT = G::WMT, WNT = G::WNT, PD = 4, NB = CHEBY ? 2 : 1;
+    const float* wp[WNT];
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) wp[j] = W + (long)((g.nt0 + j) * 32 + g.l31) * ldw + koff + (CHEBY ? 8 : 4) * g.half;
+    const float* ap0 = A0 + ((g.mt0 * 32 + g.l31) * G::LD + 4 * g.half);
+    const float* ap1 = CHEBY ? A1 + ((g.mt0 * 32 + g.l31) * G::LD + 4 * g.half) : nullptr;
+    const int NS = K / 8;                         // K-steps of 8 (per source)
+    f32x4 bq[PD][WNT][NB];
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int q = 0; q < NB; ++q) bq[u][j][q] = ld4(wp[j] + (CHEBY ? 16 : 8) * u + 4 * q);
+    for (int s = 0; s < NS; s += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            f32x4 b[WNT][NB];
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int q = 0; q < NB; ++q) b[j][q] = bq[u][j][q];
+            const int sn = min(s + u + PD, NS - 1);                 // (unconditional prefetch: the last steps re-read the final chunk)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int q = 0; q < NB; ++q) bq[u][j][q] = ld4(wp[j] + (CHEBY ? 16 : 8) * sn + 4 * q);
+            f32x4 a0[WMT], a1[WMT];
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) {
+                a0[i] = ld4(ap0 + i * 32 * G::LD + 8 * (s + u));
+                if constexpr (CHEBY) a1[i] = ld4(ap1 + i * 32 * G::LD + 8 * (s + u));
+            }
+            if constexpr (!CHEBY) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                        for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][e], b[j][0][e], acc[i][j], 0, 0, 0);
+            } else {
+                // the lane's 8 consecutive weights = (even, odd) pairs of its 4 k: w[2e] multiplies x, w[2e + 1] multiplies L x
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                        for (int j = 0; j < WNT; ++j) {
+                            const float we = e < 2 ? b[j][0][2 * e] : b[j][1][2 * e - 4];
+                            const float wo = e < 2 ? b[j][0][2 * e + 1] : b[j][1][2 * e - 3];
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][e], we, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][e], wo, acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+}
+
+// acc[i][j] += A[rows][0 .. K) . W[koff_n .. koff_n + K)[columns of N-tile]   with W stored [n][ldw] and the OUTPUT column index running
+// along W's rows' elements: out[m][c] = sum_n A[m][n] W[n0 + n][c0 + cs * c]   (backward-data of a Linear: dx = dy W; cs = 2 picks the
+// even / odd interleaved columns of a graph_conv_cheby weight)
+template <int LV>
+__device__ __forceinline__ void gemm_nn(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT], const Geo<LV>& g, const float* __restrict__ A0,
+                                        const float* __restrict__ W, int ldw, int c0, int cs, int K) {
+    using G = Cfg<LV>;
+    constexpr int WMT = G::WMT, WNT = G::WNT, PD = 2;
+    const float* wp[WNT];
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) wp[j] = W + (long)(4 * g.half) * ldw + c0 + cs * ((g.nt0 + j) * 32 + g.l31);
+    const float* ap0 = A0 + ((g.mt0 * 32 + g.l31) * G::LD + 4 * g.half);
+    const int NS = K / 8;
+    float bq[PD][WNT][4];
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bq[u][j][e] = wp[j][(long)(8 * u + e) * ldw];
+    for (int s = 0; s < NS; s += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            float b[WNT][4];
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[j][e] = bq[u][j][e];
+            const int sn = min(s + u + PD, NS - 1);
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[u][j][e] = wp[j][(long)(8 * sn + e) * ldw];
+            f32x4 a0[WMT];
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) a0[i] = ld4(ap0 + i * 32 * G::LD + 8 * (s + u));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+template <int LV>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT]) {
+#pragma unroll
+    for (int i = 0; i < Cfg<LV>::WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg<LV>::WNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// visit every accumulator element: f(row, col, value)   (32x32 block: column lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+template <int LV, typename Fn>
+__device__ __forceinline__ void acc_each(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT], const Geo<LV>& g, Fn f) {
+#pragma unroll
+    for (int i = 0; i < Cfg<LV>::WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg<LV>::WNT; ++j) {
+            const int col = (g.nt0 + j) * 32 + g.l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (g.mt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.half;
+                f(row, col, acc[i][j][r]);
+            }
+        }
+}
+
+// pdf_uniform(seed, idx) of common.h for idx < 2^32 (every index of a level is: mesh_check bounds B): the seed half of the hash is one
+// value per site, so an element costs one 32-bit hash -- and the 64 independent elements of an unrolled epilogue no longer carry
+// 64-bit index chains (round 5: those drove the kernel to 512 registers plus scratch)
+__device__ __forceinline__ uint32_t md_key(unsigned long long seed) { return pdf_hash32((uint32_t)seed) ^ ((uint32_t)(seed >> 32) * 0x9E3779B9U); }
+__device__ __forceinline__ bool md_keep(uint32_t key, uint32_t idx, float p) {
+    return (float)(pdf_hash32(idx ^ key) >> 8) * (1.0f / 16777216.0f) >= p;
+}
+__device__ __forceinline__ float md_drop(float v, float p, float sc, uint32_t key, uint32_t idx) {
+    return (p <= 0.f || md_keep(key, idx, p)) ? v * sc : 0.f;
+}
+
+// global [V][ld] (columns c0 .. c0 + C) -> LDS image [VP][LD]; rows >= V zero-filled
+template <int LV>
+__device__ __forceinline__ void load_rows(float* __restrict__ dst, const float* __restrict__ src, int ld, int c0) {
+    using G = Cfg<LV>;
+    constexpr int C4 = G::C / 4;
+    for (int i = threadIdx.x; i < G::VP * C4; i += MD_THREADS) {
+        const int v = i / C4, c = (i - v * C4) * 4;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (v < G::V) t = ld4(src + (long)v * ld + c0 + c);
+        st4(dst + v * G::LD + c, t);
+    }
+}
+// LDS image rows < V -> global [V][ld] (columns c0 ..)
+template <int LV>
+__device__ __forceinline__ void store_rows(float* __restrict__ dst, int ld, int c0, const float* __restrict__ src) {
+    using G = Cfg<LV>;
+    constexpr int C4 = G::C / 4;
+    for (int i = threadIdx.x; i < G::V * C4; i += MD_THREADS) {
+        const int v = i / C4, c = (i - v * C4) * 4;
+        st4(dst + (long)v * ld + c0 + c, ld4(src + v * G::LD + c));
+    }
+}
+
+// LX = L X on the LDS images (fixed-width ELL, <= 11 non-zeros per row); optionally writes the interleaved [x | L x] rows the weight
+// gradient of the following Linear reads (cat[v][2 (c0 + c) + {0, 1}], row stride ldcat)
+template <int LV>
+__device__ __forceinline__ void spmm(float* __restrict__ LX, const float* __restrict__ X, const int* __restrict__ col, const float* __restrict__ val,
+                                     int Wd, float* __restrict__ cat, int ldcat, int c0) {
+    using G = Cfg<LV>;
+    constexpr int C4 = G::C / 4;
+    for (int i = threadIdx.x; i < G::V * C4; i += MD_THREADS) {
+        const int v = i / C4, c = (i - v * C4) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < Wd; ++w) {
+            const float lv = val[v * Wd + w];
+            const f32x4 t = ld4(X + col[v * Wd + w] * G::LD + c);
+            a += lv * t;
+        }
+        st4(LX + v * G::LD + c, a);
+        if (cat != nullptr) {
+            const f32x4 x = ld4(X + v * G::LD + c);
+            float* o = cat + (long)v * ldcat + 2 * (c0 + c);
+            st4(o, f32x4{x[0], a[0], x[1], a[1]});
+            st4(o + 4, f32x4{x[2], a[2], x[3], a[3]});
+        }
+    }
+}
+// X += L^T-type product of T (same ELL form with the transposed tables): the backward of the above
+template <int LV>
+__device__ __forceinline__ void spmm_add(float* __restrict__ X, const float* __restrict__ T, const int* __restrict__ col, const float* __restrict__ val, int Wd) {
+    using G = Cfg<LV>;
+    constexpr int C4 = G::C / 4;
+    for (int i = threadIdx.x; i < G::V * C4; i += MD_THREADS) {
+        const int v = i / C4, c = (i - v * C4) * 4;
+        f32x4 a = ld4(X + v * G::LD + c);
+        for (int w = 0; w < Wd; ++w) {
+            const float lv = val[v * Wd + w];
+            a += lv * ld4(T + col[v * Wd + w] * G::LD + c);
+        }
+        st4(X + v * G::LD + c, a);
+    }
+}
+
+// LayerNorm of the LDS rows in place (one wave per row): buf = [relu](LN(buf) * gamma + beta); optional copies to HBM of the INPUT (zsave),
+// of (mean, rstd) and of the OUTPUT
+template <int LV>
+__device__ __forceinline__ void ln_rows(float* __restrict__ buf, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, bool relu,
+                                        float* __restrict__ zsave, float* __restrict__ st, float* __restrict__ ysave) {
+    using G = Cfg<LV>;
+    constexpr int PL = G::C / 64;                 // 4, 2, 1 elements per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gm[PL], bt[PL];
+#pragma unroll
+    for (int e = 0; e < PL; ++e) { gm[e] = gamma[lane + 64 * e]; bt[e] = beta[lane + 64 * e]; }
+    for (int v = wave; v < G::V; v += MD_THREADS / 64) {
+        float x[PL], s = 0.f;
+#pragma unroll
+        for (int e = 0; e < PL; ++e) { x[e] = buf[v * G::LD + lane + 64 * e]; s += x[e]; }
+        const float mu = wave_sum(s) / (float)G::C;
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < PL; ++e) { const float d = x[e] - mu; sq += d * d; }
+        const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)G::C + eps);
+#pragma unroll
+        for (int e = 0; e < PL; ++e) {
+            float o = (x[e] - mu) * rs * gm[e] + bt[e];
+            if (relu) o = fmaxf(o, 0.f);
+            buf[v * G::LD + lane + 64 * e] = o;
+            if (zsave != nullptr) zsave[(long)v * G::C + lane + 64 * e] = x[e];
+            if (ysave != nullptr) ysave[(long)v * G::C + lane + 64 * e] = o;
+        }
+        if (st != nullptr && lane == 0) { st[2 * v] = mu; st[2 * v + 1] = rs; }
+    }
+}
+
+// ---- attention on the matrix pipe ---------------------------------------------------------------------------------------------------
+// K, V of the attended sample: LDS images XK, XV [VP][LD] (rows >= V zero).  One wave per (head, 32-query tile):
+//   S^T[key][query] = sum_d K[key][d] (q[query][d] / sqrt(dh))        A = K rows (LDS b128), B = q rows (HBM float4)
+//   P = exp(S - max) (keys >= V masked), l = sum P, P~ = dropout(P)    registers + one cross-half shuffle
+//   O^T[d][query] = sum_key V[key][d] P~[key][query]                   A = V[key(lane)][d = lane & 31] (LDS b32), B = P~ straight from the S accumulators
+// out[query][h DH + d] = O / l; stat = (max, l) per (head, query)
+template <int LV>
+__device__ __forceinline__ void attention_fwd(const Geo<LV>& g, const float* __restrict__ XK, const float* __restrict__ XV, const float* __restrict__ q,
+                                              float* __restrict__ out, float* __restrict__ stat /*[H][V][2]*/, float p, unsigned long long seed,
+                                              unsigned long long rowbase /* bb * H * V * V */) {
+    using G = Cfg<LV>;
+    constexpr int MT = G::MT, DH = G::DH, DT = DH >= 32 ? DH / 32 : 1;
+    const float inv_norm = 1.f / sqrtf((float)DH), sc = 1.f / (1.f - p);
+    const uint32_t dkey = md_key(seed);
+    for (int item = g.wave; item < G::H * MT; item += MD_THREADS / 64) {
+        const int h = item / MT, qt = item - h * MT;
+        const int qrow = min(qt * 32 + g.l31, G::V - 1);            // (queries past V compute along and are never stored)
+        f32x4 qf[DH / 8];
+#pragma unroll
+        for (int s = 0; s < DH / 8; ++s) qf[s] = ld4(q + (long)qrow * G::C + h * DH + 8 * s + 4 * g.half) * inv_norm;
+        f32x16 S[MT];
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < DH / 8; ++s) {
+                const f32x4 kf = ld4(XK + (kt * 32 + g.l31) * G::LD + h * DH + 8 * s + 4 * g.half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[s][e], S[kt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // softmax over the keys of this lane's query: 16 MT values here + 16 MT in lane ^ 32
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.half;
+                if (kt == MT - 1 && key >= G::V) S[kt][r] = -INFINITY;
+                m = fmaxf(m, S[kt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+        const int qi = qt * 32 + g.l31;
+        const uint32_t rid = (uint32_t)rowbase + (uint32_t)((h * G::V + qi) * G::V);
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.half;
+                float pv = expf(S[kt][r] - m);
+                l += pv;
+                if (p > 0.f) pv = md_keep(dkey, rid + (uint32_t)key, p) ? pv * sc : 0.f;
+                S[kt][r] = pv;
+            }
+        l += __shfl_xor(l, 32, 64);
+        const float il = 1.f / l;
+        f32x16 O[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < MT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.half;
+                    const float vf = XV[key * G::LD + h * DH + dt * 32 + g.l31];
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, S[kt][r], O[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);                  // (keeps the compiler from hoisting all MT x 16 LDS reads ahead of the first MFMA)
+            }
+        }
+        if (qi < G::V) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = dt * 32 + 8 * r4 + 4 * g.half;          // rows d .. d + 3 of the O^T block
+                    if (d < DH) st4(out + (long)qi * G::C + h * DH + d, f32x4{O[dt][4 * r4] * il, O[dt][4 * r4 + 1] * il, O[dt][4 * r4 + 2] * il, O[dt][4 * r4 + 3] * il});
+                }
+            if (g.half == 0 && stat != nullptr) { stat[((long)h * G::V + qi) * 2] = m; stat[((long)h * G::V + qi) * 2 + 1] = l; }
+        }
+    }
+}
+
+// ---- forward stages -------------------------------------------------------------------------------------------------------------------
+template <int LV> struct Ctx {
+    using G = Cfg<LV>;
+    Geo<LV> g;
+    float* XA; float* XB;
+    int hand, b, bb, B;                           // bb = hand * B + b: index of this (hand, sample) in the stacked [2 B] batch
+    long row0;                                    // first row of this (hand, sample) in the stacked [2 B V] row space
+    float p, sc;
+    unsigned long long stepmix;
+    bool train;
+};
+
+// y[V][C] (LDS dst, +bias) = A . W^T; every wave writes its tiles.  `dst` must not be an operand of the product.
+template <int LV>
+__device__ __forceinline__ void acc_to_lds(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT], const Geo<LV>& g, float* __restrict__ dst, const float* __restrict__ bias) {
+    using G = Cfg<LV>;
+#pragma unroll
+    for (int j = 0; j < G::WNT; ++j) {
+        const float bv = bias != nullptr ? bias[(g.nt0 + j) * 32 + g.l31] : 0.f;
+#pragma unroll
+        for (int i = 0; i < G::WMT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (g.mt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.half;
+                dst[row * G::LD + (g.nt0 + j) * 32 + g.l31] = acc[i][j][r] + bv;
+            }
+    }
+}
+
+// One GCN_ResBlock (gcn.py:99-110).  In: x in HBM ([V][cin] rows of this (hand, sample)); when `x_in_lds` the block input (cin == C) already
+// sits in XA.  Out: the block output in XA (and in HBM: `xout`).
+template <int LV>
+__device__ __forceinline__ void gcn_block(Ctx<LV>& c, const PdfMeshLevel& a, const MdGcn& P, int blk, const float* __restrict__ x, int cin, bool x_in_lds,
+                                          const TapeOff& to, float* __restrict__ xout, bool relu_out) {
+    using G = Cfg<LV>;
+    constexpr int C = G::C;
+    const int hd = c.hand;
+    const int* col = a.ell_col[hd]; const float* val = a.ell_val[hd];
+    float* tape = a.tape;
+    const bool tr = c.train;
+    float* cat1 = tr ? tape + to.cat1(blk) + c.row0 * 2 * cin : nullptr;
+    f32x16 accy[G::WMT][G::WNT], accs[G::WMT][G::WNT];
+    acc_zero<LV>(accy);
+    acc_zero<LV>(accs);
+    // fc1 over cat(x, L x) and the shortcut over x, in column chunks of C (block 0: cin = 2 C)
+    for (int c0 = 0; c0 < cin; c0 += C) {
+        if (!(x_in_lds && c0 == 0)) {
+            __syncthreads();                                            // (previous readers of XA are done)
+            load_rows<LV>(c.XA, x, cin, c0);
+        }
+        __syncthreads();
+        spmm<LV>(c.XB, c.XA, col, val, a.ell_w, cat1, 2 * cin, c0);
+        __syncthreads();
+        gemm_nt<LV, true>(accy, c.g, c.XA, c.XB, P.fc1.w[hd], 2 * cin, 2 * c0, C);
+        gemm_nt<LV, false>(accs, c.g, c.XA, nullptr, P.sc.w[hd], cin, c0, C);
+    }
+    __syncthreads();
+    // y = fc1 + b1 -> LN2 + ReLU -> h (XA)
+    acc_to_lds<LV>(accy, c.g, c.XA, P.fc1.b[hd]);
+    __syncthreads();
+    ln_rows<LV>(c.XA, P.n2.g[hd], P.n2.b[hd], 1e-6f, true, tr ? tape + to.y(blk) + c.row0 * C : nullptr, tr ? tape + to.st2(blk) + c.row0 * 2 : nullptr, nullptr);
+    __syncthreads();
+    spmm<LV>(c.XB, c.XA, col, val, a.ell_w, tr ? tape + to.cat2(blk) + c.row0 * 2 * C : nullptr, 2 * C, 0);
+    __syncthreads();
+    acc_zero<LV>(accy);
+    gemm_nt<LV, true>(accy, c.g, c.XA, c.XB, P.fc2.w[hd], 2 * C, 0, C);
+    __syncthreads();
+    // z = (s + bs) + dropout(y2 + b2) -> XA; LN3 (+ ReLU between blocks)
+    {
+        const uint32_t key = md_key(P.seed + c.stepmix);
+        const uint32_t i0 = (uint32_t)(c.row0 * C);
+        const float* b2 = P.fc2.b[hd]; const float* bs = P.sc.b[hd];
+#pragma unroll
+        for (int j = 0; j < G::WNT; ++j) {
+            const int colj = (c.g.nt0 + j) * 32 + c.g.l31;
+            const float b2v = b2[colj], bsv = bs[colj];
+#pragma unroll
+            for (int i = 0; i < G::WMT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (c.g.mt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * c.g.half;
+                    const float y2 = md_drop(accy[i][j][r] + b2v, c.p, c.sc, key, i0 + (uint32_t)(row * C + colj));
+                    c.XA[row * G::LD + colj] = (accs[i][j][r] + bsv) + y2;
+                }
+        }
+    }
+    __syncthreads();
+    ln_rows<LV>(c.XA, P.n3.g[hd], P.n3.b[hd], 1e-6f, relu_out, tr ? tape + to.z(blk) + c.row0 * C : nullptr, tr ? tape + to.st3(blk) + c.row0 * 2 : nullptr, xout);
+}
+
+// LN -> q / k / v projections.  In: x in XA.  Out: h (tape), q / k / v in HBM.  XA keeps h.
+template <int LV>
+__device__ __forceinline__ void qkv_stage(Ctx<LV>& c, const MdAttn& P, float* __restrict__ hsave, float* __restrict__ stsave,
+                                          float* __restrict__ q, float* __restrict__ k, float* __restrict__ v) {
+    using G = Cfg<LV>;
+    constexpr int C = G::C;
+    const int hd = c.hand;
+    __syncthreads();
+    ln_rows<LV>(c.XA, P.ln.g[hd], P.ln.b[hd], 1e-6f, false, nullptr, stsave, hsave);
+    __syncthreads();
+    const MdLin* lin[3] = {&P.q, &P.k, &P.v};
+    float* dst[3] = {q, k, v};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        f32x16 acc[G::WMT][G::WNT];
+        acc_zero<LV>(acc);
+        gemm_nt<LV, false>(acc, c.g, c.XA, nullptr, lin[t]->w[hd], C, 0, C);
+        const float* bias = lin[t]->b[hd];
+        float* o = dst[t];
+        acc_each<LV>(acc, c.g, [&](int row, int colj, float val) { if (row < G::V) o[(long)row * C + colj] = val + bias[colj]; });
+    }
+}
+
+// attention (keys / values of stacked sample bkv) -> fc -> z = x + dropout(o) -> LN -> fc1 + ReLU + dropout -> fc2 -> x + dropout: the level's
+// second half of SelfAttn.forward / inter_attn.forward (self_attn.py:63-85, 24-33; inter_attn.py:82-125)
+template <int LV>
+__device__ __forceinline__ void attn_tail_stage(Ctx<LV>& c, const MdAttn& P, const float* __restrict__ xres /* HBM [V][C]: the residual stream */,
+                                                const float* __restrict__ q, const float* __restrict__ kk, const float* __restrict__ vv, int bkv,
+                                                float* __restrict__ asave, float* __restrict__ statsave, float* __restrict__ zsave, float* __restrict__ stzsave,
+                                                float* __restrict__ hnsave, float* __restrict__ tsave, float* __restrict__ xout) {
+    using G = Cfg<LV>;
+    constexpr int C = G::C;
+    const int hd = c.hand;
+    const long VC = (long)G::V * C;
+    __syncthreads();
+    load_rows<LV>(c.XA, kk + (long)bkv * VC, C, 0);
+    load_rows<LV>(c.XB, vv + (long)bkv * VC, C, 0);
+    __syncthreads();
+    attention_fwd<LV>(c.g, c.XA, c.XB, q + (long)c.bb * VC, asave, statsave, c.p, P.seed_att + c.stepmix, (unsigned long long)c.bb * G::H * G::V * G::V);
+    __syncthreads();                                                    // (asave written by this block: visible to it after the barrier)
+    load_rows<LV>(c.XA, asave, C, 0);
+    __syncthreads();
+    f32x16 acc[G::WMT][G::WNT];
+    acc_zero<LV>(acc);
+    gemm_nt<LV, false>(acc, c.g, c.XA, nullptr, P.fc.w[hd], C, 0, C);
+    {   // z = x + dropout(o + b) -> XB
+        const uint32_t key = md_key(P.seed_z + c.stepmix), i0 = (uint32_t)(c.row0 * C);
+        const float* bias = P.fc.b[hd];
+        acc_each<LV>(acc, c.g, [&](int row, int colj, float val) {
+            const int rr = min(row, G::V - 1);
+            const float o = md_drop(val + bias[colj], c.p, c.sc, key, i0 + (uint32_t)(row * C + colj));
+            c.XB[row * G::LD + colj] = xres[(long)rr * C + colj] + o;
+        });
+    }
+    __syncthreads();
+    ln_rows<LV>(c.XB, P.ffln.g[hd], P.ffln.b[hd], 1e-6f, false, zsave, stzsave, hnsave);     // XB = hn; z saved to HBM (it is the residual of the tail)
+    __syncthreads();
+    acc_zero<LV>(acc);
+    gemm_nt<LV, false>(acc, c.g, c.XB, nullptr, P.f1.w[hd], C, 0, C);
+    {   // t = dropout(relu(fc1)) -> XA
+        const uint32_t key = md_key(P.seed_t + c.stepmix), i0 = (uint32_t)(c.row0 * C);
+        const float* bias = P.f1.b[hd];
+        acc_each<LV>(acc, c.g, [&](int row, int colj, float val) {
+            const float t = md_drop(fmaxf(val + bias[colj], 0.f), c.p, c.sc, key, i0 + (uint32_t)(row * C + colj));
+            c.XA[row * G::LD + colj] = t;
+            if (tsave != nullptr && row < G::V) tsave[(long)row * C + colj] = t;
+        });
+    }
+    __syncthreads();
+    acc_zero<LV>(acc);
+    gemm_nt<LV, false>(acc, c.g, c.XA, nullptr, P.f2.w[hd], C, 0, C);
+    __syncthreads();
+    {   // x = z + dropout(u) -> XA and HBM.  z: in training from its HBM copy, else recomputed is not possible -> zsave is always given
+        const uint32_t key = md_key(P.seed_x + c.stepmix), i0 = (uint32_t)(c.row0 * C);
+        const float* bias = P.f2.b[hd];
+        acc_each<LV>(acc, c.g, [&](int row, int colj, float val) {
+            const int rr = min(row, G::V - 1);
+            const float u = md_drop(val + bias[colj], c.p, c.sc, key, i0 + (uint32_t)(row * C + colj));
+            const float xo = zsave[(long)rr * C + colj] + u;
+            c.XA[row * G::LD + colj] = xo;
+            if (row < G::V) xout[(long)row * C + colj] = xo;
+        });
+    }
+}
+
+template <int LV>
+__device__ __forceinline__ void ctx_init(Ctx<LV>& c, const PdfMeshLevel& a, float* smem) {
+    using G = Cfg<LV>;
+    c.XA = smem; c.XB = smem + G::BUF;
+    c.B = a.B;
+    c.bb = blockIdx.x; c.hand = c.bb / a.B; c.b = c.bb - c.hand * a.B;
+    c.row0 = (long)c.bb * G::V;
+    c.train = a.training != 0;
+    c.p = c.train ? a.p : 0.f;
+    c.sc = 1.f / (1.f - c.p);
+    c.stepmix = (a.step != nullptr && c.p > 0.f) ? a.step[0] * 0x9E3779B97F4A7C15ull : 0ull;
+}
+
+// launch 1: the four GCN_ResBlocks of this (hand, sample) and the q / k / v projections of its SelfAttn
+template <int LV>
+__global__ __launch_bounds__(MD_THREADS, 1) void mesh_gcn_kernel(const PdfMeshLevel a) {
+    using G = Cfg<LV>;
+    constexpr int C = G::C;
+    extern __shared__ float smem[];
+    Ctx<LV> c;
+    ctx_init<LV>(c, a, smem);
+    const TapeOff to = tape_offsets(LV, a.B);
+    float* tape = a.tape;
+    // the per-(hand, sample) intermediates the chain hands from stage to stage through HBM: in training they ARE the tape; in eval mode the
+    // same slots are used (the caller always provides the tape buffer)
+    const float* x = a.x + c.row0 * a.cin0;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        float* xo = tape + to.out(i) + c.row0 * C;
+        gcn_block<LV>(c, a, a.gcn[i], i, x, i == 0 ? a.cin0 : C, i > 0, to, xo, i != 3);
+        x = xo;
+    }
+    qkv_stage<LV>(c, a.self_, c.train ? tape + to.h(0) + c.row0 * C : nullptr, c.train ? tape + to.st(0) + c.row0 * 2 : nullptr,
+                  tape + to.q(0) + c.row0 * C, tape + to.k(0) + c.row0 * C, tape + to.v(0) + c.row0 * C);
+}
+
+// launch 2 (CROSS = false): SelfAttn's attention + tail, then LN1 / LN2 and the shared q / k / v of the cross-hand step;
+// launch 3 (CROSS = true): the cross-hand attention (keys / values of the other hand of the same sample, inter_attn.py:82-105) + tail
+template <int LV, bool CROSS>
+__global__ __launch_bounds__(MD_THREADS, 1) void mesh_att_kernel(const PdfMeshLevel a) {
+    using G = Cfg<LV>;
+    constexpr int C = G::C;
+    extern __shared__ float smem[];
+    Ctx<LV> c;
+    ctx_init<LV>(c, a, smem);
+    const TapeOff to = tape_offsets(LV, a.B);
+    float* tape = a.tape;
+    const long R = 2L * a.B * G::V;
+    constexpr int A = CROSS ? 1 : 0;
+    const MdAttn& P = CROSS ? a.cross : a.self_;
+    const float* xres = CROSS ? tape + to.xo(0) + c.row0 * C : tape + to.out(3) + c.row0 * C;
+    const float* q = CROSS ? a.qkv : tape + to.q(0);
+    const float* k = CROSS ? a.qkv + R * C : tape + to.k(0);
+    const float* v = CROSS ? a.qkv + 2 * R * C : tape + to.v(0);
+    const int bkv = CROSS ? (c.bb + a.B) % (2 * a.B) : c.bb;
+    float* xout = CROSS ? a.out + c.row0 * C : tape + to.xo(0) + c.row0 * C;
+    attn_tail_stage<LV>(c, P, xres, q, k, v, bkv, tape + to.a_(A) + c.row0 * C, c.train ? tape + to.stat(A) + c.row0 * 8 : nullptr,
+                        tape + to.az(A) + c.row0 * C, c.train ? tape + to.stz(A) + c.row0 * 2 : nullptr, c.train ? tape + to.hn(A) + c.row0 * C : nullptr,
+                        c.train ? tape + to.t(A) + c.row0 * C : nullptr, xout);
+    if constexpr (!CROSS)
+        qkv_stage<LV>(c, a.cross, c.train ? tape + to.h(1) + c.row0 * C : nullptr, c.train ? tape + to.st(1) + c.row0 * 2 : nullptr,
+                      a.qkv + c.row0 * C, a.qkv + R * C + c.row0 * C, a.qkv + 2 * R * C + c.row0 * C);
+}
+
+template <int LV>
+static int mesh_fwd_launch(const PdfMeshLevel& a, hipStream_t s) {
+    using G = Cfg<LV>;
+    const size_t smem = (size_t)2 * G::BUF * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_gcn_kernel<LV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) return (int)e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_kernel<LV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) return (int)e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_kernel<LV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(mesh_gcn_kernel<LV>, dim3(2 * a.B), dim3(MD_THREADS), smem, s, a);
+    PDF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((mesh_att_kernel<LV, false>), dim3(2 * a.B), dim3(MD_THREADS), smem, s, a);
+    PDF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((mesh_att_kernel<LV, true>), dim3(2 * a.B), dim3(MD_THREADS), smem, s, a);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+static int mesh_check(const PdfMeshLevel* a) {
+    if (a == nullptr || a->level < 0 || a->level > 2 || a->B < 1 || a->x == nullptr || a->out == nullptr || a->tape == nullptr || a->qkv == nullptr) return PDF_E_BADARG;
+    if (a->cin0 != 2 * (256 >> a->level) || a->ell_w < 1 || a->ell_w > 16) return PDF_E_BADARG;
+    if (a->training && (a->p < 0.f || a->p >= 1.f)) return PDF_E_BADARG;
+    if (a->B > 2048) return PDF_E_BADARG;                              // 32-bit dropout indices: 2 B H V^2 and 2 B V C stay below 2^32
+    return 0;
+}
+
+// One DualGraphLayer forward (position embedding already added to x).  Launches three kernels on `stream`; allocates nothing, synchronises nothing.
+PDF_API int pdf_mesh_level_fwd(const PdfMeshLevel* a, hipStream_t stream) {
+    if (int rc = mesh_check(a)) return rc;
+    switch (a->level) {
+        case 0: return mesh_fwd_launch<0>(*a, stream);
+        case 1: return mesh_fwd_launch<1>(*a, stream);
+        default: return mesh_fwd_launch<2>(*a, stream);
+    }
+}
+PDF_API int pdf_debug_mesh_level_size() { return (int)sizeof(PdfMeshLevel); }
+
+// =====================================================================================================================================
+// Backward.  Five launches per level: cross tail | cross attention + projections | self tail | self attention + projections | 4 GCN blocks.
+// The data gradient chain stays in LDS like the forward; every dY a weight-gradient GEMM needs goes to `gtape`, the LayerNorm parameter
+// gradients are accumulated from here with atomics (per wave: its rows' column sums), and pdf_mesh_level_bwd then issues the library's
+// weight-gradient launches on the side stream.
+
+// global [V][ld] (columns c0 ..) * scale -> LDS image; rows >= V zero
+template <int LV>
+__device__ __forceinline__ void load_rows_scaled(float* __restrict__ dst, const float* __restrict__ src, int ld, int c0, float scale) {
+    using G = Cfg<LV>;
+    constexpr int C4 = G::C / 4;
+    for (int i = threadIdx.x; i < G::VP * C4; i += MD_THREADS) {
+        const int v = i / C4, c = (i - v * C4) * 4;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (v < G::V) t = ld4(src + (long)v * ld + c0 + c) * scale;
+        st4(dst + v * G::LD + c, t);
+    }
+}
+
+// LayerNorm backward of the LDS rows in place: buf holds dL/dy (before the ReLU mask); afterwards dL/dz (+ add).
+//   y = [relu](xhat * gamma + beta), xhat = (z - mean) * rstd;  dz = rstd (g - mean(g) - xhat mean(g xhat)), g = dy' gamma
+// z, (mean, rstd) from the tape; dgamma += sum dy' xhat, dbeta += sum dy' over this workgroup's rows (one atomic per column and wave).
+template <int LV>
+__device__ __forceinline__ void ln_bwd_rows(float* __restrict__ buf, const float* __restrict__ zin, const float* __restrict__ st,
+                                            const float* __restrict__ gamma, const float* __restrict__ beta, bool relu, const float* __restrict__ add,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ save) {
+    using G = Cfg<LV>;
+    constexpr int PL = G::C / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gm[PL], bt[PL], ag[PL], ab[PL];
+#pragma unroll
+    for (int e = 0; e < PL; ++e) { gm[e] = gamma[lane + 64 * e]; bt[e] = relu ? beta[lane + 64 * e] : 0.f; ag[e] = 0.f; ab[e] = 0.f; }
+    for (int v = wave; v < G::V; v += MD_THREADS / 64) {
+        const float mu = st[2 * v], rs = st[2 * v + 1];
+        float g[PL], xh[PL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < PL; ++e) {
+            const int cc = lane + 64 * e;
+            float d = buf[v * G::LD + cc];
+            xh[e] = (zin[(long)v * G::C + cc] - mu) * rs;
+            if (relu && !(xh[e] * gm[e] + bt[e] > 0.f)) d = 0.f;
+            ag[e] += d * xh[e]; ab[e] += d;
+            g[e] = d * gm[e];
+            s1 += g[e]; s2 += g[e] * xh[e];
+        }
+        s1 = wave_sum(s1) / (float)G::C;
+        s2 = wave_sum(s2) / (float)G::C;
+#pragma unroll
+        for (int e = 0; e < PL; ++e) {
+            const int cc = lane + 64 * e;
+            float o = rs * (g[e] - s1 - xh[e] * s2);
+            if (add != nullptr) o += add[(long)v * G::C + cc];
+            buf[v * G::LD + cc] = o;
+            if (save != nullptr) save[(long)v * G::C + cc] = o;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < PL; ++e) {
+        if (dgamma != nullptr) atomicAdd(dgamma + lane + 64 * e, ag[e]);
+        if (dbeta != nullptr) atomicAdd(dbeta + lane + 64 * e, ab[e]);
+    }
+}
+
+// store the wave's accumulator tiles as rows of a global [V][ld] tensor (columns c0 + ...)
+template <int LV>
+__device__ __forceinline__ void acc_to_global(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT], const Geo<LV>& g, float* __restrict__ dst, int ld, int c0) {
+    acc_each<LV>(acc, g, [&](int row, int colj, float val) { if (row < Cfg<LV>::V) dst[(long)row * ld + c0 + colj] = val; });
+}
+
+// ---- attention backward, query side: dq of this (hand, sample)'s queries against the keys / values in XK, XV -------------------------------
+template <int LV>
+__device__ __forceinline__ void attention_bwd_q(const Geo<LV>& g, const float* __restrict__ XK, const float* __restrict__ XV, const float* __restrict__ q,
+                                                const float* __restrict__ o, const float* __restrict__ dO, const float* __restrict__ stat,
+                                                float* __restrict__ dq, float p, unsigned long long seed, unsigned long long rowbase) {
+    using G = Cfg<LV>;
+    constexpr int MT = G::MT, DH = G::DH, DT = DH >= 32 ? DH / 32 : 1;
+    const float inv_norm = 1.f / sqrtf((float)DH), sc = 1.f / (1.f - p);
+    const uint32_t dkey = md_key(seed);
+    for (int item = g.wave; item < G::H * MT; item += MD_THREADS / 64) {
+        const int h = item / MT, qt = item - h * MT;
+        const int qi = qt * 32 + g.l31, qrow = min(qi, G::V - 1);
+        f32x4 qf[DH / 8], gf[DH / 8];
+        float D = 0.f;
+#pragma unroll
+        for (int s = 0; s < DH / 8; ++s) {
+            const long off = (long)qrow * G::C + h * DH + 8 * s + 4 * g.half;
+            qf[s] = ld4(q + off) * inv_norm;
+            gf[s] = ld4(dO + off);
+            const f32x4 of = ld4(o + off);
+            D += gf[s][0] * of[0] + gf[s][1] * of[1] + gf[s][2] * of[2] + gf[s][3] * of[3];
+        }
+        D += __shfl_xor(D, 32, 64);
+        const float m = stat[((long)h * G::V + qrow) * 2], il = 1.f / stat[((long)h * G::V + qrow) * 2 + 1];
+        f32x16 S[MT], P[MT];
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[kt][r] = 0.f; P[kt][r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < DH / 8; ++s) {
+                const f32x4 kf = ld4(XK + (kt * 32 + g.l31) * G::LD + h * DH + 8 * s + 4 * g.half);
+                const f32x4 vf = ld4(XV + (kt * 32 + g.l31) * G::LD + h * DH + 8 * s + 4 * g.half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    S[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[s][e], S[kt], 0, 0, 0);
+                    P[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], gf[s][e], P[kt], 0, 0, 0);          // dP~^T[key][q] = V[key] . dO[q]
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const uint32_t rid = (uint32_t)rowbase + (uint32_t)((h * G::V + qi) * G::V);
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.half;
+                float a = expf(S[kt][r] - m) * il;
+                if (kt == MT - 1 && key >= G::V) a = 0.f;
+                float gv = P[kt][r];
+                if (p > 0.f) gv = md_keep(dkey, rid + (uint32_t)key, p) ? gv * sc : 0.f;
+                S[kt][r] = a * (gv - D) * inv_norm;
+            }
+        f32x16 O[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < MT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.half;
+                    const float kf = XK[key * G::LD + h * DH + dt * 32 + g.l31];
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, S[kt][r], O[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (qi < G::V) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = dt * 32 + 8 * r4 + 4 * g.half;
+                    if (d < DH) st4(dq + (long)qi * G::C + h * DH + d, f32x4{O[dt][4 * r4], O[dt][4 * r4 + 1], O[dt][4 * r4 + 2], O[dt][4 * r4 + 3]});
+                }
+        }
+    }
+}
+
+// ---- attention backward, key side: dk, dv of this (hand, sample)'s keys from the queries that attended to them ------------------------------
+// XQ = q / sqrt(dh) and XG = dO of the QUERYING sample (LDS images, rows >= V zero); sm = [3][H][VP]: max, 1 / sumexp, D = dO . O per (head, query)
+template <int LV>
+__device__ __forceinline__ void attention_bwd_kv(const Geo<LV>& g, const float* __restrict__ XQ, const float* __restrict__ XG, const float* __restrict__ sm,
+                                                 const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ dk, float* __restrict__ dv,
+                                                 float p, unsigned long long seed, unsigned long long rowbase) {
+    using G = Cfg<LV>;
+    constexpr int MT = G::MT, DH = G::DH, DT = DH >= 32 ? DH / 32 : 1, HV = G::H * G::VP;
+    const float sc = 1.f / (1.f - p);
+    const uint32_t dkey = md_key(seed);
+    for (int item = g.wave; item < G::H * MT; item += MD_THREADS / 64) {
+        const int h = item / MT, kt = item - h * MT;
+        const int key = kt * 32 + g.l31, krow = min(key, G::V - 1);
+        f32x4 kf[DH / 8], vf[DH / 8];
+#pragma unroll
+        for (int s = 0; s < DH / 8; ++s) {
+            const long off = (long)krow * G::C + h * DH + 8 * s + 4 * g.half;
+            kf[s] = ld4(k + off);
+            vf[s] = ld4(v + off);
+        }
+        f32x16 S[MT], P[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[mt][r] = 0.f; P[mt][r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < DH / 8; ++s) {
+                const f32x4 qa = ld4(XQ + (mt * 32 + g.l31) * G::LD + h * DH + 8 * s + 4 * g.half);
+                const f32x4 ga = ld4(XG + (mt * 32 + g.l31) * G::LD + h * DH + 8 * s + 4 * g.half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    S[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[s][e], S[mt], 0, 0, 0);          // S[q][key]
+                    P[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[e], vf[s][e], P[mt], 0, 0, 0);          // dP~[q][key] = dO[q] . V[key]
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.half;
+                const float m = sm[h * G::VP + qi], il = sm[HV + h * G::VP + qi], D = sm[2 * HV + h * G::VP + qi];
+                const float a = expf(S[mt][r] - m) * il;                       // (queries >= V: il = 0)
+                float at = a, gv = P[mt][r];
+                if (p > 0.f) {
+                    const bool keep = md_keep(dkey, (uint32_t)rowbase + (uint32_t)((h * G::V + qi) * G::V + key), p);
+                    at = keep ? a * sc : 0.f;
+                    gv = keep ? gv * sc : 0.f;
+                }
+                S[mt][r] = a * (gv - D);                                       // x (q / sqrt(dh)) below = dS q / sqrt(dh)
+                P[mt][r] = at;
+            }
+        f32x16 OK[DT], OV[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { OK[dt][r] = 0.f; OV[dt][r] = 0.f; }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.half;
+                    const float qa = XQ[qi * G::LD + h * DH + dt * 32 + g.l31];
+                    const float ga = XG[qi * G::LD + h * DH + dt * 32 + g.l31];
+                    OK[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, S[mt][r], OK[dt], 0, 0, 0);
+                    OV[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, P[mt][r], OV[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (key < G::V) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = dt * 32 + 8 * r4 + 4 * g.half;
+                    if (d < DH) {
+                        st4(dk + (long)key * G::C + h * DH + d, f32x4{OK[dt][4 * r4], OK[dt][4 * r4 + 1], OK[dt][4 * r4 + 2], OK[dt][4 * r4 + 3]});
+                        st4(dv + (long)key * G::C + h * DH + d, f32x4{OV[dt][4 * r4], OV[dt][4 * r4 + 1], OV[dt][4 * r4 + 2], OV[dt][4 * r4 + 3]});
+                    }
+                }
+        }
+    }
+}
+
+// tail of an attention block, backward: x_out = z + drop(f2(t)), t = drop(relu(f1(LN(z)))), z = x + drop(fc(a))
+//   in: dX (HBM).  out (gtape): du, dt_pre, do, dc = d a, dxr = d z (all of it)
+template <int LV, bool CROSS>
+__global__ __launch_bounds__(MD_THREADS, 1) void mesh_att_bwd1_kernel(const PdfMeshLevel a) {
+    using G = Cfg<LV>;
+    constexpr int C = G::C, A = CROSS ? 1 : 0;
+    extern __shared__ float smem[];
+    Ctx<LV> c;
+    ctx_init<LV>(c, a, smem);
+    const int hd = c.hand;
+    const TapeOff to = tape_offsets(LV, a.B);
+    const GTapeOff go = gtape_offsets(LV, a.B);
+    const MdAttn& P = CROSS ? a.cross : a.self_;
+    const MdAttnG& GP = CROSS ? a.gcross : a.gself;
+    const float* tape = a.tape;
+    float* gt = a.gtape;
+    const long ro = c.row0 * C;
+    const uint32_t i0 = (uint32_t)ro;
+    const float* dX = CROSS ? a.dout + ro : gt + go.att(1, 8) + ro;
+    // du = drop_x(dX) -> XB;  XA = dX
+    {
+        const uint32_t key = md_key(P.seed_x + c.stepmix);
+        constexpr int C4 = C / 4;
+        for (int i = threadIdx.x; i < G::VP * C4; i += MD_THREADS) {
+            const int v = i / C4, cc = (i - v * C4) * 4;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f}, u = t;
+            if (v < G::V) {
+                t = ld4(dX + (long)v * C + cc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = md_drop(t[e], c.p, c.sc, key, i0 + (uint32_t)(v * C + cc + e));
+                st4(gt + go.att(A, 0) + ro + (long)v * C + cc, u);
+            }
+            st4(c.XA + v * G::LD + cc, t);
+            st4(c.XB + v * G::LD + cc, u);
+        }
+    }
+    __syncthreads();
+    f32x16 acc[G::WMT][G::WNT];
+    acc_zero<LV>(acc);
+    gemm_nn<LV>(acc, c.g, c.XB, P.f2.w[hd], C, 0, 1, C);                // dt = du W2
+    __syncthreads();
+    {   // dt_pre = dt * sc where t != 0 -> XB, gtape
+        const float* t = tape + to.t(A) + ro;
+        float* dtp = gt + go.att(A, 1) + ro;
+        acc_each<LV>(acc, c.g, [&](int row, int colj, float val) {
+            const int rr = min(row, G::V - 1);
+            const float o = t[(long)rr * C + colj] != 0.f ? val * c.sc : 0.f;
+            c.XB[row * G::LD + colj] = row < G::V ? o : 0.f;
+            if (row < G::V) dtp[(long)row * C + colj] = o;
+        });
+    }
+    __syncthreads();
+    acc_zero<LV>(acc);
+    gemm_nn<LV>(acc, c.g, c.XB, P.f1.w[hd], C, 0, 1, C);                // d hn = dt_pre W1
+    __syncthreads();
+    acc_to_lds<LV>(acc, c.g, c.XB, nullptr);
+    __syncthreads();
+    // LN_ff backward; dz = dX + (that) -> XB and gtape.dxr
+    ln_bwd_rows<LV>(c.XB, tape + to.az(A) + ro, tape + to.stz(A) + c.row0 * 2, P.ffln.g[hd], nullptr, false, dX, GP.ffln.g[hd], GP.ffln.b[hd],
+                    gt + go.att(A, 7) + ro);
+    __syncthreads();
+    {   // do = drop_z(dz) -> XA, gtape
+        const uint32_t key = md_key(P.seed_z + c.stepmix);
+        constexpr int C4 = C / 4;
+        for (int i = threadIdx.x; i < G::V * C4; i += MD_THREADS) {
+            const int v = i / C4, cc = (i - v * C4) * 4;
+            f32x4 t = ld4(c.XB + v * G::LD + cc), u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = md_drop(t[e], c.p, c.sc, key, i0 + (uint32_t)(v * C + cc + e));
+            st4(c.XA + v * G::LD + cc, u);
+            st4(gt + go.att(A, 2) + ro + (long)v * C + cc, u);
+        }
+    }
+    __syncthreads();
+    acc_zero<LV>(acc);
+    gemm_nn<LV>(acc, c.g, c.XA, P.fc.w[hd], C, 0, 1, C);                // dc = do Wfc
+    acc_to_global<LV>(acc, c.g, gt + go.att(A, 6) + ro, C, 0);
+}
+
+// attention + projections + LN of an attention block, backward: in dc (every workgroup's: kernel boundary in front), dxr; out dq, dk, dv, dxin
+template <int LV, bool CROSS>
+__global__ __launch_bounds__(MD_THREADS, 1) void mesh_att_bwd2_kernel(const PdfMeshLevel a) {
+    using G = Cfg<LV>;
+    constexpr int C = G::C, A = CROSS ? 1 : 0, HV = G::H * G::VP;
+    extern __shared__ float smem[];
+    Ctx<LV> c;
+    ctx_init<LV>(c, a, smem);
+    float* sm = smem + 2 * G::BUF;                                      // [3][H][VP]
+    const int hd = c.hand;
+    const TapeOff to = tape_offsets(LV, a.B);
+    const GTapeOff go = gtape_offsets(LV, a.B);
+    const MdAttn& P = CROSS ? a.cross : a.self_;
+    const MdAttnG& GP = CROSS ? a.gcross : a.gself;
+    const float* tape = a.tape;
+    float* gt = a.gtape;
+    const long R = 2L * a.B * G::V, VC = (long)G::V * C, ro = c.row0 * C;
+    const float* q = CROSS ? a.qkv : tape + to.q(0);
+    const float* k = CROSS ? a.qkv + R * C : tape + to.k(0);
+    const float* v = CROSS ? a.qkv + 2 * R * C : tape + to.v(0);
+    const int bo = CROSS ? (c.bb + a.B) % (2 * a.B) : c.bb;             // the other party: whose keys my queries saw AND whose queries saw my keys
+    const float* att_o = tape + to.a_(A);
+    const float* stat = tape + to.stat(A);
+    const float* dc = gt + go.att(A, 6);
+    const float inv_norm = 1.f / sqrtf((float)G::DH);
+    // (1) dq of my queries against the other party's keys / values
+    load_rows<LV>(c.XA, k + (long)bo * VC, C, 0);
+    load_rows<LV>(c.XB, v + (long)bo * VC, C, 0);
+    __syncthreads();
+    attention_bwd_q<LV>(c.g, c.XA, c.XB, q + ro, att_o + ro, dc + ro, stat + c.row0 * 8, gt + go.att(A, 3) + ro, c.p, P.seed_att + c.stepmix,
+                        (unsigned long long)c.bb * G::H * G::V * G::V);
+    __syncthreads();
+    // (2) dk, dv of my keys from the other party's queries
+    load_rows_scaled<LV>(c.XA, q + (long)bo * VC, C, 0, inv_norm);
+    load_rows<LV>(c.XB, dc + (long)bo * VC, C, 0);
+    for (int i = threadIdx.x; i < HV; i += MD_THREADS) {
+        const int h = i / G::VP, qi = i - h * G::VP;
+        float m = 0.f, il = 0.f, D = 0.f;
+        if (qi < G::V) {
+            const float* st = stat + (long)bo * G::V * 8 + ((long)h * G::V + qi) * 2;
+            m = st[0]; il = 1.f / st[1];
+            const float* go_ = dc + (long)bo * VC + (long)qi * C + h * G::DH;
+            const float* oo = att_o + (long)bo * VC + (long)qi * C + h * G::DH;
+#pragma unroll
+            for (int d = 0; d < G::DH; d += 4) {
+                const f32x4 x = ld4(go_ + d), y = ld4(oo + d);
+                D += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+            }
+        }
+        sm[i] = m; sm[HV + i] = il; sm[2 * HV + i] = D;
+    }
+    __syncthreads();
+    attention_bwd_kv<LV>(c.g, c.XA, c.XB, sm, k + ro, v + ro, gt + go.att(A, 4) + ro, gt + go.att(A, 5) + ro, c.p, P.seed_att + c.stepmix,
+                         (unsigned long long)bo * G::H * G::V * G::V);
+    __syncthreads();
+    // (3) d n = dq Wq + dk Wk + dv Wv  (n = LN(x): the projections' common input)
+    f32x16 acc[G::WMT][G::WNT];
+    acc_zero<LV>(acc);
+    load_rows<LV>(c.XA, gt + go.att(A, 3) + ro, C, 0);
+    load_rows<LV>(c.XB, gt + go.att(A, 4) + ro, C, 0);
+    __syncthreads();
+    gemm_nn<LV>(acc, c.g, c.XA, P.q.w[hd], C, 0, 1, C);
+    gemm_nn<LV>(acc, c.g, c.XB, P.k.w[hd], C, 0, 1, C);
+    __syncthreads();
+    load_rows<LV>(c.XA, gt + go.att(A, 5) + ro, C, 0);
+    __syncthreads();
+    gemm_nn<LV>(acc, c.g, c.XA, P.v.w[hd], C, 0, 1, C);
+    acc_to_lds<LV>(acc, c.g, c.XB, nullptr);
+    __syncthreads();
+    // (4) LN backward (input: the residual stream x of the block) + the residual's own gradient dxr -> dxin
+    const float* xin = CROSS ? tape + to.xo(0) + ro : tape + to.out(3) + ro;
+    ln_bwd_rows<LV>(c.XB, xin, tape + to.st(A) + c.row0 * 2, P.ln.g[hd], nullptr, false, gt + go.att(A, 7) + ro, GP.ln.g[hd], GP.ln.b[hd],
+                    gt + go.att(A, 8) + ro);
+}
+
+// the four GCN_ResBlocks backward (gcn.py:99-110 reversed): in self.dxin; out a.dx
+template <int LV>
+__global__ __launch_bounds__(MD_THREADS, 1) void mesh_gcn_bwd_kernel(const PdfMeshLevel a) {
+    using G = Cfg<LV>;
+    constexpr int C = G::C;
+    extern __shared__ float smem[];
+    Ctx<LV> c;
+    ctx_init<LV>(c, a, smem);
+    const int hd = c.hand;
+    const TapeOff to = tape_offsets(LV, a.B);
+    const GTapeOff go = gtape_offsets(LV, a.B);
+    const float* tape = a.tape;
+    float* gt = a.gtape;
+    const long ro = c.row0 * C;
+    const uint32_t i0 = (uint32_t)ro;
+    const int* colT = a.ell_colT[hd]; const float* valT = a.ell_valT[hd];
+    float* XA = c.XA; float* XB = c.XB;
+    load_rows<LV>(XA, gt + go.att(0, 8) + ro, C, 0);                    // d out_3
+    __syncthreads();
+#pragma unroll 1
+    for (int blk = 3; blk >= 0; --blk) {
+        const MdGcn& P = a.gcn[blk];
+        const MdGcnG& GP = a.ggcn[blk];
+        const int cin = blk == 0 ? a.cin0 : C;
+        // LN3 (+ the ReLU GraphLayer puts between blocks) backward in place: XA = dz; saved for the shortcut's weight gradient
+        ln_bwd_rows<LV>(XA, tape + to.z(blk) + ro, tape + to.st3(blk) + c.row0 * 2, P.n3.g[hd], P.n3.b[hd], blk != 3, nullptr, GP.n3.g[hd], GP.n3.b[hd],
+                        gt + go.dz(blk) + ro);
+        __syncthreads();
+        {   // dy2 = drop(dz) -> XB, gtape
+            const uint32_t key = md_key(P.seed + c.stepmix);
+            constexpr int C4 = C / 4;
+            for (int i = threadIdx.x; i < G::V * C4; i += MD_THREADS) {
+                const int v = i / C4, cc = (i - v * C4) * 4;
+                f32x4 t = ld4(XA + v * G::LD + cc), u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = md_drop(t[e], c.p, c.sc, key, i0 + (uint32_t)(v * C + cc + e));
+                st4(XB + v * G::LD + cc, u);
+                st4(gt + go.dy2(blk) + ro + (long)v * C + cc, u);
+            }
+        }
+        __syncthreads();
+        {   // fc2 backward: d cat2 = dy2 W2; dh = even columns + L^T (odd columns)
+            f32x16 accE[G::WMT][G::WNT], accO[G::WMT][G::WNT];
+            acc_zero<LV>(accE);
+            acc_zero<LV>(accO);
+            gemm_nn<LV>(accO, c.g, XB, P.fc2.w[hd], 2 * C, 1, 2, C);
+            gemm_nn<LV>(accE, c.g, XB, P.fc2.w[hd], 2 * C, 0, 2, C);
+            __syncthreads();
+            acc_to_lds<LV>(accO, c.g, XA, nullptr);
+            acc_to_lds<LV>(accE, c.g, XB, nullptr);
+        }
+        __syncthreads();
+        spmm_add<LV>(XB, XA, colT, valT, a.ell_w);
+        __syncthreads();
+        // LN2 + ReLU backward in place: XB = dy
+        ln_bwd_rows<LV>(XB, tape + to.y(blk) + ro, tape + to.st2(blk) + c.row0 * 2, P.n2.g[hd], P.n2.b[hd], true, nullptr, GP.n2.g[hd], GP.n2.b[hd],
+                        gt + go.dy(blk) + ro);
+        load_rows<LV>(XA, gt + go.dz(blk) + ro, C, 0);                  // dz again (this workgroup wrote it: visible after the barrier below)
+        __syncthreads();
+        // fc1 + shortcut backward, in column chunks of C of the block input
+        for (int c0 = 0; c0 < cin; c0 += C) {
+            f32x16 accE[G::WMT][G::WNT], accO[G::WMT][G::WNT];
+            acc_zero<LV>(accE);
+            acc_zero<LV>(accO);
+            gemm_nn<LV>(accO, c.g, XB, P.fc1.w[hd], 2 * cin, 2 * c0 + 1, 2, C);
+            gemm_nn<LV>(accE, c.g, XB, P.fc1.w[hd], 2 * cin, 2 * c0, 2, C);
+            gemm_nn<LV>(accE, c.g, XA, P.sc.w[hd], cin, c0, 1, C);
+            if (cin == C) {
+                __syncthreads();
+                acc_to_lds<LV>(accO, c.g, XA, nullptr);
+                acc_to_lds<LV>(accE, c.g, XB, nullptr);
+                __syncthreads();
+                spmm_add<LV>(XB, XA, colT, valT, a.ell_w);              // XB = d x of this block = d out of the one before
+            } else {
+                // block 0: two chunks share the operands in XA / XB -- the direct part goes to a.dx, the part L^T still has to see to scratch
+                acc_to_global<LV>(accE, c.g, a.dx + c.row0 * cin, cin, c0);
+                acc_to_global<LV>(accO, c.g, gt + go.scr() + ro, C, 0);
+                __syncthreads();
+                // (every wave is past the products of this chunk; the next chunk only reads XA / XB) finish this chunk through the third image-free path:
+                // dx[:, c0 + k] += sum_w valT[v][w] T[colT[v][w]][k], T from scratch (L2)
+                {
+                    constexpr int C4 = C / 4;
+                    const float* T = gt + go.scr() + ro;
+                    float* dxp = a.dx + c.row0 * cin;
+                    for (int i = threadIdx.x; i < G::V * C4; i += MD_THREADS) {
+                        const int v = i / C4, cc = (i - v * C4) * 4;
+                        f32x4 s4 = ld4(dxp + (long)v * cin + c0 + cc);
+                        for (int w = 0; w < a.ell_w; ++w) s4 += valT[v * a.ell_w + w] * ld4(T + (long)colT[v * a.ell_w + w] * C + cc);
+                        st4(dxp + (long)v * cin + c0 + cc, s4);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (cin == C) {
+            __syncthreads();
+            float* t = XA; XA = XB; XB = t;
+            if (blk == 1) { /* block 0 follows: its d out is in XA */ }
+        }
+    }
+}

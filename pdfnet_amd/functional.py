@@ -2093,3 +2093,79 @@ def point_dist_sum(pred, gt):
     out = torch.empty(p.shape[:-2], dtype=torch.float32, device=p.device)
     _L().pdf_point_dist_sum(ptr(p), ptr(q), out.numel(), n, dim, ptr(out), stream())
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Fused mesh decoder (csrc/meshdec.hip, round 5): one DualGraphLayer (DualGraph.py:62-92) = three launches forward, see the kernel file.
+MESH_FUSED = _os.environ.get("PDFNET_MESH_FUSED", "1") != "0"
+
+
+def _pair(dst, l, r):
+    dst[0], dst[1] = ptr(l), ptr(r)
+
+
+def _mesh_lin(dst, l, r):
+    _pair(dst.w, l.weight, r.weight)
+    _pair(dst.b, l.bias, r.bias)
+
+
+def mesh_level_params(layer):
+    """The parameter tensors of a DualGraphLayer in the order of PdfMeshLevel: [(left, right) module pairs] per GCN block and attention block."""
+    gl, gr = layer.graph_left.GCN_blocks, layer.graph_right.GCN_blocks
+    at = layer.attn
+    sl, sr = at.L_self_attn_layer, at.R_self_attn_layer
+    gcn = [dict(fc1=(bl.fc1, br.fc1), fc2=(bl.fc2, br.fc2), sc=(bl.shortcut, br.shortcut), n2=(bl.norm2, br.norm2), n3=(bl.norm3, br.norm3))
+           for bl, br in zip(gl, gr)]
+    self_ = dict(ln=(sl.layer_norm, sr.layer_norm), q=(sl.w_qs, sr.w_qs), k=(sl.w_ks, sr.w_ks), v=(sl.w_vs, sr.w_vs), fc=(sl.fc, sr.fc),
+                 ffln=(sl.ff.layer_norm, sr.ff.layer_norm), f1=(sl.ff.fc1, sr.ff.fc1), f2=(sl.ff.fc2, sr.ff.fc2))
+    cross = dict(ln=(at.layer_norm1, at.layer_norm2), q=(at.w_qs, at.w_qs), k=(at.w_ks, at.w_ks), v=(at.w_vs, at.w_vs), fc=(at.fc, at.fc),
+                 ffln=(at.ffL.layer_norm, at.ffR.layer_norm), f1=(at.ffL.fc1, at.ffR.fc1), f2=(at.ffL.fc2, at.ffR.fc2))
+    return gcn, self_, cross
+
+
+_MESH_GCN_KEYS = ('fc1', 'fc2', 'sc', 'n2', 'n3')
+_MESH_ATT_KEYS = ('ln', 'q', 'k', 'v', 'fc', 'ffln', 'f1', 'f2')
+
+
+def _mesh_args(layer, x, training, out, tape, qkv):
+    """-> hip.MeshLevel filled for the forward of `layer` on x [2, B, V, cin]."""
+    a = hip.MeshLevel()
+    _, B, V, cin = x.shape
+    level = {63: 0, 126: 1, 252: 2}.get(V)
+    bl, br = layer.graph_left.GCN_blocks[0], layer.graph_right.GCN_blocks[0]
+    if level is None or cin != 2 * (256 >> level) or bl.fc1.weight.shape[0] != (256 >> level) or len(layer.graph_left.GCN_blocks) != 4 or layer.attn.n_heads != 4:
+        raise ValueError("pdfnet_amd: the fused mesh decoder covers the reference's levels (V = 63 / 126 / 252, C = 256 / 128 / 64, 4 blocks, 4 heads)")
+    p = float(layer.attn.p) if training else 0.0
+    a.level, a.B, a.training, a.cin0, a.p = level, B, 1 if training else 0, cin, p
+    a.step = ptr(step_counter(x.device)) if p > 0 else None
+    a.x, a.out, a.tape, a.qkv = ptr(x), ptr(out), ptr(tape), ptr(qkv)
+    for k, (tl, tr) in zip(('ell_col', 'ell_val', 'ell_colT', 'ell_valT'), zip(bl.ell, br.ell)):
+        _pair(getattr(a, k), tl, tr)
+    a.ell_w = bl.ell_col.shape[1]
+    gcn, self_, cross = mesh_level_params(layer)
+    for i, blk in enumerate(gcn):
+        for k in _MESH_GCN_KEYS:
+            _mesh_lin(getattr(a.gcn[i], k), *blk[k])
+        a.gcn[i].seed = next_seed() if p > 0 else 0          # (drawn in the order the unfused path draws them: same masks)
+    for dst, src in ((a.self_, self_), (a.cross, cross)):
+        for k in _MESH_ATT_KEYS:
+            _mesh_lin(getattr(dst, k), *src[k])
+        for k in ('seed_att', 'seed_z', 'seed_t', 'seed_x'):
+            setattr(dst, k, next_seed() if p > 0 else 0)
+    return a
+
+
+def mesh_level_forward(layer, x, training=False):
+    """One DualGraphLayer forward on the fused kernels, no autograd (x: [2, B, V, cin] with the position embedding added).
+    -> (out [2, B, V, C], args, tape, qkv): the last three are what the backward needs."""
+    hip.require_gpu(x)
+    x = x.contiguous()
+    _, B, V, cin = x.shape
+    C = cin // 2
+    level = {63: 0, 126: 1, 252: 2}[V]
+    out = torch.empty((2, B, V, C), dtype=torch.float32, device=x.device)
+    tape = torch.empty(_L().pdf_mesh_tape_floats(level, B), dtype=torch.float32, device=x.device)
+    qkv = torch.empty((3, 2, B, V, C), dtype=torch.float32, device=x.device)
+    a = _mesh_args(layer, x, training, out, tape, qkv)
+    _L().pdf_mesh_level_fwd(_byref(a), stream())
+    return out, a, tape, qkv

@@ -48,6 +48,41 @@ class CallOpts(ctypes.Structure):
                 ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p), ("op1_bf16_t", ctypes.c_void_p), ("ws", ctypes.c_void_p), ("ws_floats", ctypes.c_long)]
 
 
+_P2 = ctypes.c_void_p * 2
+
+
+class MeshLin(ctypes.Structure):
+    """PdfMeshLin / PdfMeshLinG / PdfMeshLN / PdfMeshLNG of include/pdfnet_hip.h: a (weight, bias) or (gamma, beta) pair per hand."""
+    _fields_ = [("w", _P2), ("b", _P2)]
+
+
+class MeshGcn(ctypes.Structure):
+    _fields_ = [("fc1", MeshLin), ("fc2", MeshLin), ("sc", MeshLin), ("n2", MeshLin), ("n3", MeshLin), ("seed", ctypes.c_ulonglong)]
+
+
+class MeshAttn(ctypes.Structure):
+    _fields_ = [("ln", MeshLin), ("q", MeshLin), ("k", MeshLin), ("v", MeshLin), ("fc", MeshLin), ("ffln", MeshLin), ("f1", MeshLin), ("f2", MeshLin),
+                ("seed_att", ctypes.c_ulonglong), ("seed_z", ctypes.c_ulonglong), ("seed_t", ctypes.c_ulonglong), ("seed_x", ctypes.c_ulonglong)]
+
+
+class MeshGcnG(ctypes.Structure):
+    _fields_ = [("fc1", MeshLin), ("fc2", MeshLin), ("sc", MeshLin), ("n2", MeshLin), ("n3", MeshLin)]
+
+
+class MeshAttnG(ctypes.Structure):
+    _fields_ = [("ln", MeshLin), ("q", MeshLin), ("k", MeshLin), ("v", MeshLin), ("fc", MeshLin), ("ffln", MeshLin), ("f1", MeshLin), ("f2", MeshLin)]
+
+
+class MeshLevel(ctypes.Structure):
+    """PdfMeshLevel of include/pdfnet_hip.h (field for field; the library's sizeof is checked at load)."""
+    _fields_ = [("level", ctypes.c_int), ("B", ctypes.c_int), ("training", ctypes.c_int), ("cin0", ctypes.c_int), ("p", ctypes.c_float),
+                ("step", ctypes.c_void_p), ("x", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("ell_col", _P2), ("ell_val", _P2), ("ell_colT", _P2), ("ell_valT", _P2), ("ell_w", ctypes.c_int),
+                ("gcn", MeshGcn * 4), ("self_", MeshAttn), ("cross", MeshAttn),
+                ("tape", ctypes.c_void_p), ("qkv", ctypes.c_void_p), ("dout", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("gtape", ctypes.c_void_p),
+                ("ggcn", MeshGcnG * 4), ("gself", MeshAttnG), ("gcross", MeshAttnG), ("wg_ws", ctypes.c_void_p), ("wg_ws_floats", ctypes.c_long)]
+
+
 class _Lib:
     def __init__(self):
         if not os.path.exists(LIB_PATH):
@@ -63,6 +98,9 @@ class _Lib:
         if self.cdll.pdf_debug_callopts_size() != ctypes.sizeof(CallOpts):
             raise ImportError("pdfnet_amd: PdfCallOpts of %s has %d bytes, this binding's has %d -- rebuild the library"
                               % (LIB_PATH, self.cdll.pdf_debug_callopts_size(), ctypes.sizeof(CallOpts)))
+        if self.cdll.pdf_debug_mesh_level_size() != ctypes.sizeof(MeshLevel):
+            raise ImportError("pdfnet_amd: PdfMeshLevel of %s has %d bytes, this binding's has %d -- rebuild the library"
+                              % (LIB_PATH, self.cdll.pdf_debug_mesh_level_size(), ctypes.sizeof(MeshLevel)))
 
     def __getattr__(self, name):
         fn = getattr(self.cdll, name)
