@@ -412,8 +412,13 @@ int pdf_mano_split_coeff_bwd(const float* params, float* dparams, int ldp, long 
  *   in_scale, in_shift   pdf_linear_fwd / pdf_linear_bwd_weight: x is read as relu(x * in_scale[k] + in_shift[k]).
  *   op1_bf16_t           pdf_conv2d_bwd_data(_add) / pdf_linear_bwd_data (bf16 mode): the weight's transposed bf16 shadow,
  *                        wt[c][tap][r] for w[r][tap][c] (pdf_cast_bf16_transposed); lets the LDS-DMA kernel take the launch.
- *   ws, ws_floats        pdf_conv2d_fwd / pdf_conv2d_bwd_data(_add) / pdf_conv2d_bwd_weight, fp32 mode: a workspace of pdf_conv2d_winograd_workspace_floats floats;
- *                        a stride-1 3x3 layer that qualifies is then computed as Winograd F(2x2, 3x3) (csrc/winograd.hip). */
+ *   ws, ws_floats        pdf_conv2d_fwd / pdf_conv2d_bwd_data(_add) / pdf_conv2d_bwd_weight, fp32 mode: a workspace of pdf_conv2d_winograd_workspace_floats floats
+ *                        (asked with backward = 0 / 1 / 2 for the three passes; 0 floats = the layer does not qualify).  A stride-1 3x3 layer with
+ *                        >= 128 input channels (PDF_WINOGRAD_MINC), 16-float aligned channel counts and planes x tiles >= 16,384 (PDF_WINOGRAD_MINPT) is
+ *                        then computed in the Winograd domain (csrc/winograd.hip): F(4x4, 3x3) -- 36 planes, 4x fewer multiplications, ~4e-5 absolute
+ *                        error on values of a few units -- where the map edges are multiples of 4 and PDF_WINOGRAD_F4 (bit mask, default 15 = every
+ *                        launch) permits, else F(2x2, 3x3) (16 planes, 2.25x fewer, MORE accurate than the direct fp32 sum); the weight gradient is
+ *                        taken in the transform domain too (backward = 2).  PDF_WINOGRAD=2: F(2x2) only; =0: the direct kernels. */
 typedef struct PdfCallOpts {
     const void* op0_bf16; const void* op1_bf16;
     void* out_bf16;
@@ -444,9 +449,9 @@ int pdf_bn_relu_maxk_fwd_x(const float* y, int ldy, int C, long R, int K, const 
 int pdf_l2norm_cat_fwd_x(int nparts, const float* const* x, const int* C, const float* const* w, float eps, long R, float* y, int ldy, float* const* norm, void* stream, PdfCallOpts* opts);
 /* number of hand-over slots currently armed on the calling thread (0 after every entry-point call), and sizeof(PdfCallOpts) as the
  * library was built (a binding checks its own layout against it) */
-/* Winograd F(2x2, 3x3) for stride-1 3x3 convolutions with >= 256 input channels (nn.Conv2d sites intaghand_encoder.py:602,617,675-693):
- * floats of workspace the layer wants (PdfCallOpts::ws) for its forward (backward = 0), backward-data (1) or weight-gradient (2) pass,
- * 0 when it does not qualify. */
+/* Winograd F(4x4, 3x3) / F(2x2, 3x3) for stride-1 3x3 convolutions with >= 128 input channels (nn.Conv2d sites intaghand_encoder.py:602,617,
+ * 675-693, 270-316 and ResNet layers 2-3; selection rule: PdfCallOpts::ws above): floats of workspace the layer wants (PdfCallOpts::ws) for its
+ * forward (backward = 0), backward-data (1) or weight-gradient (2) pass, 0 when it does not qualify.  `feat` at B = 32: ~1.5 GB per pass. */
 long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward);
 int pdf_debug_armed_slots(void);
 int pdf_debug_callopts_size(void);
@@ -496,6 +501,7 @@ long pdf_mesh_gtape_floats(int level, int B);
 int pdf_mesh_level_fwd(const PdfMeshLevel* a, void* stream);
 int pdf_mesh_level_bwd(const PdfMeshLevel* a, void* stream, void* side_stream);
 int pdf_debug_mesh_level_size(void);
+int pdf_debug_mesh_stamps(unsigned long long* out);      /* diagnostic builds (-DMD_STAMPS=1) only: stage clocks of workgroup 0; 0 otherwise */
 
 #ifdef __cplusplus
 }

@@ -1848,7 +1848,7 @@ static int pdf_conv2d_fwd_impl(const float* x, const float* w, const float* bias
         PDF_LAUNCH_CHECK();
         return 0;
     }
-    // Winograd F(2x2, 3x3) (winograd.hip): fp32 mode, the caller handed a workspace (PdfCallOpts::ws), the layer qualifies
+    // Winograd F(4x4, 3x3) / F(2x2, 3x3) (winograd.hip: pdf_internal_wino_tile picks): fp32 mode, the caller handed a workspace (PdfCallOpts::ws), the layer qualifies
     if (!g_gemm_bf16 && co.ws != nullptr && y16 == nullptr && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(co.ws) &&
         pdf_internal_wino_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad, 0) && co.ws_floats >= pdf_internal_wino_workspace(N, H, W, Cin, Cout, 0)) {
         g_last_tile = 128128;

@@ -217,8 +217,10 @@ def _O(**kw):
     return o, _byref(o)
 
 
-# Winograd F(2x2, 3x3) (csrc/winograd.hip, fp32 mode): a stride-1 3x3 convolution with many channels is handed a workspace and the
-# library computes it in the transform domain -- 2.25x fewer MFMA instructions (forward and backward-data).
+# Winograd (csrc/winograd.hip, fp32 mode): a stride-1 3x3 convolution with >= 128 channels is handed a workspace and the library computes it
+# in the transform domain -- F(4x4, 3x3) (4x fewer MFMA instructions, ~4e-5 absolute error) where the map and PDF_WINOGRAD_F4 allow, else
+# F(2x2, 3x3) (2.25x fewer, more accurate than the direct sum); forward, backward-data and the weight gradient.  The
+# workspace is a fresh torch.empty per call (GB-scale for `feat`: the caching allocator keeps a few such blocks per stream).
 WINOGRAD = _os.environ.get("PDFNET_WINOGRAD", "1") != "0"
 _wino_cache = {}
 
@@ -2127,16 +2129,15 @@ _MESH_GCN_KEYS = ('fc1', 'fc2', 'sc', 'n2', 'n3')
 _MESH_ATT_KEYS = ('ln', 'q', 'k', 'v', 'fc', 'ffln', 'f1', 'f2')
 
 
-def _mesh_args(layer, x, training, out, tape, qkv):
-    """-> hip.MeshLevel filled for the forward of `layer` on x [2, B, V, cin]."""
+def _mesh_args(layer, x, save, p, out, tape, qkv):
+    """-> hip.MeshLevel filled for the forward of `layer` on x [2, B, V, cin].  save: write the tape the backward reads; p: dropout probability."""
     a = hip.MeshLevel()
     _, B, V, cin = x.shape
     level = {63: 0, 126: 1, 252: 2}.get(V)
     bl, br = layer.graph_left.GCN_blocks[0], layer.graph_right.GCN_blocks[0]
     if level is None or cin != 2 * (256 >> level) or bl.fc1.weight.shape[0] != (256 >> level) or len(layer.graph_left.GCN_blocks) != 4 or layer.attn.n_heads != 4:
         raise ValueError("pdfnet_amd: the fused mesh decoder covers the reference's levels (V = 63 / 126 / 252, C = 256 / 128 / 64, 4 blocks, 4 heads)")
-    p = float(layer.attn.p) if training else 0.0
-    a.level, a.B, a.training, a.cin0, a.p = level, B, 1 if training else 0, cin, p
+    a.level, a.B, a.training, a.cin0, a.p = level, B, 1 if (save or p > 0) else 0, cin, p
     a.step = ptr(step_counter(x.device)) if p > 0 else None
     a.x, a.out, a.tape, a.qkv = ptr(x), ptr(out), ptr(tape), ptr(qkv)
     for k, (tl, tr) in zip(('ell_col', 'ell_val', 'ell_colT', 'ell_valT'), zip(bl.ell, br.ell)):
@@ -2155,7 +2156,7 @@ def _mesh_args(layer, x, training, out, tape, qkv):
     return a
 
 
-def mesh_level_forward(layer, x, training=False):
+def mesh_level_forward(layer, x, training=False, save=False):
     """One DualGraphLayer forward on the fused kernels, no autograd (x: [2, B, V, cin] with the position embedding added).
     -> (out [2, B, V, C], args, tape, qkv): the last three are what the backward needs."""
     hip.require_gpu(x)
@@ -2166,6 +2167,94 @@ def mesh_level_forward(layer, x, training=False):
     out = torch.empty((2, B, V, C), dtype=torch.float32, device=x.device)
     tape = torch.empty(_L().pdf_mesh_tape_floats(level, B), dtype=torch.float32, device=x.device)
     qkv = torch.empty((3, 2, B, V, C), dtype=torch.float32, device=x.device)
-    a = _mesh_args(layer, x, training, out, tape, qkv)
+    a = _mesh_args(layer, x, save or training, float(layer.attn.p) if training else 0.0, out, tape, qkv)
     _L().pdf_mesh_level_fwd(_byref(a), stream())
     return out, a, tape, qkv
+
+
+def _mesh_param_list(layer):
+    """Every parameter tensor the level uses, once, in a fixed order; and for each (group, index, key, hand, 'w' | 'b') where its gradient goes."""
+    gcn, self_, cross = mesh_level_params(layer)
+    seen, tensors, slots = {}, [], []
+
+    def add(t, where):
+        if id(t) not in seen:
+            seen[id(t)] = len(tensors)
+            tensors.append(t)
+            slots.append([])
+        slots[seen[id(t)]].append(where)
+    for i, blk in enumerate(gcn):
+        for k in _MESH_GCN_KEYS:
+            for hnd, m in enumerate(blk[k]):
+                add(m.weight, ('ggcn', i, k, hnd, 'w'))
+                add(m.bias, ('ggcn', i, k, hnd, 'b'))
+    for grp, src in (('gself', self_), ('gcross', cross)):
+        for k in _MESH_ATT_KEYS:
+            for hnd, m in enumerate(src[k]):
+                add(m.weight, (grp, None, k, hnd, 'w'))
+                add(m.bias, (grp, None, k, hnd, 'b'))
+    return tensors, slots
+
+
+class _MeshLevel(Function):
+    """One DualGraphLayer (DualGraph.py:62-92 after the position embedding) on the fused kernels: three launches forward, five backward plus
+    the layer's 28 weight-gradient GEMMs on the weight-gradient side stream (csrc/meshdec.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, layer, training, *params):
+        need = any(ctx.needs_input_grad)                     # (grad mode is off inside Function.forward: ask the context)
+        x = x.contiguous()
+        out, a, tape, qkv = mesh_level_forward(layer, x, training, save=need)
+        if need:
+            ctx.layer, ctx.args, ctx.keep = layer, a, (x, tape, qkv, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, tape, qkv, out = ctx.keep
+        a, layer = ctx.args, ctx.layer
+        L = _L()
+        dout = dout.contiguous()
+        _, B, V, cin = x.shape
+        C = cin // 2
+        dx = torch.empty_like(x)
+        gtape = torch.empty(L.pdf_mesh_gtape_floats(a.level, B), dtype=torch.float32, device=x.device)
+        M = B * V
+        nws = max(2 * L.pdf_wgrad_workspace_floats(M, C, 4 * C), 2 * L.pdf_wgrad_workspace_floats(M, C, 2 * C), 2 * L.pdf_wgrad_workspace_floats(M, C, C),
+                  L.pdf_wgrad_workspace_floats(2 * M, C, C))
+        ws = _ws(nws, x.device)
+        a.dout, a.dx, a.gtape, a.wg_ws, a.wg_ws_floats = ptr(dout), ptr(dx), ptr(gtape), ptr(ws), nws
+        tensors, slots = _mesh_param_list(layer)
+        grads = []
+        for t, where in zip(tensors, slots):
+            g = _main_grad(t, t)
+            ret = None
+            if g is None:                                    # no flat gradient buffer behind this parameter: hand autograd a fresh one
+                g = ret = torch.zeros_like(t)
+            grads.append(ret)
+            for grp, i, k, hnd, wb in where:
+                dst = getattr(a, grp)
+                if i is not None:
+                    dst = dst[i]
+                getattr(getattr(dst, k), wb)[hnd] = ptr(g)
+        cur = stream()
+        keep = [g for g in grads if g is not None]
+        with wgrad_stream(True, x, tape, qkv, gtape, ws, dout, *keep, params=tensors):
+            L.pdf_mesh_level_bwd(_byref(a), cur, stream())
+        ctx.keep = ctx.args = None
+        return (dx, None, None) + tuple(grads)
+
+
+def mesh_level(layer, x):
+    """DualGraphLayer.forward after the position embedding, fused (x [2, B, V, cin])."""
+    tensors, _ = _mesh_param_list(layer)
+    return _MeshLevel.apply(x, layer, layer.training, *tensors)
+
+
+def mesh_level_ok(layer, x):
+    """The fused kernels cover the reference's three levels (V = 63 / 126 / 252 with C = 256 / 128 / 64, four blocks, four heads) in fp32 mode."""
+    if not (MESH_FUSED and x.is_cuda and not _GEMM_BF16 and x.dim() == 4 and x.shape[0] == 2 and x.dtype == torch.float32):
+        return False
+    level = {63: 0, 126: 1, 252: 2}.get(x.shape[2])
+    return (level is not None and x.shape[3] == 2 * (256 >> level) and len(layer.graph_left.GCN_blocks) == 4 and layer.attn.n_heads == 4
+            and layer.graph_left.GCN_blocks[0].fc1.weight.shape[0] == (256 >> level) and x.shape[1] <= 2048)

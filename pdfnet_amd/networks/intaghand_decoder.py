@@ -224,6 +224,8 @@ class DualGraphLayer(nn.Module):
 
     def forward(self, x):
         x = x + self.position_embeddings.weight
+        if F.mesh_level_ok(self, x):
+            return F.mesh_level(self, x)                    # csrc/meshdec.hip: the whole layer in 3 (+ 5 backward) launches, fp32 mode
         blocks = list(zip(self.graph_left.GCN_blocks, self.graph_right.GCN_blocks))
         for i, (bl, br) in enumerate(blocks):
             x = gcn_block_pair(bl, br, x, relu_out=i != len(blocks) - 1)

@@ -67,3 +67,58 @@ def test_fused_level_forward_draws_the_same_dropout_masks_as_the_unfused_chain(l
     err = float((out - ref).abs().max())
     print("level %d train, p = 0.3: max |fused - unfused| = %.2e (max |ref| %.2f)" % (level, err, float(ref.abs().max())))
     assert err <= 5e-5 * max(1.0, float(ref.abs().max()))
+
+
+def _unfused(layer, x):
+    from pdfnet_amd.networks.intaghand_decoder import gcn_block_pair
+    h = x + layer.position_embeddings.weight
+    for i, (bl, br) in enumerate(zip(layer.graph_left.GCN_blocks, layer.graph_right.GCN_blocks)):
+        h = gcn_block_pair(bl, br, h, relu_out=i != 3)
+    return layer.attn(h)
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_fused_level_backward_equals_the_unfused_chain(level, drop):
+    """dx and every parameter gradient of one DualGraphLayer: the fused backward (five launches + the weight-gradient GEMMs on the side stream)
+    against autograd through the unfused kernels, same seeds (so with dropout on, the same masks)."""
+    from pdfnet_amd import functional as F
+    B = 5
+    layer = _layer(level, seed=5, drop=drop).train()
+    V, cin = (63, 126, 252)[level], (512, 256, 128)[level]
+    x0 = torch.randn(2, B, V, cin, generator=torch.Generator().manual_seed(level + 3)).cuda()
+    gy = torch.randn(2, B, V, cin // 2, generator=torch.Generator().manual_seed(level + 4)).cuda()
+    res = {}
+    for fused in (False, True):
+        layer.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        F.manual_seed(99)
+        F.MESH_FUSED = fused
+        try:
+            out = layer(x) if fused else _unfused(layer, x)
+        finally:
+            F.MESH_FUSED = True
+        out.backward(gy)
+        F.join_wgrad()
+        torch.cuda.synchronize()
+        res[fused] = (out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None})
+    (o0, dx0, g0), (o1, dx1, g1) = res[False], res[True]
+    assert float((o0 - o1).abs().max()) <= 5e-5 * max(1.0, float(o0.abs().max()))
+    # Two correct fp32 implementations round LayerNorm differently, so a ReLU input within ~1e-7 of zero can fall on opposite sides in the two
+    # forwards (one element per ~10^6): that (hand, sample)'s data gradient then differs by a few per cent and every parameter gradient by ~1e-2 of
+    # its size.  So: all but at most one (hand, sample) agree tightly, the odd one loosely; parameter gradients tight unless such a flip occurred.
+    top = float(dx0.abs().max())
+    per = (dx0 - dx1).abs().amax((2, 3)) / top                              # [2, B]
+    flipped = int((per > 1e-4).sum())
+    assert flipped <= 1 and float(per.max()) <= 0.2, per
+    assert set(g0) == set(g1), set(g0) ^ set(g1)
+    worst = []
+    for n in g0:
+        topg = float(g0[n].abs().max())
+        if n.endswith('w_ks.bias'):                                         # exactly zero in exact arithmetic (softmax is shift-invariant): rounding noise in both
+            topg = float(g0[n[:-4] + 'weight'].abs().max())
+        err = float((g0[n] - g1[n]).abs().max())
+        worst.append((err / (topg + 1e-30), n))
+        assert err <= (1e-1 if flipped else 2e-4) * topg + 1e-6, (n, err, topg)
+    worst.sort(reverse=True)
+    print("level %d p %.1f: %d parameter gradients, %d flipped ReLU sample(s), worst relative deviations %s" % (level, drop, len(g0), flipped, ["%s %.1e" % (n, e) for e, n in worst[:3]]))
