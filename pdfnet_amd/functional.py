@@ -2238,8 +2238,11 @@ class _MeshLevel(Function):
                     dst = dst[i]
                 getattr(getattr(dst, k), wb)[hnd] = ptr(g)
         cur = stream()
-        keep = [g for g in grads if g is not None]
-        with wgrad_stream(True, x, tape, qkv, gtape, ws, dout, *keep, params=tensors):
+        # The weight gradients go to the side stream only when they are accumulated straight into the trainer's flat buffer (nothing on the
+        # chain reads them before join_wgrad).  Gradients handed back to autograd are consumed on THIS stream right away (AccumulateGrad, DDP's
+        # bucket copy): they are produced on it too.
+        direct = all(g is None for g in grads)
+        with wgrad_stream(direct, x, tape, qkv, gtape, ws, dout, params=tensors):
             L.pdf_mesh_level_bwd(_byref(a), cur, stream())
         ctx.keep = ctx.args = None
         return (dx, None, None) + tuple(grads)
@@ -2258,3 +2261,68 @@ def mesh_level_ok(layer, x):
     level = {63: 0, 126: 1, 252: 2}.get(x.shape[2])
     return (level is not None and x.shape[3] == 2 * (256 >> level) and len(layer.graph_left.GCN_blocks) == 4 and layer.attn.n_heads == 4
             and layer.graph_left.GCN_blocks[0].fc1.weight.shape[0] == (256 >> level) and x.shape[1] <= 2048)
+
+
+# ----------------------------------------------------------------------------------------------
+# Fused mesh loss (csrc/loss.hip mesh_loss_*, round 5): every mesh term of CtdetLoss's train branch, two launches forward + one backward.
+MESH_LOSS_FUSED = _os.environ.get("PDFNET_MESH_LOSS_FUSED", "1") != "0"
+MESH_LOSS_TERMS = ('verts2d_loss', 'norm_loss', 'edge_loss', 'gcn_2d_loss', 'root_loss', 'verts_loss', 'abs_verts_loss', 'gcn_loss',
+                   'abs_joints_loss', 'joints2d_loss', 'joints_loss', 'bone_direc_loss')
+
+
+class _MeshLoss(Function):
+    """(vp [2,B,778,3], v2p [2,B,778,2], hd3 [2,B,252,3], hd2 [2,B,252,2], r [2,B,3]) -> (weighted sum [B] of the 12 terms with `coefs`, the
+    terms themselves [4 + 8 B] for the statistics, not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, vp, v2p, hd3, hd2, r, gt, consts, size, down, edge_grad, coefs):
+        hip.require_gpu(vp)
+        vp, v2p, hd3, hd2, r = (t.contiguous() for t in (vp, v2p, hd3, hd2, r))
+        B = vp.shape[1]
+        if vp.shape[2:] != (778, 3) or hd3.shape[2:] != (252, 3):
+            raise ValueError("pdfnet_amd: mesh_loss wants the decoder's 778- and 252-vertex meshes")
+        a = hip.MeshLoss()
+        keep = [vp, v2p, hd3, hd2, r]
+        for k, t in (('vp', vp), ('v2p', v2p), ('hd3', hd3), ('hd2', hd2), ('r', r)):
+            setattr(a, k, ptr(t))
+        for k in ('vgt', 'jgt', 'v2gt', 'lmsgt', 'ind', 'K', 'valid'):
+            t = gt[k].contiguous()
+            keep.append(t)
+            setattr(a, k, ptr(t))
+        regs, faces, perms = consts
+        a.reg[0], a.reg[1] = ptr(regs[0]), ptr(regs[1])
+        a.faces = ptr(faces)
+        a.perm[0], a.perm[1] = ptr(perms[0]), ptr(perms[1])
+        a.B, a.Fc, a.size, a.down, a.edge_grad = B, faces.shape[1], int(size), int(down), 1 if edge_grad else 0
+        for i, c in enumerate(coefs):
+            a.coef[i] = float(c)
+        part = torch.empty((2, B, 12), dtype=torch.float32, device=vp.device)
+        out = torch.empty(4 + 9 * B, dtype=torch.float32, device=vp.device)
+        a.part, a.out = ptr(part), ptr(out)
+        _L().pdf_mesh_loss_fwd(_byref(a), stream())
+        ctx.args, ctx.keep = a, keep + [regs, faces, perms, part]
+        terms = out[:4 + 8 * B]
+        ctx.mark_non_differentiable(terms)
+        return out[4 + 8 * B:], terms
+
+    @staticmethod
+    def backward(ctx, g, _):
+        a = ctx.args
+        vp, v2p, hd3, hd2, r = ctx.keep[:5]
+        g = g.contiguous()
+        dvp, dv2p, dhd3, dhd2, dr = (torch.empty_like(t) for t in (vp, v2p, hd3, hd2, r))
+        a.gmp = ptr(g)
+        a.dvp, a.dv2p, a.dhd3, a.dhd2, a.dr = ptr(dvp), ptr(dv2p), ptr(dhd3), ptr(dhd2), ptr(dr)
+        _L().pdf_mesh_loss_bwd(_byref(a), stream())
+        return dvp, dv2p, dhd3, dhd2, dr, None, None, None, None, None, None
+
+
+def mesh_loss(vp, v2p, hd3, hd2, r, gt, consts, size, down, edge_grad, coefs):
+    """gt: dict vgt [2,B,778,3], jgt [2,B,21,3], v2gt [2,B,778,2], lmsgt [2,B,21,2], ind [B,2] int64, K [B,3,3], valid [B,2];
+    consts: ((reg_left, reg_right) [21,778], faces [2,F,3] int64, (perm_left, perm_right) [1008] int64); coefs: the weights of the twelve
+    terms in MESH_LOSS_TERMS order.  -> (their weighted sum per sample [B] (differentiable), dict of the twelve terms (detached))."""
+    mp, terms = _MeshLoss.apply(vp, v2p, hd3, hd2, r, gt, consts, size, down, edge_grad, tuple(coefs))
+    B = vp.shape[1]
+    d = {k: terms[i] for i, k in enumerate(MESH_LOSS_TERMS[:4])}
+    d.update({k: terms[4 + i * B:4 + (i + 1) * B] for i, k in enumerate(MESH_LOSS_TERMS[4:])})
+    return mp, d

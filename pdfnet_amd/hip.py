@@ -83,6 +83,15 @@ class MeshLevel(ctypes.Structure):
                 ("ggcn", MeshGcnG * 4), ("gself", MeshAttnG), ("gcross", MeshAttnG), ("wg_ws", ctypes.c_void_p), ("wg_ws_floats", ctypes.c_long)]
 
 
+class MeshLoss(ctypes.Structure):
+    """PdfMeshLoss of include/pdfnet_hip.h (field for field)."""
+    _fields_ = [(k, ctypes.c_void_p) for k in ("vp", "v2p", "hd3", "hd2", "r", "vgt", "jgt", "v2gt", "lmsgt", "ind", "K", "valid")] + \
+               [("reg", _P2), ("faces", ctypes.c_void_p), ("perm", _P2), ("B", ctypes.c_int), ("Fc", ctypes.c_int), ("size", ctypes.c_int),
+                ("down", ctypes.c_int), ("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("coef", ctypes.c_float * 12), ("gmp", ctypes.c_void_p),
+                ("edge_grad", ctypes.c_int)] + \
+               [(k, ctypes.c_void_p) for k in ("dvp", "dv2p", "dhd3", "dhd2", "dr")]
+
+
 class _Lib:
     def __init__(self):
         if not os.path.exists(LIB_PATH):
@@ -98,6 +107,9 @@ class _Lib:
         if self.cdll.pdf_debug_callopts_size() != ctypes.sizeof(CallOpts):
             raise ImportError("pdfnet_amd: PdfCallOpts of %s has %d bytes, this binding's has %d -- rebuild the library"
                               % (LIB_PATH, self.cdll.pdf_debug_callopts_size(), ctypes.sizeof(CallOpts)))
+        if self.cdll.pdf_debug_mesh_loss_size() != ctypes.sizeof(MeshLoss):
+            raise ImportError("pdfnet_amd: PdfMeshLoss of %s has %d bytes, this binding's has %d -- rebuild the library"
+                              % (LIB_PATH, self.cdll.pdf_debug_mesh_loss_size(), ctypes.sizeof(MeshLoss)))
         if self.cdll.pdf_debug_mesh_level_size() != ctypes.sizeof(MeshLevel):
             raise ImportError("pdfnet_amd: PdfMeshLevel of %s has %d bytes, this binding's has %d -- rebuild the library"
                               % (LIB_PATH, self.cdll.pdf_debug_mesh_level_size(), ctypes.sizeof(MeshLevel)))

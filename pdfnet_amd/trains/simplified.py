@@ -99,6 +99,12 @@ class CtdetLoss(nn.Module):
             return t
         # dense-map terms (created last: their backward is issued first, ahead of the launch-bound mesh terms)
         t.update(self.dense_terms(otherInfo, batch))
+        mp = t.pop('_mesh_part', None)
+        if mp is not None:                                   # fused mesh terms: their weighted sum came out of the kernel
+            loss = mp + self.dense_part(t)
+            stats = {k: t[k] for k in self._ORDER}
+            stats['loss'] = loss
+            return loss, stats, None, None
         return self.total(t, epoch)
 
     def dense_terms(self, otherInfo, batch):
@@ -162,6 +168,18 @@ class CtdetLoss(nn.Module):
         hv = valid.t()                                                                                      # [2,B]
         gt = lambda k: torch.stack((batch[k % 'left'], batch[k % 'right']))
         vgt, jgt, v2gt, lmsgt = gt('verts_%s_gt'), gt('joints_%s_gt'), gt('verts2d_%s_gt'), gt('lms_%s_gt')
+        if F.MESH_LOSS_FUSED and not test and vgt.is_cuda and vgt.shape[2] == 778 and float(S) == int(S):
+            # round 5: all twelve terms below AND their weighted sum in two launches forward + one backward (csrc/loss.hip mesh_loss_*); the
+            # term-by-term path that follows stays as the evaluation branch and as the restatement the fused kernels are tested against
+            alpha = 0 if (epoch is None or epoch < 20) else 1
+            hd = handDictList[0]
+            named = dict(zip(self._ORDER, self.coefficients(0 if epoch is None else epoch)))
+            mp, t = F.mesh_loss(_pair(result['verts3d']), _pair(result['verts2d']), _pair(hd['verts3d']), _pair(hd['verts2d']), _pair(paramsDict['root']),
+                                {'vgt': vgt, 'jgt': jgt, 'v2gt': v2gt, 'lmsgt': lmsgt, 'ind': ind, 'K': batch['K_new'], 'valid': valid},
+                                ((self.full_regressor_left, self.full_regressor_right), self.faces_pair, (cl.graph_perm, cr.graph_perm)),
+                                int(S), getattr(o, 'down_ratio', 4), alpha != 0, [named[k] for k in F.MESH_LOSS_TERMS])
+            t['_mesh_part'] = mp
+            return t
         root_gt = jgt[:, :, 9:10]
         vgt_off = vgt - root_gt
         vp, v2p = _pair(result['verts3d']), _pair(result['verts2d'])

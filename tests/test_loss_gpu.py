@@ -147,3 +147,52 @@ def test_evaluation_loop_matches_the_reference_metric_formula():
     for k, v in want.items():
         assert abs(got[k] - v) <= 1e-4 * abs(v) + 1e-6, (k, got[k], v)
     assert abs(got['mpjpe_mm'] - (want['abs_left_joints'] + want['abs_right_joints']) / 2) <= 1e-4 * got['mpjpe_mm']
+
+
+@pytest.mark.parametrize("epoch", [0, 25])
+def test_fused_mesh_loss_equals_the_term_by_term_path(epoch):
+    """csrc/loss.hip mesh_loss_* (round 5: the twelve mesh terms and their weighted sum in two launches forward + one backward) against the
+    term-by-term kernels + aten bookkeeping it replaces -- which the test above pins to the reference's CtdetLoss: every statistic, the loss,
+    and the gradient of the loss with respect to every decoder output it reads (alpha = 0 and alpha = 1: the edge / 2-D joint terms switch)."""
+    from pdfnet_amd import functional as F
+    from pdfnet_amd.networks.intaghand_model import load_model_intag
+    from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch
+    from pdfnet_amd.trains.simplified import CtdetLoss
+    R, B = 256, 5
+    dev = torch.device('cuda')
+    opt = make_opt(R, size_train=[R, R], down_ratio=4, center_weight=200.0, reproj_weight=1.0, bone_dir_weight=200.0)
+    consts = synthetic_loss_constants()
+    crit = CtdetLoss(opt, consts).to(dev)
+    dec = load_model_intag(opt).decoder.to(dev)
+    batch = synthetic_train_batch(B, R, seed=7, consts=consts)
+    batch['valid'][1, 1] = 0.0
+    batch['valid'][3, 0] = 0.0
+    batch = tree_to(batch, dev)
+    res = {}
+    for fused in (False, True):
+        result, params, hand, other = tree_to(synthetic_model_outputs(B, R, 11), dev)
+        other['converter_left'], other['converter_right'] = dec.converter['left'], dec.converter['right']
+        # the decoder hands both hands over as halves of ONE stacked tensor: do the same, and take gradients on the stacked leaves
+        leaves = {}
+        for name, d in (('verts3d', result['verts3d']), ('verts2d', result['verts2d']), ('hd3', hand[0]['verts3d']), ('hd2', hand[0]['verts2d']),
+                        ('root', params['root'])):
+            st = torch.stack((d['left'], d['right'])).detach().requires_grad_()
+            d['left'], d['right'] = st[0], st[1]
+            leaves[name] = st
+        F.MESH_LOSS_FUSED = fused
+        try:
+            loss, stats, _, _ = crit(result, params, hand, other, batch, 'train', epoch)
+        finally:
+            F.MESH_LOSS_FUSED = True
+        w = torch.linspace(0.5, 1.5, B, device=dev)
+        (loss * w).sum().backward()
+        torch.cuda.synchronize()
+        res[fused] = (loss.detach(), {k: torch.as_tensor(v).detach().reshape(-1) for k, v in stats.items()}, {k: v.grad.clone() for k, v in leaves.items()})
+    (l0, s0, g0), (l1, s1, g1) = res[False], res[True]
+    assert torch.allclose(l0, l1, rtol=2e-5, atol=1e-4), (l0, l1)
+    for k in s0:
+        assert torch.allclose(s0[k], s1[k], rtol=2e-5, atol=1e-6), (k, s0[k], s1[k])
+    for k in g0:
+        top = float(g0[k].abs().max())
+        err = float((g0[k] - g1[k]).abs().max())
+        assert top > 0 and err <= 2e-5 * top + 1e-7, (k, err, top)

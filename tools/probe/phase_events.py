@@ -68,6 +68,20 @@ def dforward(*a, **k):
     mark('fwd: mesh decoder')
     return r
 dec.forward = dforward
+# round 5: the three DualGraphLayers on their own (forward: in / out of dual_gcn; backward: gradient of its output = loss + decoder tail done,
+# gradient of its input = the levels done)
+dg = dec.dual_gcn
+dg_fwd = dg.forward
+def dgforward(x):
+    mark('fwd:   decoder head (gf layers, PE)')
+    if x.requires_grad:
+        x.register_hook(lambda g: mark('bwd:   three mesh levels done'))
+    r = dg_fwd(x)
+    mark('fwd:   three mesh levels')
+    if r.requires_grad:
+        r.register_hook(lambda g: mark('bwd:   loss + decoder tail done (grad of the levels\' output)'))
+    return r
+dg.forward = dgforward
 model_fwd = model.forward
 def mforward(*a, **k):
     r = model_fwd(*a, **k)
