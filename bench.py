@@ -49,7 +49,7 @@ class GemmProfiler:
     algorithmic FLOPs (2*M*N*K of the contraction each call performs) from the call's own arguments."""
     NAMES = ('pdf_linear_fwd', 'pdf_linear_bwd_data', 'pdf_linear_bwd_weight', 'pdf_linear_fwd_pair', 'pdf_linear_bwd_data_pair',
              'pdf_linear_bwd_weight_pair', 'pdf_conv2d_fwd', 'pdf_conv2d_bwd_data', 'pdf_conv2d_bwd_weight',
-             'pdf_deconv2d_fwd', 'pdf_deconv2d_bwd_data', 'pdf_deconv2d_bwd_weight')
+             'pdf_deconv2d_fwd', 'pdf_deconv2d_bwd_data', 'pdf_deconv2d_bwd_weight', 'pdf_mesh_level_fwd', 'pdf_mesh_level_bwd')
     # position of (M, N, K) in the argument list and the number of GEMMs per call, include/pdfnet_hip.h
     LINEAR = {'pdf_linear_fwd': (4, 1), 'pdf_linear_bwd_data': (3, 1), 'pdf_linear_bwd_weight': (6, 1),
               'pdf_linear_fwd_pair': (6, 2), 'pdf_linear_bwd_data_pair': (4, 2), 'pdf_linear_bwd_weight_pair': (8, 2)}
@@ -61,7 +61,21 @@ class GemmProfiler:
         self.saved = {}
 
     @staticmethod
+    def mesh_level_flops(level, B):
+        """Forward contraction FLOPs of one DualGraphLayer (csrc/meshdec.hip): its 28 Linear layers per hand pair + the two attentions."""
+        V, cin, c = 63 << level, 512 >> level, 256 >> level
+        R = 2 * B * V
+        lin = 2 * R * c * (2 * cin + 2 * c + cin) + 3 * 2 * R * c * (2 * c + 2 * c + c) + 2 * 6 * 2 * R * c * c
+        att = 2 * 2 * B * 4 * 4 * V * V * (c // 4)
+        return float(lin), float(att)
+
+    @staticmethod
     def flops(name, a):
+        if name.startswith('pdf_mesh_level'):
+            lv = a[0]._obj                                      # the PdfMeshLevel structure behind byref()
+            lin, att = GemmProfiler.mesh_level_flops(lv.level, lv.B)
+            # backward: data gradients + weight gradients of every Linear (the call issues both), ~2.5x the attention's forward work
+            return lin + att if name.endswith('fwd') else 2.0 * lin + 2.5 * att
         if name in GemmProfiler.LINEAR:
             off, n = GemmProfiler.LINEAR[name]
             return 2.0 * n * a[off] * a[off + 1] * a[off + 2]
@@ -86,9 +100,11 @@ class GemmProfiler:
                     r = _fn(*a)
                     e1.record()
                     weight = 'weight' in _n
-                    tile = -1 if weight else self.lib.pdf_debug_last_tile()
-                    launches = 1 if weight else self.lib.pdf_debug_igemm_launches() - n0
-                    self.records.append((_n, self.flops(_n, a), e0, e1, tuple(v for v in a if isinstance(v, int) and abs(v) < (1 << 31)), tile, launches))
+                    mesh = _n.startswith('pdf_mesh_level')
+                    tile = -2 if mesh else -1 if weight else self.lib.pdf_debug_last_tile()
+                    launches = (3 if _n.endswith('fwd') else 8) if mesh else 1 if weight else self.lib.pdf_debug_igemm_launches() - n0
+                    ints = (a[0]._obj.level, a[0]._obj.B) if mesh else tuple(v for v in a if isinstance(v, int) and abs(v) < (1 << 31))
+                    self.records.append((_n, self.flops(_n, a), e0, e1, ints, tile, launches))
                     return r
                 setattr(self.lib, n, wrapped)
         return self
@@ -831,6 +847,14 @@ def main():
         # stream): name, launches and ms are one row of profiles/*_kernel_stats_exclusive.csv
         head, table = symbol_roofline(sym, peak, traffic, traffic_src)
         exec_flops = sum(v[1] for v in sym.values())
+        # the fused mesh decoder's own products (forward, data gradients: csrc/meshdec.hip) are not KernelTimer symbols; its weight-gradient
+        # launches are.  Add the former: (fwd) lin + att, (bwd) lin + 2.5 att per level.
+        mesh_fl = 0.0
+        for n, fl, _e0, _e1, ints, t, _l in prof.records:
+            if t == -2:
+                lin, att = GemmProfiler.mesh_level_flops(*ints)
+                mesh_fl += (lin + att) if n.endswith('fwd') else (lin + 2.5 * att)
+        exec_flops += mesh_fl
         out["roofline"] = {
             "bound": "mfma", "peak": peak, "unit": "TFLOP/s", **head,
             "per_symbol": table,
