@@ -505,13 +505,13 @@ int pdf_debug_mesh_level_size(void);
 /* ---- fused mesh loss (round 5, csrc/loss.hip) --------------------------------------------------------------------------------
  * Every mesh term of CtdetLoss.forward's train branch (lib/trains/simplified.py:425-525; lib/models/losses.py:26-94 bone directions;
  * Mano_render.py:203-223 root un-projection and pinhole projection; Mano_model.py:309-323 joint regressor) in one forward launch pair and one
- * backward launch, one workgroup per (hand, sample).  Tensors are stacked [2 (left, right)][B][...]; `part` is [2][B][12] scratch.
+ * backward launch, one workgroup per (hand, sample).  Predictions are stacked [2 (left, right)][B][...]; `part` is [2][B][12] scratch.
  * out (4 + 9 B floats): verts2d, norm, edge, gcn_2d, then B-vectors root, verts, abs_verts, gcn, abs_joints, joints2d, joints, bone (weighted by
  * `valid` and x1000 where the reference does, :506-525), then the per-sample weighted sum of the twelve with `coef` (the reference's :610-640
  * weights, same order).  The backward writes the gradients of sum_b gmp[b] * weighted_sum[b]. */
 typedef struct PdfMeshLoss {
     const float* vp; const float* v2p; const float* hd3; const float* hd2; const float* r;
-    const float* vgt; const float* jgt; const float* v2gt; const float* lmsgt;
+    const float* vgt[2]; const float* jgt[2]; const float* v2gt[2]; const float* lmsgt[2];     /* ground truth per hand, [B][...] each */
     const long long* ind; const float* K; const float* valid;
     const float* reg[2]; const long long* faces; const long long* perm[2];
     int B, Fc, size, down;

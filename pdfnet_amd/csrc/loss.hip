@@ -170,9 +170,14 @@ __global__ __launch_bounds__(256) void dense_loss_partial_kernel(const DenseLoss
     const float* pt = t.tgt + b * per;
     const float* pp = t.pred + b * per;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    // index order (pixel tile of 64, channel, pixel in tile): a wave reads 64 consecutive target pixels of one channel (NCHW) and the 64 prediction
+    // rows (NHWC) its neighbours on the channel axis read next -- with the plain (channel, pixel) order every prediction line was fetched
+    // for ONE element and again, from L2, for each of the other channels (62 + 85 us for 20 MB of maps)
     for (long i = blk * 256L + threadIdx.x; i < per; i += a.nblk * 256L) {
-        const int c = (int)(i / t.HW), p = (int)(i - (long)c * t.HW);
-        const float x = pp[(long)p * t.C + c], g = pt[i];
+        int c, p;
+        if ((t.HW & 63) == 0) { const long tile = i / (64L * t.C); const int rem = (int)(i - tile * 64L * t.C); c = rem >> 6; p = (int)(tile * 64) + (rem & 63); }
+        else { c = (int)(i / t.HW); p = (int)(i - (long)c * t.HW); }
+        const float x = pp[(long)p * t.C + c], g = pt[(long)c * t.HW + p];
         if (term == 0) { const float d = fabsf(x - g); s0 += d < 1.f ? 0.5f * d * d : d - 0.5f; }
         else if (term == 1) { const float d = x - g; s0 += d * d; }
         else {
@@ -240,9 +245,11 @@ __global__ __launch_bounds__(256) void dense_loss_bwd_kernel(const DenseLoss a, 
     else k = stat[2 + 2 * a.B] != 0.f ? -g2[b] : -g2[b] / (stat[2 + a.B + b] + 1e-3f);
     const bool no_pos = term == 2 && stat[2 + 2 * a.B] != 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += gridDim.x * 256L) {
-        const int c = (int)(i / t.HW), p = (int)(i - (long)c * t.HW);
+        int c, p;
+        if ((t.HW & 63) == 0) { const long tile = i / (64L * t.C); const int rem = (int)(i - tile * 64L * t.C); c = rem >> 6; p = (int)(tile * 64) + (rem & 63); }
+        else { c = (int)(i / t.HW); p = (int)(i - (long)c * t.HW); }
         const long o = (long)p * t.C + c;
-        const float x = pp[o], gt = pt[i];
+        const float x = pp[o], gt = pt[(long)c * t.HW + p];
         float d;
         if (term == 0) { const float e = x - gt; d = k * (fabsf(e) < 1.f ? e : (e > 0.f ? 1.f : -1.f)); }
         else if (term == 1) d = k * 2.f * (x - gt);
@@ -310,7 +317,7 @@ PDF_API int pdf_point_dist_sum(const float* pred, const float* gt, int rows, int
 #define ML_J 21
 struct MeshLoss {
     const float* vp; const float* v2p; const float* hd3; const float* hd2; const float* r;              // predictions [2][B][...]
-    const float* vgt; const float* jgt; const float* v2gt; const float* lmsgt;                          // ground truth [2][B][...]
+    const float* vgt[2]; const float* jgt[2]; const float* v2gt[2]; const float* lmsgt[2];              // ground truth per hand [B][...] (the batch's own tensors)
     const long long* ind; const float* K; const float* valid;                                          // [B][2] i64, [B][3][3], [B][2]
     const float* reg[2]; const long long* faces; const long long* perm[2];                              // [21][778] x 2, [2][F][3], [1008] x 2
     int B, Fc, size, down;
@@ -332,8 +339,8 @@ struct MlShared {
 __device__ __forceinline__ void ml_common(const MeshLoss& a, int g, int b, MlShared& S) {
     const long gb = (long)g * a.B + b;
     const float* vp = a.vp + gb * ML_V * 3;
-    const float* vg = a.vgt + gb * ML_V * 3;
-    const float* jgt = a.jgt + gb * ML_J * 3;
+    const float* vg = a.vgt[g] + (long)b * ML_V * 3;
+    const float* jgt = a.jgt[g] + (long)b * ML_J * 3;
     if (threadIdx.x < 3) S.root_gt[threadIdx.x] = jgt[9 * 3 + threadIdx.x];
     __syncthreads();
     // joints = reg . verts: (21 x 3) x 2 dot products of length 778, one per wave-turn
@@ -381,11 +388,11 @@ __global__ __launch_bounds__(256) void mesh_loss_fwd_kernel(const MeshLoss a) {
     const long gb = blockIdx.x;
     ml_common(a, g, b, S);
     const float* vp = a.vp + gb * ML_V * 3;
-    const float* vg = a.vgt + gb * ML_V * 3;
+    const float* vg = a.vgt[g] + (long)b * ML_V * 3;
     float s0 = 0.f, s1 = 0.f, s9 = 0.f;
     {
         const float* v2p = a.v2p + gb * ML_V * 2;
-        const float* v2g = a.v2gt + gb * ML_V * 2;
+        const float* v2g = a.v2gt[g] + (long)b * ML_V * 2;
         for (int i = threadIdx.x; i < ML_V * 2; i += 256) { const float d = v2p[i] - v2g[i]; s0 += d * d; }
         for (int i = threadIdx.x; i < ML_V * 3; i += 256) {
             const int k = i % 3;
@@ -397,12 +404,12 @@ __global__ __launch_bounds__(256) void mesh_loss_fwd_kernel(const MeshLoss a) {
     if (threadIdx.x < ML_J * 3) {
         const int k = threadIdx.x % 3;
         s2 = fabsf(S.jp[threadIdx.x] - S.jg[threadIdx.x]);
-        s8 = fabsf((S.jp[threadIdx.x] + S.root_gt[k]) - a.jgt[gb * ML_J * 3 + threadIdx.x]);
+        s8 = fabsf((S.jp[threadIdx.x] + S.root_gt[k]) - a.jgt[g][(long)b * ML_J * 3 + threadIdx.x]);
     }
-    if (threadIdx.x < ML_J * 2) { const float d = S.lms[threadIdx.x] - a.lmsgt[gb * ML_J * 2 + threadIdx.x]; s10 = d * d; }
+    if (threadIdx.x < ML_J * 2) { const float d = S.lms[threadIdx.x] - a.lmsgt[g][(long)b * ML_J * 2 + threadIdx.x]; s10 = d * d; }
     if (threadIdx.x < 3) s7 = fabsf(S.root_pred[threadIdx.x] - S.root_gt[threadIdx.x]);
     if (threadIdx.x < 20) {
-        const float* lg = a.lmsgt + gb * ML_J * 2;
+        const float* lg = a.lmsgt[g] + (long)b * ML_J * 2;
         const int pa = ml_bone_a[threadIdx.x], pc = ml_bone_c[threadIdx.x];
         const float vx = S.lms[pc * 2] - S.lms[pa * 2], vy = S.lms[pc * 2 + 1] - S.lms[pa * 2 + 1];
         const float gx = lg[pc * 2] - lg[pa * 2], gy = lg[pc * 2 + 1] - lg[pa * 2 + 1];
@@ -431,9 +438,9 @@ __global__ __launch_bounds__(256) void mesh_loss_fwd_kernel(const MeshLoss a) {
     {
         const float* hd3 = a.hd3 + gb * ML_VG * 3;
         const float* hd2 = a.hd2 + gb * ML_VG * 2;
-        const float* vl = a.vgt + (long)b * ML_V * 3;                    // hand 0 of this sample
-        const float* rl = a.jgt + (long)b * ML_J * 3 + 9 * 3;
-        const float* v2g = a.v2gt + gb * ML_V * 2;
+        const float* vl = a.vgt[0] + (long)b * ML_V * 3;                 // hand 0 of this sample
+        const float* rl = a.jgt[0] + (long)b * ML_J * 3 + 9 * 3;
+        const float* v2g = a.v2gt[g] + (long)b * ML_V * 2;
         const long long* pm = a.perm[g];
         for (int i = threadIdx.x; i < ML_VG * 3; i += 256) {
             const int n = i / 3, k = i - 3 * n;
@@ -540,11 +547,11 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
     __syncthreads();
     const float c10 = gsum[0];
     const float* vp = a.vp + gb * ML_V * 3;
-    const float* vg = a.vgt + gb * ML_V * 3;
+    const float* vg = a.vgt[g] + (long)b * ML_V * 3;
     // 2-D mesh term
     {
         const float* v2p = a.v2p + gb * ML_V * 2;
-        const float* v2g = a.v2gt + gb * ML_V * 2;
+        const float* v2g = a.v2gt[g] + (long)b * ML_V * 2;
         float* d = a.dv2p + gb * ML_V * 2;
         for (int i = threadIdx.x; i < ML_V * 2; i += 256) d[i] = c0 * 2.f * (v2p[i] - v2g[i]);
     }
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
     if ((threadIdx.x & 63) == 0) { atomicAdd(&droot[0], dr0); atomicAdd(&droot[1], dr1); atomicAdd(&droot[2], dr2); }
     // joint-level terms
     if (threadIdx.x < 20) {                                               // bone direction -> d lms
-        const float* lg = a.lmsgt + gb * ML_J * 2;
+        const float* lg = a.lmsgt[g] + (long)b * ML_J * 2;
         const int pa = ml_bone_a[threadIdx.x], pc = ml_bone_c[threadIdx.x];
         const float vx = S.lms[pc * 2] - S.lms[pa * 2], vy = S.lms[pc * 2 + 1] - S.lms[pa * 2 + 1];
         const float gx = lg[pc * 2] - lg[pa * 2], gy = lg[pc * 2 + 1] - lg[pa * 2 + 1];
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
     if (threadIdx.x < ML_J) {                                             // 2-D joint term + projection backward -> d jp
         const int j = threadIdx.x;
         const float* K = a.K + (long)b * 9;
-        const float* lg = a.lmsgt + gb * ML_J * 2;
+        const float* lg = a.lmsgt[g] + (long)b * ML_J * 2;
         const float dlx = dlms[j * 2] + c10 * 2.f * (S.lms[j * 2] - lg[j * 2]);
         const float dly = dlms[j * 2 + 1] + c10 * 2.f * (S.lms[j * 2 + 1] - lg[j * 2 + 1]);
         const float x = S.jp[j * 3] + S.root_gt[0], y = S.jp[j * 3 + 1] + S.root_gt[1], zz = S.jp[j * 3 + 2] + S.root_gt[2];
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
     if (threadIdx.x < ML_J * 3) {
         const int k = threadIdx.x % 3;
         const float e2 = S.jp[threadIdx.x] - S.jg[threadIdx.x];
-        const float e8 = (S.jp[threadIdx.x] + S.root_gt[k]) - a.jgt[gb * ML_J * 3 + threadIdx.x];
+        const float e8 = (S.jp[threadIdx.x] + S.root_gt[k]) - a.jgt[g][(long)b * ML_J * 3 + threadIdx.x];
         djp[threadIdx.x] += c2 * (e2 > 0.f ? 1.f : (e2 < 0.f ? -1.f : 0.f)) + c8 * (e8 > 0.f ? 1.f : (e8 < 0.f ? -1.f : 0.f));
     }
     if (threadIdx.x < 3) {                                                // root term
@@ -646,9 +653,9 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
     {
         const float* hd3 = a.hd3 + gb * ML_VG * 3;
         const float* hd2 = a.hd2 + gb * ML_VG * 2;
-        const float* vl = a.vgt + (long)b * ML_V * 3;
-        const float* rl = a.jgt + (long)b * ML_J * 3 + 9 * 3;
-        const float* v2g = a.v2gt + gb * ML_V * 2;
+        const float* vl = a.vgt[0] + (long)b * ML_V * 3;
+        const float* rl = a.jgt[0] + (long)b * ML_J * 3 + 9 * 3;
+        const float* v2g = a.v2gt[g] + (long)b * ML_V * 2;
         const long long* pm = a.perm[g];
         float* d3 = a.dhd3 + gb * ML_VG * 3;
         float* d2 = a.dhd2 + gb * ML_VG * 2;

@@ -2100,6 +2100,9 @@ def point_dist_sum(pred, gt):
 # ----------------------------------------------------------------------------------------------
 # Fused mesh decoder (csrc/meshdec.hip, round 5): one DualGraphLayer (DualGraph.py:62-92) = three launches forward, see the kernel file.
 MESH_FUSED = _os.environ.get("PDFNET_MESH_FUSED", "1") != "0"
+# bf16 mode: the mesh decoder stays on the fused fp32 kernels (its products are latency-bound, not MFMA-bound: 1 % of the step's FLOPs; the
+# fused form removes ~500 launches from a step that is bound by the host's issue time at B = 32).  0: the unfused bf16 GEMM chain of rounds 2-4.
+MESH_FUSED_BF16 = _os.environ.get("PDFNET_MESH_FUSED_BF16", "1") != "0"
 
 
 def _pair(dst, l, r):
@@ -2256,7 +2259,7 @@ def mesh_level(layer, x):
 
 def mesh_level_ok(layer, x):
     """The fused kernels cover the reference's three levels (V = 63 / 126 / 252 with C = 256 / 128 / 64, four blocks, four heads) in fp32 mode."""
-    if not (MESH_FUSED and x.is_cuda and not _GEMM_BF16 and x.dim() == 4 and x.shape[0] == 2 and x.dtype == torch.float32):
+    if not (MESH_FUSED and x.is_cuda and (MESH_FUSED_BF16 or not _GEMM_BF16) and x.dim() == 4 and x.shape[0] == 2 and x.dtype == torch.float32):
         return False
     level = {63: 0, 126: 1, 252: 2}.get(x.shape[2])
     return (level is not None and x.shape[3] == 2 * (256 >> level) and len(layer.graph_left.GCN_blocks) == 4 and layer.attn.n_heads == 4
@@ -2285,7 +2288,12 @@ class _MeshLoss(Function):
         keep = [vp, v2p, hd3, hd2, r]
         for k, t in (('vp', vp), ('v2p', v2p), ('hd3', hd3), ('hd2', hd2), ('r', r)):
             setattr(a, k, ptr(t))
-        for k in ('vgt', 'jgt', 'v2gt', 'lmsgt', 'ind', 'K', 'valid'):
+        for k in ('vgt', 'jgt', 'v2gt', 'lmsgt'):               # (left, right) pairs of the batch's own tensors: nothing is stacked
+            for i in (0, 1):
+                t = gt[k][i].contiguous()
+                keep.append(t)
+                getattr(a, k)[i] = ptr(t)
+        for k in ('ind', 'K', 'valid'):
             t = gt[k].contiguous()
             keep.append(t)
             setattr(a, k, ptr(t))
@@ -2318,7 +2326,7 @@ class _MeshLoss(Function):
 
 
 def mesh_loss(vp, v2p, hd3, hd2, r, gt, consts, size, down, edge_grad, coefs):
-    """gt: dict vgt [2,B,778,3], jgt [2,B,21,3], v2gt [2,B,778,2], lmsgt [2,B,21,2], ind [B,2] int64, K [B,3,3], valid [B,2];
+    """gt: dict vgt / jgt / v2gt / lmsgt = (left, right) pairs of [B,778,3] / [B,21,3] / [B,778,2] / [B,21,2], ind [B,2] int64, K [B,3,3], valid [B,2];
     consts: ((reg_left, reg_right) [21,778], faces [2,F,3] int64, (perm_left, perm_right) [1008] int64); coefs: the weights of the twelve
     terms in MESH_LOSS_TERMS order.  -> (their weighted sum per sample [B] (differentiable), dict of the twelve terms (detached))."""
     mp, terms = _MeshLoss.apply(vp, v2p, hd3, hd2, r, gt, consts, size, down, edge_grad, tuple(coefs))

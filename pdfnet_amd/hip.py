@@ -85,7 +85,8 @@ class MeshLevel(ctypes.Structure):
 
 class MeshLoss(ctypes.Structure):
     """PdfMeshLoss of include/pdfnet_hip.h (field for field)."""
-    _fields_ = [(k, ctypes.c_void_p) for k in ("vp", "v2p", "hd3", "hd2", "r", "vgt", "jgt", "v2gt", "lmsgt", "ind", "K", "valid")] + \
+    _fields_ = [(k, ctypes.c_void_p) for k in ("vp", "v2p", "hd3", "hd2", "r")] + [(k, _P2) for k in ("vgt", "jgt", "v2gt", "lmsgt")] + \
+               [(k, ctypes.c_void_p) for k in ("ind", "K", "valid")] + \
                [("reg", _P2), ("faces", ctypes.c_void_p), ("perm", _P2), ("B", ctypes.c_int), ("Fc", ctypes.c_int), ("size", ctypes.c_int),
                 ("down", ctypes.c_int), ("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("coef", ctypes.c_float * 12), ("gmp", ctypes.c_void_p),
                 ("edge_grad", ctypes.c_int)] + \

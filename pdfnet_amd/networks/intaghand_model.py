@@ -42,6 +42,11 @@ class HandNET_GCN(nn.Module):
         if self.run_mid_model:
             def run_mid():
                 with torch.no_grad():
+                    if self.defer_mid_model and self.training:
+                        # the pass may still run while the backward releases these tensors: the allocator must not hand their memory out before it ends
+                        for t in list(img_fmaps) + list(hms_fmaps) + list(dp_fmaps):
+                            if torch.is_tensor(t) and t.is_cuda:
+                                t.record_stream(torch.cuda.current_stream())
                     self.mid_model(img_fmaps, hms_fmaps, dp_fmaps)      # live state: its BN running statistics only
             if self.defer_mid_model and self.training:
                 # nothing reads its outputs: 0.9 ms of convolutions that need not sit between the mesh decoder and the loss.

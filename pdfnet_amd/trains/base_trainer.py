@@ -26,6 +26,7 @@ class ModleWithLoss(torch.nn.Module):
         super().__init__()
         self.model = model
         self.loss = loss
+        self.late_join = False                                 # Trainer sets it: it joins after the backward instead
         if hasattr(model, 'join_deferred') and os.environ.get('PDFNET_DEFER_MID', '1') != '0':
             model.defer_mid_model = True                       # joined below, right after the loss has been issued
 
@@ -34,7 +35,10 @@ class ModleWithLoss(torch.nn.Module):
         result, paramsDict, handDictList, otherInfo = self.model(
             batch['input'], batch['choose'], batch['cloud'], batch.get('depth'), ind, batch['K_new'], batch['valid'])
         out = self.loss(result, paramsDict, handDictList, otherInfo, batch, mode, epoch)
-        if hasattr(self.model, 'join_deferred'):
+        # mid_model's deferred pass (dead outputs, live BatchNorm statistics) is joined by whoever reads or writes that state next: the
+        # trainer after the backward (`late_join`: round 5 -- joined here it sat between the loss and the backward, 0.5 ms of the chain),
+        # everybody else right here; the model's own forward / state_dict / train() join it in any case
+        if hasattr(self.model, 'join_deferred') and not (self.late_join and mode == 'train'):
             self.model.join_deferred()
         return out
 
@@ -365,6 +369,7 @@ class Trainer:
         self.opt = opt
         self.model = model
         self.model_with_loss = ModleWithLoss(model, loss)
+        self.model_with_loss.late_join = os.environ.get('PDFNET_MID_LATE_JOIN', '1') != '0'
         named = list(model.named_parameters())
         early, late, dead = split_parameters(named)
         flat = [p for _, p in early + late + dead]             # flat order: [early | late | never used]
@@ -473,6 +478,8 @@ class Trainer:
         loss, stats, _, _ = self.model_with_loss(batch, 'train', epoch)
         loss = loss.mean()                                     # base_trainer.py:144
         loss.backward()
+        if hasattr(self.model, 'join_deferred'):
+            self.model.join_deferred()                         # mid_model's BatchNorm-statistics pass (see ModleWithLoss.forward)
         F.join_wgrad()                                         # side-stream weight-gradient kernels -> flat_g complete
         F.step_counter(loss.device).add_(1)                    # fresh dropout masks next step (also under replay)
         return loss.detach(), stats

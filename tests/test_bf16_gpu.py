@@ -249,6 +249,8 @@ def test_bf16_train_step_against_the_fp32_oracle(bf16_mode):
     e.zero_grad()
 
     def rounded(name, mod):
+        if name.startswith('decoder.dual_gcn.') and F.MESH_FUSED and F.MESH_FUSED_BF16:
+            return False                                       # round 5: the three DualGraphLayers run on the fused fp32 kernels in bf16 mode too
         cin = mod.in_features if isinstance(mod, torch.nn.Linear) else mod.in_channels
         return cin % 16 == 0 or name.endswith('netR_3.0')      # netR_3's 259 input channels are zero-padded to 272 on the HIP side
     with torch.no_grad():

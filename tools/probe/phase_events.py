@@ -101,6 +101,7 @@ def step():
     loss = loss.mean()
     mark('fwd: loss')
     loss.backward()
+    model.join_deferred()
     mark('bwd: main chain + forked streams done')
     join0()
     mark('bwd: weight-gradient side streams joined')
