@@ -387,7 +387,7 @@ class ResNetSimple(nn.Module):
         st['ind'] = ind
         return st
 
-    def dense_branches(self, st, defer=False):
+    def dense_branches(self, st, defer=False, lazy_heads=False):
         """The two up-sampling decoders (need only x1) and the wh / params heads (need only x0; no loss term): heavy
         convolutions with few launches, each on its own side stream, joined right away.  (Starting them as early as their
         inputs exist, next to the pyramid / feat convolutions, was measured: 346 vs 366 img/s -- MFMA-bound work gains
@@ -403,13 +403,19 @@ class ResNetSimple(nn.Module):
                     fc = getattr(self, head)
                     out[head] = fc[2](fc[0](x0, F.ACT_RELU))
             return out
-        f_heads = F.fork(other_heads)
+        # lazy_heads (round 5, the trainer's switch): the wh / params heads carry no loss term (lib/trains/simplified.py:397-399), so nothing in the
+        # step waits for them: `join` then returns their closure instead of their outputs, and the caller issues it AFTER the loss -- beside the
+        # launch-bound start of the backward instead of beside the mesh decoder, where 0.9 ms of their convolutions widened the forward
+        f_heads = None if lazy_heads else F.fork(other_heads)
         def join():
             ret = dict(st['ret'])
             for head in self.opt.heads:                                                    # keep the reference's key order
                 if head != 'hm':
                     ret[head] = None
-            ret.update(f_heads.join())
+            if f_heads is not None:
+                ret.update(f_heads.join())
+            else:
+                ret['_lazy_heads'] = other_heads
             hms, hms_f = f_hms.join()
             mask, dp_f = f_dp.join() if f_dp is not None else st['dp']
             return hms, mask, ret, hms_f, dp_f

@@ -21,7 +21,9 @@ class HandNET_GCN(nn.Module):
         # state the reference updates every step; keep it on by default for state parity.
         self.run_mid_model = run_mid_model
         self.defer_mid_model = False       # set by ModleWithLoss: mid_model on a side stream, joined after the loss
+        self.defer_lossless_heads = False  # set by the Trainer (CtdetLoss only): wh / params heads issued after the loss, see run_deferred_heads
         self._deferred = []
+        self._lazy_heads = None
 
     def forward(self, img, choose, cloud, depth, ind, K_new, valid):
         # a previous train-mode call that nobody joined (a direct `model(...)` outside ModleWithLoss): its mid_model pass still
@@ -36,7 +38,8 @@ class HandNET_GCN(nn.Module):
         gl, gr = img_fmaps[0][:, 0], img_fmaps[0][:, 1]                 # what mid_model hands on (intaghand_encoder.py:881)
         # ... and joined only AFTER the mesh decoder has been issued: in the forward the decoder's small kernels run next to
         # the branches' convolutions (404.5 -> 406.8 img/s), while the autograd order of the backward stays as it was.
-        join_dense = self.encoder.dense_branches(st, defer=True)
+        lazy = self.defer_lossless_heads and self.training and torch.is_grad_enabled()
+        join_dense = self.encoder.dense_branches(st, defer=True, lazy_heads=lazy)
         result, paramsDict, handDictList, otherInfo = self.decoder(gl, gr)
         hms, mask, ret, hms_fmaps, dp_fmaps = join_dense()
         if self.run_mid_model:
@@ -55,6 +58,7 @@ class HandNET_GCN(nn.Module):
             else:
                 run_mid()
         BatchNorm.flush_counters()
+        self._lazy_heads = (ret.pop('_lazy_heads'), ret) if '_lazy_heads' in ret else None
         otherInfo['hms'] = hms
         otherInfo['mask'] = mask
         otherInfo['ret'] = ret
@@ -63,8 +67,20 @@ class HandNET_GCN(nn.Module):
         otherInfo['converter_right'] = self.decoder.converter['right']
         return result, paramsDict, handDictList, otherInfo
 
+    def run_deferred_heads(self):
+        """Issue the wh / params heads the last forward left out (`defer_lossless_heads`) on a side stream and fill them into the `ret` dict that
+        forward returned; `join_deferred` makes them visible to the current stream."""
+        if getattr(self, '_lazy_heads', None) is None:
+            return
+        fn, ret = self._lazy_heads
+        self._lazy_heads = None
+        f = F.fork(fn)
+        ret.update(f.out)
+        self._deferred.append(f)
+
     def join_deferred(self):
-        """Make the current stream wait for the work `forward` left on side streams (see `defer_mid_model`)."""
+        """Make the current stream wait for the work `forward` left on side streams (see `defer_mid_model`, `defer_lossless_heads`)."""
+        self.run_deferred_heads()                              # (nobody issued them: do it now)
         for f in self._deferred:
             f.join()
         self._deferred.clear()

@@ -35,6 +35,8 @@ class ModleWithLoss(torch.nn.Module):
         result, paramsDict, handDictList, otherInfo = self.model(
             batch['input'], batch['choose'], batch['cloud'], batch.get('depth'), ind, batch['K_new'], batch['valid'])
         out = self.loss(result, paramsDict, handDictList, otherInfo, batch, mode, epoch)
+        if hasattr(self.model, 'run_deferred_heads'):
+            self.model.run_deferred_heads()                    # the loss-less wh / params heads, when the trainer deferred them (beside the backward)
         # mid_model's deferred pass (dead outputs, live BatchNorm statistics) is joined by whoever reads or writes that state next: the
         # trainer after the backward (`late_join`: round 5 -- joined here it sat between the loss and the backward, 0.5 ms of the chain),
         # everybody else right here; the model's own forward / state_dict / train() join it in any case
@@ -370,6 +372,13 @@ class Trainer:
         self.model = model
         self.model_with_loss = ModleWithLoss(model, loss)
         self.model_with_loss.late_join = os.environ.get('PDFNET_MID_LATE_JOIN', '1') != '0'
+        # the wh / params heads have no term in CtdetLoss (lib/trains/simplified.py:397-399): under THIS loss they are issued after it and joined
+        # with mid_model after the backward; any other loss module sees them computed in place
+        from .simplified import CtdetLoss as _Ctdet
+        if hasattr(model, 'defer_lossless_heads') and isinstance(loss, _Ctdet) and self.model_with_loss.late_join:
+            # measured neutral (627 vs 628 img/s: the forward's mesh-level window shrinks 3.4 -> 2.5 ms, the backward's first windows grow by as
+            # much -- the step conserves work, the heads' 0.9 ms of convolutions just move): opt-in
+            model.defer_lossless_heads = os.environ.get('PDFNET_DEFER_HEADS', '0') != '0'
         named = list(model.named_parameters())
         early, late, dead = split_parameters(named)
         flat = [p for _, p in early + late + dead]             # flat order: [early | late | never used]
