@@ -156,10 +156,14 @@ class KernelTimer:
         self.lib = hip.lib()
 
     def __enter__(self):
+        from pdfnet_amd import graphed
+        graphed.SUSPEND = True                               # (a replayed hipGraph launches nothing from the host: the timers would miss the trunk)
         self.lib.pdf_debug_kernel_timing(1)
         return self
 
     def __exit__(self, *exc):
+        from pdfnet_amd import graphed
+        graphed.SUSPEND = False
         self.lib.pdf_debug_kernel_timing(0)
 
     def by_symbol(self):
@@ -756,8 +760,8 @@ def main():
     model = load_model_intag(opt).to(dev)
     consts = synthetic_loss_constants()
     loss = CtdetLoss(opt, consts).to(dev)
-    if args.graph and not os.environ.get('PDF_GRAPH_WGRAD_STREAM'):
-        F.ASYNC_WGRAD = False              # hipGraph replay of the forked wgrad stream measured slower than the plain graph
+    if args.graph and os.environ.get('PDF_GRAPH_WGRAD_STREAM') == '0':
+        F.ASYNC_WGRAD = False              # (the weight-gradient branch inside the capture: grouped launches, Trainer.GRAPH_WGRAD_GROUP -- r05_wgrad_group.txt)
     trainer = Trainer(opt, model, loss, lr=1e-4, use_graph=args.graph, broadcast_buffers=args.broadcast_buffers,
                       grad_comm_dtype=torch.bfloat16 if bf16 else None)   # world > 1: replicas synced from rank 0
     batch = to_device(synthetic_train_batch(B, R, seed=1 + rank, consts=consts), dev)

@@ -366,10 +366,11 @@ class wgrad_stream:
     non-atomic `dW += ...` launches on two side streams at once: `params` names the accumulation targets, and a side
     stream first waits for the stream that last accumulated into the same parameter."""
 
-    def __init__(self, enabled, *tensors, params=()):
+    def __init__(self, enabled, *tensors, params=(), also_wait=None):
         self.enabled = enabled and ASYNC_WGRAD and USE_SIDE_STREAMS
         self.tensors = tensors
         self.params = params
+        self.also_wait = also_wait                  # raw stream the inputs were produced on, when it is not the current one (flush_wgrad)
 
     def __enter__(self):
         if not self.enabled:
@@ -387,6 +388,8 @@ class wgrad_stream:
         side, side_raw = ent[0], ent[1]
         wait = _L().pdf_stream_wait
         wait(side_raw, cur_raw)
+        if self.also_wait is not None and self.also_wait != cur_raw:
+            wait(side_raw, self.also_wait)
         for p in self.params:
             if p is not None:
                 last = getattr(p, '_pdf_wg_last', None)
@@ -411,9 +414,42 @@ class wgrad_stream:
         return False
 
 
+# Weight gradients in groups (round 5).  Every switch to the side stream is one cross-stream edge: an event record in the main chain
+# (eager: ~3 us of queue bubble per edge; inside a captured hipGraph ~14 us per edge -- profiles/r05_hipgraph_branches.txt, the reason the
+# forked capture replayed slower than the single-stream one) plus ~11 us of host time.  With WGRAD_GROUP = G > 1 the launches are kept as
+# closures (which hold their operands alive) and issued G at a time behind ONE edge.  Nothing reads a weight gradient before join_wgrad /
+# the trainer's early-slice hook, and both flush first.  Lists are per launching stream: a group is flushed while that stream is current.
+WGRAD_GROUP = int(_os.environ.get("PDFNET_WGRAD_GROUP", "1"))
+_wg_pending = {}
+
+
+def _wg_defer(fn, tensors, params):
+    key = hip._raw_stream(hip._raw_device())
+    lst = _wg_pending.setdefault(key, [])
+    lst.append((fn, tensors, params))
+    if len(lst) >= WGRAD_GROUP:
+        _wg_flush_key(key)
+
+
+def _wg_flush_key(key):
+    items = _wg_pending.pop(key, None)
+    if not items:
+        return
+    with wgrad_stream(True, *[t for it in items for t in it[1]], params=[p for it in items for p in it[2]], also_wait=key):
+        for it in items:
+            it[0]()
+
+
+def flush_wgrad():
+    """Issue every deferred weight-gradient launch now (on the current stream's side stream, after the stream each was deferred on)."""
+    for key in list(_wg_pending):
+        _wg_flush_key(key)
+
+
 def join_wgrad(keep=False):
     """Make the current stream wait for every outstanding side-stream weight-gradient kernel.  keep: the streams stay listed
     (a later join -- another stream's, or the one after the backward -- still waits for them)."""
+    flush_wgrad()
     cur = hip.stream()
     for key in list(_wg_used):
         _L().pdf_stream_wait(cur, _wg_streams[key][1])
@@ -466,11 +502,16 @@ def _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, C, R, flops, fused
     if mg_w is not None or mg_b is not None:
         # (the bf16 shadows the launch reads are side-stream inputs like x and g: recorded, or the allocator could hand their
         # memory out again while the weight-gradient kernel still reads it)
-        with wgrad_stream(flops >= ASYNC_WGRAD_MIN_FLOP, x, g, *shadows, params=(w_par, b_par)):
+        def run():
             if mg_w is not None:
                 launch_w(mg_w, mg_b if ride else None, 1)
             if mg_b is not None and not ride:
                 _colsum_into(g, C, R, C, mg_b)
+        if WGRAD_GROUP > 1 and ASYNC_WGRAD and USE_SIDE_STREAMS and flops >= ASYNC_WGRAD_MIN_FLOP:
+            _wg_defer(run, (x, g) + tuple(shadows), (w_par, b_par))
+        else:
+            with wgrad_stream(flops >= ASYNC_WGRAD_MIN_FLOP, x, g, *shadows, params=(w_par, b_par)):
+                run()
     if need_w and mg_w is None:
         dw = torch.empty_like(w)
         if ride:

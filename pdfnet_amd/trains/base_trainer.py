@@ -444,6 +444,7 @@ class Trainer:
                 self._adam_stream = torch.cuda.Stream()
             side = self._adam_stream.cuda_stream
             self.optimizer.begin_step()
+            F.flush_wgrad()
             wait = hip.lib().pdf_stream_wait
             wait(side, cur)
             for key in list(F._wg_used):
@@ -471,6 +472,7 @@ class Trainer:
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream()
         comm = self._comm_stream.cuda_stream
+        F.flush_wgrad()                                        # (grouped weight gradients: the early slice's last group goes out now)
         wait = hip.lib().pdf_stream_wait
         wait(comm, cur)
         for key in list(F._wg_used):
@@ -520,6 +522,7 @@ class Trainer:
             self._auto_select()
         return loss
 
+    GRAPH_WGRAD_GROUP = int(os.environ.get('PDFNET_GRAPH_WGRAD_GROUP', '16'))
     AUTO_STEPS = 4                                             # timed steps per mode ...
     AUTO_SKIP = 3                                              # ... after this many untimed ones (allocator warm-up; capture)
 
@@ -566,21 +569,27 @@ class Trainer:
             saved = [b.clone() for b in bufs]
             ctr = F.step_counter(self.optimizer.flat_p.device)
             ctr_saved = ctr.clone()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):                         # warm-up on a side stream
-                for _ in range(2):
-                    self._fwd_bwd(static, epoch)
-                BatchNorm.flush_counters()
-            torch.cuda.current_stream().wait_stream(s)
-            for b, v in zip(bufs, saved):
-                b.copy_(v)
-            ctr.copy_(ctr_saved)
-            graph = torch.cuda.CUDAGraph()
-            if self._graph_pool is None:
-                self._graph_pool = torch.cuda.graph_pool_handle()     # one private pool for every key (not one multi-GB pool per key)
-            with torch.cuda.graph(graph, pool=self._graph_pool):
-                loss_out, _ = self._fwd_bwd(static, epoch)
+            # inside a captured graph every cross-stream edge costs ~14 us of the main chain (profiles/r05_hipgraph_branches.txt): the
+            # weight gradients leave for their side stream GRAPH_WGRAD_GROUP at a time instead of one by one
+            group_saved, F.WGRAD_GROUP = F.WGRAD_GROUP, max(F.WGRAD_GROUP, self.GRAPH_WGRAD_GROUP)
+            try:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):                     # warm-up on a side stream
+                    for _ in range(2):
+                        self._fwd_bwd(static, epoch)
+                    BatchNorm.flush_counters()
+                torch.cuda.current_stream().wait_stream(s)
+                for b, v in zip(bufs, saved):
+                    b.copy_(v)
+                ctr.copy_(ctr_saved)
+                graph = torch.cuda.CUDAGraph()
+                if self._graph_pool is None:
+                    self._graph_pool = torch.cuda.graph_pool_handle()     # one private pool for every key (not one multi-GB pool per key)
+                with torch.cuda.graph(graph, pool=self._graph_pool):
+                    loss_out, _ = self._fwd_bwd(static, epoch)
+            finally:
+                F.WGRAD_GROUP = group_saved
             entry = self._graphs[key] = (graph, static, loss_out)
         graph, static, loss_out = entry
         for k, v in tens.items():

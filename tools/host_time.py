@@ -10,13 +10,18 @@ from pdfnet_amd.synthetic import synthetic_loss_constants, synthetic_train_batch
 from pdfnet_amd.trains.simplified import CtdetLoss
 from pdfnet_amd.trains.base_trainer import Trainer
 
+import pdfnet_amd.functional as F
+DT = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+if DT == 'bf16':
+    F.set_gemm_precision('bf16')
 dev = torch.device('cuda')
 opt = make_opt(256)
 torch.manual_seed(0)
 model = load_model_intag(opt).to(dev)
 consts = synthetic_loss_constants()
-trainer = Trainer(opt, model, CtdetLoss(opt, consts).to(dev), lr=1e-4)
-batch = to_device(synthetic_train_batch(32, 256, consts=consts), dev)
+trainer = Trainer(opt, model, CtdetLoss(opt, consts).to(dev), lr=1e-4, grad_comm_dtype=torch.bfloat16 if DT == 'bf16' else None)
+batch = to_device(synthetic_train_batch(B, 256, consts=consts), dev)
 for _ in range(5):
     trainer.train_step(batch)
 torch.cuda.synchronize()
@@ -30,6 +35,7 @@ for _ in range(N):
 t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
+print(DT, "B=%d" % B)
 print("issue per step: " + " ".join("%.1f" % (x * 1e3) for x in issue) + " ms")
 print("host issue total %.1f ms, synchronised total %.1f ms for %d steps (%.1f ms/step)" % (t_issue * 1e3, t_all * 1e3, N, t_all / N * 1e3))
 # phase split of the host time of one step
