@@ -313,12 +313,8 @@ class ResNetSimple(nn.Module):
             from ..graphed import GraphedSegment
             r = self.resnet
 
-            def run(t):
-                x4 = r.layer1(t)
-                x3 = r.layer2(x4)
-                x2 = r.layer3(x3)
-                return x4, x3, x2, r.layer4(x2)
-            seg = self.__dict__['_trunk_seg'] = GraphedSegment(run, [r.layer1, r.layer2, r.layer3, r.layer4])
+            layers = [r.layer1, r.layer2, r.layer3, r.layer4]
+            seg = self.__dict__['_trunk_seg'] = GraphedSegment(layers, layers)
         return seg(pooled)
 
     def trunk(self, img, ind, choose, cloud, depth=None, K_new=None, valid=None):

@@ -13,6 +13,5 @@ for l in sys.stdin:
 for a in "" "--dtype bf16 --batch 32" "--dtype bf16 --batch 64"; do
 run "$a" PDFNET_TRUNK_GRAPH=0
 run "$a" PDFNET_TRUNK_GRAPH=1
-run "$a" PDFNET_TRUNK_GRAPH=1 PDFNET_TRUNK_GRAPH_WGRAD_GROUP=4
 done
 cat $out

@@ -7,6 +7,7 @@
 //   graph1     the serial form captured into one hipGraph
 //   graph2     the two-stream form captured (fork / join inside the capture) -> a graph with two branches
 //   graph2x    the same graph launched with explicit dependencies built by hand (hipGraphAddKernelNode), no capture
+//   2graphs    chain A and chain B as two linear graphs launched on two streams;  g+eager: graph A on stream 0 beside eager B on stream 1
 //   ladder / ladder-g   the weight-gradient pattern: B_i waits for A_i only (one event per rung), eager / captured
 // and, from in-kernel timestamps (s_memrealtime, 100 MHz) of the graph2 replay: how much of chain B ran while chain A was running.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/probe/graph_branch tools/probe/graph_branch.hip
@@ -98,6 +99,26 @@ int main(int argc, char** argv) {
     hipGraph_t g4; hipGraphExec_t e4;
     CK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal)); ladder(); CK(hipStreamEndCapture(s0, &g4));
     CK(hipGraphInstantiate(&e4, g4, nullptr, nullptr, 0));
+    // two LINEAR graphs (chain A, chain B) launched on two streams
+    hipGraph_t ga, gb; hipGraphExec_t ea, eb;
+    auto chain = [&](hipStream_t s, int base) { for (int i = 0; i < NK; ++i) hipLaunchKernelGGL(spin, dim3(blocks), dim3(256), 0, s, stamps, base + i, ticks); };
+    CK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal)); chain(s0, 0); CK(hipStreamEndCapture(s0, &ga));
+    CK(hipStreamBeginCapture(s1, hipStreamCaptureModeThreadLocal)); chain(s1, NK); CK(hipStreamEndCapture(s1, &gb));
+    CK(hipGraphInstantiate(&ea, ga, nullptr, nullptr, 0));
+    CK(hipGraphInstantiate(&eb, gb, nullptr, nullptr, 0));
+    auto twographs = [&]() {
+        CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0));
+        CK(hipGraphLaunch(ea, s0)); CK(hipGraphLaunch(eb, s1));
+        CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0));
+    };
+    // a linear graph on stream 0 beside EAGER launches on stream 1
+    auto graph_eager = [&]() {
+        CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0));
+        CK(hipGraphLaunch(ea, s0)); chain(s1, NK);
+        CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0));
+    };
+    timeit("2graphs", twographs);
+    timeit("g+eager", graph_eager);
     timeit("ladder", ladder);
     timeit("ladder-g", [&] { CK(hipGraphLaunch(e4, s0)); });
     timeit("graph1", [&] { CK(hipGraphLaunch(e1, s0)); });
@@ -116,6 +137,8 @@ int main(int argc, char** argv) {
         printf("%-8s chain A %7.1f us, chain B %7.1f us, both %7.1f us; mean gap between consecutive kernels of a chain: A %.2f us, B %.2f us\n", name,
                (a1 - a0) / 100.0, (b1 - b0) / 100.0, (hi - lo) / 100.0, gapA / (NK - 1) / 100.0, gapB / (NK - 1) / 100.0);
     };
+    overlap("2graphs", twographs);
+    overlap("g+eager", graph_eager);
     overlap("ladder", ladder);
     overlap("ladder-g", [&] { CK(hipGraphLaunch(e4, s0)); });
     overlap("serial", [&] { serial(s0); });
