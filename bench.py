@@ -156,14 +156,10 @@ class KernelTimer:
         self.lib = hip.lib()
 
     def __enter__(self):
-        from pdfnet_amd import graphed
-        graphed.SUSPEND = True                               # (a replayed hipGraph launches nothing from the host: the timers would miss the trunk)
         self.lib.pdf_debug_kernel_timing(1)
         return self
 
     def __exit__(self, *exc):
-        from pdfnet_amd import graphed
-        graphed.SUSPEND = False
         self.lib.pdf_debug_kernel_timing(0)
 
     def by_symbol(self):
@@ -747,9 +743,6 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or plain `python bench.py --gpus %d`)"
                  % (args.gpus, world, args.gpus, args.gpus))
     dev = torch.device('cuda', local)
-    if os.environ.get('PDFNET_BENCH_STREAM', '0') != '0':      # experiment: issue the step on a created stream, '2': a high-priority one (tools/experiments/r05_trunk_graph2.sh)
-        torch.cuda.set_device(dev)
-        torch.cuda.set_stream(torch.cuda.Stream(priority=-1 if os.environ['PDFNET_BENCH_STREAM'] == '2' else 0))
     if args.config == 'rgb-encoder':
         assert world == 1, "--config rgb-encoder is a one-GPU kernel benchmark"
         return rgb_encoder_bench(args, dev, rank, world)

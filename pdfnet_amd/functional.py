@@ -34,20 +34,6 @@ def _record(obj, stream_):
             _record(o, stream_)
 
 
-# torch hands out side streams round-robin from a pool of 32 per device, and ROCclr multiplexes HIP streams onto GPU_MAX_HW_QUEUES (4)
-# hardware queues in creation order: WHICH logical streams share a hardware queue is decided by how many torch.cuda.Stream() calls came
-# first.  PDFNET_STREAM_BURN=k skips k pool slots before this package takes its first side stream (tools/experiments/r05_hw_queues.sh).
-_STREAM_BURN = int(_os.environ.get("PDFNET_STREAM_BURN", "0"))
-_burned = []
-
-
-def _burn_once():
-    global _STREAM_BURN
-    while _STREAM_BURN > 0:
-        _burned.append(torch.cuda.Stream())
-        _STREAM_BURN -= 1
-
-
 class fork:
     """Start `fn` on a side HIP stream now; `.join()` makes the current stream wait for it and returns its result.
     Lets independent sub-networks (sibling decoders, heads) overlap the main chain instead of queueing behind it."""
@@ -64,7 +50,6 @@ class fork:
         busy = fork._busy.setdefault(dev, set())
         free = [i for i in range(len(pool)) if i not in busy]
         if not free:
-            _burn_once()
             pool.append(torch.cuda.Stream())
             free = [len(pool) - 1]
         self.idx, self.dev = free[0], dev
@@ -250,10 +235,7 @@ def _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, backward, dev):
         n = _wino_cache[key] = _L().pdf_conv2d_winograd_workspace_floats(N, H, W, Cin, Cout, KH, KW, stride, pad, backward)
     if n <= 0:
         return None, None
-    t = torch.empty(n, dtype=torch.float32, device=dev)
-    if _ws_pins is not None:
-        _ws_pins.append(t)
-    return t, n
+    return torch.empty(n, dtype=torch.float32, device=dev), n
 
 
 def _O2(a, b):
@@ -355,14 +337,8 @@ def _zeros_cl(shape, dev):
     return torch.empty(shape, dtype=torch.float32, device=dev, memory_format=CL).zero_()
 
 
-_ws_pins = None      # a list while graphed.GraphedSegment captures a weight-gradient graph: workspaces stay allocated for the graph's lifetime
-
-
 def _ws(nfloats, dev):
-    t = torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=dev)
-    if _ws_pins is not None:
-        _ws_pins.append(t)
-    return t
+    return torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=dev)
 
 
 def _wgrad_ws(M, NI, NJ, dev):
@@ -462,25 +438,6 @@ def _wg_flush_key(key):
     with wgrad_stream(True, *[t for it in items for t in it[1]], params=[p for it in items for p in it[2]], also_wait=key):
         for it in items:
             it[0]()
-
-
-def take_pending_wgrads():
-    """-> the deferred weight-gradient launches [(closure, operand tensors, parameters)], which are forgotten here: the caller issues them
-    (graphed.GraphedSegment captures them into a graph of their own)."""
-    items = [it for key in list(_wg_pending) for it in _wg_pending.pop(key)]
-    return items
-
-
-def wgrad_side_stream():
-    """The weight-gradient side stream of the current stream (created on first use), marked as used so that join_wgrad waits for it."""
-    dev = hip._raw_device()
-    key = (dev, hip._raw_stream(dev))
-    ent = _wg_streams.get(key)
-    if ent is None:
-        s = torch.cuda.Stream(priority=WGRAD_STREAM_PRIORITY)
-        ent = _wg_streams[key] = (s, s.cuda_stream, s.stream_id, s.device_index, s.device_type)
-    _wg_used.add(key)
-    return ent[0]
 
 
 def flush_wgrad():
