@@ -222,6 +222,7 @@ def _O(**kw):
 # F(2x2, 3x3) (2.25x fewer, more accurate than the direct sum); forward, backward-data and the weight gradient.  The
 # workspace is a fresh torch.empty per call (GB-scale for `feat`: the caching allocator keeps a few such blocks per stream).
 WINOGRAD = _os.environ.get("PDFNET_WINOGRAD", "1") != "0"
+WINOGRAD_INFERENCE = _os.environ.get("PDFNET_WINOGRAD_INFERENCE", "0") != "0"     # also for forwards without autograd (eval / no_grad)
 _wino_cache = {}
 
 
@@ -259,6 +260,17 @@ BN_EPILOGUE_STATS = _os.environ.get("PDFNET_BN_EPILOGUE_STATS", "1") != "0"
 # (tools/experiments/r04/bf16_stats_ab.sh).  Default 'auto': convolutions over >= BF16_STORAGE_MIN_BATCH images, like the bf16 storage; 1 / 0 force it.
 _be = _os.environ.get("PDFNET_BN_EPILOGUE_STATS_BF16", "auto")
 BN_EPILOGUE_STATS_BF16 = 'auto' if _be == "auto" else _be != "0"
+
+
+def bf16_modes(batch):
+    """What the bf16 mode resolves to for convolutions over `batch` images -- the 'auto' rules switch at BF16_STORAGE_MIN_BATCH, so a
+    B=32 and a B=64 run of the same model follow different rounding models; the Trainer logs this once per run."""
+    if not _GEMM_BF16:
+        return {'gemm': 'fp32'}
+    stats = (batch >= BF16_STORAGE_MIN_BATCH) if BN_EPILOGUE_STATS_BF16 == 'auto' else bool(BN_EPILOGUE_STATS_BF16)
+    return {'gemm': 'bf16', 'shadows': BF16_SHADOWS, 'conv_to_bn_storage': 'bf16' if storage_on(batch) else 'fp32',
+            'bn_statistics': ('fp32 accumulators in the GEMM epilogue' if (stats and BN_EPILOGUE_STATS) else "the BatchNorm's own pass over the stored tensor"),
+            'auto_threshold_batch': BF16_STORAGE_MIN_BATCH}
 
 
 def _stats_request(stats, rows, cols, dev, batch=None):
@@ -552,7 +564,9 @@ class _Conv2d(Function):
         if (stats and storage_on(N) and b is None and act == ACT_NONE and Cin % 16 == 0 and Cout % 16 == 0
                 and (N * OH * OW) % 128 == 0):
             y16 = torch.empty_like(y, dtype=torch.bfloat16)  # the output: y itself stays unwritten (see BF16_STORAGE)
-        ws, nws = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 0, x.device)
+        #  F(4x4) carries ~4e-5 absolute error against 1e-6..3e-6 of the direct kernels: it is a TRAINING trade.  A forward that
+        # nothing will be differentiated through (eval, no_grad) gets no workspace and therefore the direct kernels, unless asked otherwise.
+        ws, nws = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 0, x.device) if (WINOGRAD_INFERENCE or any(ctx.needs_input_grad[:3])) else (None, None)
         o, oa = _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16), out_bf16=ptr(y16), stats_out=ptr(part), stats_cap=part.numel() if part is not None else None,
                    ws=ptr(ws), ws_floats=nws)
         _L().pdf_conv2d_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream(), oa)

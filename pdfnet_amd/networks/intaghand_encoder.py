@@ -18,6 +18,9 @@ def _pad16(c):
     return (c + 15) // 16 * 16
 
 
+LAZY_TRUNK_BN = os.environ.get("PDFNET_LAZY_TRUNK_BN", "1") != "0"
+
+
 class Bottleneck(nn.Module):
     """ResNet v1.5 bottleneck, stride on conv2 (reference twin lib/models/networks/resnet.py:76-122)."""
 
@@ -44,8 +47,17 @@ class Bottleneck(nn.Module):
         else:
             y, sc = self.conv1(x, stats=self.bn1.training), x
         y = self.bn1(y, relu=True)
-        y = self.bn2(self.conv2(y, stats=self.bn2.training), relu=True)
-        y = self.conv3(y, stats=self.bn3.training)
+        y = self.conv2(y, stats=self.bn2.training)
+        if LAZY_TRUNK_BN and self.bn2.training and y.requires_grad and not F._GEMM_BF16:
+            # relu(bn2(.)) has ONE consumer and it is a 1x1 convolution -- a linear layer over the NHWC rows: the normalised tensor is
+            # never written; conv3 applies scale / shift / ReLU while it stages its rows, forward and weight gradient (F.batch_norm lazy,
+            # the set-abstraction MLPs' arrangement; VERDICT r4 item 3, the part of it that needs no new kernel)
+            n_, c_, h_, w_ = y.shape
+            z = self.bn2(F.carry_stats(y, y.permute(0, 2, 3, 1).reshape(-1, c_)), relu=True, lazy=True)
+            y3 = F.linear(z, F.as_matrix(self.conv3.weight), None, stats=self.bn3.training)
+            y = F.carry_stats(y3, y3.view(n_, h_, w_, -1).permute(0, 3, 1, 2))
+        else:
+            y = self.conv3(self.bn2(y, relu=True), stats=self.bn3.training)
         if self.downsample is not None:
             sc = self.downsample[1](self.downsample[0](sc, stats=self.downsample[1].training))
         return self.bn3(y, relu=True, res=sc)          # relu(bn3(y) + shortcut) in one pass

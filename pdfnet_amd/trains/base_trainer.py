@@ -9,6 +9,7 @@ MI355X-first differences from the reference loop:
     base_trainer.py:95) simply keep a zero gradient in the flat buffer -- no per-iteration graph walk;
   * the step has no host synchronisation, so forward+loss+backward (and the optimizer) replay as a hipGraph.
 """
+import logging
 import os
 import re
 
@@ -409,6 +410,7 @@ class Trainer:
                 use_graph, self._auto = False, {'phase': 'eager', 'marks': [], 'eager_ms': None}
         self.use_graph = use_graph
         self._graphs = {}
+        self._modes_logged = False
         self._graph_pool = None
         # (measured on MI355X: 446 vs 450 img/s -- the 2.4 GB Adam pass takes HBM bandwidth and CUs from the trunk backward's
         # BatchNorm / GEMM kernels; off by default)
@@ -498,6 +500,13 @@ class Trainer:
     def train_step(self, batch, epoch=0):
         """batch: dict of device tensors. Returns the (device) scalar loss; no host sync."""
         self.model_with_loss.train()
+        if not self._modes_logged:                             # once per run: what the 'auto' switches resolved to for this batch size
+            self._modes_logged = True
+            b = next((v.shape[0] for v in batch.values() if torch.is_tensor(v) and v.dim() > 0), 0)
+            self.resolved_modes = dict(F.bf16_modes(b), batch=b, world=self.world, launch='hipGraph' if self.use_graph is True else ('auto' if self._auto is not None else 'eager'),
+                                       mesh_decoder='fused' if F.MESH_FUSED else 'per-op', mesh_loss='fused' if F.MESH_LOSS_FUSED else 'per-term')
+            if self.rank == 0:
+                logging.getLogger('pdfnet_amd').info("trainer modes: %s", self.resolved_modes)
         if F.shadows_on() and not self.optimizer._p16_synced:
             self.optimizer.refresh_bf16_shadows()              # (after a step() the shadows are re-cast in place: nothing to do)
         if self.broadcast_buffers and self.world > 1 and self.collectives:

@@ -308,6 +308,21 @@ def test_bf16_storage_defaults_to_the_batches_where_it_wins(monkeypatch):
     assert F._stats_request(True, 1024, 64, 'cpu', batch=2) is not None
 
 
+def test_resolved_bf16_modes_are_reportable(monkeypatch):
+    """the bf16 'auto' rules switch at 48 images per GPU, so B=32 and B=64 follow different rounding models -- the Trainer logs
+    what they resolved to (Trainer.resolved_modes); this is the resolution itself."""
+    from pdfnet_amd import functional as F
+    assert F.bf16_modes(32) == {'gemm': 'fp32'}
+    monkeypatch.setattr(F, '_GEMM_BF16', True)
+    monkeypatch.setattr(F, 'BF16_SHADOWS', True)
+    monkeypatch.setattr(F, 'BF16_STORAGE', 'auto')
+    monkeypatch.setattr(F, 'BN_EPILOGUE_STATS_BF16', 'auto')
+    lo, hi = F.bf16_modes(32), F.bf16_modes(64)
+    assert lo['conv_to_bn_storage'] == 'fp32' and hi['conv_to_bn_storage'] == 'bf16'
+    assert 'own pass' in lo['bn_statistics'] and 'epilogue' in hi['bn_statistics']
+    assert lo['auto_threshold_batch'] == F.BF16_STORAGE_MIN_BATCH
+
+
 def test_committed_pmc_profile_matches_the_committed_kernel_sources():
     """bench.py looks `roofline.traffic` (HBM bytes per launch from the rocprofv3 --pmc passes) up in the newest profiles/*_pmc_traffic.json
     and WITHHOLDS it when the kernel sources have changed since the profile was taken (sha256 recorded in the profile).  A kernel edit

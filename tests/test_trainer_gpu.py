@@ -185,6 +185,7 @@ def test_headline_batch_32_properties():
     tr = Trainer(opt, m, crit, lr=1e-4)
     losses = [float(tr.train_step(batch, 0)) for _ in range(3)]
     assert all(np.isfinite(losses)) and losses[2] < losses[0], losses
+    assert tr.resolved_modes['batch'] == B and tr.resolved_modes['gemm'] == 'fp32' and tr.resolved_modes['launch'] == 'eager'
     g = tr.optimizer.flat_g
     assert torch.isfinite(g).all() and float(g[tr.n_live:].abs().max()) == 0.0
     live_zero = [n for (n, p) in m.named_parameters() if p.grad is not None and float(p.grad.abs().max()) == 0.0]
