@@ -418,7 +418,11 @@ int pdf_mano_split_coeff_bwd(const float* params, float* dparams, int ldp, long 
  *                        then computed in the Winograd domain (csrc/winograd.hip): F(4x4, 3x3) -- 36 planes, 4x fewer multiplications, ~4e-5 absolute
  *                        error on values of a few units -- where the map edges are multiples of 4 and PDF_WINOGRAD_F4 (bit mask, default 15 = every
  *                        launch) permits, else F(2x2, 3x3) (16 planes, 2.25x fewer, MORE accurate than the direct fp32 sum); the weight gradient is
- *                        taken in the transform domain too (backward = 2).  PDF_WINOGRAD=2: F(2x2) only; =0: the direct kernels. */
+ *                        taken in the transform domain too (backward = 2).  PDF_WINOGRAD=2: F(2x2) only; =0: the direct kernels.  *   wino_v               pdf_conv2d_bwd_weight (Winograd F(4x4) path): the transformed input V [36][tiles][Cin] that the FORWARD of the same
+ *                        convolution left in its workspace (at float offset pdf_conv2d_winograd_v_offset(...) of the forward `ws`): the
+ *                        weight gradient then skips its own input transform (same kernel, same values).  The caller keeps that workspace
+ *                        alive and unmodified from the forward to the weight-gradient call.
+ */
 typedef struct PdfCallOpts {
     const void* op0_bf16; const void* op1_bf16;
     void* out_bf16;
@@ -429,7 +433,10 @@ typedef struct PdfCallOpts {
     const float* in_scale; const float* in_shift;
     const void* op1_bf16_t;
     float* ws; long ws_floats;
+    const float* wino_v;
 } PdfCallOpts;
+/* float offset of V inside the forward workspace of this convolution, or -1 when its forward is not an F(4x4) launch (no V the weight gradient could take) */
+long pdf_conv2d_winograd_v_offset(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int pdf_linear_fwd_x(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream, PdfCallOpts* opts);
 int pdf_linear_fwd_pair_x(const float* x, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int M, int N, int K, int ldx, int ldw, int ldy, int act, void* stream, PdfCallOpts* opts);
 int pdf_linear_bwd_data_x(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, int ldw, int lddx, void* stream, PdfCallOpts* opts);

@@ -118,7 +118,8 @@ struct PdfCallOpts {
     const float* tile_stats; long tile_n, tile_rows; // BatchNorm: such partials instead of its own statistics pass
     const float* in_scale; const float* in_shift;    // x read as relu(x * scale[k] + shift[k]) (linear fwd / weight gradient)
     const void* op1_bf16_t;                          // backward-data: the weight's TRANSPOSED bf16 shadow wt[c][tap][r] (pdf_cast_bf16_transposed)
-    float* ws; long ws_floats;                       // conv2d forward / backward-data: workspace of pdf_conv2d_winograd_workspace_floats -> Winograd path
+    float* ws; long ws_floats;                       // conv2d forward / backward-data / weight gradient: workspace of pdf_conv2d_winograd_workspace_floats -> Winograd path
+    const float* wino_v;                             // conv2d weight gradient: the forward's transformed input (pdf_conv2d_winograd_v_offset into ITS ws)
 };
 PdfCallOpts pdf_tls_take_all();                      // the thread's armed slots, cleared
 void pdf_tls_publish(const PdfCallOpts& o);          // stats_tiles / stats_rows -> pdf_stats_result_*

@@ -20,10 +20,15 @@ int pdf_internal_conv3x3_winograd(const float* x, int ldx, const float* w, const
                                   int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, hipStream_t s);
 int pdf_internal_wino_wgrad_eligible(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 long pdf_internal_wino_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
+long pdf_internal_wino_v_offset(int N, int H, int W, int Ck, int Cn);
 int pdf_internal_conv3x3_winograd_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* db, float* ws,
-                                        int N, int H, int W, int Cin, int Cout, int accumulate, hipStream_t s);
+                                        int N, int H, int W, int Cin, int Cout, int accumulate, const float* v_cached, hipStream_t s);
 // Workspace (floats) a stride-1 3x3 convolution [Cout][3][3][Cin] on N x H x W maps wants for its Winograd path -- backward = 0: the
 // forward pass, 1: backward-data, 2: the weight gradient -- or 0 when the layer does not qualify (then no workspace is needed)
+PDF_API long pdf_conv2d_winograd_v_offset(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (!pdf_internal_wino_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad, 0) || !pdf_internal_wino_wgrad_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad)) return -1;
+    return pdf_internal_wino_v_offset(N, H, W, Cin, Cout);
+}
 PDF_API long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward) {
     if (backward == 2) return pdf_internal_wino_wgrad_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad) ? pdf_internal_wino_wgrad_workspace(N, H, W, Cin, Cout) : 0;
     const int Ck = backward ? Cout : Cin, Cn = backward ? Cin : Cout;
@@ -2276,7 +2281,8 @@ static int pdf_conv2d_bwd_weight_impl(const float* x, const float* dy, float* dw
     if (!g_gemm_bf16 && co.ws != nullptr && dy != nullptr && OH == H && OW == W && ldx % 4 == 0 && lddy % 4 == 0 && aligned16(x) && aligned16(dy) &&
         aligned16(co.ws) && pdf_internal_wino_wgrad_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad) &&
         co.ws_floats >= pdf_internal_wino_wgrad_workspace(N, H, W, Cin, Cout))
-        return pdf_internal_conv3x3_winograd_wgrad(x, ldx, dy, lddy, dw, db, co.ws, N, H, W, Cin, Cout, accumulate, s);
+        return pdf_internal_conv3x3_winograd_wgrad(x, ldx, dy, lddy, dw, db, co.ws, N, H, W, Cin, Cout, accumulate,
+                                                   (co.wino_v != nullptr && aligned16(co.wino_v) && pdf_internal_wino_v_offset(N, H, W, Cin, Cout) >= 0) ? co.wino_v : nullptr, s);
     // bf16 storage mode: dy exists only as bf16 (dy == NULL) -- the launch must be one the bf16 kernel takes with a shadow operand
     if (dy == nullptr && (sh.op1 == nullptr || db != nullptr || !g_gemm_bf16 || Cin % 16 != 0 || Cout % 16 != 0 || lddy % 8 != 0)) return PDF_E_BADARG;
     if (Cin == 3 && Cout == 3 && KH == 3 && KW == 3 && stride == 1 && db == nullptr && (long)N * OH * OW >= (1L << 16) && ws_floats >= 81L * 64) {

@@ -411,18 +411,19 @@ long pdf_internal_wino_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
     return 36L * T * Cin + 36L * T * Cout + 36L * wino_wgrad_splits(T, Cout, Cin) * Cout * Cin + pdf_internal_colsum_ws(Cout, (long)N * H * W) + 64;
 }
 // dw [Cout][3][3][Cin] (+)= the weight gradient of the stride-1 3x3 convolution; db [Cout] (+)= column sums of dy (optional)
+// v_cached: the forward's V for the same x (pdf_internal_wino_v_offset), or NULL -- then the input is transformed here
 int pdf_internal_conv3x3_winograd_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* db, float* ws,
-                                        int N, int H, int W, int Cin, int Cout, int accumulate, hipStream_t s) {
+                                        int N, int H, int W, int Cin, int Cout, int accumulate, const float* v_cached, hipStream_t s) {
     const long T = (long)N * (H / 4) * (W / 4);
     float* V = ws;
     float* Yh = V + 36L * T * Cin;
     float* slab = Yh + 36L * T * Cout;
     int splits = wino_wgrad_splits(T, Cout, Cin);
     float* cws = slab + 36L * splits * Cout * Cin;
-    hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(T * (Cin / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, V, N, H, W, Cin);
+    if (v_cached == nullptr) hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(T * (Cin / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, V, N, H, W, Cin);
     hipLaunchKernelGGL(wino4_dy_kernel, dim3(grid_for(T * (Cout / 2), 256, 256 * 32)), dim3(256), 0, s, dy, lddy, Yh, N, H, W, Cout);
     PDF_LAUNCH_CHECK();
-    const int used = pdf_internal_batched_wgemm(Yh, V, slab, 36, T * Cout, T * Cin, (int)T, Cout, Cin, splits, s);
+    const int used = pdf_internal_batched_wgemm(Yh, v_cached != nullptr ? v_cached : V, slab, 36, T * Cout, T * Cin, (int)T, Cout, Cin, splits, s);
     if (used <= 0) return used < 0 ? used : PDF_E_BADARG;
     if (used > 1) hipLaunchKernelGGL(wino4_slab_sum_kernel, dim3(grid_for(36L * Cout * Cin / 4)), dim3(256), 0, s, slab, used, (long)Cout * Cin / 4);
     hipLaunchKernelGGL(wino4_wgrad_out_kernel, dim3(grid_for((long)Cout * Cin)), dim3(256), 0, s, slab, used, dw, Cout, Cin, accumulate);
@@ -469,6 +470,10 @@ long pdf_internal_wino_workspace(int N, int H, int W, int Ck, int Cn, int flip) 
     if (m == 0) return 0;
     const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
     return P * Cn * Ck + P * T * Ck + P * T * Cn;
+}
+// where V starts in the forward workspace (U comes first), or -1 when the forward is not an F(4x4) launch
+long pdf_internal_wino_v_offset(int N, int H, int W, int Ck, int Cn) {
+    return pdf_internal_wino_tile(N, H, W, Ck, Cn, 0) == 4 ? 36L * Cn * Ck : -1;
 }
 // Is this convolution taken by the Winograd path?  (3x3, stride 1, pad 1, map edges multiples of the tile, channel counts the fast GEMM
 // tiles like, enough work)

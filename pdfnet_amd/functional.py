@@ -239,6 +239,20 @@ def _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, backward, dev):
     return torch.empty(n, dtype=torch.float32, device=dev), n
 
 
+WINOGRAD_KEEP_V = _os.environ.get("PDFNET_WINOGRAD_KEEP_V", "1") != "0"
+_wino_voff = {}
+
+
+def _wino_v_offset(N, H, W, Cin, Cout, KH, KW, stride, pad):
+    """Float offset of the transformed input V inside this convolution's forward Winograd workspace, or -1 (no F(4x4) forward, or the
+    weight gradient does not take the Winograd path)."""
+    key = (N, H, W, Cin, Cout, KH, KW, stride, pad)
+    off = _wino_voff.get(key)
+    if off is None:
+        off = _wino_voff[key] = _L().pdf_conv2d_winograd_v_offset(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    return off
+
+
 def _O2(a, b):
     """_O2(a, b) for the most frequent call shape: the two operand shadows of a GEMM-family launch."""
     if a is None and b is None:
@@ -575,6 +589,13 @@ class _Conv2d(Function):
             if DEBUG_PHANTOMS:
                 y.fill_(float('nan'))                       # any reader of the unwritten fp32 storage then shows up as NaN downstream
             y._pdf_y16 = (y16, y._version)
+        # Winograd F(4x4): the weight gradient needs the same transformed input V the forward just wrote into its workspace -- keep the
+        # workspace for it (one input-transform pass per layer and step less; V of `feat` at B=32 is 1.2 GB, all 17 layers ~5.5 GB)
+        ctx.wino_v = None
+        if ws is not None and WINOGRAD_KEEP_V and ctx.needs_input_grad[1]:
+            off = _wino_v_offset(N, H, W, Cin, Cout, KH, KW, stride, pad)
+            if off >= 0:
+                ctx.wino_v = (ws, off)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.s16 = (x16, w16)
         ctx.w16t = shadow_t_of(w) if w16 is not None else None
@@ -616,12 +637,17 @@ class _Conv2d(Function):
         w_par, b_par = ctx.params
         R = N * OH * OW
 
+        keep = ctx.wino_v
+        ctx.wino_v = None
+
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(R, Cout, KH * KW * Cin, x.device)
             wws, nww = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 2, x.device) if (OH == H and OW == W and gp is not None) else (None, None)
+            v = (keep[0].data_ptr() + 4 * keep[1]) if (keep is not None and wws is not None) else None
             L.pdf_conv2d_bwd_weight_x(ptr(x), gp, ptr(out), ptr(out_b), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                      stride, pad, OH, OW, Cout, acc, stream(), _O(op0_bf16=ptr(x16), op1_bf16=ptr(g16), ws=ptr(wws), ws_floats=nww)[1])
-        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True, shadows=(x16, g16))
+                                      stride, pad, OH, OW, Cout, acc, stream(), _O(op0_bf16=ptr(x16), op1_bf16=ptr(g16), ws=ptr(wws), ws_floats=nww, wino_v=v)[1])
+        dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, R, 2.0 * R * Cout * KH * KW * Cin, fused_bias=True,
+                              shadows=(x16, g16, keep[0] if keep is not None else None))
         return dx, dw, db, None, None, None, None, None
 
 

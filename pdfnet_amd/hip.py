@@ -45,7 +45,8 @@ class CallOpts(ctypes.Structure):
     _fields_ = [("op0_bf16", ctypes.c_void_p), ("op1_bf16", ctypes.c_void_p), ("out_bf16", ctypes.c_void_p), ("bn_x_bf16", ctypes.c_void_p),
                 ("stats_out", ctypes.c_void_p), ("stats_cap", ctypes.c_long), ("stats_tiles", ctypes.c_long), ("stats_rows", ctypes.c_long),
                 ("tile_stats", ctypes.c_void_p), ("tile_n", ctypes.c_long), ("tile_rows", ctypes.c_long),
-                ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p), ("op1_bf16_t", ctypes.c_void_p), ("ws", ctypes.c_void_p), ("ws_floats", ctypes.c_long)]
+                ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p), ("op1_bf16_t", ctypes.c_void_p), ("ws", ctypes.c_void_p), ("ws_floats", ctypes.c_long),
+                ("wino_v", ctypes.c_void_p)]
 
 
 _P2 = ctypes.c_void_p * 2

@@ -317,6 +317,29 @@ def test_winograd_f4_weight_gradient_noise_on_the_feat_shape_is_pinned(monkeypat
     assert errs[False] <= 8e-6, errs
 
 
+def test_weight_gradient_from_the_forwards_transformed_input_is_bit_identical(monkeypatch):
+    """Round 5: the F(4x4) weight gradient takes V, the transformed input, from the workspace the forward of the same convolution kept
+    (PdfCallOpts::wino_v) instead of transforming x again -- same kernel, same values, so the gradient must not change by one bit.
+    The 256 -> 256 layer of the pyramid heads at its real size (B = 32, 64x64)."""
+    from pdfnet_amd import functional as F
+    N, Cin, H, W, Cout = 32, 256, 64, 64, 256
+    x = _rnd(N, Cin, H, W, seed=21).cuda().contiguous(memory_format=torch.channels_last)
+    gy = _rnd(N, Cout, H, W, seed=22).cuda().contiguous(memory_format=torch.channels_last)
+    w = _rnd(Cout, Cin, 3, 3, seed=23, scale=(Cin * 9) ** -0.5)
+    assert F._wino_v_offset(N, H, W, Cin, Cout, 3, 3, 1, 1) == 36 * Cin * Cout          # V follows U in the forward workspace
+    grads = {}
+    for keep in (True, False):
+        monkeypatch.setattr(F, "WINOGRAD_KEEP_V", keep)
+        wd = w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        xd = x.clone().requires_grad_()
+        F.conv2d(xd, wd, None, 1, 1, 0).backward(gy)
+        F.join_wgrad()
+        torch.cuda.synchronize()
+        grads[keep] = (wd.grad.clone(), xd.grad.clone())
+    assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1], grads[False][1])
+    assert float(grads[True][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("cfg", [(32, 512, 32, 32, 256, 4, 2, 1), (32, 1024, 16, 16, 256, 4, 4, 0), (32, 2048, 8, 8, 256, 8, 8, 0)])
 def test_pyramid_transposed_convolutions_at_their_real_size(cfg):
     """p3 / p4 / p5 (intaghand_encoder.py:602-605): p5's weight is the largest tensor of the model (33.5 M elements)."""

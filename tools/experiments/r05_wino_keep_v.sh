@@ -1,0 +1,15 @@
+#!/bin/bash
+# Winograd F(4x4): weight gradient re-uses the forward's transformed input (PDFNET_WINOGRAD_KEEP_V) off / on -> gpurun_out/r05_wino_keep_v.txt
+root=${GRAFT_REPO_ROOT:-$PWD}
+out=$root/gpurun_out/r05_wino_keep_v.txt
+: > $out
+B="--no-cpu-baseline --no-roofline --no-mpjpe --no-bf16-legs --no-collective-path --steps 40 --warmup 10"
+run() { echo "== $*" >> $out; env "${@:2}" timeout 300 python3 $root/bench.py $B $1 2>/dev/null | python3 -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('   %.1f img/s  %.2f ms/step  median %.2f  loss %s' % (d['value'], d['ms_per_step'], d.get('median_step_ms', 0), d['config'].get('final_loss')))" >> $out; }
+for r in 1 2; do for l in 0 1; do
+run "" PDFNET_WINOGRAD_KEEP_V=$l
+done; done
+cat $out
