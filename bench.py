@@ -351,10 +351,10 @@ def pmc_traffic():
         return None, None, "unreadable profile: %s" % e
 
 
-def pmc_traffic_bf16():
+def pmc_traffic_bf16(batch=64):
     """{bf16 kernel symbol: HBM bytes per launch} from the last committed PMC profile's `bf16_symbols` (tools/profile_step.sh: separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --dtype bf16 --batch 64`), withheld when csrc/gemm_bf16.hip / gemm_dma.hip
-    have changed since (same rule as pmc_traffic)."""
+    --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --dtype bf16 --batch 64`; `bf16_symbols_B32` for the B=32 step's own passes),
+    withheld when csrc/gemm_bf16.hip / gemm_dma.hip have changed since (same rule as pmc_traffic)."""
     import glob
     import hashlib
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
@@ -363,14 +363,16 @@ def pmc_traffic_bf16():
     p = files[-1]
     try:
         d = json.load(open(p))
-        if "bf16_symbols" not in d:
+        key = "bf16_symbols" if batch == 64 or ("bf16_symbols_B%d" % batch) not in d else "bf16_symbols_B%d" % batch
+        run_b = 64 if key == "bf16_symbols" else batch
+        if key not in d:
             return None, "%s has no bf16 pass" % os.path.basename(p)
         h = hashlib.sha256()
         for f in ("gemm_bf16.hip", "gemm_dma.hip"):
             h.update(open(os.path.join(ROOT, "pdfnet_amd", "csrc", f), "rb").read())
         if d.get("bf16_src_sha256") != h.hexdigest():
             return None, "%s is older than csrc/gemm_bf16.hip / gemm_dma.hip (withheld)" % os.path.basename(p)
-        return {k: round(v["bytes_per_launch"]) for k, v in d["bf16_symbols"].items()}, "%s (rocprofv3 --pmc, bf16 B=64 run)" % os.path.basename(p)
+        return {k: round(v["bytes_per_launch"]) for k, v in d[key].items()}, "%s (rocprofv3 --pmc, bf16 B=%d run)" % (os.path.basename(p), run_b)
     except Exception as e:                                     # noqa: BLE001
         return None, "unreadable profile: %s" % e
 
@@ -579,7 +581,7 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
             tr.train_step(batch)
         sym = kt.by_symbol()
         F.USE_SIDE_STREAMS = True
-        tr16, tr16_src = pmc_traffic_bf16()
+        tr16, tr16_src = pmc_traffic_bf16(B)
         head, _ = symbol_roofline(sym, PEAK_BF16_MFMA_TFLOPS, tr16, tr16_src)
         fl, sec = sum(v[1] for v in sym.values()), sum(v[3] for v in sym.values())
         out = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
@@ -839,7 +841,7 @@ def main():
         secs = sum(v[2] for v in per.values())
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         if bf16:
-            traffic, traffic_src = pmc_traffic_bf16()
+            traffic, traffic_src = pmc_traffic_bf16(B)
             traffic_all = None
         else:
             traffic, traffic_all, traffic_src = pmc_traffic()

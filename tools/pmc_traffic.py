@@ -91,9 +91,11 @@ def hbm_family(fdir, wdir, steps):
     return out
 
 
-def bf16_symbols(fdir, wdir, steps, out):
-    """`--bf16 <fetch_dir> <write_dir> <steps> <out.json>`: merge the per-symbol HBM bytes of a bf16 run (bench.py --dtype bf16 --batch 64)
-    into an existing profile as `bf16_symbols`, tied to the bf16 kernel sources by `bf16_src_sha256`."""
+def bf16_symbols(fdir, wdir, steps, out, batch=64):
+    """`--bf16 <fetch_dir> <write_dir> <steps> <out.json> [batch]`: merge the per-symbol HBM bytes of a bf16 run (bench.py --dtype bf16
+    --batch 64, or 32) into an existing profile as `bf16_symbols` (`bf16_symbols_B32` for the B=32 run), tied to the bf16 kernel sources by
+    `bf16_src_sha256`."""
+    key = "bf16_symbols" if batch == 64 else "bf16_symbols_B%d" % batch
     def by_symbol(d, counter):
         f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
         agg = collections.defaultdict(lambda: [0, 0.0])
@@ -106,13 +108,13 @@ def bf16_symbols(fdir, wdir, steps, out):
         return agg
     fs, ws = by_symbol(fdir, "FETCH_SIZE"), by_symbol(wdir, "WRITE_SIZE")
     res = json.load(open(out))
-    res["bf16_symbols"] = {}
+    res[key] = {}
     for k in sorted(set(fs) | set(ws)):
         n = fs[k][0] or ws[k][0]
         rb, wb = fs[k][1] * 1024 * 2, ws[k][1] * 1024
-        res["bf16_symbols"][k] = {"launches_per_step": n / steps, "read_MB_per_launch": rb / max(n, 1) / 1e6, "write_MB_per_launch": wb / max(n, 1) / 1e6,
+        res[key][k] = {"launches_per_step": n / steps, "read_MB_per_launch": rb / max(n, 1) / 1e6, "write_MB_per_launch": wb / max(n, 1) / 1e6,
                                   "bytes_per_launch": (rb + wb) / max(n, 1)}
-    res["bf16_run"] = "bench.py --dtype bf16 --batch 64 (separate --pmc FETCH_SIZE / WRITE_SIZE passes, side streams off)"
+    res["bf16_run" if batch == 64 else "bf16_run_B%d" % batch] = "bench.py --dtype bf16 --batch %d (separate --pmc FETCH_SIZE / WRITE_SIZE passes, side streams off)" % batch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
     for f in ("gemm_bf16.hip", "gemm_dma.hip"):
@@ -126,7 +128,7 @@ def bf16_symbols(fdir, wdir, steps, out):
 
 def main():
     if sys.argv[1] == "--bf16":
-        return bf16_symbols(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
+        return bf16_symbols(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 64)
     fdir, wdir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     fe, wr = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py (separate passes)",
