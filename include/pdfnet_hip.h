@@ -422,6 +422,8 @@ int pdf_mano_split_coeff_bwd(const float* params, float* dparams, int ldp, long 
  *                        convolution left in its workspace (at float offset pdf_conv2d_winograd_v_offset(...) of the forward `ws`): the
  *                        weight gradient then skips its own input transform (same kernel, same values).  The caller keeps that workspace
  *                        alive and unmodified from the forward to the weight-gradient call.
+ *                        pdf_conv2d_fwd (F(4x4) launches): V of the SAME input tensor from another convolution's forward workspace (several
+ *                        heads reading one feature map): this forward skips its input transform.  V depends on (x, N, H, W, Cin) only.
  */
 typedef struct PdfCallOpts {
     const void* op0_bf16; const void* op1_bf16;

@@ -17,7 +17,7 @@
 long pdf_internal_wino_workspace(int N, int H, int W, int Ck, int Cn, int flip);
 int pdf_internal_wino_eligible(int N, int H, int W, int Ck, int Cn, int KH, int KW, int stride, int pad, int flip);
 int pdf_internal_conv3x3_winograd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* ws,
-                                  int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, hipStream_t s);
+                                  int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, const float* v_shared, hipStream_t s);
 int pdf_internal_wino_wgrad_eligible(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 long pdf_internal_wino_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
 long pdf_internal_wino_v_offset(int N, int H, int W, int Ck, int Cn);
@@ -1857,7 +1857,8 @@ static int pdf_conv2d_fwd_impl(const float* x, const float* w, const float* bias
     if (!g_gemm_bf16 && co.ws != nullptr && y16 == nullptr && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(co.ws) &&
         pdf_internal_wino_eligible(N, H, W, Cin, Cout, KH, KW, stride, pad, 0) && co.ws_floats >= pdf_internal_wino_workspace(N, H, W, Cin, Cout, 0)) {
         g_last_tile = 128128;
-        return pdf_internal_conv3x3_winograd(x, ldx, w, bias, y, ldy, co.ws, N, H, W, Cin, Cout, act, 0, 0, s);
+        return pdf_internal_conv3x3_winograd(x, ldx, w, bias, y, ldy, co.ws, N, H, W, Cin, Cout, act, 0, 0,
+                                             (co.wino_v != nullptr && aligned16(co.wino_v) && pdf_internal_wino_v_offset(N, H, W, Cin, Cout) >= 0) ? co.wino_v : nullptr, s);
     }
     IGemm g = {};
     g.A = x; g.B = w; g.C = y; g.bias = bias;
@@ -1892,7 +1893,7 @@ static int conv2d_bwd_data(const float* dy, const float* w, float* dx,
     if (!g_gemm_bf16 && co.ws != nullptr && lddx % 4 == 0 && lddy % 4 == 0 && aligned16(dy) && aligned16(dx) && aligned16(co.ws) && OH == H && OW == W &&
         pdf_internal_wino_eligible(N, H, W, Cout, Cin, KH, KW, stride, pad, 1) && co.ws_floats >= pdf_internal_wino_workspace(N, H, W, Cout, Cin, 1)) {
         g_last_tile = 128128;
-        return pdf_internal_conv3x3_winograd(dy, lddy, w, nullptr, dx, lddx, co.ws, N, H, W, Cout, Cin, 0, accumulate, 1, s);
+        return pdf_internal_conv3x3_winograd(dy, lddy, w, nullptr, dx, lddx, co.ws, N, H, W, Cout, Cin, 0, accumulate, 1, nullptr, s);
     }
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {

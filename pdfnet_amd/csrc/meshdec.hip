@@ -1,21 +1,32 @@
 // Fused mesh decoder for gfx950 (round 5): one DualGraphLayer of the IntagHand-style dual-hand GCN / attention decoder
 // (lib/models/networks/model_attn/DualGraph.py:62-92, gcn.py:34-69,99-110, self_attn.py:17-85, inter_attn.py:73-125) as
-// TWO launches per direction instead of ~50 dependent 5-20 us launches:
+// THREE launches forward and NINE backward (+ its 28 weight-gradient GEMMs on the side stream) instead of ~330 dependent 5-20 us launches:
 //
-//   part 1  x -> 4 x GCN_ResBlock -> SelfAttn (LN, q/k/v, attention, fc, residual, MLP block) -> LN1/LN2 + shared q/k/v of the cross-hand step
-//   part 2  cross-hand attention (keys / values of the OTHER hand of the same sample: the only inter-block dependence) -> fc -> MLP block
+//   forward   mesh_gcn_kernel        x -> the GCN_ResBlocks (LayerNorm, Chebyshev ELL product, linear, dropout, residual)
+//             mesh_att_kernel<self>  SelfAttn (LN, q/k/v, attention, fc, residual, MLP block) -> LN + q/k/v of the cross-hand step
+//             mesh_att_kernel<cross> attention over the keys / values of the OTHER hand of the same sample (the only dependence between
+//                                    workgroups, hence the launch boundary) -> fc -> MLP block -> level output
+//   backward  mesh_att_bwd1 / bwd2 per attention (the MLP block and fc back to the attention's output; then the attention itself in
+//             key chunks, q/k/v linears, LayerNorm), mesh_gcn_bwd_kernel once per GCN block (one accumulator set at a time: the
+//             register file, not the launch count, bounds these kernels); dY operands of every linear go to a gradient tape and the
+//             weight gradients stay ordinary full-chip GEMM launches (pdf_linear_bwd_weight_pair) issued from here on the side stream.
+//   (One launch per direction was the first form: it spilled -- 64-bit dropout index chains, tape offsets in scratch, three accumulator
+//   sets live -- and ran slower than the split form; the splits are at points where nothing is live in registers.)
 //
-// One 256-thread workgroup per (hand, sample) keeps that hand's [V][C] features of the sample on ONE CU for the whole chain:
+// One 256-thread workgroup per (hand, sample) keeps that hand's [V][C] features of the sample on ONE CU for a whole kernel:
 // V x C = 63 x 256 = 126 x 128 = 252 x 64 = 16,128 floats at every level, so two [V][C + 4] staging buffers (<= 139 KB) fit the
 // 160 KB LDS.  Every matrix product is "activation-stationary": the A operand (this hand's rows) is read from LDS by
 // ds_read_b128 -- lane l takes row l & 31 and the four k of chunk l >> 5, which feeds four v_mfma_f32_32x32x2_f32 (fp32 in, exact
-// fmaf chains) -- and the weights stream L2 -> registers once per workgroup, each lane one float4 of its output column (prefetched
-// four K-steps ahead).  No barrier inside a K loop; LayerNorm, the Chebyshev ELL product, softmax, dropout and the residuals run
-// on the LDS image between the products.  Attention runs on the matrix pipe too: S^T = K Q^T per (head, 32-query tile) stays in
-// accumulator registers (keys along rows), the softmax over keys is a register reduction plus ONE cross-half shuffle, and P goes
-// straight back into the MFMA as the B operand of O^T = V^T P.
-// Everything the backward (and the weight-gradient GEMMs, which stay ordinary side-stream launches) needs is written to a "tape"
-// in HBM as the chain passes; in eval mode nothing but the level output and q / k / v is written.
+// fmaf chains) -- and the weights stream L2 -> registers once per workgroup, each lane eight consecutive floats of its output column
+// per step (lanes l and l + 32 consume one 64-byte line), prefetched four K-steps ahead through a register ring in a fully unrolled
+// loop fenced with sched_barrier (the compiler otherwise sinks the loads next to their use).  No barrier inside a K loop; LayerNorm,
+// the Chebyshev ELL product (ELL rows staged in LDS), softmax, dropout and the residuals run on the LDS image between the products.
+// Attention runs on the matrix pipe too: S^T = K Q^T per (head, 32-query tile) stays in accumulator registers (keys along rows), the
+// softmax over keys is a register reduction plus ONE cross-half shuffle, and P goes straight back into the MFMA as the B operand of
+// O^T = V^T P.  Dropout masks are a stateless hash of (seed, step, element index) -- the same function the per-op kernels use, so the
+// fused and the per-op paths draw identical masks.
+// Everything the backward (and the weight-gradient GEMMs) needs is written to a "tape" in HBM as the chain passes; in eval mode
+// nothing but the level output and q / k / v is written.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -485,22 +485,24 @@ int pdf_internal_wino_eligible(int N, int H, int W, int Ck, int Cn, int KH, int 
 }
 // x [N][H][W][Ck] (ldx) * w -> y [N][H][W][Cn] (ldy).  flip = 0: forward, w = [Cn][3][3][Ck]; flip = 1: backward-data, w = [Ck][3][3][Cn]
 // (x = dy, y = dx).  ws: pdf_internal_wino_workspace(N, H, W, Ck, Cn) floats.
+// v_shared (forward, F(4x4) only): V of the same input tensor, written by another convolution's forward -- the input transform is skipped
 int pdf_internal_conv3x3_winograd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* ws,
-                                  int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, hipStream_t s) {
+                                  int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, const float* v_shared, hipStream_t s) {
     const int m = pdf_internal_wino_tile(N, H, W, Ck, Cn, flip);
     const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
     float* U = ws;
-    float* V = U + P * Cn * Ck;
-    float* Mx = V + P * T * Ck;
+    const float* V = U + P * Cn * Ck;
+    float* Mx = ws + P * Cn * Ck + P * T * Ck;
     const int gw = grid_for((long)Cn * Ck);
     if (m == 4) {
         if (flip) hipLaunchKernelGGL((wino4_weight_kernel<true>), dim3(gw), dim3(256), 0, s, w, U, Ck, Cn);
         else hipLaunchKernelGGL((wino4_weight_kernel<false>), dim3(gw), dim3(256), 0, s, w, U, Cn, Ck);
-        hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(T * (Ck / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, V, N, H, W, Ck);
+        if (v_shared != nullptr && !flip) V = v_shared;
+        else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(T * (Ck / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, U + P * Cn * Ck, N, H, W, Ck);
     } else {
         if (flip) hipLaunchKernelGGL((wino_weight_kernel<true>), dim3(gw), dim3(256), 0, s, w, U, Ck, Cn);        // w [Cout = Ck][3][3][Cin = Cn]
         else hipLaunchKernelGGL((wino_weight_kernel<false>), dim3(gw), dim3(256), 0, s, w, U, Cn, Ck);
-        hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(T * (Ck / 4), 256, 256 * 32)), dim3(256), 0, s, x, ldx, V, N, H, W, Ck);
+        hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(T * (Ck / 4), 256, 256 * 32)), dim3(256), 0, s, x, ldx, U + P * Cn * Ck, N, H, W, Ck);
     }
     PDF_LAUNCH_CHECK();
     if (int rc = pdf_internal_batched_gemm(V, U, Mx, (int)P, T * Ck, (long)Cn * Ck, T * Cn, (int)T, Cn, Ck, s)) return rc;

@@ -253,6 +253,16 @@ def _wino_v_offset(N, H, W, Cin, Cout, KH, KW, stride, pad):
     return off
 
 
+WINOGRAD_SHARE = _os.environ.get("PDFNET_WINOGRAD_SHARE", "1") != "0"
+
+
+def share_winograd_input(x):
+    """Mark `x` as read by several stride-1 3x3 convolutions: their F(4x4) forwards (and weight gradients) share one transformed input."""
+    if WINOGRAD_SHARE and x is not None and getattr(x, '_pdf_wino_share', None) is None:
+        x._pdf_wino_share = {}
+    return x
+
+
 def _O2(a, b):
     """_O2(a, b) for the most frequent call shape: the two operand shadows of a GEMM-family launch."""
     if a is None and b is None:
@@ -581,9 +591,26 @@ class _Conv2d(Function):
         #  F(4x4) carries ~4e-5 absolute error against 1e-6..3e-6 of the direct kernels: it is a TRAINING trade.  A forward that
         # nothing will be differentiated through (eval, no_grad) gets no workspace and therefore the direct kernels, unless asked otherwise.
         ws, nws = _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 0, x.device) if (WINOGRAD_INFERENCE or any(ctx.needs_input_grad[:3])) else (None, None)
+        # several convolutions reading ONE feature map (the heads on x0): the first F(4x4) forward leaves V, the transformed input, in its
+        # workspace and the others take it from there (share_winograd_input) -- V depends on the input only
+        share = getattr(x_in, '_pdf_wino_share', None) if (ws is not None and WINOGRAD_KEEP_V) else None
+        v_off = _wino_v_offset(N, H, W, Cin, Cout, KH, KW, stride, pad) if (ws is not None and WINOGRAD_KEEP_V) else -1
+        v_src = None
+        if share is not None and v_off >= 0:
+            ent = share.get((N, H, W, Cin))
+            if ent is not None and ent[2] == x_in._version:
+                v_src = ent
+                if ent[4] != hip._raw_stream(hip._raw_device()):        # written on another stream: order after it, and tell the allocator
+                    cs = torch.cuda.current_stream()
+                    cs.wait_event(ent[3])
+                    ent[0].record_stream(cs)
         o, oa = _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16), out_bf16=ptr(y16), stats_out=ptr(part), stats_cap=part.numel() if part is not None else None,
-                   ws=ptr(ws), ws_floats=nws)
+                   ws=ptr(ws), ws_floats=nws, wino_v=(v_src[0].data_ptr() + 4 * v_src[1]) if v_src is not None else None)
         _L().pdf_conv2d_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, act, stream(), oa)
+        if share is not None and v_off >= 0 and v_src is None:
+            ev = torch.cuda.Event()
+            ev.record()
+            share[(N, H, W, Cin)] = (ws, v_off, x_in._version, ev, hip._raw_stream(hip._raw_device()))
         _stats_attach(y, part, o)
         if y16 is not None:
             if DEBUG_PHANTOMS:
@@ -592,10 +619,8 @@ class _Conv2d(Function):
         # Winograd F(4x4): the weight gradient needs the same transformed input V the forward just wrote into its workspace -- keep the
         # workspace for it (one input-transform pass per layer and step less; V of `feat` at B=32 is 1.2 GB, all 17 layers ~5.5 GB)
         ctx.wino_v = None
-        if ws is not None and WINOGRAD_KEEP_V and ctx.needs_input_grad[1]:
-            off = _wino_v_offset(N, H, W, Cin, Cout, KH, KW, stride, pad)
-            if off >= 0:
-                ctx.wino_v = (ws, off)
+        if v_off >= 0 and ctx.needs_input_grad[1]:
+            ctx.wino_v = (v_src[0], v_src[1]) if v_src is not None else (ws, v_off)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.s16 = (x16, w16)
         ctx.w16t = shadow_t_of(w) if w16 is not None else None

@@ -357,6 +357,7 @@ class ResNetSimple(nn.Module):
         pyr = F.l2norm_cat([self.p2(x4), self.p3(x3), self.p4(x2), self.p5(x1)],         # NHWC channel concat, written in place
                            [self.p2_l2.weight, self.p3_l2.weight, self.p4_l2.weight, self.p5_l2.weight])
         x0 = self.feat_bn(self.feat(pyr, stats=self.feat_bn.training), relu=True)                 # :740-744
+        F.share_winograd_input(x0)                  # hm / wh / params heads and center_feat_up0 all read x0: one input transform
         st['x0'] = x0
         hm_fc = self.hm
         st['ret']['hm'] = hm_fc[2](hm_fc[0](x0, F.ACT_RELU))                               # 'hm' is first in opt.heads (:291)

@@ -340,6 +340,37 @@ def test_weight_gradient_from_the_forwards_transformed_input_is_bit_identical(mo
     assert float(grads[True][0].abs().max()) > 0
 
 
+def test_heads_reading_one_feature_map_share_its_transformed_input():
+    """Round 5: the hm / wh / params heads and center_feat_up0 all convolve x0 (3x3, stride 1): after F.share_winograd_input(x0) the first
+    F(4x4) forward leaves V in its workspace and the others (here: a second convolution with another width, issued on ANOTHER stream) take
+    it from there, forward and weight gradient.  Outputs and every gradient must equal the unshared run bit for bit."""
+    from pdfnet_amd import functional as F
+    N, Cin, H, W = 32, 256, 64, 64
+    x = _rnd(N, Cin, H, W, seed=31).cuda().contiguous(memory_format=torch.channels_last)
+    ws_ = [_rnd(c, Cin, 3, 3, seed=32 + i, scale=(Cin * 9) ** -0.5) for i, c in enumerate((256, 512))]
+    gys = [_rnd(N, c, H, W, seed=35 + i).cuda().contiguous(memory_format=torch.channels_last) for i, c in enumerate((256, 512))]
+    res = {}
+    for shared in (True, False):
+        xd = x.clone().requires_grad_()
+        if shared:
+            F.share_winograd_input(xd)
+        wd = [w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_() for w in ws_]
+        y0 = F.conv2d(xd, wd[0], None, 1, 1, 0)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            y1 = F.conv2d(xd, wd[1], None, 1, 1, 0)
+        torch.cuda.current_stream().wait_stream(side)
+        if shared:
+            assert len(xd._pdf_wino_share) == 1                 # one V for both
+        ((y0 * gys[0]).sum() + (y1 * gys[1]).sum()).backward()
+        F.join_wgrad()
+        torch.cuda.synchronize()
+        res[shared] = (y0.detach().clone(), y1.detach().clone(), wd[0].grad.clone(), wd[1].grad.clone(), xd.grad.clone())
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("cfg", [(32, 512, 32, 32, 256, 4, 2, 1), (32, 1024, 16, 16, 256, 4, 4, 0), (32, 2048, 8, 8, 256, 8, 8, 0)])
 def test_pyramid_transposed_convolutions_at_their_real_size(cfg):
     """p3 / p4 / p5 (intaghand_encoder.py:602-605): p5's weight is the largest tensor of the model (33.5 M elements)."""
