@@ -377,9 +377,22 @@ def _ws(nfloats, dev):
     return torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=dev)
 
 
+_wgrad_ws_cache = {}
+_bn_ws_cache = {}
+
+
 def _wgrad_ws(M, NI, NJ, dev):
-    n = _L().pdf_wgrad_workspace_floats(M, NI, NJ)
+    n = _wgrad_ws_cache.get((M, NI, NJ))                    # (the sizes depend on the shape only: one library call per shape, not per launch)
+    if n is None:
+        n = _wgrad_ws_cache[(M, NI, NJ)] = _L().pdf_wgrad_workspace_floats(M, NI, NJ)
     return _ws(n, dev), n
+
+
+def _bn_ws_floats(C, R):
+    n = _bn_ws_cache.get((C, R))
+    if n is None:
+        n = _bn_ws_cache[(C, R)] = _L().pdf_bn_workspace_floats(C, R)
+    return n
 
 
 ASYNC_WGRAD = _os.environ.get("PDFNET_ASYNC_WGRAD", "1") != "0"
@@ -433,7 +446,7 @@ class wgrad_stream:
                     wait(side_raw, last[1])
                 p._pdf_wg_last = ent
         for t in self.tensors:                      # produced / owned by the main stream, read on the side stream
-            if t is not None:
+            if t is not None:                       # (keeping them referenced until the join instead was measured: no difference, r05_keepalive.txt)
                 t.record_stream(side)
                 s16 = getattr(t, '_pdf_bf16', None)
                 if s16 is not None:
@@ -507,13 +520,13 @@ def _main_grad(param, like):
 
 
 def _colsum_into(g, C, R, ldg, out):
-    ws = _ws(_L().pdf_bn_workspace_floats(C, R), g.device)
+    ws = _ws(_bn_ws_floats(C, R), g.device)
     _L().pdf_colsum(ptr(g), ldg, C, R, ptr(out), 1, ptr(ws), stream())
 
 
 def _colsum(g, C, R, ldg):
     out = torch.empty(C, dtype=torch.float32, device=g.device)
-    ws = _ws(_L().pdf_bn_workspace_floats(C, R), g.device)
+    ws = _ws(_bn_ws_floats(C, R), g.device)
     _L().pdf_colsum(ptr(g), ldg, C, R, ptr(out), 0, ptr(ws), stream())
     return out
 
@@ -880,7 +893,7 @@ class _LinearPair(Function):
             L.pdf_linear_bwd_weight_pair(ptr(x), ptr(g), ptr(o0), ptr(o1), ptr(p0), ptr(p1), ptr(_ws(n, x.device)), n, M, Nn, K, K, Nn, acc, stream())
 
         def launch_b(o0, o1, acc):
-            ws = _ws(2 * L.pdf_bn_workspace_floats(Nn, M), x.device)
+            ws = _ws(2 * _bn_ws_floats(Nn, M), x.device)
             L.pdf_colsum_pair(ptr(g), Nn, Nn, M, ptr(o0), ptr(o1), acc, ptr(ws), stream())
         dw0 = dw1 = db0 = db1 = None
         ride = need_w and need_b and direct_w == direct_b                 # the bias gradients ride along with the weight launch
@@ -934,7 +947,7 @@ class _BatchNorm(Function):
             if tiles is not None:                           # statistics came out of the producing GEMM's epilogue
                 ws = None
             else:
-                ws = _ws(L.pdf_bn_workspace_floats(C, R), dev)
+                ws = _ws(_bn_ws_floats(C, R), dev)
             # lazy: statistics and (scale, shift) only -- the ONE consumer, a linear layer, applies BN + ReLU while it stages its rows
             # (PdfCallOpts::in_scale / in_shift) and y is never written: it only carries (x, scale, shift) to that consumer (_lazy_bn)
             lazy = bool(lazy) and relu and res is None and x16 is None and not _GEMM_BF16 and x.dim() == 2 and C % 16 == 0 and R % 16 == 0
@@ -981,7 +994,7 @@ class _BatchNorm(Function):
         dgamma = mg_g if direct else torch.empty(C, device=x.device)
         dbeta = mg_b if direct else torch.empty(C, device=x.device)
         L = _L()
-        ws = _ws(L.pdf_bn_workspace_floats(C, R) + 3 * C, x.device)
+        ws = _ws(_bn_ws_floats(C, R) + 3 * C, x.device)
         dx16 = new_shadow(dx) if C % 4 == 0 else None
         _, oa = _O(out_bf16=ptr(dx16), bn_x_bf16=ptr(x) if x_is_16 else None)
         L.pdf_bn_train_bwd_x(ptr(g), C, ptr(y), C, mode, None if x_is_16 else ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R,
@@ -1717,7 +1730,7 @@ class _BnReluMaxK(Function):
         if tiles is not None:
             ws = None
         else:
-            ws = _ws(L.pdf_bn_workspace_floats(C, R * K), dev)
+            ws = _ws(_bn_ws_floats(C, R * K), dev)
         _, oa = _O(tile_stats=ptr(tiles[0]) if tiles is not None else None, tile_n=tiles[1] if tiles is not None else None,
                    tile_rows=tiles[2] if tiles is not None else None)
         L.pdf_bn_relu_maxk_fwd_x(ptr(x), C, C, R, K, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps, int(training),
@@ -1741,7 +1754,7 @@ class _BnReluMaxK(Function):
         dgamma = mg_g if direct else torch.empty(C, device=x.device)
         dbeta = mg_b if direct else torch.empty(C, device=x.device)
         L = _L()
-        ws = _ws(L.pdf_bn_workspace_floats(C, R) + 3 * C, x.device)
+        ws = _ws(_bn_ws_floats(C, R) + 3 * C, x.device)
         L.pdf_bn_relu_maxk_bwd(ptr(g), C, ptr(arg), ptr(x), C, ptr(mean), ptr(rstd), ptr(gamma), ptr(scale), ptr(shift), C, R, K,
                                ptr(dx), C, ptr(dgamma), ptr(dbeta), int(direct), ptr(ws), stream())
         if direct:
