@@ -47,6 +47,16 @@ constexpr bool FRAG_PIPE = PDF_FRAG_PIPE != 0;
 #define PDF_IG_DEEP 1
 #endif
 constexpr bool IG_DEEP = PDF_IG_DEEP != 0;      // igemm_nt, buffer-load form: two K-steps of prefetch in flight
+// Round 5: operand fragments as ONE ds_read_b128 per 32 rows and 8 k.  Lane l reads the four consecutive k of chunk (l >> 5) of row (l & 31);
+// MFMA t of the group pairs k = 8 g + t (lanes 0-31) with k = 8 g + 4 + t (lanes 32-63) -- any pairing is a valid reduction order as long
+// as A and B use the same.  Rows are BK + 4 floats apart (16-byte aligned, stride = 4 mod 8 floats: conflict-free for b128), so the staging
+// store is one ds_write_b128 per thread and row too: 4x fewer LDS instructions on both sides than the [BK + 1] image with scalar accesses.
+// MEASURED (profiles/r05_ig_b128.txt): no layer gains, the [K][N] backward-data forms lose 5-10 %, the step 50.7 vs 49.8 ms -- LDS instruction
+// issue is not what bounds these loops (the what-if builds of round 3 said the same of the loads).  Off; kept as a compile-time switch.
+#ifndef PDF_IG_B128
+#define PDF_IG_B128 0
+#endif
+constexpr bool IG_B128 = PDF_IG_B128 != 0;
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 as_f4(const u32x4v& v) { return *reinterpret_cast<const float4*>(&v); }
 
@@ -60,12 +70,12 @@ __device__ __forceinline__ float4 as_f4(const u32x4v& v) { return *reinterpret_c
 template <int BM, int BN, int WM, int WN, bool FAST, bool KN, int BKT, bool BUF, bool AFF>
 __device__ __forceinline__ void igemm_nt_body(const IGemm& g) {    // (128x128: 3 waves per SIMD = 3 blocks per CU, as its LDS allows)
     constexpr int NT = WM * WN * 64;                     // threads: one wave per (BM/WM) x (BN/WN) sub-tile
-    constexpr int BK = BKT, LD = BK + 1;                 // K-step: 16, or 32 for the small tile (half the barriers per flop)
+    constexpr int BK = BKT, LD = IG_B128 ? BK + 4 : BK + 1;      // K-step: 16, or 32 for the small tile (half the barriers per flop)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int TPR = BK / 4, RPP = NT / TPR;          // threads per staged row (a float4 each), rows per pass of the block
     constexpr int RA = BM / RPP, RB = BN / RPP;
-    __shared__ float As[2][BM * LD];
-    __shared__ float Bs[2][BN * LD];
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -240,7 +250,8 @@ __device__ __forceinline__ void igemm_nt_body(const IGemm& g) {    // (128x128: 
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             float* p = &As[buf][(lrow + i * RPP) * LD + kq];
-            p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+            if constexpr (IG_B128) *reinterpret_cast<float4*>(p) = ra[i];
+            else { p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w; }
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -249,16 +260,38 @@ __device__ __forceinline__ void igemm_nt_body(const IGemm& g) {    // (128x128: 
                 p[0] = rb[i].x; p[LD] = rb[i].y; p[2 * LD] = rb[i].z; p[3 * LD] = rb[i].w;
             } else {
                 float* p = &Bs[buf][(lrow + i * RPP) * LD + kq];
-                p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w;
+                if constexpr (IG_B128) *reinterpret_cast<float4*>(p) = rb[i];
+                else { p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w; }
             }
         }
     };
 
-    const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5);
-    const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5);
+    const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5) * (IG_B128 ? 4 : 1);
+    const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5) * (IG_B128 ? 4 : 1);
     auto compute = [&](int cur) {
         const float* as = As[cur];
         const float* bs = Bs[cur];
+        if constexpr (IG_B128) {
+#pragma unroll
+            for (int g8 = 0; g8 < BK / 8; ++g8) {
+                float4 a4[TM], b4[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const float4*>(as + arow + i * 32 * LD + g8 * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(bs + brow + j * 32 * LD + g8 * 8);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float av = t == 0 ? a4[i].x : t == 1 ? a4[i].y : t == 2 ? a4[i].z : a4[i].w;
+                            const float bv = t == 0 ? b4[j].x : t == 1 ? b4[j].y : t == 2 ? b4[j].z : b4[j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+            }
+            return;
+        }
         // fragments of k-pair kk + 1 are read while the MFMAs of pair kk run (two register sets, FRAG_PIPE)
         float a[2][TM], b[2][TN];
         auto frag = [&](int set, int kk) {
