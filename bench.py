@@ -566,13 +566,23 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
             for _ in range(8):
                 tr.train_step(batch)
                 torch.cuda.synchronize()
-            t0 = time.time()
-            marks[0].record()
-            for i in range(steps):
-                last = tr.train_step(batch)
-                marks[i + 1].record()                      # (events on the launch stream: per-step times without a host sync)
-            torch.cuda.synchronize()
-            dt = time.time() - t0
+            stalled = None
+            for attempt in range(2):
+                t0 = time.time()
+                marks[0].record()
+                for i in range(steps):
+                    last = tr.train_step(batch)
+                    marks[i + 1].record()                  # (events on the launch stream: per-step times without a host sync)
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                ps = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+                # a one-off stall inside the window (seen once in round 5: a 1.7 s step among 20 of 54 ms -- the allocator re-growing after the
+                # launch-mode trial's pool was returned; r04 had the same, see above) is not the step's throughput: time the window once more and
+                # say so.  A second stalled window is reported as it is.
+                if attempt == 0 and ps[-1] > 5.0 * ps[steps // 2]:
+                    stalled = {"first_window_images_per_s": round(B * steps / dt, 2), "longest_step_ms": round(ps[-1], 1), "median_step_ms": round(ps[steps // 2], 3)}
+                    continue
+                break
         finally:
             gc.enable()
             gc.unfreeze()
@@ -594,7 +604,7 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
         fl, sec = sum(v[1] for v in sym.values()), sum(v[3] for v in sym.values())
         out = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
                "median_step_ms": round(median_ms, 3), "images_per_s_at_median_step": round(B / median_ms * 1e3, 2),
-               "batch": B, "steps": steps, "warmup": warmup, "launch": launch,
+               "batch": B, "steps": steps, "warmup": warmup, "launch": launch, "retimed_after_stall": stalled,
                "auto_choice_ms": {k: round(v, 3) for k, v in choice.items()} if choice else None,
                "final_loss": round(loss_val, 4),
                "dominant_kernel": {k: head[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "ms_per_step", "algorithmic_bytes_per_launch", "traffic", "traffic_source")},
