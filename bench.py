@@ -156,10 +156,14 @@ class KernelTimer:
         self.lib = hip.lib()
 
     def __enter__(self):
+        from pdfnet_amd import taped
+        taped.SUSPEND = True                                 # (a replayed tape calls the library past the profilers' wrappers: they would miss the trunk)
         self.lib.pdf_debug_kernel_timing(1)
         return self
 
     def __exit__(self, *exc):
+        from pdfnet_amd import taped
+        taped.SUSPEND = False
         self.lib.pdf_debug_kernel_timing(0)
 
     def by_symbol(self):

@@ -161,12 +161,13 @@ def new_shadow(t):
 # bf16 shadow of it for the backward GEMMs; now it writes nothing else).  Autograd still sees fp32 tensors of the right shape --
 # allocated, never written ("phantoms"), carrying the bf16 tensor as an attribute; the library gets a NULL fp32 pointer for them
 # and refuses (PDF_E_BADARG) any launch that would have to read it.
-# Default 'auto': on for convolutions over >= BF16_STORAGE_MIN_BATCH images -- measured per GPU: B=64 1,046-1,050 -> 1,063-1,076 img/s (the
+# Default 'auto': on for convolutions over >= BF16_STORAGE_MIN_BATCH images (48 until round 5, when the B=32 step stopped being bound by the host:
+# storage + epilogue statistics 954 -> 990 img/s there, profiles/r05_bf16_b32_modes.txt; now 32) -- measured per GPU: B=64 1,046-1,050 -> 1,063-1,076 img/s (the
 # covered BatchNorm sites 9.5 -> 5.5 ms), while at B=32 the step is bound by the host's issue time and the extra allocations and calls
 # cost more than the kernels gain (868 -> 799).  PDFNET_BF16_STORAGE=1 / 0 forces it on / off.
 _bs = _os.environ.get("PDFNET_BF16_STORAGE", "auto")
 BF16_STORAGE = 'auto' if _bs == "auto" else _bs != "0"
-BF16_STORAGE_MIN_BATCH = int(_os.environ.get("PDFNET_BF16_STORAGE_MIN_BATCH", "48"))
+BF16_STORAGE_MIN_BATCH = int(_os.environ.get("PDFNET_BF16_STORAGE_MIN_BATCH", "32"))
 
 
 def storage_on(batch=None):

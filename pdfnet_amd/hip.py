@@ -124,12 +124,15 @@ class _Lib:
             rc = fn(*args)
             if is_status and rc != 0:
                 raise RuntimeError("libpdfnet_hip: %s failed with code %d" % (name, rc))
+            if _tape is not None and is_status:                # (taped.TapedSegment is recording: launches only, not size queries)
+                _tape.append((call, args))
             return rc
         setattr(self, name, call)
         return call
 
 
 _lib = None
+_tape = None            # a list while pdfnet_amd.taped records a segment: every status-returning library call is appended as (callable, args)
 
 
 def lib():

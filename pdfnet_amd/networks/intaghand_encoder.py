@@ -318,6 +318,17 @@ class ResNetSimple(nn.Module):
                            [self.p2_l2.weight, self.p3_l2.weight, self.p4_l2.weight, self.p5_l2.weight])
         return self.feat_bn(self.feat(pyr, stats=self.feat_bn.training), relu=True), emb0, x1     # :740-744
 
+    def trunk_layers(self, pooled):
+        """layer1..layer4 -> (x4, x3, x2, x1); under a Trainer replayed from a tape of its library calls (pdfnet_amd/taped.py): same launches,
+        none of the Python between them."""
+        seg = self.__dict__.get('_trunk_seg')
+        if seg is None:
+            from ..taped import TapedSegment
+            r = self.resnet
+            layers = [r.layer1, r.layer2, r.layer3, r.layer4]
+            seg = self.__dict__['_trunk_seg'] = TapedSegment(layers, layers)
+        return seg(pooled)
+
     def trunk(self, img, ind, choose, cloud, depth=None, K_new=None, valid=None):
         """Everything the mesh decoder waits on: ResNet, pyramid, `feat`, the centre heat-map head, centre features,
         PointNet++ per hand and the SFT fusion.  Returns a state dict for `dense_branches`."""
@@ -345,10 +356,7 @@ class ResNetSimple(nn.Module):
                 xr, yr, _, _ = pn.stage_a(cloud[:, 1], e0, e1, choose[:, 1], True)
                 return (xl, yl), (xr, yr)
             f_pn = F.fork(both_hands)
-        x4 = r.layer1(pooled)
-        x3 = r.layer2(x4)
-        x2 = r.layer3(x3)
-        x1 = r.layer4(x2)
+        x4, x3, x2, x1 = self.trunk_layers(pooled)
         if self.on_trunk_output_grad is not None and x1.requires_grad:
             # fires in the backward once d loss / d x1 is complete, i.e. when every branch above the trunk has run its backward
             cb = self.on_trunk_output_grad

@@ -242,3 +242,82 @@ def test_use_graph_auto_times_both_modes_and_keeps_one():
     assert all(l == l for l in losses) and losses[-1] < losses[0]
     if not tr.use_graph:
         assert not tr._graphs
+
+
+def test_taped_trunk_equals_the_eager_trunk_bit_for_bit(monkeypatch):
+    """Round 5: the ResNet trunk replayed from a tape of its library calls (pdfnet_amd/taped.py) issues the same kernels with the same
+    arguments on the same streams as the eager trunk.  In isolation (one external gradient per output, so no fan-in order can differ) the
+    outputs, the input gradient and EVERY weight gradient in the trainer's flat buffer must equal the eager trunk's bit for bit -- on
+    the first replay (right after the recording pass, whose own effects on gradients and running statistics must have been undone) and on
+    the second."""
+    from pdfnet_amd import functional as F
+    from pdfnet_amd import taped
+    from pdfnet_amd.trains.base_trainer import Trainer
+    opt, m, crit, _ = _setup(R=128, B=2)
+    tr = Trainer(opt, m, crit, lr=1e-4)
+    m.train()
+    enc = m.encoder
+    bn = enc.resnet.layer3[2].bn2
+    x = torch.randn(4, 64, 32, 32, device='cuda').contiguous(memory_format=torch.channels_last)
+    gs, ref = None, None
+    for tape in (False, True, True):
+        monkeypatch.setattr(taped, 'TRUNK_TAPE', tape)
+        if not tape or not enc.__dict__['_trunk_seg'].enabled:
+            enc.__dict__.pop('_trunk_seg', None)               # (the segment reads the switch when it is created)
+        tr.optimizer.zero_grad()
+        rm0 = bn.running_mean.clone()
+        xr = x.clone().requires_grad_()
+        outs = enc.trunk_layers(xr)
+        if gs is None:
+            torch.manual_seed(1)
+            gs = [torch.randn_like(o) for o in outs]
+        torch.autograd.backward(outs, gs)
+        F.join_wgrad()
+        torch.cuda.synchronize()
+        cur = ([o.detach().clone() for o in outs], xr.grad.clone(), tr.optimizer.flat_g.clone(), (bn.running_mean - rm0).clone(), rm0)
+        if not tape:
+            ref = cur
+            continue
+        seg = enc.__dict__['_trunk_seg']
+        assert len(seg.entries) == 1 and all(e is not False for e in seg.entries.values())      # it WAS taped
+        assert all(torch.equal(a, b) for a, b in zip(ref[0], cur[0]))
+        assert torch.equal(ref[1], cur[1]) and torch.equal(ref[2], cur[2])
+        assert float(cur[2].abs().max()) > 0
+        # running statistics advanced exactly once per call, as in the eager trunk (the recording pass's own update was rolled back):
+        # delta = momentum * (batch mean - running mean before), the batch mean taken from the eager call
+        mean = ref[4] + ref[3] / bn.momentum
+        assert torch.allclose(cur[3], bn.momentum * (mean - cur[4]), rtol=1e-4, atol=1e-6)
+
+
+def test_taped_trunk_inside_the_train_step(monkeypatch):
+    """... and inside the train step, at frozen weights (lr = 0: the optimizer must not amplify last-bit noise -- two EAGER runs of this step
+    differ in the last bits of some gradients too, a few kernels add with float atomics): the loss of every step is bit-identical to the eager
+    run's, the gradient after the last backward agrees to 1e-5 of its largest element, the running statistics and `num_batches_tracked`
+    advance once per step, an eval pass in between leaves the tape alone."""
+    from pdfnet_amd import functional as F
+    from pdfnet_amd import taped
+    from pdfnet_amd.networks.layers import BatchNorm
+    from pdfnet_amd.trains.base_trainer import Trainer
+    runs = {}
+    for tape in (False, True):
+        monkeypatch.setattr(taped, 'TRUNK_TAPE', tape)
+        opt, m, crit, batch = _setup(R=128, B=4)
+        F.manual_seed(99)
+        tr = Trainer(opt, m, crit, lr=0.0)
+        losses = [float(tr.train_step(batch, 0)) for _ in range(2)]
+        m.eval()
+        with torch.no_grad():
+            m(batch['input'], batch['choose'], batch['cloud'], batch['depth'], None, batch['K_new'], batch['valid'])
+        losses += [float(tr.train_step(batch, 0)) for _ in range(2)]
+        torch.cuda.synchronize()
+        seg = m.encoder.__dict__.get('_trunk_seg')
+        assert seg is not None and (len(seg.entries) == 1 and all(e is not False for e in seg.entries.values())) == tape
+        BatchNorm.flush_counters()
+        bn = m.encoder.resnet.layer3[2].bn2
+        runs[tape] = (losses, tr.optimizer.flat_g.clone(), bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked))
+        del tr, m
+    a, b = runs[False], runs[True]
+    assert a[0] == b[0] and len(set(a[0])) == 1, (a[0], b[0])
+    assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(a[1].abs().max())
+    assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-7)
+    assert a[4] == b[4] == 4
