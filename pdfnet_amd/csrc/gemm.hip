@@ -85,7 +85,7 @@ __device__ __forceinline__ void igemm_nt_body(const IGemm& g) {    // (128x128: 
     else if (blockIdx.y) { Ap += g.gsA; Cp += g.gsC; Bp = g.B1; biasp = g.bias1; }
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     int tmi, tni;
-    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
+    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni, g.gm);
     const int m0 = tmi * BM, n0 = tni * BN;
 
     const int lrow = tid / TPR, kq = (tid % TPR) * 4;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, 3) void igemm_halo3x3(const IGemm g) {
     float* __restrict__ Cp = g.C;
     const int ntm = g.M / BM, ntn = (g.N + BN - 1) / BN;
     int tmi, tni;
-    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
+    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni, g.gm);
     const int m0 = tmi * BM, n0 = tni * BN;
     const int W = g.W, H = g.H, HC = W + 2, R = BM / W, HP = (R + 2) * HC;
     const int img = m0 / (H * W), y0 = (m0 - img * H * W) / W;
@@ -1198,10 +1198,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning overrides for tools/gemm_bench.py sweeps.  The environment is read ONCE (std::call_once: the main thread and the
 // autograd thread both launch GEMMs); an unset variable stays "unset", so every call site applies its OWN default --
 // several sites pass shape-dependent defaults (round-1 bug: the first caller's default was cached for everybody).
-enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_IG_BUFSTORE, ENV_IG_BF16_STATS, ENV_IG_DMA, ENV_IG_DMA128, ENV_WG_BATCH_XCD, ENV_COUNT };
+enum { ENV_IG_T128, ENV_IG_BK32, ENV_WG_TARGET, ENV_WG_MINROWS, ENV_WG_TAPMAJOR, ENV_WG_BK32, ENV_WG_DMA, ENV_IG_HALO_MINC, ENV_IG_HALO, ENV_IG_T32, ENV_WG_INLAUNCH, ENV_WG_QUANT, ENV_IG_SPLITK, ENV_WG_LDSPAD, ENV_IG_SHORTK, ENV_WG_ATOMIC, ENV_WG_STEM, ENV_IG_SPLITK_MAXT, ENV_IG_SPLITK_TARGET, ENV_WG_SLOTS, ENV_WG_BUF, ENV_IG_BUF, ENV_WG_UNIFORM, ENV_IG_BUFSTORE, ENV_IG_BF16_STATS, ENV_IG_DMA, ENV_IG_DMA128, ENV_WG_BATCH_XCD, ENV_IG_GROUPM, ENV_COUNT };
 static int env_int(int which, int dflt) {
     static const char* const names[ENV_COUNT] = {"PDF_IG_T128", "PDF_IG_BK32", "PDF_WG_TARGET", "PDF_WG_MINROWS", "PDF_WG_TAPMAJOR",
-                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM", "PDF_IG_BUFSTORE", "PDF_IG_BF16_STATS", "PDF_IG_DMA", "PDF_IG_DMA128", "PDF_WG_BATCH_XCD"};
+                                                 "PDF_WG_BK32", "PDF_WG_DMA", "PDF_IG_HALO_MINC", "PDF_IG_HALO", "PDF_IG_T32", "PDF_WG_INLAUNCH", "PDF_WG_QUANT", "PDF_IG_SPLITK", "PDF_WG_LDSPAD", "PDF_IG_SHORTK", "PDF_WG_ATOMIC", "PDF_WG_STEM", "PDF_IG_SPLITK_MAXT", "PDF_IG_SPLITK_TARGET", "PDF_WG_SLOTS", "PDF_WG_BUF", "PDF_IG_BUF", "PDF_WG_UNIFORM", "PDF_IG_BUFSTORE", "PDF_IG_BF16_STATS", "PDF_IG_DMA", "PDF_IG_DMA128", "PDF_WG_BATCH_XCD", "PDF_IG_GROUPM"};
     static int vals[ENV_COUNT];
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1381,6 +1381,7 @@ static void stat_plan(IGemm& g, long cap, int BM) {
 // groups == 2: paired launch (see IGemm::B1), blockIdx.y selects the group
 static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap = 0) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
+    g.gm = env_int(ENV_IG_GROUPM, 4);               // (round 5: L2-miss reads of the 64x64 family 112 -> 81 MB per launch, of the transposed convolutions 1,539 -> 583; times unchanged -- profiles/r05_groupm.txt)
     ++g_igemm_launches;
     if (groups > 1) g.stat = nullptr;
     float* const stat_req = g.stat;

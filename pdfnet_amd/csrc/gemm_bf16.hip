@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IGemm g) {
     const unsigned short* const z16 = reinterpret_cast<const unsigned short*>(g_zero32);
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     int tmi, tni;
-    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
+    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni, g.gm);
     const int m0 = tmi * BM, n0 = tni * BN;
 
     // ---- A: ROW staging.  chunk q = tid + 256 i -> (row q / CPR, chunk q % CPR)

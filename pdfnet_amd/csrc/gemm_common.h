@@ -48,17 +48,28 @@ struct IGemm {
     // batched plain GEMMs in one launch (winograd.hip: the 16 transform-domain products): blockIdx.y = batch index b, operands
     // advanced by b * gsA / gsB / gsC floats (batch > 0 replaces the two-group meaning of blockIdx.y)
     int batch; long gsB;
+    int gm;                                          // tile order: row-tiles per group (xcd_tile); 0 / 1 = rows of tiles one after the other
     int dy[MAX_TAPS], dx[MAX_TAPS], wt[MAX_TAPS];    // int, not short: a uniform index then compiles to s_load_dword; 16-bit entries become vector loads whose vmcnt(0) wait drains the prefetch
 };
 
 // the word masked lanes read instead of branching around their load
 static __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
-__device__ __forceinline__ void xcd_tile(int bid, int nblk, int ntn, int& tm, int& tn) {
+// gm > 1 (round 5, IGemm::gm): the tile list is walked in groups of gm row-tiles -- within a group the row index runs fastest -- so that the ~32
+// blocks an XCD has in flight form a gm x (32 / gm) patch of the output instead of a 1 x 32 strip and share gm A panels AND 32 / gm B panels
+// through its L2 (the "group-M" order of the GEMM literature).
+__device__ __forceinline__ void xcd_tile(int bid, int nblk, int ntn, int& tm, int& tn, int gm = 1) {
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous chunk of the
     // tile list so the n-tiles that re-read one A panel hit the same L2 (guide T1, bijective form)
     int q = nblk >> 3, r = nblk & 7, x = bid & 7;
     int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    if (gm > 1) {
+        const int ntm = nblk / ntn, per = gm * ntn, grp = lin / per, first = grp * gm, rem = lin - grp * per;
+        const int gsz = min(ntm - first, gm);
+        tm = first + rem % gsz;
+        tn = rem / gsz;
+        return;
+    }
     tn = lin % ntn;
     tm = lin / ntn;
 }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void igemm_dma(const IGemm g) {
     if (blockIdx.y) { Ap += g.gsA; Cp += g.gsC; Bp = g.B1; biasp = g.bias1; }
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     int tmi, tni;
-    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
+    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni, g.gm);
     const int m0 = tmi * BM, n0 = tni * BN;
 
     const i32x4 rsA = dma_rsrc(Ap, g.abytes), rsB = dma_rsrc(Bp, g.bbytes);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_dma(const IGemm g) {
     if (blockIdx.y) { A16 += g.gsA; Cp += g.gsC; B16 = reinterpret_cast<const unsigned short*>(g.B116); biasp = g.bias1; }
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     int tmi, tni;
-    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni);
+    xcd_tile(blockIdx.x, ntm * ntn, ntn, tmi, tni, g.gm);
     const int m0 = tmi * BM, n0 = tni * BN;
     const i32x4 rsA = dma_rsrc(A16, g.abytes / 2), rsB = dma_rsrc(B16, g.bbytes / 2);
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const unsigned char*)smem;
