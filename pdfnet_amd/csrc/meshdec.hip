@@ -1,13 +1,15 @@
 // Fused mesh decoder for gfx950 (round 5): one DualGraphLayer of the IntagHand-style dual-hand GCN / attention decoder
 // (lib/models/networks/model_attn/DualGraph.py:62-92, gcn.py:34-69,99-110, self_attn.py:17-85, inter_attn.py:73-125) as
-// THREE launches forward and NINE backward (+ its 28 weight-gradient GEMMs on the side stream) instead of ~330 dependent 5-20 us launches:
+// THREE launches forward and ELEVEN backward (+ its 28 weight-gradient GEMMs on the side stream) instead of ~330 dependent 5-20 us launches:
 //
 //   forward   mesh_gcn_kernel        x -> the GCN_ResBlocks (LayerNorm, Chebyshev ELL product, linear, dropout, residual)
 //             mesh_att_kernel<self>  SelfAttn (LN, q/k/v, attention, fc, residual, MLP block) -> LN + q/k/v of the cross-hand step
 //             mesh_att_kernel<cross> attention over the keys / values of the OTHER hand of the same sample (the only dependence between
 //                                    workgroups, hence the launch boundary) -> fc -> MLP block -> level output
 //   backward  mesh_att_bwd1 / bwd2 per attention (the MLP block and fc back to the attention's output; then the attention itself in
-//             key chunks, q/k/v linears, LayerNorm), mesh_gcn_bwd_kernel once per GCN block (one accumulator set at a time: the
+//             key chunks -- the dq pass and the dk / dv pass in separate workgroups, their (head, tile) items shared by 2-4 workgroups each:
+//             the only part of the chain with that much independent work, a quarter of the backward at level 2 -- then q/k/v linears and
+//             LayerNorm in a second launch), mesh_gcn_bwd_kernel once per GCN block (one accumulator set at a time: the
 //             register file, not the launch count, bounds these kernels); dY operands of every linear go to a gradient tape and the
 //             weight gradients stay ordinary full-chip GEMM launches (pdf_linear_bwd_weight_pair) issued from here on the side stream.
 //   (One launch per direction was the first form: it spilled -- 64-bit dropout index chains, tape offsets in scratch, three accumulator
@@ -1019,12 +1021,14 @@ __device__ __forceinline__ void acc_to_global(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV
 template <int LV>
 __device__ __forceinline__ void attention_bwd_q(const Geo<LV>& g, const float* __restrict__ XK, const float* __restrict__ XV, const float* __restrict__ q,
                                                 const float* __restrict__ o, const float* __restrict__ dO, const float* __restrict__ stat,
-                                                float* __restrict__ dq, float p, unsigned long long seed, unsigned long long rowbase) {
+                                                float* __restrict__ dq, float p, unsigned long long seed, unsigned long long rowbase,
+                                                int part = 0, int parts = 1) {
     using G = Cfg<LV>;
     constexpr int MT = G::MT, DH = G::DH, DT = DH >= 32 ? DH / 32 : 1, MTC = MT < 4 ? MT : 4;
     const float inv_norm = 1.f / sqrtf((float)DH), sc = 1.f / (1.f - p);
     const uint32_t dkey = md_key(seed);
-    for (int item = g.wave; item < G::H * MT; item += MD_THREADS / 64) {
+    // (head, query tile) items: independent; `parts` workgroups share them (part = this one's share)
+    for (int item = g.wave + part * (MD_THREADS / 64); item < G::H * MT; item += parts * (MD_THREADS / 64)) {
         const int h = item / MT, qt = item - h * MT;
         const int qi = qt * 32 + g.l31, qrow = min(qi, G::V - 1);
         f32x4 qf[DH / 8], gf[DH / 8];
@@ -1108,12 +1112,12 @@ __device__ __forceinline__ void attention_bwd_q(const Geo<LV>& g, const float* _
 template <int LV>
 __device__ __forceinline__ void attention_bwd_kv(const Geo<LV>& g, const float* __restrict__ XQ, const float* __restrict__ XG, const float* __restrict__ sm,
                                                  const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ dk, float* __restrict__ dv,
-                                                 float p, unsigned long long seed, unsigned long long rowbase) {
+                                                 float p, unsigned long long seed, unsigned long long rowbase, int part = 0, int parts = 1) {
     using G = Cfg<LV>;
     constexpr int MT = G::MT, DH = G::DH, DT = DH >= 32 ? DH / 32 : 1, HV = G::H * G::VP, MTC = MT < 4 ? MT : 4;
     const float sc = 1.f / (1.f - p);
     const uint32_t dkey = md_key(seed);
-    for (int item = g.wave; item < G::H * MT; item += MD_THREADS / 64) {
+    for (int item = g.wave + part * (MD_THREADS / 64); item < G::H * MT; item += parts * (MD_THREADS / 64)) {
         const int h = item / MT, kt = item - h * MT;
         const int key = kt * 32 + g.l31, krow = min(key, G::V - 1);
         f32x4 kf[DH / 8], vf[DH / 8];
@@ -1268,8 +1272,12 @@ __global__ __launch_bounds__(MD_THREADS, 1) void mesh_att_bwd1_kernel(const PdfM
 }
 
 // attention + projections + LN of an attention block, backward: in dc (every workgroup's: kernel boundary in front), dxr; out dq, dk, dv, dxin
-template <int LV, bool CROSS>
-__global__ __launch_bounds__(MD_THREADS, 1) void mesh_att_bwd2_kernel(const PdfMeshLevel a) {
+// PART 0: everything in one workgroup per (hand, sample).  PART 1 / 2 (round 5, late): the two attention passes -- (1) dq, (2) dk / dv: independent,
+// together three quarters of this kernel at level 2 -- in TWO workgroups per (hand, sample) (blockIdx.y), then the projections and the LayerNorm
+// in a second launch: the 64-workgroup chain becomes 128 + 64.
+// PART 1 takes `parts`: the (head, tile) items of each pass are shared by that many workgroups -- grid (2 B, 2 * parts).
+template <int LV, bool CROSS, int PART>
+__global__ __launch_bounds__(MD_THREADS, 1) void mesh_att_bwd2_kernel(const PdfMeshLevel a, const int parts) {
     using G = Cfg<LV>;
     constexpr int C = G::C, A = CROSS ? 1 : 0, HV = G::H * G::VP;
     extern __shared__ float smem[];
@@ -1293,14 +1301,19 @@ __global__ __launch_bounds__(MD_THREADS, 1) void mesh_att_bwd2_kernel(const PdfM
     const float* dc = gt + go.att(A, 6);
     const float inv_norm = 1.f / sqrtf((float)G::DH);
     MD_STAMP(3, 0);
+    const int np = PART == 1 ? parts : 1, part = PART == 1 ? (int)blockIdx.y % np : 0;
+    const bool do1 = PART == 0 || (PART == 1 && (int)blockIdx.y < np), do2 = PART == 0 || (PART == 1 && (int)blockIdx.y >= np);
+    if (do1) {
     // (1) dq of my queries against the other party's keys / values
     load_rows<LV>(c.XA, k + (long)bo * VC, C, 0);
     load_rows<LV>(c.XB, v + (long)bo * VC, C, 0);
     __syncthreads();
     attention_bwd_q<LV>(c.g, c.XA, c.XB, q + ro, att_o + ro, dc + ro, stat + c.row0 * 8, gt + go.att(A, 3) + ro, c.p, P.seed_att + c.stepmix,
-                        (unsigned long long)c.bb * G::H * G::V * G::V);
+                        (unsigned long long)c.bb * G::H * G::V * G::V, part, np);
     __syncthreads();
     MD_STAMP(3, 1);                                                     // loads + dq
+    }
+    if (do2) {
     // (2) dk, dv of my keys from the other party's queries
     load_rows_scaled<LV>(c.XA, q + (long)bo * VC, C, 0, inv_norm);
     load_rows<LV>(c.XB, dc + (long)bo * VC, C, 0);
@@ -1323,9 +1336,11 @@ __global__ __launch_bounds__(MD_THREADS, 1) void mesh_att_bwd2_kernel(const PdfM
     __syncthreads();
     MD_STAMP(3, 2);                                                     // loads + D
     attention_bwd_kv<LV>(c.g, c.XA, c.XB, sm, k + ro, v + ro, gt + go.att(A, 4) + ro, gt + go.att(A, 5) + ro, c.p, P.seed_att + c.stepmix,
-                         (unsigned long long)bo * G::H * G::V * G::V);
+                         (unsigned long long)bo * G::H * G::V * G::V, part, np);
     __syncthreads();
     MD_STAMP(3, 3);                                                     // dk, dv
+    }
+    if constexpr (PART == 1) return;
     // (3) d n = dq Wq + dk Wk + dv Wv  (n = LN(x): the projections' common input)
     f32x16 acc[G::WMT][G::WNT];
     acc_zero<LV>(acc);
@@ -1485,8 +1500,12 @@ static int mesh_bwd_launch(const PdfMeshLevel& a, hipStream_t s, hipStream_t sid
     if (!attr_done) {
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd1_kernel<LV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) return (int)e;
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd1_kernel<LV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) return (int)e;
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd2_kernel<LV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)) return (int)e;
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd2_kernel<LV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)) return (int)e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd2_kernel<LV, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)) return (int)e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd2_kernel<LV, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)) return (int)e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd2_kernel<LV, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)) return (int)e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd2_kernel<LV, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)) return (int)e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd2_kernel<LV, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)) return (int)e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_att_bwd2_kernel<LV, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)) return (int)e;
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_gcn_bwd_kernel<LV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g)) return (int)e;
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_gcn_bwd_kernel<LV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g)) return (int)e;
         attr_done = true;
@@ -1494,11 +1513,24 @@ static int mesh_bwd_launch(const PdfMeshLevel& a, hipStream_t s, hipStream_t sid
     const dim3 grid(2 * a.B), blk(MD_THREADS);
     hipLaunchKernelGGL((mesh_att_bwd1_kernel<LV, true>), grid, blk, smem, s, a);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((mesh_att_bwd2_kernel<LV, true>), grid, blk, smem2, s, a);
+    static const int att_split = getenv("PDF_MESH_ATT_SPLIT") ? atoi(getenv("PDF_MESH_ATT_SPLIT")) : 7;      // bit LV: the split form at that level
+    const bool split = (att_split >> LV) & 1;
+    // workgroups per attention pass: the (head, tile) items are 8 / 16 / 32 at level 0 / 1 / 2, four waves take four at a time
+    static const int att_parts_env = getenv("PDF_MESH_ATT_PARTS") ? atoi(getenv("PDF_MESH_ATT_PARTS")) : 0;      // e.g. 124 = 1 / 2 / 4 at level 0 / 1 / 2
+    const int parts_default[3] = {2, 2, 4};                 // (measured, profiles/r05_att_split.txt: 1-1-1 49.4, 1-2-2 49.4, 1-2-4 49.3, 2-2-4 49.05, 2-4-8 49.4 ms per step; one workgroup for everything: 50.0)
+    int parts = att_parts_env > 0 ? (LV == 0 ? att_parts_env / 100 : LV == 1 ? (att_parts_env / 10) % 10 : att_parts_env % 10) : parts_default[LV];
+    parts = max(1, min(parts, G::H * G::MT / 4));
+    if (split) {
+        hipLaunchKernelGGL((mesh_att_bwd2_kernel<LV, true, 1>), dim3(2 * a.B, 2 * parts), blk, smem2, s, a, parts);
+        hipLaunchKernelGGL((mesh_att_bwd2_kernel<LV, true, 2>), grid, blk, smem2, s, a, 1);
+    } else hipLaunchKernelGGL((mesh_att_bwd2_kernel<LV, true, 0>), grid, blk, smem2, s, a, 1);
     PDF_LAUNCH_CHECK();
     hipLaunchKernelGGL((mesh_att_bwd1_kernel<LV, false>), grid, blk, smem, s, a);
     PDF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((mesh_att_bwd2_kernel<LV, false>), grid, blk, smem2, s, a);
+    if (split) {
+        hipLaunchKernelGGL((mesh_att_bwd2_kernel<LV, false, 1>), dim3(2 * a.B, 2 * parts), blk, smem2, s, a, parts);
+        hipLaunchKernelGGL((mesh_att_bwd2_kernel<LV, false, 2>), grid, blk, smem2, s, a, 1);
+    } else hipLaunchKernelGGL((mesh_att_bwd2_kernel<LV, false, 0>), grid, blk, smem2, s, a, 1);
     PDF_LAUNCH_CHECK();
     for (int b = 3; b >= 1; --b) {
         hipLaunchKernelGGL((mesh_gcn_bwd_kernel<LV, false>), grid, blk, smem_g, s, a, b);
