@@ -21,7 +21,7 @@ model = load_model_intag(opt).to(dev)
 consts = synthetic_loss_constants()
 trainer = Trainer(opt, model, CtdetLoss(opt, consts).to(dev), lr=1e-4)
 if os.environ.get('PDFNET_GEMM') == 'bf16':
-    F._L().pdf_set_gemm_precision(1)
+    F.set_gemm_precision('bf16')                               # (the host layer's switch: it sets the library's and its own)
 batch = to_device(synthetic_train_batch(B, 256, consts=consts), dev)
 marks = []
 
