@@ -509,6 +509,10 @@ long pdf_mesh_tape_floats(int level, int B);
 long pdf_mesh_gtape_floats(int level, int B);
 int pdf_mesh_level_fwd(const PdfMeshLevel* a, void* stream);
 int pdf_mesh_level_bwd(const PdfMeshLevel* a, void* stream, void* side_stream);
+/* The same level with its LINEAR products on the bf16 MFMA (operands rounded to bf16 as they are fed, fp32 accumulation; attention, LayerNorm,
+ * graph product in fp32): for the library's bf16 mode (BASELINE configs 4-5).  Same argument block and tape layout. */
+int pdf_mesh_level_fwd_bf16(const PdfMeshLevel* a, void* stream);
+int pdf_mesh_level_bwd_bf16(const PdfMeshLevel* a, void* stream, void* side_stream);
 int pdf_debug_mesh_level_size(void);
 
 /* ---- fused mesh loss (round 5, csrc/loss.hip) --------------------------------------------------------------------------------

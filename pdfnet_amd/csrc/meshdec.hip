@@ -30,11 +30,32 @@
 // Everything the backward (and the weight-gradient GEMMs) needs is written to a "tape" in HBM as the chain passes; in eval mode
 // nothing but the level output and q / k / v is written.
 #include "common.h"
+#ifndef MD_BF16
+#define MD_BF16 0
+#endif
+#if MD_BF16
+namespace md_bf16_build {                      // the second compilation of this file: its kernels need names of their own
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MD_THREADS 256
+// MD_BF16 = 1 (csrc/meshdec_bf16.hip compiles this file a second time): the LINEAR products run on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32
+// accumulate) -- a lane holds 8 consecutive k of its activation row and of its weight row anyway, which is exactly one bf16 MFMA's operand pair
+// instead of eight fp32 ones; operands are rounded (RNE) as they are fed, like the library's bf16 GEMM mode does.  Attention, LayerNorm, the graph
+// product and all accumulation stay fp32.  Entry points pdf_mesh_level_fwd_bf16 / _bwd_bf16; everything else of this file is unchanged.
+#ifndef MD_BF16
+#define MD_BF16 0
+#endif
+#if MD_BF16
+typedef __bf16 md_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ md_bf16x8 md_pack8(float a, float b, float c, float d, float e, float f, float g_, float h) {
+    union { unsigned u[4]; md_bf16x8 v; } x;
+    x.u[0] = pdf_pk_bf16(a, b); x.u[1] = pdf_pk_bf16(c, d); x.u[2] = pdf_pk_bf16(e, f); x.u[3] = pdf_pk_bf16(g_, h);
+    return x.v;
+}
+#endif
 #ifndef MD_WHATIF
 #define MD_WHATIF 0
 #endif
@@ -144,8 +165,10 @@ __host__ __device__ inline GTapeOff gtape_offsets(int level, int B) {
     o.RC = 2L * B * (63L << level) * (256L >> level);
     return o;
 }
+#if !MD_BF16
 PDF_API long pdf_mesh_tape_floats(int level, int B) { return level < 0 || level > 2 || B < 1 ? 0 : tape_offsets(level, B).total(); }
 PDF_API long pdf_mesh_gtape_floats(int level, int B) { return level < 0 || level > 2 || B < 1 ? 0 : gtape_offsets(level, B).total(); }
+#endif
 
 // ---- wave / lane geometry ---------------------------------------------------------------------------------------------------------
 template <int LV> struct Geo {
@@ -215,6 +238,22 @@ __device__ __forceinline__ void gemm_nt(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT
                 a1[i] = ld4(ap0 + i * 32 * G::LD + 16 * s + 4);
             }
         }
+#if MD_BF16
+        {
+            md_bf16x8 a8[WMT], b8[WNT];
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)                        // CHEBY: (x, L x) pairs interleaved like the weight row's (even, odd) columns
+                a8[i] = CHEBY ? md_pack8(a0[i][0], a1[i][0], a0[i][1], a1[i][1], a0[i][2], a1[i][2], a0[i][3], a1[i][3])
+                              : md_pack8(a0[i][0], a0[i][1], a0[i][2], a0[i][3], a1[i][0], a1[i][1], a1[i][2], a1[i][3]);
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) b8[j] = md_pack8(b[j][0][0], b[j][0][1], b[j][0][2], b[j][0][3], b[j][1][0], b[j][1][1], b[j][1][2], b[j][1][3]);
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (false) {
+#else
         if constexpr (!CHEBY) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -225,7 +264,8 @@ __device__ __forceinline__ void gemm_nt(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][e], b[j][0][e], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][e], b[j][1][e], acc[i][j], 0, 0, 0);
                     }
-        } else {
+#endif
+        } else if constexpr (!MD_BF16) {
             // the lane's 8 consecutive weights = (even, odd) pairs of its 4 k: w[2e] multiplies x, w[2e + 1] multiplies L x
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -273,6 +313,10 @@ __device__ __forceinline__ void gemm_nn(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT
     // NS <= 16 steps: one straight line.  NS = 32 (level 0): two passes of 16 -- a kernel with five 32-step products in one basic block made the
     // register allocator spill hundreds of registers; the one drain at the pass boundary costs ~1 k cycles of 16 k
     constexpr int UNR = NS < 16 ? NS : 16;
+#if MD_BF16
+    f32x4 ae[WMT];
+    float be[WNT][4];
+#endif
 #pragma unroll 1
     for (int s0 = 0; s0 < NS; s0 += UNR) {
 #pragma unroll
@@ -292,12 +336,31 @@ __device__ __forceinline__ void gemm_nn(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT
             f32x4 a0[WMT];
 #pragma unroll
             for (int i = 0; i < WMT; ++i) a0[i] = ld4(ap0 + i * 32 * G::LD + 8 * (s0 + u));
+#if MD_BF16
+            // two steps (2 x 4 k per half) make one bf16 MFMA: the even step's operands wait in registers for the odd step's
+            if ((u & 1) == 0) {
+#pragma unroll
+                for (int i = 0; i < WMT; ++i) ae[i] = a0[i];
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) be[j][e] = b[j][e];
+            } else {
+#pragma unroll
+                for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WNT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(md_pack8(ae[i][0], ae[i][1], ae[i][2], ae[i][3], a0[i][0], a0[i][1], a0[i][2], a0[i][3]),
+                                                                            md_pack8(be[j][0], be[j][1], be[j][2], be[j][3], b[j][0], b[j][1], b[j][2], b[j][3]), acc[i][j], 0, 0, 0);
+            }
+#else
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < WMT; ++i)
 #pragma unroll
                     for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][e], b[j][e], acc[i][j], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -887,6 +950,10 @@ static int mesh_check(const PdfMeshLevel* a) {
 }
 
 // One DualGraphLayer forward (position embedding already added to x).  Launches three kernels on `stream`; allocates nothing, synchronises nothing.
+#if MD_BF16
+#define pdf_mesh_level_fwd pdf_mesh_level_fwd_bf16
+#define pdf_mesh_level_bwd pdf_mesh_level_bwd_bf16
+#endif
 PDF_API int pdf_mesh_level_fwd(const PdfMeshLevel* a, hipStream_t stream) {
     if (int rc = mesh_check(a)) return rc;
     switch (a->level) {
@@ -895,7 +962,9 @@ PDF_API int pdf_mesh_level_fwd(const PdfMeshLevel* a, hipStream_t stream) {
         default: return mesh_fwd_launch<2>(*a, stream);
     }
 }
+#if !MD_BF16
 PDF_API int pdf_debug_mesh_level_size() { return (int)sizeof(PdfMeshLevel); }
+#endif
 
 // =====================================================================================================================================
 // Backward.  Five launches per level: cross tail | cross attention + projections | self tail | self attention + projections | 4 GCN blocks.
@@ -1594,6 +1663,7 @@ PDF_API int pdf_mesh_level_bwd(const PdfMeshLevel* a, hipStream_t stream, hipStr
     }
 }
 
+#if !MD_BF16
 // diagnostic build only: copies the stage stamps of the last launches to out[8 * 3 * 64]; returns 0 when the library was built without them
 PDF_API int pdf_debug_mesh_stamps(unsigned long long* out) {
 #if MD_STAMPS
@@ -1604,3 +1674,6 @@ PDF_API int pdf_debug_mesh_stamps(unsigned long long* out) {
     return 0;
 #endif
 }
+#else
+}   // namespace md_bf16_build
+#endif

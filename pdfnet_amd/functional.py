@@ -2223,6 +2223,11 @@ MESH_FUSED = _os.environ.get("PDFNET_MESH_FUSED", "1") != "0"
 # bf16 mode: the mesh decoder stays on the fused fp32 kernels (its products are latency-bound, not MFMA-bound: 1 % of the step's FLOPs; the
 # fused form removes ~500 launches from a step that is bound by the host's issue time at B = 32).  0: the unfused bf16 GEMM chain of rounds 2-4.
 MESH_FUSED_BF16 = _os.environ.get("PDFNET_MESH_FUSED_BF16", "1") != "0"
+MESH_BF16_MFMA = _os.environ.get("PDFNET_MESH_BF16_MFMA", "1") != "0"       # bf16 mode: the fused levels' linears on the bf16 MFMA (0: fp32 math there)
+
+
+def mesh_bf16_mfma():
+    return _GEMM_BF16 and MESH_BF16_MFMA
 
 
 def _pair(dst, l, r):
@@ -2291,7 +2296,8 @@ def mesh_level_forward(layer, x, training=False, save=False):
     tape = torch.empty(_L().pdf_mesh_tape_floats(level, B), dtype=torch.float32, device=x.device)
     qkv = torch.empty((3, 2, B, V, C), dtype=torch.float32, device=x.device)
     a = _mesh_args(layer, x, save or training, float(layer.attn.p) if training else 0.0, out, tape, qkv)
-    _L().pdf_mesh_level_fwd(_byref(a), stream())
+    # bf16 mode: the build of the same kernels whose linear products run on the bf16 MFMA (csrc/meshdec_bf16.hip); same tape
+    (_L().pdf_mesh_level_fwd_bf16 if mesh_bf16_mfma() else _L().pdf_mesh_level_fwd)(_byref(a), stream())
     return out, a, tape, qkv
 
 
@@ -2366,7 +2372,7 @@ class _MeshLevel(Function):
         # bucket copy): they are produced on it too.
         direct = all(g is None for g in grads)
         with wgrad_stream(direct, x, tape, qkv, gtape, ws, dout, params=tensors):
-            L.pdf_mesh_level_bwd(_byref(a), cur, stream())
+            (L.pdf_mesh_level_bwd_bf16 if mesh_bf16_mfma() else L.pdf_mesh_level_bwd)(_byref(a), cur, stream())
         ctx.keep = ctx.args = None
         return (dx, None, None) + tuple(grads)
 

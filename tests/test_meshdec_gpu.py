@@ -122,3 +122,44 @@ def test_fused_level_backward_equals_the_unfused_chain(level, drop):
         assert err <= (1e-1 if flipped else 2e-4) * topg + 1e-6, (n, err, topg)
     worst.sort(reverse=True)
     print("level %d p %.1f: %d parameter gradients, %d flipped ReLU sample(s), worst relative deviations %s" % (level, drop, len(g0), flipped, ["%s %.1e" % (n, e) for e, n in worst[:3]]))
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_bf16_build_of_the_fused_level_is_as_good_a_bf16_path_as_the_per_op_chain(level):
+    """csrc/meshdec_bf16.hip: the same kernels with their LINEAR products on the bf16 MFMA (operands rounded to bf16, fp32 accumulation; what the
+    library's bf16 mode does to every linear layer of the per-op chain).  One DualGraphLayer, forward + backward, dropout off, three ways: fp32
+    fused (the reference here), bf16 fused, bf16 per-op.  bf16 rounding moves ReLU inputs across zero, so the two bf16 paths sit ~0.5 % (output),
+    ~11 % (input gradient), ~6 % (weight gradients) from fp32 in relative L2 -- BOTH of them; the fused build must be no further from fp32 than
+    the per-op chain (x 1.15) and the two bf16 paths must be closer to each other than either is to fp32."""
+    from pdfnet_amd import functional as F
+    B = 5
+    layer = _layer(level, seed=6, drop=0.0).train()
+    V, cin = (63, 126, 252)[level], (512, 256, 128)[level]
+    x0 = torch.randn(2, B, V, cin, generator=torch.Generator().manual_seed(level + 5)).cuda()
+    gy = torch.randn(2, B, V, cin // 2, generator=torch.Generator().manual_seed(level + 6)).cuda()
+    res = {}
+    try:
+        for name, bf, fused in (("fp32", False, True), ("bf16 fused", True, True), ("bf16 per-op", True, False)):
+            F.set_gemm_precision('bf16' if bf else 'fp32')
+            F.MESH_FUSED = fused
+            layer.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_()
+            F.manual_seed(99)
+            out = layer(x)
+            out.backward(gy)
+            F.join_wgrad()
+            torch.cuda.synchronize()
+            res[name] = (out.detach().clone(), x.grad.clone(), torch.cat([p.grad.flatten() for n, p in layer.named_parameters() if p.grad is not None and p.dim() > 1]))
+    finally:
+        F.set_gemm_precision('fp32')
+        F.MESH_FUSED = True
+
+    def l2(a, b):
+        return float((a - b).norm() / a.norm())
+    for k, name in enumerate(("out", "dx", "dW")):
+        ref, fu, po = res["fp32"][k], res["bf16 fused"][k], res["bf16 per-op"][k]
+        d_fu, d_po, d_between = l2(ref, fu), l2(ref, po), l2(po, fu)
+        print("level %d %s: bf16 fused vs fp32 %.2e, bf16 per-op vs fp32 %.2e, fused vs per-op %.2e (relative L2)" % (level, name, d_fu, d_po, d_between))
+        assert torch.isfinite(fu).all() and d_fu > 1e-5                        # the bf16 path really ran
+        assert d_fu <= 1.15 * d_po + 1e-4, (name, d_fu, d_po)
+        assert d_between <= 0.6 * max(d_fu, d_po), (name, d_between, d_fu, d_po)
