@@ -194,6 +194,18 @@ def symbol_roofline(sym, peak, traffic_by_symbol=None, traffic_src=None):
             "launches_per_step": dom[0], "ms_per_step": round(dom[3] * 1e3, 3),
             "algorithmic_gflop_per_launch": round(dom[1] / max(dom[0], 1) / 1e9, 2), "avg_launch_ms": round(dom[3] / max(dom[0], 1) * 1e3, 4),
             "algorithmic_bytes_per_launch": round(dom[2] / max(dom[0], 1)), "traffic": tr, "traffic_source": traffic_src}
+    # the kernel TEMPLATE with the most time when its instantiations are summed (two boolean instantiations of one
+    # igemm_nt<64, 64, ...> loop were the largest pool of the step while `kernel` named a smaller single symbol)
+    fam = {}
+    for k, v in mfma.items():
+        base = k.split('<')[0] + ('<' + ', '.join(k.split('<', 1)[1].split(', ')[:2]).rstrip('>') + ', ...>' if '<' in k else '')
+        f = fam.setdefault(base, [0, 0.0, 0.0, 0.0])
+        for i in range(4):
+            f[i] += v[i]
+    if fam:
+        fname, fv = max(fam.items(), key=lambda kv: kv[1][3])
+        head["largest_template"] = {"template": fname, "launches_per_step": fv[0], "ms_per_step": round(fv[3] * 1e3, 3),
+                                    "achieved": round(fv[1] / max(fv[3], 1e-9) / 1e12, 2), "frac": round(fv[1] / max(fv[3], 1e-9) / 1e12 / peak, 4)}
     return head, table
 
 
@@ -570,23 +582,14 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
             for _ in range(8):
                 tr.train_step(batch)
                 torch.cuda.synchronize()
-            stalled = None
-            for attempt in range(2):
-                t0 = time.time()
-                marks[0].record()
-                for i in range(steps):
-                    last = tr.train_step(batch)
-                    marks[i + 1].record()                  # (events on the launch stream: per-step times without a host sync)
-                torch.cuda.synchronize()
-                dt = time.time() - t0
-                ps = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
-                # a one-off stall inside the window (seen once in round 5: a 1.7 s step among 20 of 54 ms -- the allocator re-growing after the
-                # launch-mode trial's pool was returned; r04 had the same, see above) is not the step's throughput: time the window once more and
-                # say so.  A second stalled window is reported as it is.
-                if attempt == 0 and ps[-1] > 5.0 * ps[steps // 2]:
-                    stalled = {"first_window_images_per_s": round(B * steps / dt, 2), "longest_step_ms": round(ps[-1], 1), "median_step_ms": round(ps[steps // 2], 3)}
-                    continue
-                break
+            # timed ONCE (round 6: the window is never replaced -- a stalled step stays in `images_per_s`; `longest_step_ms` and the median say so)
+            t0 = time.time()
+            marks[0].record()
+            for i in range(steps):
+                last = tr.train_step(batch)
+                marks[i + 1].record()                      # (events on the launch stream: per-step times without a host sync)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
         finally:
             gc.enable()
             gc.unfreeze()
@@ -608,7 +611,7 @@ def bf16_leg(opt, R, B, dev, consts, steps, warmup):
         fl, sec = sum(v[1] for v in sym.values()), sum(v[3] for v in sym.values())
         out = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
                "median_step_ms": round(median_ms, 3), "images_per_s_at_median_step": round(B / median_ms * 1e3, 2),
-               "batch": B, "steps": steps, "warmup": warmup, "launch": launch, "retimed_after_stall": stalled,
+               "longest_step_ms": round(per_step[-1], 3), "batch": B, "steps": steps, "warmup": warmup, "launch": launch,
                "auto_choice_ms": {k: round(v, 3) for k, v in choice.items()} if choice else None,
                "final_loss": round(loss_val, 4),
                "dominant_kernel": {k: head[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "ms_per_step", "algorithmic_bytes_per_launch", "traffic", "traffic_source")},
@@ -826,7 +829,9 @@ def main():
                                "%s, %dx%d" % ("3/4" if bf16 else "2", B, "bf16 MFMA GEMMs (fp32 accumulate, fp32 master weights / statistics / loss)" if bf16 else "fp32", R, R), "global_batch": world * B, "parallelism": "dp%d" % world,
                    "launch": "hipGraph(fwd+loss+bwd) + fused Adam" if args.graph else "eager, weight-gradient kernels overlapped on a side HIP stream, fused Adam", "final_loss": round(loss_val, 4),
                    "rccl_ranks": rccl_ranks, "allreduce_mb_per_step": round(trainer.n_live * (2 if bf16 else 4) / 1e6, 1) if world > 1 else 0.0,
-                   "broadcast_buffers": bool(args.broadcast_buffers)},
+                   "broadcast_buffers": bool(args.broadcast_buffers),
+                   # what pdfnet_amd/taped.py keeps alive for the life of the process (the trunk's activations of every recorded signature)
+                   "taped_pinned_mb": round(getattr(model.encoder.__dict__.get('_trunk_seg'), 'pinned_bytes', lambda: 0)() / 1e6, 1)},
     }
     if world == 1 and not bf16 and not args.graph and not args.no_collective_path:
         try:

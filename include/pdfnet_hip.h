@@ -465,6 +465,23 @@ long pdf_conv2d_winograd_workspace_floats(int N, int H, int W, int Cin, int Cout
 int pdf_debug_armed_slots(void);
 int pdf_debug_callopts_size(void);
 
+/* ---- x3 arithmetic (round 6, csrc/gemm_x3.hip): fp32 products on the bf16 matrix pipe ------------------------------------------
+ * gfx950 has no TF32 and its fp32 MFMA runs at 1/16 of the bf16 MFMA rate.  A fp32 value is exactly h + m + l with three bf16 values
+ * (8 + 8 + 8 significand bits), so six bf16 MFMAs with fp32 accumulation (hh', hm', mh', mm', hl', lh') reproduce the fp32 product to
+ * ~2^-24 relative -- the order of the native instruction's own rounding -- in 6/16 of the matrix-pipe time.  Operands are "x3 planes":
+ * three bf16 tensors of the operand's shape, component c at base + c * cs elements.  Used by the Winograd-domain products of the stride-1
+ * 3x3 convolutions (nn.Conv2d sites intaghand_encoder.py:602,617,675-693 and ResNet layers 2-3; PDF_X3=0 keeps the native fp32 MFMA).
+ *   pdf_x3_split            x [n] fp32 -> out: 3 planes of n bf16 (n % 8 == 0, cs % 8 == 0, 16-byte aligned)
+ *   pdf_x3_batched_gemm_nt  C_b [M][N] = A_b [M][K] B_b [N][K]^T, b < batch, both operands x3 planes (batch strides gsA / gsB in elements,
+ *                           gsC in floats); K % 32 == 0; variant: tile choice (0 = 256x128, 1 = 128x128, 2 = 128x64); nprod: 6 | 9 | 3
+ *   pdf_x3_batched_gemm_tn  slab_b [split][NI][NJ] = sum over the rows m of split of P_b [m][NI]^T Q_b [m][NJ] (weight-gradient shape)
+ *   pdf_batched_gemm_nt     the native fp32-MFMA batched product on plain fp32 operands (the comparison arm of tools/x3_bench.py) */
+int pdf_x3_split(const float* x, void* out, long n, long cs, void* stream);
+int pdf_x3_batched_gemm_nt(const void* A3, long csA, const void* B3, long csB, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, int variant, int nprod, void* stream);
+int pdf_batched_gemm_nt(const float* A, const float* B, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, void* stream);
+int pdf_x3_batched_gemm_tn(const void* P3, long csP, const void* Q3, long csQ, float* slab, int batch, long gsP, long gsQ, int M, int NI, int NJ, int splits, int variant, int nprod, void* stream);
+int pdf_batched_gemm_tn(const float* P, const float* Q, float* slab, int batch, long gsP, long gsQ, int M, int NI, int NJ, int splits, void* stream);
+
 /* ---- fused mesh decoder (round 5, csrc/meshdec.hip) ---------------------------------------------------------------------
  * One DualGraphLayer of the dual-hand GCN / attention decoder (lib/models/networks/model_attn/DualGraph.py:62-92: 4 x GCN_ResBlock per hand,
  * gcn.py:99-110 / 34-69; SelfAttn per hand, self_attn.py:63-85; cross-hand attention + MLP blocks, inter_attn.py:73-125) in two launches per

@@ -129,6 +129,40 @@ def op_decoder_blocks():
     save("op_inter_attn", x=x, y=y, outL=oL, outR=oR, **{"w_" + k: v for k, v in ia.state_dict().items()})
 
 
+def op_dualgraph_layers():
+    """One whole DualGraphLayer of the reference (model_attn/DualGraph.py:21-92: position embedding, 4 GCN_ResBlocks per hand, cross-hand
+    attention) at the REAL dimensions of the three levels -- the unit csrc/meshdec.hip fuses.  Dropout 0, so train and eval modes are the same
+    arithmetic; weights = synth.det_state_dict of the layer's own keys (salt level + 1), inputs = synth.dualgraph_case: neither is stored."""
+    DG = rh.ref_module("lib.models.networks.model_attn.DualGraph")
+    z = np.load(os.path.join(OUT, "..", "..", "pdfnet_amd", "data", "gcn_core.npz"))
+
+    def dense(hand, V):
+        ip, ix, dt = z["L_%s_%d_indptr" % (hand, V)], z["L_%s_%d_indices" % (hand, V)], z["L_%s_%d_data" % (hand, V)]
+        D = np.zeros((V, V), np.float32)
+        D[np.repeat(np.arange(V), np.diff(ip)), ix] = dt
+        return D
+    for level, (V, cin, cout) in enumerate(synth.DUALGRAPH_DIMS):
+        img = (12, 24, 48)[level]
+        layer = DG.DualGraphLayer(cin, cout, dense("left", V), dense("right", V), 2, 4, img, 256, 6, (256, 128, 64)[level], 4, 0.0)     # intaghand_decoder.py:125-139
+        layer.load_state_dict(synth.det_state_dict(layer.state_dict(), salt=level + 1))
+        layer.train()
+        xn, gyn = synth.dualgraph_case(level)
+        x = torch.from_numpy(xn).requires_grad_()
+        Lf, Rf = layer(x[0], x[1], torch.zeros(xn.shape[1], 256, img, img))
+        out = torch.stack((Lf, Rf))
+        out.backward(torch.from_numpy(gyn))
+        with torch.no_grad():
+            layer.eval()
+            Le, Re = layer(x[0], x[1], torch.zeros(xn.shape[1], 256, img, img))
+            assert float((torch.stack((Le, Re)) - out).abs().max()) == 0.0          # dropout 0: the two modes are one computation
+        names = [n for n, p in layer.named_parameters() if p.grad is not None]
+        gn = np.array([float(dict(layer.named_parameters())[n].grad.double().norm()) for n in names])
+        gh = np.stack([np.pad(dict(layer.named_parameters())[n].grad.flatten()[:64].numpy(), (0, max(0, 64 - dict(layer.named_parameters())[n].grad.numel()))) for n in names])
+        dx = x.grad
+        save("op_dualgraph_layer_L%d" % level, out=out, dx_sub=dx[..., level::8].contiguous(), dx_norm=dx.double().flatten(2).norm(dim=2),
+             grad_names=np.array(names), grad_norm=gn, grad_head=gh.astype(np.float32))
+
+
 def op_mano():
     """Reference ManoLayer (manolayer.py:257-334) driven by SYNTHETIC MANO-shaped constants written
     to a temporary pickle (the MPI-licensed MANO_*.pkl are not redistributed)."""
@@ -434,6 +468,8 @@ if __name__ == "__main__":
         e2e()
     if "e2e64" in which or "e2e" in which:
         e2e_fp64_oracle()
+    if "dualgraph" in which or "ops" in which:
+        op_dualgraph_layers()
     if "d2p" in which:
         depth2pcl_golden()
     if "fps" in which or "ops" in which:

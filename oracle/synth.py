@@ -105,6 +105,16 @@ def synthetic_batch(B, R=256, seed=1, variant='plain'):
     return dict(input=img, depth=depth, cloud=cloud, choose=choose, ind=ind, K_new=K, valid=valid)
 
 
+DUALGRAPH_DIMS = ((63, 512, 256), (126, 256, 128), (252, 128, 64))       # (V, C_in, C_out) of DualGraph layers 0 / 1 / 2 (intaghand_decoder.py:125-139)
+
+
+def dualgraph_case(level, B=3):
+    """Inputs of the op_dualgraph_layer_L* fixtures: x [2 (left, right), B, V, C_in] and the output gradient gy [2, B, V, C_out]."""
+    V, cin, cout = DUALGRAPH_DIMS[level]
+    g = np.random.Generator(np.random.PCG64(9100 + level))
+    return g.standard_normal((2, B, V, cin), dtype=np.float32), g.standard_normal((2, B, V, cout), dtype=np.float32)
+
+
 def to_torch(batch, device='cpu'):
     return {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
 

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpdfnet_hip.so")
-SOURCES = ["gemm.hip", "gemm_dma.hip", "winograd.hip", "gemm_bf16.hip", "pointops.hip", "norm.hip", "elementwise.hip", "graph.hip", "meshdec.hip", "meshdec_bf16.hip", "mano.hip", "frontend.hip", "loss.hip"]
+SOURCES = ["gemm.hip", "gemm_dma.hip", "gemm_x3.hip", "winograd.hip", "gemm_bf16.hip", "pointops.hip", "norm.hip", "elementwise.hip", "graph.hip", "meshdec.hip", "meshdec_bf16.hip", "mano.hip", "frontend.hip", "loss.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wno-unused-result"]
 
 

@@ -106,6 +106,22 @@ __device__ __forceinline__ unsigned int pdf_pk_bf16(float a, float b) {      // 
     pdf_bf16x2 v = __builtin_convertvector(f, pdf_bf16x2);
     return *reinterpret_cast<unsigned int*>(&v);
 }
+// x3 arithmetic (gemm_x3.hip): a fp32 pair -> its three bf16 components, packed pairs h / m / l with a = h + m + l exactly
+__device__ __forceinline__ void pdf_x3_split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = pdf_pk_bf16(a, b);
+    float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pdf_pk_bf16(ra, rb);
+    ra -= __uint_as_float(m << 16); rb -= __uint_as_float(m & 0xffff0000u);
+    l = pdf_pk_bf16(ra, rb);
+}
+// ... stored at element offsets o, o + cs, o + 2 cs of a bf16 tensor (o even)
+__device__ __forceinline__ void pdf_x3_store2(unsigned short* base, long o, long cs, float a, float b) {
+    unsigned h, m, l;
+    pdf_x3_split2(a, b, h, m, l);
+    *reinterpret_cast<unsigned*>(base + o) = h;
+    *reinterpret_cast<unsigned*>(base + o + cs) = m;
+    *reinterpret_cast<unsigned*>(base + o + 2 * cs) = l;
+}
 // Everything a call may take beyond its positional arguments -- must match `PdfCallOpts` of include/pdfnet_hip.h field for field
 // (tests/c_abi/c_client.c compares sizeof with pdf_debug_callopts_size()).  The `_x` form of an entry point takes it explicitly; the
 // plain form takes (and clears) the thread's hand-over slots FIRST THING, so no return path leaves a slot armed.

@@ -1,0 +1,505 @@
+// gemm_x3: fp32 products on the bf16 matrix pipe ("x3" arithmetic).
+//
+// gfx950 has no TF32 and its fp32 MFMA runs at the fp32 VECTOR rate, 1/16 of the bf16 MFMA rate (MI355X_MICROARCH.md "Matrix cores").
+// A fp32 value a is EXACTLY the sum of three bf16 values,  a = h + m + l  with  h = bf16(a), m = bf16(a - h), l = bf16(a - h - m)
+// (8 + 8 + 8 significand bits; each residual is exact in fp32), so a fp32 product is
+//     a b = hh' + (hm' + mh') + (mm' + hl' + lh') + (ml' + lm' + ll'),
+// every partial product exact in the fp32 accumulator's input (8 x 8 bits), the last group below 2^-24 |a b|.  Six bf16 MFMAs (the first
+// three groups) reproduce the fp32 product to ~2^-24 relative -- the same order as the one rounding the native v_mfma_f32_32x32x2_f32
+// makes per product -- at 6 / 16 of its matrix-pipe time.  Measured error against float64 beside the native kernel: tools/x3_bench.py.
+//
+// Operands come PRE-SPLIT ("x3 planes"): three bf16 tensors of the operand's shape, component c at base + c * cs elements.  The producers
+// that already stream the data write them (the Winograd transforms, winograd.hip); pdf_x3_split converts a plain fp32 tensor.
+//
+//   x3gemm_nt   C_b[M][N] = A_b[M][K] B_b[N][K]^T      both operands K-contiguous (transform-domain forward / backward-data products)
+//   x3gemm_tn   W_b[I][J] = sum_m P_b[m][I] Q_b[m][J]   both operands reduction-major (transform-domain weight gradient), split over m
+//
+// Both kernels: LDS-DMA ring (buffer_load_dwordx4 ... lds, gemm_dma.hip), one [rows][4 chunks] (NT) or [k][columns] (TN) image per
+// component, conflict-free fragment reads by XOR-swizzling WHICH global chunk a DMA lane fetches.
+#include "gemm_common.h"
+#include <cstdio>
+
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 x3_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r = {(int)(unsigned)(a & 0xffffffffu), (int)(unsigned)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    return r;
+}
+// (inline assembly: through the builtin the compiler drains the ring in front of every LDS read -- see gemm_dma.hip)
+__device__ __forceinline__ void x3_dma16(const i32x4& rsrc, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+
+// ---- fp32 -> x3 planes: 8 elements per thread, three 16-byte stores
+__global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ o, long n8, long cs) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const float4 u = reinterpret_cast<const float4*>(x)[2 * i], v = reinterpret_cast<const float4*>(x)[2 * i + 1];
+        uint4 h, m, l;
+        pdf_x3_split2(u.x, u.y, h.x, m.x, l.x); pdf_x3_split2(u.z, u.w, h.y, m.y, l.y);
+        pdf_x3_split2(v.x, v.y, h.z, m.z, l.z); pdf_x3_split2(v.z, v.w, h.w, m.w, l.w);
+        *reinterpret_cast<uint4*>(o + 8 * i) = h;
+        *reinterpret_cast<uint4*>(o + cs + 8 * i) = m;
+        *reinterpret_cast<uint4*>(o + 2 * cs + 8 * i) = l;
+    }
+}
+PDF_API int pdf_x3_split(const float* x, void* out, long n, long cs, hipStream_t s) {
+    if (n % 8 != 0 || cs % 8 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return PDF_E_BADARG;
+    hipLaunchKernelGGL(x3_split_kernel, dim3(grid_for(n / 8, 256, 256 * 16)), dim3(256), 0, s, x, (unsigned short*)out, n / 8, cs);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+struct X3Gemm {
+    const unsigned short* A; const unsigned short* B; float* C;
+    long csA, csB;                                      // component strides (elements)
+    long gsA, gsB, gsC;                                 // batch strides (elements of A / B, floats of C)
+    int M, N, K, batch, ldc;
+    int lda, ldb;                                       // NT: row strides of A / B in elements (>= K, multiples of 8)
+    int col_major_tiles;                                // NT: tile order (see the kernel)
+    int rows_per_split, splits;                         // TN: rows of the reduction per block (multiple of 32)
+};
+
+// the NPROD products of one (A fragment set, B fragment set) pair as (component of A, component of B), smallest terms first
+template <int NPROD> struct X3Prod;
+template <> struct X3Prod<3> { static constexpr int a[3] = {1, 0, 0}, b[3] = {0, 1, 0}; };
+template <> struct X3Prod<6> { static constexpr int a[6] = {2, 0, 1, 1, 0, 0}, b[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct X3Prod<9> { static constexpr int a[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, b[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; };
+
+// the linear tile list of a batched launch, each XCD a contiguous chunk (blocks b and b + 8 share an XCD; bijective form, guide T1)
+__device__ __forceinline__ int x3_xcd_lin(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+// one LDS-DMA instruction: lane l fetches 16 bytes at voff + soff (soff scalar: the K-step's advance costs no vector instruction)
+__device__ __forceinline__ void x3_dma16s(const i32x4& rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// Schedule shared by both kernels (round 6, profiles/r06_x3_sq.txt).  A K-step of 32 is NG = 2 TM TN accumulator-tile visits of NPROD MFMAs
+// each.  Issued as "all DMA, all LDS reads, then all MFMAs" the kernel ran at load time PLUS matrix time (the matrix pipe drains 32 cycles
+// after the last MFMA while the wave issues ~60-cycle DMA instructions): 45 % MFMA busy.  So the stream is cut into SLOTS of two MFMAs and
+// every slot carries at most one DMA instruction of the next tile and one fragment read of the second k-sub-step; the K advance of a DMA is
+// a scalar offset and rows past the matrix edge are CLAMPED to the last row (their products land in rows / columns the epilogue never
+// stores), so a DMA costs no vector instruction at all.
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// x3gemm_nt.  Block = WM x WN waves, each TM x TN accumulator tiles of 32 x 32; K-step 32: a row of a component image is 64 bytes = 4
+// chunks, chunk (r, c) at slot r * 4 + (c ^ ((r >> 2) & 3)) -- the 16 lanes of a ds_read_b128 group then hit 16 different 16-byte bank
+// groups (as igemm_bf16_dma, CPR = 4).  Lane l of an MFMA operand holds 8 consecutive k of row l & 31 at k-offset 8 (l >> 5).
+template <int WM, int WN, int TM, int TN, int ST, int NPROD>
+__global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
+    constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int AIMG = BM * 64, BIMG = BN * 64, STAGE = 3 * (AIMG + BIMG);
+    constexpr int NIA = 3 * BM / 16 / NW, NIB = 3 * BN / 16 / NW;         // DMA instructions per wave and K-step
+    static_assert(3 * BM / 16 % NW == 0 && 3 * BN / 16 % NW == 0, "tile / wave count");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN, per = ntm * ntn;
+    const int lin = x3_xcd_lin(blockIdx.x, per * g.batch);
+    const int b = lin / per, rem = lin - b * per;
+    int tmi, tni;
+    if (g.col_major_tiles) { tni = rem / ntm; tmi = rem - tni * ntm; }     // consecutive blocks share a B panel (few row tiles, many column tiles)
+    else { tmi = rem / ntn; tni = rem - tmi * ntn; }
+    const int m0 = tmi * BM, n0 = tni * BN;
+    const unsigned short* Ab = g.A + (long)b * g.gsA;
+    const unsigned short* Bb = g.B + (long)b * g.gsB;
+    float* __restrict__ Cb = g.C + (long)b * g.gsC;
+    // (one descriptor per operand spans its three components: the host checks 2 cs + rows K < 2^31 elements)
+    const i32x4 rsA = x3_rsrc(Ab, 0xfffffff0u), rsB = x3_rsrc(Bb, 0xfffffff0u);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const unsigned char*)smem;
+    auto swz = [](int r) { return (r >> 2) & 3; };
+
+    unsigned aoff[NIA], boff[NIB], alds[NIA], blds[NIB];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int gi = wave * NIA + i, comp = gi / (BM / 16), rb = gi - comp * (BM / 16);
+        const int row = rb * 16 + (lane >> 2);
+        const int kc = (lane & 3) ^ swz(row);
+        alds[i] = (unsigned)(comp * AIMG + rb * 1024);
+        aoff[i] = (unsigned)((comp * g.csA + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int gi = wave * NIB + i, comp = gi / (BN / 16), rb = gi - comp * (BN / 16);
+        const int row = rb * 16 + (lane >> 2);
+        const int kc = (lane & 3) ^ swz(row);
+        blds[i] = (unsigned)(3 * AIMG + comp * BIMG + rb * 1024);
+        boff[i] = (unsigned)((comp * g.csB + (long)min(n0 + row, g.N - 1) * g.ldb + kc * 8) * 2);
+    }
+    const int nk = g.K / 32;
+    int nissued = 0;
+    unsigned ko = 0, sbase = lds0;
+    auto piece = [&](int p) {
+        if (p < NIA) x3_dma16s(rsA, sbase + alds[p], aoff[p], ko);
+        else x3_dma16s(rsB, sbase + blds[p - NIA], boff[p - NIA], ko);
+    };
+    auto begin_issue = [&](int stage) {
+        ko = (unsigned)min(nissued, nk - 1) * 64u;      // (a tile past the end re-reads the last one into a stage nobody consumes: uniform vmcnt counts)
+        ++nissued;
+        sbase = lds0 + (unsigned)(stage * STAGE);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    const int h = lane >> 5;
+    int arow[TM], acx[TM], brow[TN], bcx[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { const int r = (wm * TM + i) * 32 + (lane & 31); arow[i] = r * 64; acx[i] = h ^ swz(r); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int r = (wn * TN + j) * 32 + (lane & 31); brow[j] = 3 * AIMG + r * 64; bcx[j] = h ^ swz(r); }
+
+#pragma unroll
+    for (int p = 0; p < ST - 1; ++p) {
+        begin_issue(p);
+#pragma unroll
+        for (int q = 0; q < NIA + NIB; ++q) piece(q);
+    }
+    int st = 0, stn = ST - 1;
+    constexpr int NG = 2 * TM * TN, NP = NIA + NIB, NR = (TM + TN) * 3;      // tile visits, DMA pieces, fragment reads of one k-sub-step
+    constexpr int NSLOT = NG * NPROD / 2;
+    using PR = X3Prod<NPROD>;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * (NIA + NIB)) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        begin_issue(stn);
+        const unsigned char* sp = smem + st * STAGE;
+        bf16x8v af[2][TM][3], bf[2][TN][3];
+        auto read1 = [&](int ks, int q) {                    // fragment read q < NR of k-sub-step ks
+            if (q < TM * 3) { const int i = q / 3, c = q % 3; af[ks][i][c] = *reinterpret_cast<const bf16x8v*>(sp + c * AIMG + arow[i] + ((acx[i] ^ (2 * ks)) << 4)); }
+            else { const int j = (q - TM * 3) / 3, c = (q - TM * 3) % 3; bf[ks][j][c] = *reinterpret_cast<const bf16x8v*>(sp + c * BIMG + brow[j] + ((bcx[j] ^ (2 * ks)) << 4)); }
+        };
+#pragma unroll
+        for (int q = 0; q < NR; ++q) read1(0, q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NG * NPROD; ++q) {
+            const int gi = q / NPROD, pr = q % NPROD;
+            const int ks = gi / (TM * TN), i = (gi / TN) % TM, j = gi % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PR::a[pr]], bf[ks][j][PR::b[pr]], acc[i][j], 0, 0, 0);
+            if (q % 2 == 1 || q == NG * NPROD - 1) {
+                const int slot = q / 2;
+                __builtin_amdgcn_sched_barrier(0);
+                // second sub-step's reads in the first slots (they are needed from slot NSLOT / 2 on), the DMA pieces on every other slot
+#pragma unroll
+                for (int r = slot * NR / (NSLOT / 2 - 1); r < (slot + 1) * NR / (NSLOT / 2 - 1) && r < NR; ++r)
+                    if (slot < NSLOT / 2 - 1) read1(1, r);
+                if (slot % 2 == 0 && slot / 2 < NP) piece(slot / 2);
+                if (slot == NSLOT - 1) {
+#pragma unroll
+                    for (int p = (NSLOT + 1) / 2; p < NP; ++p) piece(p);     // (more pieces than slots: the rest at the end)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        st = st == ST - 1 ? 0 : st + 1;
+        stn = stn == ST - 1 ? 0 : stn + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const bool whole = m0 + BM <= g.M && (double)g.M * g.ldc * 4.0 < 4294967000.0;
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cb, 0, whole ? (unsigned)g.M * (unsigned)g.ldc * 4u : 0u, 0x00020000);
+    const unsigned ldc4 = (unsigned)g.ldc * 4u;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool cok = col < g.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r0 = m0 + (wm * TM + i) * 32 + 4 * h;
+            if (whole) {
+                const unsigned vo = cok ? (unsigned)(r0 * g.ldc + col) * 4u : 0xffffffffu;
+                float v[16];                                   // (a copy first: __builtin_bit_cast on acc[i][j][r] itself stored element 0 sixteen times, hipcc 7.2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsC, vo, ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = r0 + (r & 3) + 8 * (r >> 2);
+                    if (cok && row < g.M) Cb[(long)row * g.ldc + col] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int ST>
+static int x3_launch_nt(const X3Gemm& g, int nprod, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const dim3 grid((unsigned)(cdiv(g.M, BM) * cdiv(g.N, BN) * g.batch));
+    char nm[96];
+    snprintf(nm, sizeof nm, "x3gemm_nt<%d, %d, %d, %d, %d, %d>", WM, WN, TM, TN, ST, nprod);
+    KTimer kt(nm, 2.0 * g.batch * g.M * g.N * g.K, g.batch * (6.0 * ((double)g.M + g.N) * g.K + 4.0 * g.M * g.N), s);
+    if (nprod == 9) hipLaunchKernelGGL((x3gemm_nt<WM, WN, TM, TN, ST, 9>), grid, dim3(WM * WN * 64), 0, s, g);
+    else if (nprod == 3) hipLaunchKernelGGL((x3gemm_nt<WM, WN, TM, TN, ST, 3>), grid, dim3(WM * WN * 64), 0, s, g);
+    else hipLaunchKernelGGL((x3gemm_nt<WM, WN, TM, TN, ST, 6>), grid, dim3(WM * WN * 64), 0, s, g);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// C_b [M][N] (row stride N) = A_b [M][K] B_b [N][K]^T for b < batch, operands as x3 planes.  K % 32 == 0.
+// variant: 0 = 256 x 128 tile, 8 waves;  1 = 128 x 128, 4 waves, 3-stage ring;  2 = 128 x 64, 4 waves;  nprod: 6 (default) | 9 | 3
+int pdf_internal_x3_batched_gemm(const void* A3, long csA, const void* B3, long csB, float* C, int batch, long gsA, long gsB, long gsC,
+                                 int M, int N, int K, int variant, int nprod, hipStream_t s) {
+    if (K % 32 != 0 || K < 32 || M < 1 || N < 1 || batch < 1) return PDF_E_BADARG;
+    if (2.0 * csA + (double)M * K >= 2147483000.0 || 2.0 * csB + (double)N * K >= 2147483000.0) return PDF_E_BADARG;      // 32-bit byte offsets
+    X3Gemm g = {};
+    g.A = (const unsigned short*)A3; g.B = (const unsigned short*)B3; g.C = C;
+    g.csA = csA; g.csB = csB; g.gsA = gsA; g.gsB = gsB; g.gsC = gsC;
+    g.M = M; g.N = N; g.K = K; g.batch = batch; g.ldc = N; g.lda = K; g.ldb = K;
+    g.col_major_tiles = cdiv(N, 128) > 4 * cdiv(M, 128);
+    if (variant < 0) {                                     // auto (tools/x3_bench.py): the 256-row tile where its row blocks fill the chip
+        variant = (long)cdiv(M, 256) * cdiv(N, 128) * batch >= 512 ? 0 : 1;
+    }
+    if (variant == 1) return x3_launch_nt<2, 2, 2, 2, 3>(g, nprod, s);
+    if (variant == 2) return x3_launch_nt<2, 2, 2, 1, 3>(g, nprod, s);
+    if (variant == 3) return x3_launch_nt<2, 2, 1, 1, 2>(g, nprod, s);     // 64 x 64, 48 KB of LDS
+    return x3_launch_nt<4, 2, 2, 2, 2>(g, nprod, s);
+}
+PDF_API int pdf_x3_batched_gemm_nt(const void* A3, long csA, const void* B3, long csB, float* C, int batch, long gsA, long gsB, long gsC,
+                                   int M, int N, int K, int variant, int nprod, hipStream_t s) {
+    return pdf_internal_x3_batched_gemm(A3, csA, B3, csB, C, batch, gsA, gsB, gsC, M, N, K, variant, nprod, s);
+}
+int pdf_internal_batched_gemm(const float* A, const float* B, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, hipStream_t s);
+// the native fp32-MFMA batched product (gemm.hip) behind the same shape of call: the comparison arm of tools/x3_bench.py
+PDF_API int pdf_batched_gemm_nt(const float* A, const float* B, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, hipStream_t s) {
+    return pdf_internal_batched_gemm(A, B, C, batch, gsA, gsB, gsC, M, N, K, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// x3gemm_tn.  The reduction index m is the slow axis of both operands, so a component image is [32 k-rows][BI columns] exactly as it
+// lies in HBM and the MFMA operand -- 8 consecutive k of ONE column per lane -- comes out of two transposing reads (ds_read_b64_tr_b16:
+// the 16 lanes of a group read 4 k-rows x 16 columns and receive them column-major; layout as gemm_bf16.hip frag_col).  The 32 lanes of
+// a tr-read service group touch 4 k-rows x 64 bytes: the 64-byte blocks of a row are XOR-swizzled by the row (k & 3; rows of 128 bytes:
+// (k >> 1) & 1) so that they fall on 4 different quarters of the 256-byte bank line -- again by choosing which global chunk a DMA lane
+// fetches.  Rows [split * rows_per_split, ...) of the reduction per block; the caller sums the splits.
+template <int WM, int WN, int TM, int TN, int ST, int NPROD>
+__global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
+    constexpr int NW = WM * WN, BI = WM * TM * 32, BJ = WN * TN * 32;
+    constexpr int PIMG = 32 * BI * 2, QIMG = 32 * BJ * 2, STAGE = 3 * (PIMG + QIMG);
+    constexpr int CP = BI / 8, CQ = BJ / 8;                               // 16-byte chunks per k-row
+    constexpr int NIP = 3 * 32 * CP / 64 / NW, NIQ = 3 * 32 * CQ / 64 / NW;
+    static_assert((3 * 32 * CP / 64) % NW == 0 && (3 * 32 * CQ / 64) % NW == 0, "tile / wave count");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int NI = g.M, NJ = g.N;                                         // (descriptor reuse: M = NI, N = NJ, K = rows of the reduction, % 32 == 0)
+    const int nti = (NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ, tiles = nti * ntj;
+    const int lin = x3_xcd_lin(blockIdx.x, tiles * g.splits * g.batch);
+    const int grp = lin / tiles, tile = lin - grp * tiles;
+    const int b = grp / g.splits, split = grp - b * g.splits;
+    const int ti = tile / ntj, tj = tile - ti * ntj;
+    const int i0 = ti * BI, j0 = tj * BJ;
+    const int ms = split * g.rows_per_split, me = min(g.K, ms + g.rows_per_split);
+    const int nk = (me - ms) / 32;
+    const unsigned short* Pb = g.A + (long)b * g.gsA;
+    const unsigned short* Qb = g.B + (long)b * g.gsB;
+    float* __restrict__ Wb = g.C + ((long)b * g.splits + split) * (long)NI * NJ;
+    const i32x4 rsP = x3_rsrc(Pb, 0xfffffff0u), rsQ = x3_rsrc(Qb, 0xfffffff0u);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const unsigned char*)smem;
+    auto swzp = [](int k) { return BI >= 128 ? (k & 3) << 2 : ((k >> 1) & 1) << 2; };      // XOR on the chunk index (a 64-byte block = 4 chunks)
+    auto swzq = [](int k) { return BJ >= 128 ? (k & 3) << 2 : ((k >> 1) & 1) << 2; };
+
+    unsigned poff[NIP], qoff[NIQ], plds[NIP], qlds[NIQ];
+#pragma unroll
+    for (int i = 0; i < NIP; ++i) {
+        constexpr int IPC = 32 * CP / 64, RPI = 64 / CP;                   // instructions per component image, k-rows per instruction
+        const int gi = wave * NIP + i, comp = gi / IPC, sub = gi - comp * IPC;
+        const int row = sub * RPI + lane / CP, ch = (lane % CP) ^ swzp(row);
+        plds[i] = (unsigned)(comp * PIMG + sub * 1024);
+        poff[i] = (unsigned)((comp * g.csA + (long)(ms + row) * NI + min(i0 + ch * 8, NI - 8)) * 2);     // (columns past NI: clamped, never stored)
+    }
+#pragma unroll
+    for (int i = 0; i < NIQ; ++i) {
+        constexpr int IPC = 32 * CQ / 64, RPI = 64 / CQ;
+        const int gi = wave * NIQ + i, comp = gi / IPC, sub = gi - comp * IPC;
+        const int row = sub * RPI + lane / CQ, ch = (lane % CQ) ^ swzq(row);
+        qlds[i] = (unsigned)(3 * PIMG + comp * QIMG + sub * 1024);
+        qoff[i] = (unsigned)((comp * g.csB + (long)(ms + row) * NJ + min(j0 + ch * 8, NJ - 8)) * 2);
+    }
+    int nissued = 0;
+    unsigned kp = 0, kq = 0, sbase = lds0;
+    auto piece = [&](int p) {
+        if (p < NIP) x3_dma16s(rsP, sbase + plds[p], poff[p], kp);
+        else x3_dma16s(rsQ, sbase + qlds[p - NIP], qoff[p - NIP], kq);
+    };
+    auto begin_issue = [&](int stage) {
+        const unsigned t = (unsigned)min(nissued, nk - 1);  // (past the end: the last tile again, into a stage nobody consumes)
+        kp = t * 64u * (unsigned)NI; kq = t * 64u * (unsigned)NJ;
+        ++nissued;
+        sbase = lds0 + (unsigned)(stage * STAGE);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    // transposing fragment reads: lane (g, q, p) = (lane >> 4, (lane & 15) >> 2, lane & 3) reads k-row 8 (g >> 1) + q (and + 4), columns c0 + 16 (g & 1) + 4 p ...
+    const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+    const int fk = 8 * (fg >> 1) + fq;                                     // (fk & 3 == fq, (fk + 4) & 3 == fq: one swizzle for both reads)
+    int pfo[TM], qfo[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int col = (wm * TM + i) * 32 + 16 * (fg & 1) + 4 * fp;       // chunk col / 8, byte (col & 7) * 2 inside it
+        pfo[i] = fk * BI * 2 + (((col >> 3) ^ swzp(fk)) << 4) + (col & 7) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 32 + 16 * (fg & 1) + 4 * fp;
+        qfo[j] = 3 * PIMG + fk * BJ * 2 + (((col >> 3) ^ swzq(fk)) << 4) + (col & 7) * 2;
+    }
+    typedef __attribute__((address_space(3))) s16x4v lds_s16x4;
+    auto frag = [&](const unsigned char* p, int rowbytes) {
+        const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+        const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * rowbytes));
+        s16x8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return *reinterpret_cast<bf16x8v*>(&v);
+    };
+
+#pragma unroll
+    for (int p = 0; p < ST - 1; ++p) {
+        begin_issue(p);
+#pragma unroll
+        for (int q = 0; q < NIP + NIQ; ++q) piece(q);
+    }
+    int st = 0, stn = ST - 1;
+    constexpr int NG = 2 * TM * TN, NP = NIP + NIQ, NR = (TM + TN) * 3;
+    constexpr int NSLOT = NG * NPROD / 2;
+    using PR = X3Prod<NPROD>;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * (NIP + NIQ)) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        begin_issue(stn);
+        const unsigned char* sp = smem + st * STAGE;
+        bf16x8v af[2][TM][3], bf[2][TN][3];
+        auto read1 = [&](int ks, int q) {
+            if (q < TM * 3) { const int i = q / 3, c = q % 3; af[ks][i][c] = frag(sp + c * PIMG + ks * 16 * BI * 2 + pfo[i], BI * 2); }
+            else { const int j = (q - TM * 3) / 3, c = (q - TM * 3) % 3; bf[ks][j][c] = frag(sp + c * QIMG + ks * 16 * BJ * 2 + qfo[j], BJ * 2); }
+        };
+#pragma unroll
+        for (int q = 0; q < NR; ++q) read1(0, q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NG * NPROD; ++q) {               // (schedule: see above x3gemm_nt)
+            const int gi = q / NPROD, pr = q % NPROD;
+            const int ks = gi / (TM * TN), i = (gi / TN) % TM, j = gi % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PR::a[pr]], bf[ks][j][PR::b[pr]], acc[i][j], 0, 0, 0);
+            if (q % 2 == 1 || q == NG * NPROD - 1) {
+                const int slot = q / 2;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = slot * NR / (NSLOT / 2 - 1); r < (slot + 1) * NR / (NSLOT / 2 - 1) && r < NR; ++r)
+                    if (slot < NSLOT / 2 - 1) read1(1, r);
+                if (slot % 2 == 0 && slot / 2 < NP) piece(slot / 2);
+                if (slot == NSLOT - 1) {
+#pragma unroll
+                    for (int p = (NSLOT + 1) / 2; p < NP; ++p) piece(p);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        st = st == ST - 1 ? 0 : st + 1;
+        stn = stn == ST - 1 ? 0 : stn + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int h = lane >> 5;
+    const bool whole = i0 + BI <= NI && (double)NI * NJ * 4.0 < 4294967000.0;
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, whole ? (unsigned)NI * (unsigned)NJ * 4u : 0u, 0x00020000);
+    const unsigned ldw4 = (unsigned)NJ * 4u;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = j0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool cok = col < NJ;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r0 = i0 + (wm * TM + i) * 32 + 4 * h;
+            if (whole) {
+                const unsigned vo = cok ? (unsigned)(r0 * NJ + col) * 4u : 0xffffffffu;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsW, vo, ((r & 3) + 8 * (r >> 2)) * ldw4, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = r0 + (r & 3) + 8 * (r >> 2);
+                    if (cok && row < NI) Wb[(long)row * NJ + col] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int ST>
+static int x3_launch_tn(const X3Gemm& g, int nprod, hipStream_t s) {
+    constexpr int BI = WM * TM * 32, BJ = WN * TN * 32;
+    const dim3 grid((unsigned)(cdiv(g.M, BI) * cdiv(g.N, BJ) * g.splits * g.batch));
+    char nm[96];
+    snprintf(nm, sizeof nm, "x3gemm_tn<%d, %d, %d, %d, %d, %d>", WM, WN, TM, TN, ST, nprod);
+    KTimer kt(nm, 2.0 * g.batch * g.K * g.M * g.N, g.batch * (6.0 * g.K * ((double)g.M + g.N) + 4.0 * g.splits * g.M * g.N), s);
+    if (nprod == 9) hipLaunchKernelGGL((x3gemm_tn<WM, WN, TM, TN, ST, 9>), grid, dim3(WM * WN * 64), 0, s, g);
+    else if (nprod == 3) hipLaunchKernelGGL((x3gemm_tn<WM, WN, TM, TN, ST, 3>), grid, dim3(WM * WN * 64), 0, s, g);
+    else hipLaunchKernelGGL((x3gemm_tn<WM, WN, TM, TN, ST, 6>), grid, dim3(WM * WN * 64), 0, s, g);
+    PDF_LAUNCH_CHECK();
+    return 0;
+}
+
+// rows of the reduction per split and the split count actually used (rows per split a multiple of 32)
+int pdf_internal_x3_tn_splits(int M, int splits) {
+    const int rps = cdiv(cdiv(M, splits < 1 ? 1 : splits), 32) * 32;
+    return cdiv(M, rps);
+}
+// slab_b [split][NI][NJ] = sum over the rows m of the split of P_b[m][:]^T Q_b[m][:], operands as x3 planes (P_b [M][NI], Q_b [M][NJ]).
+// NI % 8 == 0, NJ % 8 == 0, M % 32 == 0.  -> the split count used (> 0) or a negative error.  variant: 0 = 128 x 128 tile; 1 = 128 x 64; 2 = 256 x 128 (8 waves)
+int pdf_internal_x3_batched_wgemm(const void* P3, long csP, const void* Q3, long csQ, float* slab, int batch, long gsP, long gsQ,
+                                  int M, int NI, int NJ, int splits, int variant, int nprod, hipStream_t s) {
+    if (NI % 8 != 0 || NJ % 8 != 0 || M < 32 || M % 32 != 0 || batch < 1) return PDF_E_BADARG;
+    if (2.0 * csP + (double)M * NI >= 2147483000.0 || 2.0 * csQ + (double)M * NJ >= 2147483000.0) return PDF_E_BADARG;
+    X3Gemm g = {};
+    g.A = (const unsigned short*)P3; g.B = (const unsigned short*)Q3; g.C = slab;
+    g.csA = csP; g.csB = csQ; g.gsA = gsP; g.gsB = gsQ;
+    g.M = NI; g.N = NJ; g.K = M; g.batch = batch;
+    g.splits = pdf_internal_x3_tn_splits(M, splits);
+    g.rows_per_split = cdiv(cdiv(M, splits < 1 ? 1 : splits), 32) * 32;
+    int rc;
+    if (variant < 0) variant = (NI % 256 == 0 && (long)(NI / 256) * cdiv(NJ, 128) * g.splits * batch >= 512) ? 2 : 0;
+    if (variant == 1) rc = x3_launch_tn<2, 2, 2, 1, 3>(g, nprod, s);
+    else if (variant == 2) rc = x3_launch_tn<4, 2, 2, 2, 2>(g, nprod, s);
+    else rc = x3_launch_tn<2, 2, 2, 2, 3>(g, nprod, s);
+    return rc != 0 ? (rc < 0 ? rc : -rc) : g.splits;
+}
+PDF_API int pdf_x3_batched_gemm_tn(const void* P3, long csP, const void* Q3, long csQ, float* slab, int batch, long gsP, long gsQ,
+                                   int M, int NI, int NJ, int splits, int variant, int nprod, hipStream_t s) {
+    const int rc = pdf_internal_x3_batched_wgemm(P3, csP, Q3, csQ, slab, batch, gsP, gsQ, M, NI, NJ, splits, variant, nprod, s);
+    return rc > 0 ? 0 : (rc == 0 ? PDF_E_BADARG : rc);
+}
+int pdf_internal_batched_wgemm(const float* P, const float* Q, float* slab, int batch, long gsP, long gsQ, int M, int NI, int NJ, int splits, hipStream_t s);
+// the native fp32 weight-gradient-shaped batched product (gemm.hip; rows per split a multiple of 16)
+PDF_API int pdf_batched_gemm_tn(const float* P, const float* Q, float* slab, int batch, long gsP, long gsQ, int M, int NI, int NJ, int splits, hipStream_t s) {
+    const int rc = pdf_internal_batched_wgemm(P, Q, slab, batch, gsP, gsQ, M, NI, NJ, splits, s);
+    return rc > 0 ? 0 : (rc == 0 ? PDF_E_BADARG : rc);
+}

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 //   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-template <bool FLIP>
+// X3: U is written as x3 planes (three bf16 tensors [36][N][K], component stride 36 N K elements -- gemm_x3.hip) instead of fp32
+template <bool FLIP, bool X3>
 __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
     const int N = FLIP ? Cin : Cout, K = FLIP ? Cout : Cin;
     const long total = (long)N * K;
@@ -173,12 +174,17 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             const float g0 = t[a][0], g1 = t[a][1], g2 = t[a][2];
-            U[(long)(a * 6 + 0) * total + i] = g0 * 0.25f;
-            U[(long)(a * 6 + 1) * total + i] = -(g0 + g1 + g2) * (1.f / 6.f);
-            U[(long)(a * 6 + 2) * total + i] = -(g0 - g1 + g2) * (1.f / 6.f);
-            U[(long)(a * 6 + 3) * total + i] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
-            U[(long)(a * 6 + 4) * total + i] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
-            U[(long)(a * 6 + 5) * total + i] = g2;
+            const float u[6] = {g0 * 0.25f, -(g0 + g1 + g2) * (1.f / 6.f), -(g0 - g1 + g2) * (1.f / 6.f),
+                                g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f), g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f), g2};
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                if constexpr (X3) {
+                    unsigned h, m, l;
+                    pdf_x3_split2(u[b], 0.f, h, m, l);
+                    unsigned short* o = reinterpret_cast<unsigned short*>(U) + (long)(a * 6 + b) * total + i;
+                    o[0] = (unsigned short)h; o[36 * total] = (unsigned short)m; o[72 * total] = (unsigned short)l;
+                } else U[(long)(a * 6 + b) * total + i] = u[b];
+            }
         }
     }
 }
@@ -201,6 +207,7 @@ __device__ __forceinline__ void wino4_bt(float2 (&v)[6]) {
 #undef E5
 }
 // x [N][H][W][C] -> V [36][T][C], T = N (H/4) (W/4); one thread = 2 channels of one 6x6 patch (72 registers of data)
+template <bool X3>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, int N, int H, int W, int C) {
     const int C2 = C >> 1, TW = W >> 2, TH = H >> 2;
     const long T = (long)N * TH * TW, total = T * C2;
@@ -231,7 +238,10 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
         for (int a = 0; a < 6; ++a) {                        // rows: (B^T d) B
             wino4_bt(d[a]);
 #pragma unroll
-            for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(o + (long)(a * 6 + b) * plane) = d[a][b];
+            for (int b = 0; b < 6; ++b) {
+                if constexpr (X3) pdf_x3_store2(reinterpret_cast<unsigned short*>(V), t * C + c + (long)(a * 6 + b) * plane, 36 * plane, d[a][b].x, d[a][b].y);
+                else *reinterpret_cast<float2*>(o + (long)(a * 6 + b) * plane) = d[a][b];
+            }
         }
     }
 }
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 //     dL/dU[xi][n][c] = sum_t dYh[xi][t][n] V[xi][t][c],   dYh = A dY A^T (each 4x4 tile of dy -> 6x6),   dL/dg = G^T (dL/dU) G
 // i.e. 36 weight-gradient-shaped products over T = N H W / 16 tiles instead of one over N H W pixels x 9 taps: 4x fewer multiplications.
 // dy [N][H][W][Co] -> dYh [36][T][Co]: A = (A^T)^T = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1]
+template <bool X3>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ Yh, int N, int H, int W, int Co) {
     const int C2 = Co >> 1, TW = W >> 2, TH = H >> 2;
     const long T = (long)N * TH * TW, total = T * C2;
@@ -328,12 +339,12 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
 #define Q3(k) e0.k + 2.f * e1.k + 4.f * e2.k + 8.f * e3.k
 #define Q4(k) e0.k - 2.f * e1.k + 4.f * e2.k - 8.f * e3.k
 #define Q5(k) e3.k
-            *reinterpret_cast<float2*>(o + (long)(a * 6 + 0) * plane) = A2(Q0);
-            *reinterpret_cast<float2*>(o + (long)(a * 6 + 1) * plane) = A2(Q1);
-            *reinterpret_cast<float2*>(o + (long)(a * 6 + 2) * plane) = A2(Q2);
-            *reinterpret_cast<float2*>(o + (long)(a * 6 + 3) * plane) = A2(Q3);
-            *reinterpret_cast<float2*>(o + (long)(a * 6 + 4) * plane) = A2(Q4);
-            *reinterpret_cast<float2*>(o + (long)(a * 6 + 5) * plane) = A2(Q5);
+            const float2 q[6] = {A2(Q0), A2(Q1), A2(Q2), A2(Q3), A2(Q4), A2(Q5)};
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                if constexpr (X3) pdf_x3_store2(reinterpret_cast<unsigned short*>(Yh), t * Co + c + (long)(a * 6 + b) * plane, 36 * plane, q[b].x, q[b].y);
+                else *reinterpret_cast<float2*>(o + (long)(a * 6 + b) * plane) = q[b];
+            }
 #undef Q0
 #undef Q1
 #undef Q2
@@ -385,6 +396,23 @@ __global__ __launch_bounds__(256) void wino4_wgrad_out_kernel(const float* __res
     }
 }
 int pdf_internal_batched_wgemm(const float* P, const float* Q, float* slab, int batch, long gsP, long gsQ, int M, int NI, int NJ, int splits, hipStream_t s);
+int pdf_internal_x3_batched_gemm(const void* A3, long csA, const void* B3, long csB, float* C, int batch, long gsA, long gsB, long gsC,
+                                 int M, int N, int K, int variant, int nprod, hipStream_t s);
+int pdf_internal_x3_batched_wgemm(const void* P3, long csP, const void* Q3, long csQ, float* slab, int batch, long gsP, long gsQ,
+                                  int M, int NI, int NJ, int splits, int variant, int nprod, hipStream_t s);
+// x3 arithmetic for the F(4x4) transform-domain products (gemm_x3.hip): the transforms write their outputs as x3 planes (6 bytes per element
+// instead of 4) and the 36 products run on the bf16 matrix pipe, six MFMAs per fp32 product.  Whether a transformed tensor [36][T][C] is x3
+// depends on (T, C) ONLY, so every launch that reads it -- the forward that made V, a head sharing it, the weight gradient -- agrees:
+// C % 32 == 0 (a K-step of the products) and the three components within 32-bit byte offsets.  PDF_X3=0: the native fp32 MFMA.
+static int x3_mode() {
+    static const int v = getenv("PDF_X3") ? atoi(getenv("PDF_X3")) : 1;
+    return v;
+}
+static int x3_nprod() {
+    static const int v = getenv("PDF_X3_NPROD") ? atoi(getenv("PDF_X3_NPROD")) : 6;
+    return v;
+}
+static bool wino_x3(long T, int C) { return x3_mode() != 0 && C % 32 == 0 && T % 32 == 0 && 73.0 * (double)T * C < 2147483000.0; }
 int pdf_internal_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s);
 long pdf_internal_colsum_ws(int C, long R);
 static long wino_minpt();
@@ -408,22 +436,32 @@ int pdf_internal_wino_wgrad_eligible(int N, int H, int W, int Cin, int Cout, int
 }
 long pdf_internal_wino_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
     const long T = (long)N * (H / 4) * (W / 4);
-    return 36L * T * Cin + 36L * T * Cout + 36L * wino_wgrad_splits(T, Cout, Cin) * Cout * Cin + pdf_internal_colsum_ws(Cout, (long)N * H * W) + 64;
+    const bool x3 = wino_x3(T, Cin) && wino_x3(T, Cout);
+    return (x3 ? 54L : 36L) * T * Cin + (x3 ? 54L : 36L) * T * Cout + 36L * wino_wgrad_splits(T, Cout, Cin) * Cout * Cin + pdf_internal_colsum_ws(Cout, (long)N * H * W) + 64;
 }
 // dw [Cout][3][3][Cin] (+)= the weight gradient of the stride-1 3x3 convolution; db [Cout] (+)= column sums of dy (optional)
 // v_cached: the forward's V for the same x (pdf_internal_wino_v_offset), or NULL -- then the input is transformed here
 int pdf_internal_conv3x3_winograd_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* db, float* ws,
                                         int N, int H, int W, int Cin, int Cout, int accumulate, const float* v_cached, hipStream_t s) {
     const long T = (long)N * (H / 4) * (W / 4);
+    const bool x3 = wino_x3(T, Cin) && wino_x3(T, Cout);
+    if (v_cached != nullptr && wino_x3(T, Cin) != x3) v_cached = nullptr;       // (the forward's V is in the other format: transform here)
+    const long per = x3 ? 54L : 36L;                           // floats of workspace per (tile, channel): 36 fp32 or 3 x 36 bf16
     float* V = ws;
-    float* Yh = V + 36L * T * Cin;
-    float* slab = Yh + 36L * T * Cout;
-    int splits = wino_wgrad_splits(T, Cout, Cin);
+    float* Yh = V + per * T * Cin;
+    float* slab = Yh + per * T * Cout;
+    const int splits = wino_wgrad_splits(T, Cout, Cin);       // (the x3 product may use fewer: rows per split a multiple of 32)
     float* cws = slab + 36L * splits * Cout * Cin;
-    if (v_cached == nullptr) hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(T * (Cin / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, V, N, H, W, Cin);
-    hipLaunchKernelGGL(wino4_dy_kernel, dim3(grid_for(T * (Cout / 2), 256, 256 * 32)), dim3(256), 0, s, dy, lddy, Yh, N, H, W, Cout);
+    if (v_cached == nullptr) {
+        if (x3) hipLaunchKernelGGL((wino4_input_kernel<true>), dim3(grid_for(T * (Cin / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, V, N, H, W, Cin);
+        else hipLaunchKernelGGL((wino4_input_kernel<false>), dim3(grid_for(T * (Cin / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, V, N, H, W, Cin);
+    }
+    if (x3) hipLaunchKernelGGL((wino4_dy_kernel<true>), dim3(grid_for(T * (Cout / 2), 256, 256 * 32)), dim3(256), 0, s, dy, lddy, Yh, N, H, W, Cout);
+    else hipLaunchKernelGGL((wino4_dy_kernel<false>), dim3(grid_for(T * (Cout / 2), 256, 256 * 32)), dim3(256), 0, s, dy, lddy, Yh, N, H, W, Cout);
     PDF_LAUNCH_CHECK();
-    const int used = pdf_internal_batched_wgemm(Yh, v_cached != nullptr ? v_cached : V, slab, 36, T * Cout, T * Cin, (int)T, Cout, Cin, splits, s);
+    const float* Vq = v_cached != nullptr ? v_cached : V;
+    const int used = x3 ? pdf_internal_x3_batched_wgemm(Yh, 36L * T * Cout, Vq, 36L * T * Cin, slab, 36, T * Cout, T * Cin, (int)T, Cout, Cin, splits, -1, x3_nprod(), s)
+                        : pdf_internal_batched_wgemm(Yh, Vq, slab, 36, T * Cout, T * Cin, (int)T, Cout, Cin, splits, s);
     if (used <= 0) return used < 0 ? used : PDF_E_BADARG;
     if (used > 1) hipLaunchKernelGGL(wino4_slab_sum_kernel, dim3(grid_for(36L * Cout * Cin / 4)), dim3(256), 0, s, slab, used, (long)Cout * Cin / 4);
     hipLaunchKernelGGL(wino4_wgrad_out_kernel, dim3(grid_for((long)Cout * Cin)), dim3(256), 0, s, slab, used, dw, Cout, Cin, accumulate);
@@ -464,16 +502,18 @@ int pdf_internal_wino_tile(int N, int H, int W, int Ck, int Cn, int flip) {
     }
     return 0;
 }
-// floats of workspace a call needs: U + V + M
+// floats of workspace a call needs: U + V + M (U and V at 6 bytes per element when the launch is x3)
 long pdf_internal_wino_workspace(int N, int H, int W, int Ck, int Cn, int flip) {
     const int m = pdf_internal_wino_tile(N, H, W, Ck, Cn, flip);
     if (m == 0) return 0;
     const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
+    if (m == 4 && wino_x3(T, Ck)) return 54L * Cn * Ck + 54L * T * Ck + P * T * Cn;
     return P * Cn * Ck + P * T * Ck + P * T * Cn;
 }
 // where V starts in the forward workspace (U comes first), or -1 when the forward is not an F(4x4) launch
 long pdf_internal_wino_v_offset(int N, int H, int W, int Ck, int Cn) {
-    return pdf_internal_wino_tile(N, H, W, Ck, Cn, 0) == 4 ? 36L * Cn * Ck : -1;
+    if (pdf_internal_wino_tile(N, H, W, Ck, Cn, 0) != 4) return -1;
+    return (wino_x3((long)N * (H / 4) * (W / 4), Ck) ? 54L : 36L) * Cn * Ck;
 }
 // Is this convolution taken by the Winograd path?  (3x3, stride 1, pad 1, map edges multiples of the tile, channel counts the fast GEMM
 // tiles like, enough work)
@@ -490,22 +530,29 @@ int pdf_internal_conv3x3_winograd(const float* x, int ldx, const float* w, const
                                   int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, const float* v_shared, hipStream_t s) {
     const int m = pdf_internal_wino_tile(N, H, W, Ck, Cn, flip);
     const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
+    const bool x3 = m == 4 && wino_x3(T, Ck);
+    const long upl = x3 ? 54L * Cn * Ck : P * Cn * Ck, vpl = x3 ? 54L * T * Ck : P * T * Ck;      // floats of U and V
     float* U = ws;
-    const float* V = U + P * Cn * Ck;
-    float* Mx = ws + P * Cn * Ck + P * T * Ck;
+    const float* V = U + upl;
+    float* Mx = ws + upl + vpl;
     const int gw = grid_for((long)Cn * Ck);
     if (m == 4) {
-        if (flip) hipLaunchKernelGGL((wino4_weight_kernel<true>), dim3(gw), dim3(256), 0, s, w, U, Ck, Cn);
-        else hipLaunchKernelGGL((wino4_weight_kernel<false>), dim3(gw), dim3(256), 0, s, w, U, Cn, Ck);
+        if (x3 && flip) hipLaunchKernelGGL((wino4_weight_kernel<true, true>), dim3(gw), dim3(256), 0, s, w, U, Ck, Cn);
+        else if (x3) hipLaunchKernelGGL((wino4_weight_kernel<false, true>), dim3(gw), dim3(256), 0, s, w, U, Cn, Ck);
+        else if (flip) hipLaunchKernelGGL((wino4_weight_kernel<true, false>), dim3(gw), dim3(256), 0, s, w, U, Ck, Cn);
+        else hipLaunchKernelGGL((wino4_weight_kernel<false, false>), dim3(gw), dim3(256), 0, s, w, U, Cn, Ck);
         if (v_shared != nullptr && !flip) V = v_shared;
-        else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(T * (Ck / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, U + P * Cn * Ck, N, H, W, Ck);
+        else if (x3) hipLaunchKernelGGL((wino4_input_kernel<true>), dim3(grid_for(T * (Ck / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, U + upl, N, H, W, Ck);
+        else hipLaunchKernelGGL((wino4_input_kernel<false>), dim3(grid_for(T * (Ck / 2), 256, 256 * 32)), dim3(256), 0, s, x, ldx, U + upl, N, H, W, Ck);
     } else {
         if (flip) hipLaunchKernelGGL((wino_weight_kernel<true>), dim3(gw), dim3(256), 0, s, w, U, Ck, Cn);        // w [Cout = Ck][3][3][Cin = Cn]
         else hipLaunchKernelGGL((wino_weight_kernel<false>), dim3(gw), dim3(256), 0, s, w, U, Cn, Ck);
-        hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(T * (Ck / 4), 256, 256 * 32)), dim3(256), 0, s, x, ldx, U + P * Cn * Ck, N, H, W, Ck);
+        hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(T * (Ck / 4), 256, 256 * 32)), dim3(256), 0, s, x, ldx, U + upl, N, H, W, Ck);
     }
     PDF_LAUNCH_CHECK();
-    if (int rc = pdf_internal_batched_gemm(V, U, Mx, (int)P, T * Ck, (long)Cn * Ck, T * Cn, (int)T, Cn, Ck, s)) return rc;
+    if (x3) {
+        if (int rc = pdf_internal_x3_batched_gemm(V, 36L * T * Ck, U, 36L * Cn * Ck, Mx, 36, T * Ck, (long)Cn * Ck, T * Cn, (int)T, Cn, Ck, -1, x3_nprod(), s)) return rc;
+    } else if (int rc = pdf_internal_batched_gemm(V, U, Mx, (int)P, T * Ck, (long)Cn * Ck, T * Cn, (int)T, Cn, Ck, s)) return rc;
     if (m == 4) hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(T * (Cn / 2), 256, 256 * 32)), dim3(256), 0, s, Mx, bias, y, ldy, N, H, W, Cn, act, accum);
     else hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(T * (Cn / 4), 256, 256 * 32)), dim3(256), 0, s, Mx, bias, y, ldy, N, H, W, Cn, act, accum);
     PDF_LAUNCH_CHECK();

@@ -21,7 +21,12 @@ is the segment.  Same contract as torch.cuda.make_graphed_callables, restated fo
   * bf16 shadows travel as Python attributes of tensors: the replayed outputs get theirs re-attached;
   * the few aten kernels inside the segment (gradient fan-in additions, zero fills) are taped as out-variant calls on the pinned tensors; any
     other aten kernel aborts the recording and the segment stays eager.
-Results are bit-identical to the eager segment (`tests/test_trainer_gpu.py::test_taped_trunk_steps_equal_eager_steps`).
+Results are bit-identical to the eager segment (`tests/test_trainer_gpu.py::test_taped_trunk_equals_the_eager_trunk_bit_for_bit`,
+`::test_taped_trunk_inside_the_train_step`, `::test_taped_trunk_is_not_recorded_over_accumulated_gradients`).
+
+Guard rails (round 6): a recording is REFUSED -- the call runs eagerly and the next qualifying call tries again -- while any gradient of the
+segment's parameters is non-zero (the recording pass zeroes them afterwards: with a micro-batch already accumulated that would lose it);
+`TapedSegment.pinned_bytes()` reports what the tapes hold alive (bench.py: config.taped_pinned_mb).
 """
 import os
 
@@ -159,7 +164,10 @@ class TapedSegment:
         if entry is None:
             if len(self.entries) >= self.MAX_ENTRIES:          # every signature pins its own activations: a stream of changing shapes stays eager
                 return self.eager(x)
-            entry = self.entries[key] = self._record(x)
+            entry = self._record(x)
+            if entry is None:                                  # gradients already hold something: not now (see _record)
+                return self.eager(x)
+            self.entries[key] = entry
         if entry is False or entry['busy']:                    # refused once for this signature / a second forward before the first one's backward
             return self.eager(x)
         return _Replay.apply(self, entry, x)
@@ -170,6 +178,10 @@ class TapedSegment:
             # (weight-gradient work in flight belongs to a backward pass: the passes below would add to the same gradients)
             raise RuntimeError("pdfnet_amd: a taped segment must be recorded before the step's backward has started")
         params = [p for m in self.modules for p in m.parameters() if p.requires_grad]
+        # the recording pass ends by zeroing these gradients (it is a real pass that must leave no trace): refuse while they hold a previous
+        # micro-batch of an accumulation loop -- one reduction and one host read, once per signature
+        if params and float(torch.stack(torch._foreach_norm([p.grad for p in params])).sum()) != 0.0:
+            return None
         bufs = [b for m in self.modules for b in m.buffers()]
         BatchNorm.flush_counters()
         saved = [b.clone() for b in bufs]
@@ -213,4 +225,25 @@ class TapedSegment:
             warnings.warn("pdfnet_amd: segment not taped, it runs aten kernels the tape does not know: %s" % sorted(set(rec.refused)))
             return False
         return {'busy': False, 'x': sx, 'outs': tuple(outs), 'gouts': gouts, 'gx': gin, 'fwd': fwd, 'bwd': bwd, 'pins': pins, 'wg_keys': wg_keys,
-                'stream': hip._raw_stream(hip._raw_device())}
+                'stream': hip._raw_stream(hip._raw_device()), 'pinned_bytes': _storage_bytes(pins)}
+
+    def pinned_bytes(self):
+        """Device bytes the recorded tapes keep alive for the life of the process (every activation of every recorded signature)."""
+        return sum(e['pinned_bytes'] for e in self.entries.values() if e)
+
+
+def _storage_bytes(obj, seen=None):
+    """Bytes of the distinct device storages reachable from a nest of tuples / lists of tensors."""
+    seen = {} if seen is None else seen
+    stack = [obj]
+    while stack:
+        o = stack.pop()
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                s = o.untyped_storage()
+                seen[s.data_ptr()] = max(seen.get(s.data_ptr(), 0), s.nbytes())
+        elif isinstance(o, (tuple, list)):
+            stack.extend(o)
+        elif isinstance(o, dict):
+            stack.extend(o.values())
+    return sum(seen.values())

@@ -70,6 +70,30 @@ def test_attention_blocks():
     assert np.allclose(oR.detach().numpy(), g["outR"], atol=2e-5)
 
 
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_dualgraph_layer_at_the_real_dimensions(level):
+    """The oracle's DualGraphLayer against the reference's (DualGraph.py:21-92) on op_dualgraph_layer_L*: output, input gradient, gradient norms."""
+    from oracle import synth
+    g = gold("op_dualgraph_layer_L%d" % level)
+    V, cin, cout = synth.DUALGRAPH_DIMS[level]
+    gc = O.load_graph_constants()
+    layer = O.DualGraphLayer(V, cin, cout, gc['L_left'][level], gc['L_right'][level], 4, [12, 24, 48][level], 256, 6, (256, 128, 64)[level], 4, 0.0)
+    layer.load_state_dict(synth.det_state_dict(layer.state_dict(), salt=level + 1))
+    xn, gyn = synth.dualgraph_case(level)
+    x = T(xn).requires_grad_()
+    Lf, Rf = layer(x[0], x[1])
+    out = torch.stack((Lf, Rf))
+    out.backward(T(gyn))
+    assert np.abs(out.detach().numpy() - g["out"]).max() <= 2e-5 * max(1.0, np.abs(g["out"]).max())
+    assert np.abs(x.grad[..., level::8].numpy() - g["dx_sub"]).max() <= 1e-4 * np.abs(g["dx_sub"]).max()
+    grads = {n: p.grad for n, p in layer.named_parameters() if p.grad is not None}
+    assert set(grads) == set(str(n) for n in g["grad_names"])
+    for i, n in enumerate(g["grad_names"]):
+        if str(n).endswith("w_ks.bias"):
+            continue
+        assert abs(float(grads[str(n)].double().norm()) / float(g["grad_norm"][i]) - 1) <= 1e-3, n
+
+
 def test_mano_layer():
     g = gold("op_mano_layer")
     for side in ("left", "right"):

@@ -321,3 +321,39 @@ def test_taped_trunk_inside_the_train_step(monkeypatch):
     assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(a[1].abs().max())
     assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-7)
     assert a[4] == b[4] == 4
+
+
+def test_taped_trunk_is_not_recorded_over_accumulated_gradients(monkeypatch):
+    """Round 6 guard rail: the recording pass of pdfnet_amd/taped.py ends by zeroing the segment's gradients.  If the first taped call ever happens
+    in the SECOND micro-batch of an accumulation loop that would silently lose the first one -- so the recording is refused while any of those
+    gradients is non-zero (the call runs eagerly, the accumulated gradient survives) and happens at the next call that finds them clean."""
+    from pdfnet_amd import functional as F
+    from pdfnet_amd import taped
+    from pdfnet_amd.trains.base_trainer import Trainer
+    monkeypatch.setattr(taped, 'TRUNK_TAPE', True)
+    opt, m, crit, _ = _setup(R=128, B=2)
+    tr = Trainer(opt, m, crit, lr=1e-4)
+    m.train()
+    enc = m.encoder
+    enc.__dict__.pop('_trunk_seg', None)
+    x = torch.randn(4, 64, 32, 32, device='cuda').contiguous(memory_format=torch.channels_last)
+    tr.optimizer.zero_grad()
+    w = enc.resnet.layer2[0].conv1.weight
+    w.grad.fill_(0.25)                                           # "a previous micro-batch"
+    xr = x.clone().requires_grad_()
+    outs = enc.trunk_layers(xr)
+    seg = enc.__dict__['_trunk_seg']
+    assert len(seg.entries) == 0 and seg.pinned_bytes() == 0      # refused: nothing recorded, nothing pinned
+    torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+    F.join_wgrad()
+    torch.cuda.synchronize()
+    assert float((w.grad - 0.25).abs().max()) > 0 and float(w.grad.abs().min()) >= 0          # accumulated ON TOP of the 0.25, not from zero
+    g1 = w.grad.clone()
+    tr.optimizer.zero_grad()
+    xr = x.clone().requires_grad_()
+    outs = enc.trunk_layers(xr)                                    # clean gradients: recorded now
+    assert len(seg.entries) == 1 and all(e for e in seg.entries.values()) and seg.pinned_bytes() > 0
+    torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+    F.join_wgrad()
+    torch.cuda.synchronize()
+    assert torch.allclose(w.grad + 0.25, g1, rtol=1e-5, atol=1e-6)
