@@ -477,6 +477,7 @@ int pdf_debug_callopts_size(void);
  *   pdf_x3_batched_gemm_tn  slab_b [split][NI][NJ] = sum over the rows m of split of P_b [m][NI]^T Q_b [m][NJ] (weight-gradient shape)
  *   pdf_batched_gemm_nt     the native fp32-MFMA batched product on plain fp32 operands (the comparison arm of tools/x3_bench.py) */
 int pdf_x3_split(const float* x, void* out, long n, long cs, void* stream);
+int pdf_debug_x3_stamps(unsigned long long* out);       /* diagnostic builds (-DX3_STAMPS=1) only: phase clocks of block 0 of the last x3gemm_nt launch; 0 otherwise */
 int pdf_x3_batched_gemm_nt(const void* A3, long csA, const void* B3, long csB, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, int variant, int nprod, void* stream);
 int pdf_batched_gemm_nt(const float* A, const float* B, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, void* stream);
 int pdf_x3_batched_gemm_tn(const void* P3, long csP, const void* Q3, long csQ, float* slab, int batch, long gsP, long gsQ, int M, int NI, int NJ, int splits, int variant, int nprod, void* stream);

@@ -53,6 +53,15 @@ PDF_API int pdf_x3_split(const float* x, void* out, long n, long cs, hipStream_t
     return 0;
 }
 
+// diagnostic build (-DX3_STAMPS=1): wave 0 of block 0 sums the shader clocks it spends (a) parked at the top-of-loop wait + barrier, (b) from there to
+// its first MFMA (fragment reads), (c) in the MFMA / DMA slots, and stamps s_memtime / s_memrealtime around the K loop (the clock the chip holds)
+#ifndef X3_STAMPS
+#define X3_STAMPS 0
+#endif
+#if X3_STAMPS
+__device__ unsigned long long g_x3_stamps[16];
+#define X3_T() __builtin_readcyclecounter()
+#endif
 struct X3Gemm {
     const unsigned short* A; const unsigned short* B; float* C;
     long csA, csB;                                      // component strides (elements)
@@ -171,9 +180,18 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
     constexpr int NG = 2 * TM * TN, NP = NIA + NIB, NR = (TM + TN) * 3;      // tile visits, DMA pieces, fragment reads of one k-sub-step
     constexpr int NSLOT = NG * NPROD / 2;
     using PR = X3Prod<NPROD>;
+#if X3_STAMPS
+    unsigned long long tw = 0, tr = 0, tm = 0, t0 = X3_T(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+#if X3_STAMPS
+        const unsigned long long s0 = X3_T();
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * (NIA + NIB)) : "memory");
         asm volatile("s_barrier" ::: "memory");
+#if X3_STAMPS
+        const unsigned long long s1 = X3_T();
+#endif
         begin_issue(stn);
         const unsigned char* sp = smem + st * STAGE;
         bf16x8v af[2][TM][3], bf[2][TN][3];
@@ -184,6 +202,11 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
 #pragma unroll
         for (int q = 0; q < NR; ++q) read1(0, q);
         __builtin_amdgcn_sched_barrier(0);
+#if X3_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long s2 = X3_T();
+        tw += s1 - s0; tr += s2 - s1;
+#endif
 #pragma unroll
         for (int q = 0; q < NG * NPROD; ++q) {
             const int gi = q / NPROD, pr = q % NPROD;
@@ -204,9 +227,18 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if X3_STAMPS
+        tm += X3_T() - s2;
+#endif
         st = st == ST - 1 ? 0 : st + 1;
         stn = stn == ST - 1 ? 0 : stn + 1;
     }
+#if X3_STAMPS
+    if (blockIdx.x == 0 && tid == 0) {
+        g_x3_stamps[0] = tw; g_x3_stamps[1] = tr; g_x3_stamps[2] = tm; g_x3_stamps[3] = X3_T() - t0;
+        g_x3_stamps[4] = __builtin_amdgcn_s_memrealtime() - rt0; g_x3_stamps[5] = nk;
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
     const bool whole = m0 + BM <= g.M && (double)g.M * g.ldc * 4.0 < 4294967000.0;
@@ -274,6 +306,14 @@ int pdf_internal_x3_batched_gemm(const void* A3, long csA, const void* B3, long 
 PDF_API int pdf_x3_batched_gemm_nt(const void* A3, long csA, const void* B3, long csB, float* C, int batch, long gsA, long gsB, long gsC,
                                    int M, int N, int K, int variant, int nprod, hipStream_t s) {
     return pdf_internal_x3_batched_gemm(A3, csA, B3, csB, C, batch, gsA, gsB, gsC, M, N, K, variant, nprod, s);
+}
+// diagnostic builds (-DX3_STAMPS=1) only: the six stamps of the last x3gemm_nt launch (see X3_STAMPS); returns 0 otherwise
+PDF_API int pdf_debug_x3_stamps(unsigned long long* out) {
+#if X3_STAMPS
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 16 : 0;
+#else
+    (void)out; return 0;
+#endif
 }
 int pdf_internal_batched_gemm(const float* A, const float* B, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, hipStream_t s);
 // the native fp32-MFMA batched product (gemm.hip) behind the same shape of call: the comparison arm of tools/x3_bench.py

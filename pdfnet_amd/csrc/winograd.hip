@@ -412,7 +412,16 @@ static int x3_nprod() {
     static const int v = getenv("PDF_X3_NPROD") ? atoi(getenv("PDF_X3_NPROD")) : 6;
     return v;
 }
-static bool wino_x3(long T, int C) { return x3_mode() != 0 && C % 32 == 0 && T % 32 == 0 && 73.0 * (double)T * C < 2147483000.0; }
+static int x3_minc() {
+    static const int v = getenv("PDF_X3_MINC") ? atoi(getenv("PDF_X3_MINC")) : 512;
+    return v;
+}
+// (T, C) of a transformed tensor that SEVERAL launches read (the forward's V: heads sharing it, the weight gradient): x3 where the products it
+// feeds are long enough reductions to be bound by the matrix pipe -- C >= PDF_X3_MINC (512: `feat`; the 128- / 256-channel layers gain 0-25 % on
+// the product and lose as much on the 1.5x larger transform writes: profiles/r06_x3_step_ab.txt)
+static bool wino_x3(long T, int C) { return x3_mode() != 0 && C >= x3_minc() && C % 32 == 0 && T % 32 == 0 && 73.0 * (double)T * C < 2147483000.0; }
+// a transformed tensor PRIVATE to one launch (backward-data's V of dy; the weight gradient's Yh): its format follows the launch
+static bool wino_x3_fits(long T, int C) { return x3_mode() != 0 && C % 32 == 0 && T % 32 == 0 && 73.0 * (double)T * C < 2147483000.0; }
 int pdf_internal_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s);
 long pdf_internal_colsum_ws(int C, long R);
 static long wino_minpt();
@@ -436,7 +445,7 @@ int pdf_internal_wino_wgrad_eligible(int N, int H, int W, int Cin, int Cout, int
 }
 long pdf_internal_wino_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
     const long T = (long)N * (H / 4) * (W / 4);
-    const bool x3 = wino_x3(T, Cin) && wino_x3(T, Cout);
+    const bool x3 = wino_x3(T, Cin) && wino_x3_fits(T, Cout);
     return (x3 ? 54L : 36L) * T * Cin + (x3 ? 54L : 36L) * T * Cout + 36L * wino_wgrad_splits(T, Cout, Cin) * Cout * Cin + pdf_internal_colsum_ws(Cout, (long)N * H * W) + 64;
 }
 // dw [Cout][3][3][Cin] (+)= the weight gradient of the stride-1 3x3 convolution; db [Cout] (+)= column sums of dy (optional)
@@ -444,7 +453,7 @@ long pdf_internal_wino_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
 int pdf_internal_conv3x3_winograd_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* db, float* ws,
                                         int N, int H, int W, int Cin, int Cout, int accumulate, const float* v_cached, hipStream_t s) {
     const long T = (long)N * (H / 4) * (W / 4);
-    const bool x3 = wino_x3(T, Cin) && wino_x3(T, Cout);
+    const bool x3 = wino_x3(T, Cin) && wino_x3_fits(T, Cout);
     if (v_cached != nullptr && wino_x3(T, Cin) != x3) v_cached = nullptr;       // (the forward's V is in the other format: transform here)
     const long per = x3 ? 54L : 36L;                           // floats of workspace per (tile, channel): 36 fp32 or 3 x 36 bf16
     float* V = ws;
@@ -507,7 +516,7 @@ long pdf_internal_wino_workspace(int N, int H, int W, int Ck, int Cn, int flip) 
     const int m = pdf_internal_wino_tile(N, H, W, Ck, Cn, flip);
     if (m == 0) return 0;
     const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
-    if (m == 4 && wino_x3(T, Ck)) return 54L * Cn * Ck + 54L * T * Ck + P * T * Cn;
+    if (m == 4 && (flip ? (wino_x3_fits(T, Ck) && (Ck >= x3_minc() || Cn >= x3_minc())) : wino_x3(T, Ck))) return 54L * Cn * Ck + 54L * T * Ck + P * T * Cn;
     return P * Cn * Ck + P * T * Ck + P * T * Cn;
 }
 // where V starts in the forward workspace (U comes first), or -1 when the forward is not an F(4x4) launch
@@ -530,7 +539,7 @@ int pdf_internal_conv3x3_winograd(const float* x, int ldx, const float* w, const
                                   int N, int H, int W, int Ck, int Cn, int act, int accum, int flip, const float* v_shared, hipStream_t s) {
     const int m = pdf_internal_wino_tile(N, H, W, Ck, Cn, flip);
     const long T = (long)N * (H / m) * (W / m), P = (m + 2) * (m + 2);
-    const bool x3 = m == 4 && wino_x3(T, Ck);
+    const bool x3 = m == 4 && (flip ? (wino_x3_fits(T, Ck) && (Ck >= x3_minc() || Cn >= x3_minc())) : wino_x3(T, Ck));      // (as pdf_internal_wino_workspace)
     const long upl = x3 ? 54L * Cn * Ck : P * Cn * Ck, vpl = x3 ? 54L * T * Ck : P * T * Ck;      // floats of U and V
     float* U = ws;
     const float* V = U + upl;
