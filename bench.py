@@ -187,6 +187,11 @@ def symbol_roofline(sym, peak, traffic_by_symbol=None, traffic_src=None):
     """-> (`roofline` fields of the symbol with the most time, per-symbol table)."""
     table = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[3] * 1e3, 3), "tflops": round(v[1] / max(v[3], 1e-9) / 1e12, 1),
                  "algorithmic_MB_per_launch": round(v[2] / max(v[0], 1) / 1e6, 1)} for k, v in sorted(sym.items(), key=lambda kv: -kv[1][3])}
+    for k, row in table.items():
+        if k.startswith('x3gemm'):                           # fp32-equivalent FLOPs executed as six bf16 MFMAs each: the pipe's own rate and peak beside them
+            row["arithmetic"] = "x3: six bf16 MFMAs per fp32 product"
+            row["bf16_mfma_tflops"] = round(6.0 * row["tflops"], 1)
+            row["frac_of_bf16_mfma_peak"] = round(6.0 * row["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)
     mfma = {k: v for k, v in sym.items() if v[1] > 0}
     name, dom = max(mfma.items(), key=lambda kv: kv[1][3]) if mfma else ("none", [0, 0.0, 0.0, 1e-9])
     tr = (traffic_by_symbol or {}).get(name)
@@ -833,6 +838,35 @@ def main():
                    # what pdfnet_amd/taped.py keeps alive for the life of the process (the trunk's activations of every recorded signature)
                    "taped_pinned_mb": round(getattr(model.encoder.__dict__.get('_trunk_seg'), 'pinned_bytes', lambda: 0)() / 1e6, 1)},
     }
+    x3_mode = F._L().pdf_debug_x3_mode() if not bf16 else 0
+    if x3_mode:
+        # the layers that run as x3 products are named, and the all-native-fp32-MFMA step is timed beside the shipped one (same
+        # trainer, same batch, x3 switched off at run time; a third of the steps, not part of `value`)
+        out["arithmetic"] = {
+            "x3_mode": x3_mode,
+            "x3_layers": "fp32 via 3 x bf16 split (six bf16 MFMAs per fp32 product), fp32 accumulate: " + ", ".join(
+                (["`feat` 3x3 1024 -> 256 Winograd F(4x4)-domain products (forward, backward-data, weight gradient)"] if x3_mode & 1 else []) +
+                (["p4 / p5 transposed convolutions (forward, backward-data)"] if x3_mode & 2 else [])),
+            "everything_else": "native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+            "error_vs_float64": "x3 products 0.80-0.89x the native kernel's rms error, max error <= native (profiles/r06_x3_bench.txt)"}
+        if world == 1 and not args.graph:
+            try:
+                F.set_x3(0)
+                kn = max(5, args.steps // 3)
+                for _ in range(3):
+                    trainer.train_step(batch)
+                barrier()
+                tn0 = time.time()
+                for _ in range(kn):
+                    trainer.train_step(batch)
+                barrier()
+                dtn = time.time() - tn0
+                out["arithmetic"]["native_fp32_mfma_step"] = {"images_per_s": round(B * kn / dtn, 2), "ms_per_step": round(dtn / kn * 1e3, 3), "steps": kn}
+            finally:
+                F.set_x3(None)
+                for _ in range(2):
+                    trainer.train_step(batch)                  # (the instrumented step below runs the shipped configuration, allocator warm)
+                barrier()
     if world == 1 and not bf16 and not args.graph and not args.no_collective_path:
         try:
             cp = collective_path(trainer, batch)

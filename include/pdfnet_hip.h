@@ -477,6 +477,15 @@ int pdf_debug_callopts_size(void);
  *   pdf_x3_batched_gemm_tn  slab_b [split][NI][NJ] = sum over the rows m of split of P_b [m][NI]^T Q_b [m][NJ] (weight-gradient shape)
  *   pdf_batched_gemm_nt     the native fp32-MFMA batched product on plain fp32 operands (the comparison arm of tools/x3_bench.py) */
 int pdf_x3_split(const float* x, void* out, long n, long cs, void* stream);
+/* x3 form of a transposed convolution with kernel == stride and a long reduction (the pyramid's p4 / p5, intaghand_encoder.py:603-611): floats of
+ * workspace (PdfCallOpts::ws of pdf_deconv2d_fwd_x, backward = 0, pdf_deconv2d_bwd_data_x, backward = 1, and pdf_deconv2d_bwd_weight_x, backward = 2) with which
+ * the call runs as a plain x3 GEMM (+ pixel shuffle); 0 when the layer does not qualify (PDF_X3_DECONV=0 / PDF_X3=0: never). */
+long pdf_deconv2d_x3_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward);
+/* which launches take the x3 form: bit 0 = the wide Winograd-domain products, bit 1 = the kernel == stride transposed convolutions (default 3; env PDF_X3=0 /
+ * PDF_X3_DECONV=0); -1 = back to the environment's choice.  Workspace sizes (pdf_conv2d_winograd_workspace_floats, _v_offset, pdf_deconv2d_x3_workspace_floats)
+ * depend on it: query them again after a change. */
+int pdf_set_x3_mode(int mode);
+int pdf_debug_x3_mode(void);
 int pdf_debug_x3_stamps(unsigned long long* out);       /* diagnostic builds (-DX3_STAMPS=1) only: phase clocks of block 0 of the last x3gemm_nt launch; 0 otherwise */
 int pdf_x3_batched_gemm_nt(const void* A3, long csA, const void* B3, long csB, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, int variant, int nprod, void* stream);
 int pdf_batched_gemm_nt(const float* A, const float* B, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, void* stream);

@@ -1431,7 +1431,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
     // up-projections): a handful of CUs would walk K step by step at load latency.  Split K over blockIdx.z so that ~512 blocks
     // run, partial tiles through the scratch ring, bias / activation in splitk_finish.  (round 3: up to 256 tiles instead of 128 and
     // ~512 blocks instead of ~320 -- ResNet layer-4 3x3: 79 -> 90 TFLOP/s forward and backward-data, its 1x1 backward-data 75 -> 83;
-    // at 512 tiles the layer-3 1x1 layers lose 7 %, tools/experiments/r03/run_r3q.sh)
+    // at 512 tiles the layer-3 1x1 layers lose 7 %; round 3)
     const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
     // (also the valid 3x3 convolutions on the 5x5 / 3x3 centre windows: taps are walked in K order, a split may start inside any tap)
     const bool sk_plain = g.T == 1 && g.plain_in, sk_taps = g.T > 1 && !g.plain_in && fast && g.Cin % 32 == 0 && g.K == g.T * g.Cin;
@@ -1561,6 +1561,16 @@ int pdf_internal_batched_gemm(const float* A, const float* B, float* C, int batc
     return launch_igemm(g, s, batch);
 }
 
+long pdf_internal_x3_deconv_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward);
+int pdf_internal_x3_deconv_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin, int Cout,
+                               int KH, int KW, int stride, int OH, int OW, int ldy, hipStream_t s);
+int pdf_internal_x3_deconv_bwd_data(const float* dy, const float* w, float* dx, float* ws, int N, int H, int W, int Cin, int lddx, int Cout,
+                                    int KH, int KW, int stride, int OH, int OW, int lddy, hipStream_t s);
+int pdf_internal_x3_deconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int N, int H, int W, int Cin, int Cout,
+                                      int KH, int KW, int stride, int OH, int OW, int lddy, int accumulate, hipStream_t s);
+PDF_API long pdf_deconv2d_x3_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward) {
+    return g_gemm_bf16 ? 0 : pdf_internal_x3_deconv_workspace(N, H, W, Cin, Cout, KH, KW, stride, pad, backward);
+}
 static void conv_taps(IGemm& g, int KH, int KW, int pad, int dil) {
     g.T = KH * KW;
     for (int ky = 0; ky < KH; ++ky)
@@ -2390,6 +2400,13 @@ static int pdf_deconv2d_fwd_impl(const float* x, const float* w, const float* bi
                              int stride, int pad, int OH, int OW, int ldy, hipStream_t s, PdfCallOpts& co) {
     const Shadows sh = {co.op0_bf16, co.op1_bf16};                       // op0: x, op1: w
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    if (!g_gemm_bf16 && co.ws != nullptr && ldx == Cin && ldy == Cout) {  // x3 form (gemm_x3.hip): kernel == stride, long reduction, workspace handed in
+        const long need = pdf_internal_x3_deconv_workspace(N, H, W, Cin, Cout, KH, KW, stride, pad, 0);
+        if (need > 0 && co.ws_floats >= need && ((uintptr_t)co.ws & 15) == 0) {
+            const CurCall cur(co);
+            return pdf_internal_x3_deconv_fwd(x, w, bias, y, co.ws, N, H, W, Cin, Cout, KH, KW, stride, OH, OW, ldy, s);
+        }
+    }
     if (KH == stride && KW == stride && pad == 0) {
         IGemm g = {};
         g.A = x; g.B = w; g.C = y; g.bias = bias; g.A16 = sh.op0; g.B16 = sh.op1;
@@ -2448,6 +2465,13 @@ static int pdf_deconv2d_bwd_data_impl(const float* dy, const float* w, float* dx
                                   int stride, int pad, int OH, int OW, int lddy, hipStream_t s, PdfCallOpts& co) {
     const Shadows sh = {co.op0_bf16, co.op1_bf16};                       // op0: dy, op1: w
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    if (!g_gemm_bf16 && co.ws != nullptr && lddy == Cout && lddx >= Cin) {
+        const long need = pdf_internal_x3_deconv_workspace(N, H, W, Cin, Cout, KH, KW, stride, pad, 1);
+        if (need > 0 && co.ws_floats >= need && ((uintptr_t)co.ws & 15) == 0) {
+            const CurCall cur(co);
+            return pdf_internal_x3_deconv_bwd_data(dy, w, dx, co.ws, N, H, W, Cin, lddx, Cout, KH, KW, stride, OH, OW, lddy, s);
+        }
+    }
     IGemm g = {};
     g.A = dy; g.B = w; g.C = dx; g.bias = nullptr; g.A16 = sh.op0; g.B16 = sh.op1;
     g.M = N * H * W; g.N = Cin; g.K = KH * KW * Cout; g.Cin = Cout; g.lda = lddy; g.ldb = KH * KW * Cout; g.ldc = lddx;
@@ -2470,6 +2494,13 @@ static int pdf_deconv2d_bwd_weight_impl(const float* x, const float* dy, float* 
                                     int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s, PdfCallOpts& co) {
     const Shadows sh = {co.op0_bf16, co.op1_bf16};                       // op0: x, op1: dy
     if (KH * KW > MAX_TAPS) return PDF_E_BADARG;
+    if (!g_gemm_bf16 && co.ws != nullptr && ldx == Cin && lddy == Cout) {  // x3 form (gemm_x3.hip), workspace in PdfCallOpts::ws
+        const long need = pdf_internal_x3_deconv_workspace(N, H, W, Cin, Cout, KH, KW, stride, pad, 2);
+        if (need > 0 && co.ws_floats >= need && ((uintptr_t)co.ws & 15) == 0) {
+            const CurCall cur(co);
+            return pdf_internal_x3_deconv_bwd_weight(x, dy, dw, co.ws, N, H, W, Cin, Cout, KH, KW, stride, OH, OW, lddy, accumulate, s);
+        }
+    }
     WGemm g = {};
     g.P = x; g.Q = dy; g.P16 = sh.op0; g.Q16 = sh.op1; g.M = N * H * W; g.NI = Cin; g.Cq = Cout; g.T = KH * KW;
     g.ldp = ldx; g.ldq = lddy; g.ldw = KH * KW * Cout;

@@ -46,6 +46,22 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
         *reinterpret_cast<uint4*>(o + 2 * cs + 8 * i) = l;
     }
 }
+// the same for a matrix [R][C] (row stride ldx) into planes with their own row stride ldo (a padded stride keeps 2^k-byte rows off one memory channel)
+__global__ __launch_bounds__(256) void x3_split_rows_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ o, long ldo, long cs, long R, int C8) {
+    const long total = R * C8;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / C8;
+        const int c = (int)(i - r * C8) * 8;
+        const float4 u = *reinterpret_cast<const float4*>(x + r * ldx + c), v = *reinterpret_cast<const float4*>(x + r * ldx + c + 4);
+        uint4 h, m, l;
+        pdf_x3_split2(u.x, u.y, h.x, m.x, l.x); pdf_x3_split2(u.z, u.w, h.y, m.y, l.y);
+        pdf_x3_split2(v.x, v.y, h.z, m.z, l.z); pdf_x3_split2(v.z, v.w, h.w, m.w, l.w);
+        unsigned short* d = o + r * ldo + c;
+        *reinterpret_cast<uint4*>(d) = h;
+        *reinterpret_cast<uint4*>(d + cs) = m;
+        *reinterpret_cast<uint4*>(d + 2 * cs) = l;
+    }
+}
 PDF_API int pdf_x3_split(const float* x, void* out, long n, long cs, hipStream_t s) {
     if (n % 8 != 0 || cs % 8 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return PDF_E_BADARG;
     hipLaunchKernelGGL(x3_split_kernel, dim3(grid_for(n / 8, 256, 256 * 16)), dim3(256), 0, s, x, (unsigned short*)out, n / 8, cs);
@@ -69,7 +85,12 @@ struct X3Gemm {
     int M, N, K, batch, ldc;
     int lda, ldb;                                       // NT: row strides of A / B in elements (>= K, multiples of 8)
     int col_major_tiles;                                // NT: tile order (see the kernel)
+    // NT epilogue of a transposed convolution with kernel == stride (pixel shuffle): row m = pixel (ni, qy, qx) of a QH x QW map, column n = (tap, co)
+    // with ps_cout channels per tap and ps_kw taps per kernel row -> y[ni][qy * ps_s + ky][qx * ps_s + kx][co] (row stride ldc) + bias[co].  ps_cout == 0: plain C
+    int ps_cout, ps_kw, ps_s, QH, QW, OH, OW;
+    const float* bias;
     int rows_per_split, splits;                         // TN: rows of the reduction per block (multiple of 32)
+    int accum;                                          // TN, one split: W += the product (a gradient accumulated into an existing one)
 };
 
 // the NPROD products of one (A fragment set, B fragment set) pair as (component of A, component of B), smallest terms first
@@ -241,6 +262,27 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
 #endif
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
+    if (g.ps_cout > 0) {                                     // pixel-shuffled output (+ bias): 32 lanes of a store = 32 consecutive channels of one output pixel
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const bool cok = col < g.N;
+            const int tap = col / g.ps_cout, co = col - tap * g.ps_cout;
+            const int ky = tap / g.ps_kw, kx = tap - ky * g.ps_kw;
+            const float bv = (g.bias != nullptr && cok) ? g.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    if (cok && row < g.M) {
+                        const int hw = g.QH * g.QW, ni = row / hw, rem2 = row - ni * hw, qy = rem2 / g.QW, qx = rem2 - qy * g.QW;
+                        Cb[(((long)ni * g.OH + qy * g.ps_s + ky) * g.OW + qx * g.ps_s + kx) * g.ldc + co] = acc[i][j][r] + bv;
+                    }
+                }
+        }
+        return;
+    }
     const bool whole = m0 + BM <= g.M && (double)g.M * g.ldc * 4.0 < 4294967000.0;
     const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cb, 0, whole ? (unsigned)g.M * (unsigned)g.ldc * 4u : 0u, 0x00020000);
     const unsigned ldc4 = (unsigned)g.ldc * 4u;
@@ -341,6 +383,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int NI = g.M, NJ = g.N;                                         // (descriptor reuse: M = NI, N = NJ, K = rows of the reduction, % 32 == 0)
+    const int ldp = g.lda > 0 ? g.lda : NI, ldq = g.ldb > 0 ? g.ldb : NJ;      // row strides of P / Q (elements)
     const int nti = (NI + BI - 1) / BI, ntj = (NJ + BJ - 1) / BJ, tiles = nti * ntj;
     const int lin = x3_xcd_lin(blockIdx.x, tiles * g.splits * g.batch);
     const int grp = lin / tiles, tile = lin - grp * tiles;
@@ -364,7 +407,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
         const int gi = wave * NIP + i, comp = gi / IPC, sub = gi - comp * IPC;
         const int row = sub * RPI + lane / CP, ch = (lane % CP) ^ swzp(row);
         plds[i] = (unsigned)(comp * PIMG + sub * 1024);
-        poff[i] = (unsigned)((comp * g.csA + (long)(ms + row) * NI + min(i0 + ch * 8, NI - 8)) * 2);     // (columns past NI: clamped, never stored)
+        poff[i] = (unsigned)((comp * g.csA + (long)(ms + row) * ldp + min(i0 + ch * 8, NI - 8)) * 2);     // (columns past NI: clamped, never stored)
     }
 #pragma unroll
     for (int i = 0; i < NIQ; ++i) {
@@ -372,7 +415,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
         const int gi = wave * NIQ + i, comp = gi / IPC, sub = gi - comp * IPC;
         const int row = sub * RPI + lane / CQ, ch = (lane % CQ) ^ swzq(row);
         qlds[i] = (unsigned)(3 * PIMG + comp * QIMG + sub * 1024);
-        qoff[i] = (unsigned)((comp * g.csB + (long)(ms + row) * NJ + min(j0 + ch * 8, NJ - 8)) * 2);
+        qoff[i] = (unsigned)((comp * g.csB + (long)(ms + row) * ldq + min(j0 + ch * 8, NJ - 8)) * 2);
     }
     int nissued = 0;
     unsigned kp = 0, kq = 0, sbase = lds0;
@@ -382,7 +425,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
     };
     auto begin_issue = [&](int stage) {
         const unsigned t = (unsigned)min(nissued, nk - 1);  // (past the end: the last tile again, into a stage nobody consumes)
-        kp = t * 64u * (unsigned)NI; kq = t * 64u * (unsigned)NJ;
+        kp = t * 64u * (unsigned)ldp; kq = t * 64u * (unsigned)ldq;
         ++nissued;
         sbase = lds0 + (unsigned)(stage * STAGE);
     };
@@ -480,6 +523,10 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+                if (g.accum) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW, vo, ((r & 3) + 8 * (r >> 2)) * ldw4, 0));
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsW, vo, ((r & 3) + 8 * (r >> 2)) * ldw4, 0);
@@ -487,7 +534,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = r0 + (r & 3) + 8 * (r >> 2);
-                    if (cok && row < NI) Wb[(long)row * NJ + col] = acc[i][j][r];
+                    if (cok && row < NI) Wb[(long)row * NJ + col] = acc[i][j][r] + (g.accum ? Wb[(long)row * NJ + col] : 0.f);
                 }
             }
         }
@@ -542,4 +589,161 @@ int pdf_internal_batched_wgemm(const float* P, const float* Q, float* slab, int 
 PDF_API int pdf_batched_gemm_tn(const float* P, const float* Q, float* slab, int batch, long gsP, long gsQ, int M, int NI, int NJ, int splits, hipStream_t s) {
     const int rc = pdf_internal_batched_wgemm(P, Q, slab, batch, gsP, gsQ, M, NI, NJ, splits, s);
     return rc > 0 ? 0 : (rc == 0 ? PDF_E_BADARG : rc);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Transposed convolutions with kernel == stride (the pyramid's p4: 1024 -> 256, k = s = 4 and p5: 2048 -> 256, k = s = 8; reference
+// intaghand_encoder.py:603-611) are plain GEMMs -- y_ps[m][(tap, co)] = x[m][:] . w[:][(tap, co)] with the output pixel-shuffled, and
+// dx[m][ci] = dy_unshuffled[m][:] . w[ci][:] -- with 2,048 - 16,384 wide reductions over small activations: bound by the matrix pipe, the shape
+// x3 is for (tools/probe/x3_stamps.py: 222 TFLOP/s-equivalent on the p5 shape against 116 of the native kernel).  The operands are split by
+// pre-passes (the weights change every step): x -> x3 planes, w [Cin][taps * Cout] -> its transpose as x3 planes (forward) or as it lies
+// (backward-data), dy -> un-shuffled x3 planes [m][(tap, co)].
+// W [K][N] fp32 -> Wt3 [3][N][K]: 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void x3_split_transpose_kernel(const float* __restrict__ w, unsigned short* __restrict__ o, int K, int N, long ldo, long cs) {
+    __shared__ float sm[64][65];
+    const int tk = blockIdx.y * 64, tn = blockIdx.x * 64, t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = t / 16 + 16 * i, c = (t % 16) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tk + r < K && tn + c < N) v = *reinterpret_cast<const float4*>(w + (long)(tk + r) * N + tn + c);
+        sm[r][c] = v.x; sm[r][c + 1] = v.y; sm[r][c + 2] = v.z; sm[r][c + 3] = v.w;
+    }
+    __syncthreads();
+    const int n = t / 4, k0 = (t % 4) * 16;
+    if (tn + n < N && tk + k0 < K) {
+        uint4 h[2], m[2], l[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            unsigned* hh = reinterpret_cast<unsigned*>(&h[q]); unsigned* mm = reinterpret_cast<unsigned*>(&m[q]); unsigned* ll = reinterpret_cast<unsigned*>(&l[q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pdf_x3_split2(sm[k0 + 8 * q + 2 * e][n], sm[k0 + 8 * q + 2 * e + 1][n], hh[e], mm[e], ll[e]);
+        }
+        unsigned short* d = o + (long)(tn + n) * ldo + tk + k0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<uint4*>(d + 8 * q) = h[q];
+            *reinterpret_cast<uint4*>(d + cs + 8 * q) = m[q];
+            *reinterpret_cast<uint4*>(d + 2 * cs + 8 * q) = l[q];
+        }
+    }
+}
+// dy [ni][OH][OW][C] (row stride lddy) -> x3 planes [3][M][taps * C], row m = input pixel (ni, qy, qx), column (ky, kx, c) = dy[ni][qy s + ky][qx s + kx][c]
+__global__ __launch_bounds__(256) void x3_split_unshuffle_kernel(const float* __restrict__ dy, int lddy, unsigned short* __restrict__ o, long ldo, long cs,
+                                                                 long M, int QH, int QW, int OH, int OW, int s, int C) {
+    const int C8 = C / 8, T = s * s;
+    const long total = M * T * C8;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        const long r = i / C8;
+        const int tap = (int)(r % T);
+        const long m = r / T;
+        const int ky = tap / s, kx = tap - ky * s;
+        const int hw = QH * QW, ni = (int)(m / hw), rem = (int)(m - (long)ni * hw), qy = rem / QW, qx = rem - qy * QW;
+        const float* src = dy + (((long)ni * OH + qy * s + ky) * OW + qx * s + kx) * lddy + c8 * 8;
+        const float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
+        uint4 h, mm, l;
+        pdf_x3_split2(u.x, u.y, h.x, mm.x, l.x); pdf_x3_split2(u.z, u.w, h.y, mm.y, l.y);
+        pdf_x3_split2(v.x, v.y, h.z, mm.z, l.z); pdf_x3_split2(v.z, v.w, h.w, mm.w, l.w);
+        unsigned short* d = o + m * ldo + (long)tap * C + c8 * 8;
+        *reinterpret_cast<uint4*>(d) = h;
+        *reinterpret_cast<uint4*>(d + cs) = mm;
+        *reinterpret_cast<uint4*>(d + 2 * cs) = l;
+    }
+}
+// Which launches take the x3 form: bit 0 = the wide Winograd-domain products (winograd.hip), bit 1 = the kernel == stride transposed convolutions.
+// Default 3 (PDF_X3=0: none; PDF_X3_DECONV=0: not the transposed convolutions); pdf_set_x3_mode changes it at run time (bench.py times the native
+// fp32-MFMA step beside the shipped one).  Workspace sizes depend on it: a caller that caches them (functional.py) drops its cache on a change.
+static int g_x3_mode = -1;
+int pdf_internal_x3_mode() {
+    if (g_x3_mode < 0) {
+        int v = getenv("PDF_X3") ? (atoi(getenv("PDF_X3")) ? 3 : 0) : 3;
+        if (getenv("PDF_X3_DECONV") && !atoi(getenv("PDF_X3_DECONV"))) v &= ~2;
+        g_x3_mode = v;
+    }
+    return g_x3_mode;
+}
+PDF_API int pdf_set_x3_mode(int mode) { g_x3_mode = mode < 0 ? -1 : (mode & 3); return 0; }
+PDF_API int pdf_debug_x3_mode(void) { return pdf_internal_x3_mode(); }
+static int x3_deconv_mode() { return (pdf_internal_x3_mode() & 2) != 0; }
+// row stride (elements) of a pre-split operand with K columns: one 128-byte line of padding, so that rows of 2^k bytes (p5: 4 KB and 32 KB) do not
+// all start on the same L2 / HBM channel (without it p5's backward-data ran 1.57 ms against 1.29 of the native kernel: profiles/r06_x3_deconv.txt)
+static long x3_ld(long K) { return K + 64; }
+// floats of workspace the x3 form of this transposed convolution wants (backward = 0: forward, 1: backward-data, 2: weight gradient), 0 when it does not qualify
+long pdf_internal_x3_deconv_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward) {
+    if (!x3_deconv_mode() || KH != stride || KW != stride || pad != 0 || stride < 2) return 0;
+    const long M = (long)N * H * W, NT = (long)KH * KW * Cout;
+    if (Cin % 32 != 0 || Cout % 32 != 0 || M < 1024 || 2.0 * M * NT * Cin < 3.0e10) return 0;      // (a long reduction over a large product: p4, p5)
+    if (backward == 2 && (M % 32 != 0 || 3.0 * Cin * NT * 4.0 >= 4294967000.0)) return 0;
+    const long wel = backward == 2 ? M * x3_ld(Cin) : backward ? Cin * x3_ld(NT) : NT * x3_ld(Cin), ael = backward ? M * x3_ld(NT) : M * x3_ld(Cin);
+    if (3.0 * wel >= 2147483000.0 || 3.0 * ael >= 2147483000.0) return 0;
+    return ((3 * wel + 1) / 2 + 3) / 4 * 4 + ((3 * ael + 1) / 2 + 3) / 4 * 4 + 64;
+}
+static void x3_gemm_desc(X3Gemm& g, const void* A3, long csA, long lda, const void* B3, long csB, long ldb, float* C, int M, int N, int K, int ldc) {
+    g = X3Gemm{};
+    g.A = (const unsigned short*)A3; g.B = (const unsigned short*)B3; g.C = C;
+    g.csA = csA; g.csB = csB; g.M = M; g.N = N; g.K = K; g.batch = 1; g.ldc = ldc; g.lda = (int)lda; g.ldb = (int)ldb;
+    g.col_major_tiles = cdiv(N, 128) > 4 * cdiv(M, 128);
+}
+// the 256 x 128 tile (8 waves) where its blocks fill the chip twice over, else 128 x 128 (p5's backward-data is 2,048 x 2,048 over a 16,384-long
+// reduction: 128 of the wide tiles would leave half the CUs idle -- 1.54 ms against 1.29 of the native kernel, profiles/r06_x3_deconv.txt)
+static int x3_launch_auto(const X3Gemm& g, hipStream_t s) {
+    if ((long)cdiv(g.M, 256) * cdiv(g.N, 128) * g.batch >= 512) return x3_launch_nt<4, 2, 2, 2, 2>(g, 6, s);
+    return x3_launch_nt<2, 2, 2, 2, 3>(g, 6, s);
+}
+// y [N][OH][OW][Cout] (row stride ldy) = ConvTranspose2d(x [N][H][W][Cin] dense, w [Cin][KH][KW][Cout]) + bias, kernel == stride, pad 0
+int pdf_internal_x3_deconv_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin, int Cout,
+                               int KH, int KW, int stride, int OH, int OW, int ldy, hipStream_t s) {
+    const long M = (long)N * H * W, NT = (long)KH * KW * Cout, ld = x3_ld(Cin);
+    unsigned short* w3 = reinterpret_cast<unsigned short*>(ws);
+    unsigned short* x3 = reinterpret_cast<unsigned short*>(ws + ((3 * NT * ld + 1) / 2 + 3) / 4 * 4);
+    {
+        KTimer kt("x3_split_transpose_kernel", 0.0, 10.0 * NT * Cin, s);
+        hipLaunchKernelGGL(x3_split_transpose_kernel, dim3((unsigned)cdiv(NT, 64), (unsigned)cdiv(Cin, 64)), dim3(256), 0, s, w, w3, Cin, (int)NT, ld, NT * ld);
+    }
+    hipLaunchKernelGGL(x3_split_rows_kernel, dim3(grid_for(M * Cin / 8, 256, 256 * 16)), dim3(256), 0, s, x, (long)Cin, x3, ld, M * ld, M, Cin / 8);
+    PDF_LAUNCH_CHECK();
+    X3Gemm g;
+    x3_gemm_desc(g, x3, M * ld, ld, w3, NT * ld, ld, y, (int)M, (int)NT, Cin, ldy);
+    g.ps_cout = Cout; g.ps_kw = KW; g.ps_s = stride; g.QH = H; g.QW = W; g.OH = OH; g.OW = OW; g.bias = bias;
+    return x3_launch_auto(g, s);
+}
+// dx [N][H][W][Cin] (row stride lddx) = the input gradient of that layer from dy [N][OH][OW][Cout] (row stride lddy)
+int pdf_internal_x3_deconv_bwd_data(const float* dy, const float* w, float* dx, float* ws, int N, int H, int W, int Cin, int lddx, int Cout,
+                                    int KH, int KW, int stride, int OH, int OW, int lddy, hipStream_t s) {
+    const long M = (long)N * H * W, NT = (long)KH * KW * Cout, ld = x3_ld(NT);
+    unsigned short* w3 = reinterpret_cast<unsigned short*>(ws);
+    unsigned short* d3 = reinterpret_cast<unsigned short*>(ws + ((3 * Cin * ld + 1) / 2 + 3) / 4 * 4);
+    {
+        KTimer kt("x3_split_rows_kernel", 0.0, 10.0 * NT * Cin, s);
+        hipLaunchKernelGGL(x3_split_rows_kernel, dim3(grid_for(NT * Cin / 8, 256, 256 * 16)), dim3(256), 0, s, w, NT, w3, ld, Cin * ld, (long)Cin, (int)(NT / 8));
+    }
+    {
+        KTimer kt("x3_split_unshuffle_kernel", 0.0, 10.0 * M * NT, s);
+        hipLaunchKernelGGL(x3_split_unshuffle_kernel, dim3(grid_for(M * NT / 8, 256, 256 * 16)), dim3(256), 0, s, dy, lddy, d3, ld, M * ld, M, H, W, OH, OW, stride, Cout);
+    }
+    PDF_LAUNCH_CHECK();
+    X3Gemm g;
+    x3_gemm_desc(g, d3, M * ld, ld, w3, Cin * ld, ld, dx, (int)M, Cin, (int)NT, lddx);
+    return x3_launch_auto(g, s);
+}
+
+// dw [Cin][KH][KW][Cout] (+)= the weight gradient of that layer: sum over the input pixels m of x[m][ci] dy_unshuffled[m][(tap, co)] -- one x3gemm_tn launch,
+// no split of the reduction (p5: 2,048 rows against 2,048 output tiles), the accumulation into an existing gradient done by the epilogue
+int pdf_internal_x3_deconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int N, int H, int W, int Cin, int Cout,
+                                      int KH, int KW, int stride, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
+    const long M = (long)N * H * W, NT = (long)KH * KW * Cout, ldx3 = x3_ld(Cin), ldd = x3_ld(NT);
+    unsigned short* x3 = reinterpret_cast<unsigned short*>(ws);
+    unsigned short* d3 = reinterpret_cast<unsigned short*>(ws + ((3 * M * ldx3 + 1) / 2 + 3) / 4 * 4);
+    hipLaunchKernelGGL(x3_split_rows_kernel, dim3(grid_for(M * Cin / 8, 256, 256 * 16)), dim3(256), 0, s, x, (long)Cin, x3, ldx3, M * ldx3, M, Cin / 8);
+    {
+        KTimer kt("x3_split_unshuffle_kernel", 0.0, 10.0 * M * NT, s);
+        hipLaunchKernelGGL(x3_split_unshuffle_kernel, dim3(grid_for(M * NT / 8, 256, 256 * 16)), dim3(256), 0, s, dy, lddy, d3, ldd, M * ldd, M, H, W, OH, OW, stride, Cout);
+    }
+    PDF_LAUNCH_CHECK();
+    X3Gemm g = {};
+    g.A = x3; g.B = d3; g.C = dw;
+    g.csA = M * ldx3; g.csB = M * ldd; g.lda = (int)ldx3; g.ldb = (int)ldd;
+    g.M = Cin; g.N = (int)NT; g.K = (int)M; g.batch = 1; g.splits = 1; g.rows_per_split = (int)M; g.accum = accumulate;
+    return x3_launch_tn<2, 2, 2, 2, 3>(g, 6, s);
 }

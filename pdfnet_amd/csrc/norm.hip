@@ -482,7 +482,7 @@ static long bn_chunks(int C, long R) {
     const long ctiles = (C + BN_CT - 1) / BN_CT;
     long want = blocks / ctiles;                            // ~1024 blocks over (channel tiles x chunks)
     // at most 256 chunks -- but at least 512 blocks: a 64-channel tensor (one channel tile: the stem's 1M-row BatchNorm) ran its
-    // statistics passes on 256 blocks, one per CU, at 4.3 TB/s; 512 chunks: 5.2 (tools/experiments/r04/bn_ab3.sh; 1024+ lose again)
+    // statistics passes on 256 blocks, one per CU, at 4.3 TB/s; 512 chunks: 5.2 (profiles/r04_bn_chunks_ab.txt; 1024+ lose again)
     const long cap = cap_env > 0 ? cap_env : (512 / ctiles > 256 ? 512 / ctiles : 256);
     if (want > cap) want = cap;
     long by_rows = (R + 63) / 64;                           // at least 64 rows per chunk

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 // F(4x4, 3x3): 6x6 patches at stride 4, 36 transform-domain planes, 4x fewer multiplications than the direct sum (F(2x2): 2.25x) and
 // only 2.25x the input's bytes in the transform domain (F(2x2): 4x).  The price is accuracy: the matrices hold 4, 5, 8, 1/6, 1/24, so
 // a result carries ~4e-5 absolute error on values of a few units where F(2x2) and the direct kernels stay at 1e-6 ... 3e-6 (measured,
-// tools/experiments/r04/wino_error.py).  Standard matrices (Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks", 2016):
+// profiles/r04_winograd_ab.txt).  Standard matrices (Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks", 2016):
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 //   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
@@ -403,11 +403,9 @@ int pdf_internal_x3_batched_wgemm(const void* P3, long csP, const void* Q3, long
 // x3 arithmetic for the F(4x4) transform-domain products (gemm_x3.hip): the transforms write their outputs as x3 planes (6 bytes per element
 // instead of 4) and the 36 products run on the bf16 matrix pipe, six MFMAs per fp32 product.  Whether a transformed tensor [36][T][C] is x3
 // depends on (T, C) ONLY, so every launch that reads it -- the forward that made V, a head sharing it, the weight gradient -- agrees:
-// C % 32 == 0 (a K-step of the products) and the three components within 32-bit byte offsets.  PDF_X3=0: the native fp32 MFMA.
-static int x3_mode() {
-    static const int v = getenv("PDF_X3") ? atoi(getenv("PDF_X3")) : 1;
-    return v;
-}
+// C % 32 == 0 (a K-step of the products) and the three components within 32-bit byte offsets.  PDF_X3=0 / pdf_set_x3_mode(0): the native fp32 MFMA.
+int pdf_internal_x3_mode();                                  // gemm_x3.hip: bit 0 = these products (PDF_X3, pdf_set_x3_mode)
+static int x3_mode() { return pdf_internal_x3_mode() & 1; }
 static int x3_nprod() {
     static const int v = getenv("PDF_X3_NPROD") ? atoi(getenv("PDF_X3_NPROD")) : 6;
     return v;
@@ -490,7 +488,7 @@ static int wino_mode() {
 // float64 oracle, over the fixed 1.5e-3 bar; the oracle's own float32 run deviates by 3.8e-2 on that tensor, a sum of +- terms
 // that nearly cancel, so the bar of tests/test_headline_gpu.py is now the fixed one plus twice the fp32 oracle's own deviation and the
 // launch is no exception any more: worst tensor 0.48 of its bar, every tensor that is not noise in fp32 below its FIXED bar;
-// profiles/r04_winograd_ab.txt, tools/experiments/r04/wino_parity.sh, f4_ab.sh.)
+// profiles/r04_winograd_ab.txt.)
 static long wino_minpt() {                                   // planes x tiles a launch must have: 16384 takes ResNet layer 3 (36 x 512) in
     static const long v = getenv("PDF_WINOGRAD_MINPT") ? atol(getenv("PDF_WINOGRAD_MINPT")) : 16384;
     return v;

@@ -240,6 +240,33 @@ def _wino_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, backward, dev):
     return torch.empty(n, dtype=torch.float32, device=dev), n
 
 
+# x3 arithmetic for the pyramid's kernel == stride transposed convolutions (csrc/gemm_x3.hip: fp32 products as six bf16 MFMAs on 3-way split
+# operands, fp32-exact to ~2^-24): the library asks for a workspace for the split operands; 0 floats = the layer does not qualify.
+X3_DECONV = _os.environ.get("PDFNET_X3_DECONV", "1") != "0"
+_x3d_cache = {}
+
+
+def set_x3(mode):
+    """Which launches run as x3 products (include/pdfnet_hip.h pdf_set_x3_mode: bit 0 Winograd-domain products of the wide layers, bit 1 the
+    kernel == stride transposed convolutions; None = the environment's choice).  Drops the cached workspace sizes, which depend on it."""
+    _L().pdf_set_x3_mode(-1 if mode is None else int(mode))
+    _wino_cache.clear()
+    _wino_voff.clear()
+    _x3d_cache.clear()
+
+
+def _x3_deconv_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, backward, dev):
+    if not X3_DECONV or _GEMM_BF16 or KH != stride or KW != stride or pad != 0:
+        return None, None
+    key = (N, H, W, Cin, Cout, KH, stride, backward)
+    n = _x3d_cache.get(key)
+    if n is None:
+        n = _x3d_cache[key] = _L().pdf_deconv2d_x3_workspace_floats(N, H, W, Cin, Cout, KH, KW, stride, pad, backward)
+    if n <= 0:
+        return None, None
+    return torch.empty(n, dtype=torch.float32, device=dev), n
+
+
 WINOGRAD_KEEP_V = _os.environ.get("PDFNET_WINOGRAD_KEEP_V", "1") != "0"
 _wino_voff = {}
 
@@ -282,7 +309,7 @@ def _O2(a, b):
 BN_EPILOGUE_STATS = _os.environ.get("PDFNET_BN_EPILOGUE_STATS", "1") != "0"
 # bf16 mode: the kernels can do it too (whole tiles).  Round 3 (register-staged bf16 kernels): B=32 850 -> 868 img/s, B=64 1,038 -> 1,013, so it
 # was opt-in.  Round 4 (LDS-DMA kernels): B=64 1,098 -> 1,120, B=32 (bound by the host's issue time) 818 -> 717 on a slow host
-# (tools/experiments/r04/bf16_stats_ab.sh).  Default 'auto': convolutions over >= BF16_STORAGE_MIN_BATCH images, like the bf16 storage; 1 / 0 force it.
+# (profiles/r04_bf16_storage_ab.txt).  Default 'auto': convolutions over >= BF16_STORAGE_MIN_BATCH images, like the bf16 storage; 1 / 0 force it.
 _be = _os.environ.get("PDFNET_BN_EPILOGUE_STATS_BF16", "auto")
 BN_EPILOGUE_STATS_BF16 = 'auto' if _be == "auto" else _be != "0"
 
@@ -402,7 +429,7 @@ _wg_used = set()
 
 
 # queue priority of the weight-gradient side streams (torch: 0 = normal, -1 = high; the default stream the step is issued on outranks a
-# normal-priority stream in practice -- tools/experiments/r04/stream_priority.py)
+# normal-priority stream in practice)
 WGRAD_STREAM_PRIORITY = int(_os.environ.get("PDFNET_WGRAD_STREAM_PRIORITY", "0"))
 
 
@@ -716,8 +743,9 @@ class _Deconv2d(Function):
         L = _L()
         y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=CL)
         x16, w16 = shadow_of(x), shadow_of(w)
+        ws, nws = _x3_deconv_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 0, x.device)
         L.pdf_deconv2d_fwd_x(ptr(x), ptr(w), ptr(b), ptr(y), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(),
-                             _O2(x16, w16))
+                             _O(op0_bf16=ptr(x16), op1_bf16=ptr(w16), ws=ptr(ws), ws_floats=nws)[1])
         ctx.save_for_backward(x, w)
         ctx.s16 = (x16, w16)
         ctx.cfg = (stride, pad, b is not None)
@@ -738,14 +766,16 @@ class _Deconv2d(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            ws, nws = _x3_deconv_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 1, x.device)
             L.pdf_deconv2d_bwd_data_x(ptr(g), ptr(w), ptr(dx), N, H, W, Cin, Cin, Cout, KH, KW, stride, pad, OH, OW, Cout, stream(),
-                                      _O2(g16, w16))
+                                      _O(op0_bf16=ptr(g16), op1_bf16=ptr(w16), ws=ptr(ws), ws_floats=nws)[1])
         w_par, b_par = ctx.params
 
         def launch_w(out, out_b, acc):
             ws, n = _wgrad_ws(N * H * W, Cin, KH * KW * Cout, x.device)
+            xws, nx = _x3_deconv_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, 2, x.device)
             L.pdf_deconv2d_bwd_weight_x(ptr(x), ptr(g), ptr(out), ptr(ws), n, N, H, W, Cin, Cin, Cout, KH, KW,
-                                        stride, pad, OH, OW, Cout, acc, stream(), _O2(x16, g16))
+                                        stride, pad, OH, OW, Cout, acc, stream(), _O(op0_bf16=ptr(x16), op1_bf16=ptr(g16), ws=ptr(xws), ws_floats=nx)[1])
         dw, db = _param_grads(ctx, x, g, w, w_par, b_par, has_b, launch_w, Cout, N * OH * OW, 2.0 * N * H * W * Cin * KH * KW * Cout, shadows=(x16, g16))
         return dx, dw, db, None, None
 

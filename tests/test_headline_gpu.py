@@ -217,9 +217,15 @@ def test_train_step_at_the_headline_batch_matches_the_fp64_oracle(headline):
     for name, a, b in (('hms', res[3]['hms'], hms_o), ('mask', res[3]['mask'], mask_o),
                        ('verts3d_left', res[0]['verts3d']['left'], v3_o['left']), ('verts3d_right', res[0]['verts3d']['right'], v3_o['right'])):
         err = float((a.detach().cpu().double() - b).abs().max())
-        assert err <= 1e-3 + 1e-4 * float(b.abs().max()), (name, err)
+        print("train-mode forward at B=%d, %s: max |hip - fp64 oracle| = %.3e (max |ref| %.3g; pinned at %.1e)" % (B_HEAD, name, err, float(b.abs().max()), TRAIN_FWD_PIN[name]))
+        assert err <= TRAIN_FWD_PIN[name], (name, err)
     print("headline train-step parity: B=%d, fp64 oracle step %.1f s on %d threads, %d gradients checked, loss %.6f vs %.6f"
           % (B_HEAD, t_cpu, _threads(), checked, loss_g, loss_o))
+
+
+# The train-mode forward of the TIMED configuration (Winograd F(4x4) + x3 on, batch statistics) against the float64 oracle: measured in round 6
+# (profiles/r06_train_forward_error.txt) and pinned at 2x the measurement instead of the flat 1e-3 + 1e-4 max|ref| of rounds 4-5.
+TRAIN_FWD_PIN = {'hms': 2.1e-4, 'mask': 2.1e-4, 'verts3d_left': 5e-5, 'verts3d_right': 5e-5}       # measured 1.03e-4, 1.05e-4, 2.3e-5, 1.9e-5
 
 
 # ---- the heaviest GEMM shapes of the B=32 step, exactly as profiles/r03_gemm_shapes.txt lists them -------------------------------
@@ -256,7 +262,7 @@ def test_heaviest_convolutions_of_the_step_at_their_real_size(cfg, winograd, mon
     """winograd: the stride-1 3x3 layers with >= 128 channels go through the Winograd path (csrc/winograd.hip: F(4x4, 3x3), F(2x2, 3x3)
     for the forward of `feat`) by default; False keeps the direct implicit-GEMM kernels (LDS-halo 128x128 tile, 64x64 tile) value-checked
     at the same sizes.  F(4x4) arithmetic itself carries ~4e-5 absolute error on values of a few units in fp32 (its transform matrices
-    hold 4, 5, 8, 1/6, 1/24; measured with a float32 emulation of the algorithm against float64, tools/experiments/r04/wino_error.py):
+    hold 4, 5, 8, 1/6, 1/24; measured with a float32 emulation of the algorithm against float64, profiles/r04_winograd_ab.txt):
     the forward / input-gradient bars of a Winograd run are widened by that much -- the model-level parity bars are NOT (the B=32
     train step keeps every gradient inside its bar against the float64 oracle with this path on)."""
     from pdfnet_amd import functional as F
@@ -371,11 +377,19 @@ def test_heads_reading_one_feature_map_share_its_transformed_input():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("x3", [True, False])
 @pytest.mark.parametrize("cfg", [(32, 512, 32, 32, 256, 4, 2, 1), (32, 1024, 16, 16, 256, 4, 4, 0), (32, 2048, 8, 8, 256, 8, 8, 0)])
-def test_pyramid_transposed_convolutions_at_their_real_size(cfg):
-    """p3 / p4 / p5 (intaghand_encoder.py:602-605): p5's weight is the largest tensor of the model (33.5 M elements)."""
+def test_pyramid_transposed_convolutions_at_their_real_size(cfg, x3, monkeypatch):
+    """p3 / p4 / p5 (intaghand_encoder.py:602-605): p5's weight is the largest tensor of the model (33.5 M elements).  x3: the kernel == stride
+    layers (p4, p5) run forward and backward-data as x3 GEMMs by default (csrc/gemm_x3.hip: six bf16 MFMAs per fp32 product on 3-way split
+    operands); False keeps the native fp32-MFMA implicit GEMM value-checked at the same bars."""
     from pdfnet_amd import functional as F
     N, Cin, H, W, Cout, k, s, p = cfg
+    if not x3 and k != s:
+        pytest.skip("not an x3 layer: one run is enough")
+    monkeypatch.setattr(F, "X3_DECONV", x3)
+    if x3 and k == s:
+        assert F._x3_deconv_ws(N, H, W, Cin, Cout, k, k, s, p, 0, 'cuda')[1] > 0 and F._x3_deconv_ws(N, H, W, Cin, Cout, k, k, s, p, 1, 'cuda')[1] > 0
     torch.set_num_threads(_threads())
     x = _rnd(N, Cin, H, W, seed=1)
     w = _rnd(Cin, Cout, k, k, seed=2, scale=Cin ** -0.5)

@@ -55,9 +55,45 @@ def wino_like(shape, dev, scale):
     return (x * f * scale).contiguous()
 
 
+def deconvs():
+    """The pyramid's transposed convolutions through the Python op (forward, backward-data + weight gradient), x3 form off / on."""
+    from pdfnet_amd import functional as F
+    for name, Cin, H, Cout, k, s, p in (("p5 2048->256 k8s8 @8", 2048, 8, 256, 8, 8, 0), ("p4 1024->256 k4s4 @16", 1024, 16, 256, 4, 4, 0)):
+        x = torch.randn(32, Cin, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(Cin, Cout, k, k, device="cuda") * Cin ** -0.5).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(Cout, device="cuda")
+        fl = 2.0 * 32 * H * H * Cin * k * k * Cout
+        outs = {}
+        gy = None
+        for x3 in (False, True):
+            F.X3_DECONV = x3
+            xr = x.clone().requires_grad_()
+            with torch.no_grad():
+                tf = timeit(lambda: F.deconv2d(xr, w, b, s, p))
+            y = F.deconv2d(xr, w, b, s, p)
+            gy = torch.randn_like(y) if gy is None else gy
+            tb = timeit(lambda: torch.autograd.grad(y, xr, gy, retain_graph=True))
+            outs[x3] = (y.detach().clone(), torch.autograd.grad(y, xr, gy, retain_graph=True)[0].clone())
+            wr = w.clone().requires_grad_()
+
+            def wgrad():
+                yy = F.deconv2d(x, wr, None, s, p)
+                torch.autograd.grad(yy, wr, gy)
+                F.join_wgrad()
+            tw = timeit(wgrad) - tf                             # (forward + weight gradient, minus the forward)
+            print("%-24s x3 %-5s  forward %.3f ms (%.1f TF-eq)   backward-data %.3f ms (%.1f TF-eq)   weight gradient ~%.3f ms (%.1f TF-eq)"
+                  % (name, x3, tf * 1e3, fl / tf * 1e-12, tb * 1e3, fl / tb * 1e-12, tw * 1e3, fl / tw * 1e-12))
+        dy = (outs[True][0] - outs[False][0]).abs().max().item() / outs[False][0].abs().max().item()
+        dx = (outs[True][1] - outs[False][1]).abs().max().item() / outs[False][1].abs().max().item()
+        print("%-24s x3 vs native: max |dy| / max|y| = %.2e, max |d dx| / max|dx| = %.2e" % (name, dy, dx))
+    F.X3_DECONV = True
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     flt = args[0] if args else ""
+    if flt == "deconv":
+        return deconvs()
     opt = {a.split("=")[0]: a.split("=")[1] for a in sys.argv[1:] if a.startswith("--") and "=" in a}
     variants = [int(v) for v in opt.get("--variants", "0,1").split(",")]
     nprods = [int(v) for v in opt.get("--nprod", "6").split(",")]
