@@ -846,7 +846,7 @@ def main():
             "x3_mode": x3_mode,
             "x3_layers": "fp32 via 3 x bf16 split (six bf16 MFMAs per fp32 product), fp32 accumulate: " + ", ".join(
                 (["`feat` 3x3 1024 -> 256 Winograd F(4x4)-domain products (forward, backward-data, weight gradient)"] if x3_mode & 1 else []) +
-                (["p4 / p5 transposed convolutions (forward, backward-data)"] if x3_mode & 2 else [])),
+                (["p3 / p4 / p5 transposed convolutions (forward, backward-data, weight gradient)"] if x3_mode & 2 else [])),
             "everything_else": "native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
             "error_vs_float64": "x3 products 0.80-0.89x the native kernel's rms error, max error <= native (profiles/r06_x3_bench.txt)"}
         if world == 1 and not args.graph:

@@ -1566,6 +1566,12 @@ int pdf_internal_x3_deconv_fwd(const float* x, const float* w, const float* bias
                                int KH, int KW, int stride, int OH, int OW, int ldy, hipStream_t s);
 int pdf_internal_x3_deconv_bwd_data(const float* dy, const float* w, float* dx, float* ws, int N, int H, int W, int Cin, int lddx, int Cout,
                                     int KH, int KW, int stride, int OH, int OW, int lddy, hipStream_t s);
+int pdf_internal_x3_deconv_general_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin, int Cout,
+                                       int K, int stride, int pad, int OH, int OW, int ldy, hipStream_t s);
+int pdf_internal_x3_deconv_general_bwd_data(const float* dy, const float* w, float* dx, float* ws, int N, int H, int W, int Cin, int lddx, int Cout,
+                                            int K, int stride, int pad, int OH, int OW, int lddy, hipStream_t s);
+int pdf_internal_x3_deconv_general_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int N, int H, int W, int Cin, int Cout,
+                                              int K, int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s);
 int pdf_internal_x3_deconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int N, int H, int W, int Cin, int Cout,
                                       int KH, int KW, int stride, int OH, int OW, int lddy, int accumulate, hipStream_t s);
 PDF_API long pdf_deconv2d_x3_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward) {
@@ -2404,6 +2410,7 @@ static int pdf_deconv2d_fwd_impl(const float* x, const float* w, const float* bi
         const long need = pdf_internal_x3_deconv_workspace(N, H, W, Cin, Cout, KH, KW, stride, pad, 0);
         if (need > 0 && co.ws_floats >= need && ((uintptr_t)co.ws & 15) == 0) {
             const CurCall cur(co);
+            if (KH != stride || pad != 0) return pdf_internal_x3_deconv_general_fwd(x, w, bias, y, co.ws, N, H, W, Cin, Cout, KH, stride, pad, OH, OW, ldy, s);
             return pdf_internal_x3_deconv_fwd(x, w, bias, y, co.ws, N, H, W, Cin, Cout, KH, KW, stride, OH, OW, ldy, s);
         }
     }
@@ -2469,6 +2476,7 @@ static int pdf_deconv2d_bwd_data_impl(const float* dy, const float* w, float* dx
         const long need = pdf_internal_x3_deconv_workspace(N, H, W, Cin, Cout, KH, KW, stride, pad, 1);
         if (need > 0 && co.ws_floats >= need && ((uintptr_t)co.ws & 15) == 0) {
             const CurCall cur(co);
+            if (KH != stride || pad != 0) return pdf_internal_x3_deconv_general_bwd_data(dy, w, dx, co.ws, N, H, W, Cin, lddx, Cout, KH, stride, pad, OH, OW, lddy, s);
             return pdf_internal_x3_deconv_bwd_data(dy, w, dx, co.ws, N, H, W, Cin, lddx, Cout, KH, KW, stride, OH, OW, lddy, s);
         }
     }
@@ -2498,6 +2506,7 @@ static int pdf_deconv2d_bwd_weight_impl(const float* x, const float* dy, float* 
         const long need = pdf_internal_x3_deconv_workspace(N, H, W, Cin, Cout, KH, KW, stride, pad, 2);
         if (need > 0 && co.ws_floats >= need && ((uintptr_t)co.ws & 15) == 0) {
             const CurCall cur(co);
+            if (KH != stride || pad != 0) return pdf_internal_x3_deconv_general_bwd_weight(x, dy, dw, co.ws, N, H, W, Cin, Cout, KH, stride, pad, OH, OW, lddy, accumulate, s);
             return pdf_internal_x3_deconv_bwd_weight(x, dy, dw, co.ws, N, H, W, Cin, Cout, KH, KW, stride, OH, OW, lddy, accumulate, s);
         }
     }

@@ -88,7 +88,17 @@ struct X3Gemm {
     // NT epilogue of a transposed convolution with kernel == stride (pixel shuffle): row m = pixel (ni, qy, qx) of a QH x QW map, column n = (tap, co)
     // with ps_cout channels per tap and ps_kw taps per kernel row -> y[ni][qy * ps_s + ky][qx * ps_s + kx][co] (row stride ldc) + bias[co].  ps_cout == 0: plain C
     int ps_cout, ps_kw, ps_s, QH, QW, OH, OW;
+    int ooy, oox;                                       // ... output pixel offset (one parity class of a strided transposed convolution)
     const float* bias;
+    // NT, implicit A (template IM): row m = position (ni, qy, qx) of the QH x QW grid, K = T taps x Cc channels; element (m, t, c) is
+    // A[ni][qy sy + tdy[t]][qx sx + tdx[t]][c] of an AH x AW map with pixel stride lda, zero outside the map (masked lanes read the zero row at
+    // element offset zrow of every component plane, which the pre-pass appends).  Cc % 32 == 0.
+    int AH, AW, sy, sx, T, Cc;
+    long zrow;
+    int tdy[16], tdx[16];
+    // TN, implicit Q (template IQ): row m of the reduction = position (ni, iy, ix) of a QH x QW grid (both powers of two: lw = log2 QW, lhw = log2 QH QW);
+    // column j = (tap, c): Q[m][j] = B[ni][iy sy + tdy[tap]][ix sx + tdx[tap]][c] of an AH x AW map with pixel stride ldb, zero outside (zero row at zrow)
+    int lw, lhw;
     int rows_per_split, splits;                         // TN: rows of the reduction per block (multiple of 32)
     int accum;                                          // TN, one split: W += the product (a gradient accumulated into an existing one)
 };
@@ -120,7 +130,7 @@ __device__ __forceinline__ void x3_dma16s(const i32x4& rsrc, unsigned lds_addr, 
 // x3gemm_nt.  Block = WM x WN waves, each TM x TN accumulator tiles of 32 x 32; K-step 32: a row of a component image is 64 bytes = 4
 // chunks, chunk (r, c) at slot r * 4 + (c ^ ((r >> 2) & 3)) -- the 16 lanes of a ds_read_b128 group then hit 16 different 16-byte bank
 // groups (as igemm_bf16_dma, CPR = 4).  Lane l of an MFMA operand holds 8 consecutive k of row l & 31 at k-offset 8 (l >> 5).
-template <int WM, int WN, int TM, int TN, int ST, int NPROD>
+template <int WM, int WN, int TM, int TN, int ST, int NPROD, bool IM = false>
 __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
     constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int AIMG = BM * 64, BIMG = BN * 64, STAGE = 3 * (AIMG + BIMG);
@@ -147,6 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
     auto swz = [](int r) { return (r >> 2) & 3; };
 
     unsigned aoff[NIA], boff[NIB], alds[NIA], blds[NIB];
+    int aiy0[IM ? NIA : 1], aix0[IM ? NIA : 1], anb[IM ? NIA : 1]; unsigned acomp[IM ? NIA : 1], azero[IM ? NIA : 1];
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
         const int gi = wave * NIA + i, comp = gi / (BM / 16), rb = gi - comp * (BM / 16);
@@ -154,6 +165,12 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
         const int kc = (lane & 3) ^ swz(row);
         alds[i] = (unsigned)(comp * AIMG + rb * 1024);
         aoff[i] = (unsigned)((comp * g.csA + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8) * 2);
+        if constexpr (IM) {
+            const int r = min(m0 + row, g.M - 1), hw = g.QH * g.QW, ni = r / hw, rem2 = r - ni * hw, qy = rem2 / g.QW, qx = rem2 - qy * g.QW;
+            aiy0[i] = qy * g.sy; aix0[i] = qx * g.sx; anb[i] = ni * g.AH * g.AW;
+            acomp[i] = (unsigned)((comp * g.csA + kc * 8) * 2);
+            azero[i] = (unsigned)((comp * g.csA + g.zrow + kc * 8) * 2);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
@@ -165,15 +182,31 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
     }
     const int nk = g.K / 32;
     int nissued = 0;
-    unsigned ko = 0, sbase = lds0;
+    unsigned ko = 0, koa = 0, sbase = lds0;
+    int cur_tap = -1;
     auto piece = [&](int p) {
-        if (p < NIA) x3_dma16s(rsA, sbase + alds[p], aoff[p], ko);
+        if (p < NIA) x3_dma16s(rsA, sbase + alds[p], aoff[p], IM ? koa : ko);
         else x3_dma16s(rsB, sbase + blds[p - NIA], boff[p - NIA], ko);
     };
     auto begin_issue = [&](int stage) {
-        ko = (unsigned)min(nissued, nk - 1) * 64u;      // (a tile past the end re-reads the last one into a stage nobody consumes: uniform vmcnt counts)
+        const int kt = min(nissued, nk - 1);            // (a tile past the end re-reads the last one into a stage nobody consumes: uniform vmcnt counts)
+        ko = (unsigned)kt * 64u;
         ++nissued;
         sbase = lds0 + (unsigned)(stage * STAGE);
+        if constexpr (IM) {
+            const int tap = kt * 32 / g.Cc;
+            koa = (unsigned)(kt * 32 - tap * g.Cc) * 2u;
+            if (tap != cur_tap) {                         // every Cc / 32 K-steps: this lane's pixel of the new tap, or the zero row
+                cur_tap = tap;
+                const int dy = g.tdy[tap], dx = g.tdx[tap];
+#pragma unroll
+                for (int i = 0; i < NIA; ++i) {
+                    const int iy = aiy0[i] + dy, ix = aix0[i] + dx;
+                    const bool ok = ((unsigned)iy < (unsigned)g.AH) & ((unsigned)ix < (unsigned)g.AW);
+                    aoff[i] = ok ? acomp[i] + (unsigned)(anb[i] + iy * g.AW + ix) * (unsigned)(g.lda * 2) : azero[i];
+                }
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -277,7 +310,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
                     const int row = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
                     if (cok && row < g.M) {
                         const int hw = g.QH * g.QW, ni = row / hw, rem2 = row - ni * hw, qy = rem2 / g.QW, qx = rem2 - qy * g.QW;
-                        Cb[(((long)ni * g.OH + qy * g.ps_s + ky) * g.OW + qx * g.ps_s + kx) * g.ldc + co] = acc[i][j][r] + bv;
+                        Cb[(((long)ni * g.OH + qy * g.ps_s + ky + g.ooy) * g.OW + qx * g.ps_s + kx + g.oox) * g.ldc + co] = acc[i][j][r] + bv;
                     }
                 }
         }
@@ -317,9 +350,10 @@ static int x3_launch_nt(const X3Gemm& g, int nprod, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const dim3 grid((unsigned)(cdiv(g.M, BM) * cdiv(g.N, BN) * g.batch));
     char nm[96];
-    snprintf(nm, sizeof nm, "x3gemm_nt<%d, %d, %d, %d, %d, %d>", WM, WN, TM, TN, ST, nprod);
+    snprintf(nm, sizeof nm, g.T > 0 ? "x3gemm_nt<%d, %d, %d, %d, %d, %d, true>" : "x3gemm_nt<%d, %d, %d, %d, %d, %d>", WM, WN, TM, TN, ST, g.T > 0 ? 6 : nprod);
     KTimer kt(nm, 2.0 * g.batch * g.M * g.N * g.K, g.batch * (6.0 * ((double)g.M + g.N) * g.K + 4.0 * g.M * g.N), s);
-    if (nprod == 9) hipLaunchKernelGGL((x3gemm_nt<WM, WN, TM, TN, ST, 9>), grid, dim3(WM * WN * 64), 0, s, g);
+    if (g.T > 0) hipLaunchKernelGGL((x3gemm_nt<WM, WN, TM, TN, ST, 6, true>), grid, dim3(WM * WN * 64), 0, s, g);       // implicit A (six products only)
+    else if (nprod == 9) hipLaunchKernelGGL((x3gemm_nt<WM, WN, TM, TN, ST, 9>), grid, dim3(WM * WN * 64), 0, s, g);
     else if (nprod == 3) hipLaunchKernelGGL((x3gemm_nt<WM, WN, TM, TN, ST, 3>), grid, dim3(WM * WN * 64), 0, s, g);
     else hipLaunchKernelGGL((x3gemm_nt<WM, WN, TM, TN, ST, 6>), grid, dim3(WM * WN * 64), 0, s, g);
     PDF_LAUNCH_CHECK();
@@ -370,7 +404,7 @@ PDF_API int pdf_batched_gemm_nt(const float* A, const float* B, float* C, int ba
 // a tr-read service group touch 4 k-rows x 64 bytes: the 64-byte blocks of a row are XOR-swizzled by the row (k & 3; rows of 128 bytes:
 // (k >> 1) & 1) so that they fall on 4 different quarters of the 256-byte bank line -- again by choosing which global chunk a DMA lane
 // fetches.  Rows [split * rows_per_split, ...) of the reduction per block; the caller sums the splits.
-template <int WM, int WN, int TM, int TN, int ST, int NPROD>
+template <int WM, int WN, int TM, int TN, int ST, int NPROD, bool IQ = false>
 __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
     constexpr int NW = WM * WN, BI = WM * TM * 32, BJ = WN * TN * 32;
     constexpr int PIMG = 32 * BI * 2, QIMG = 32 * BJ * 2, STAGE = 3 * (PIMG + QIMG);
@@ -401,6 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
     auto swzq = [](int k) { return BJ >= 128 ? (k & 3) << 2 : ((k >> 1) & 1) << 2; };
 
     unsigned poff[NIP], qoff[NIQ], plds[NIP], qlds[NIQ];
+    int qrowl[IQ ? NIQ : 1], qdy[IQ ? NIQ : 1], qdx[IQ ? NIQ : 1]; unsigned qcol[IQ ? NIQ : 1], qzero[IQ ? NIQ : 1];
 #pragma unroll
     for (int i = 0; i < NIP; ++i) {
         constexpr int IPC = 32 * CP / 64, RPI = 64 / CP;                   // instructions per component image, k-rows per instruction
@@ -416,18 +451,35 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
         const int row = sub * RPI + lane / CQ, ch = (lane % CQ) ^ swzq(row);
         qlds[i] = (unsigned)(3 * PIMG + comp * QIMG + sub * 1024);
         qoff[i] = (unsigned)((comp * g.csB + (long)(ms + row) * ldq + min(j0 + ch * 8, NJ - 8)) * 2);
+        if constexpr (IQ) {
+            const int col = min(j0 + ch * 8, NJ - 8), tap = col / g.Cc;
+            qrowl[i] = row;
+            qcol[i] = (unsigned)((comp * g.csB + (col - tap * g.Cc)) * 2);
+            qzero[i] = (unsigned)((comp * g.csB + g.zrow + (col - tap * g.Cc)) * 2);
+            qdy[i] = g.tdy[tap]; qdx[i] = g.tdx[tap];
+        }
     }
     int nissued = 0;
     unsigned kp = 0, kq = 0, sbase = lds0;
     auto piece = [&](int p) {
         if (p < NIP) x3_dma16s(rsP, sbase + plds[p], poff[p], kp);
-        else x3_dma16s(rsQ, sbase + qlds[p - NIP], qoff[p - NIP], kq);
+        else x3_dma16s(rsQ, sbase + qlds[p - NIP], qoff[p - NIP], IQ ? 0u : kq);
     };
     auto begin_issue = [&](int stage) {
         const unsigned t = (unsigned)min(nissued, nk - 1);  // (past the end: the last tile again, into a stage nobody consumes)
         kp = t * 64u * (unsigned)ldp; kq = t * 64u * (unsigned)ldq;
         ++nissued;
         sbase = lds0 + (unsigned)(stage * STAGE);
+        if constexpr (IQ) {                                  // this K-step's 32 rows of the reduction -> their pixels of the tile's tap (or the zero row)
+#pragma unroll
+            for (int i = 0; i < NIQ; ++i) {
+                const int m = ms + (int)t * 32 + qrowl[i];
+                const int ni = m >> g.lhw, iy = (m >> g.lw) & (g.QH - 1), ix = m & (g.QW - 1);
+                const int yy = iy * g.sy + qdy[i], xx = ix * g.sx + qdx[i];
+                const bool ok = ((unsigned)yy < (unsigned)g.AH) & ((unsigned)xx < (unsigned)g.AW);
+                qoff[i] = ok ? qcol[i] + (unsigned)((ni * g.AH + yy) * g.AW + xx) * (unsigned)(ldq * 2) : qzero[i];
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -546,9 +598,10 @@ static int x3_launch_tn(const X3Gemm& g, int nprod, hipStream_t s) {
     constexpr int BI = WM * TM * 32, BJ = WN * TN * 32;
     const dim3 grid((unsigned)(cdiv(g.M, BI) * cdiv(g.N, BJ) * g.splits * g.batch));
     char nm[96];
-    snprintf(nm, sizeof nm, "x3gemm_tn<%d, %d, %d, %d, %d, %d>", WM, WN, TM, TN, ST, nprod);
+    snprintf(nm, sizeof nm, g.T > 0 ? "x3gemm_tn<%d, %d, %d, %d, %d, %d, true>" : "x3gemm_tn<%d, %d, %d, %d, %d, %d>", WM, WN, TM, TN, ST, g.T > 0 ? 6 : nprod);
     KTimer kt(nm, 2.0 * g.batch * g.K * g.M * g.N, g.batch * (6.0 * g.K * ((double)g.M + g.N) + 4.0 * g.splits * g.M * g.N), s);
-    if (nprod == 9) hipLaunchKernelGGL((x3gemm_tn<WM, WN, TM, TN, ST, 9>), grid, dim3(WM * WN * 64), 0, s, g);
+    if (g.T > 0) hipLaunchKernelGGL((x3gemm_tn<WM, WN, TM, TN, ST, 6, true>), grid, dim3(WM * WN * 64), 0, s, g);       // implicit Q (six products only)
+    else if (nprod == 9) hipLaunchKernelGGL((x3gemm_tn<WM, WN, TM, TN, ST, 9>), grid, dim3(WM * WN * 64), 0, s, g);
     else if (nprod == 3) hipLaunchKernelGGL((x3gemm_tn<WM, WN, TM, TN, ST, 3>), grid, dim3(WM * WN * 64), 0, s, g);
     else hipLaunchKernelGGL((x3gemm_tn<WM, WN, TM, TN, ST, 6>), grid, dim3(WM * WN * 64), 0, s, g);
     PDF_LAUNCH_CHECK();
@@ -598,15 +651,19 @@ PDF_API int pdf_batched_gemm_tn(const float* P, const float* Q, float* slab, int
 // x3 is for (tools/probe/x3_stamps.py: 222 TFLOP/s-equivalent on the p5 shape against 116 of the native kernel).  The operands are split by
 // pre-passes (the weights change every step): x -> x3 planes, w [Cin][taps * Cout] -> its transpose as x3 planes (forward) or as it lies
 // (backward-data), dy -> un-shuffled x3 planes [m][(tap, co)].
-// W [K][N] fp32 -> Wt3 [3][N][K]: 64 x 64 tiles through LDS
-__global__ __launch_bounds__(256) void x3_split_transpose_kernel(const float* __restrict__ w, unsigned short* __restrict__ o, int K, int N, long ldo, long cs) {
+// W [K][N] fp32 (row stride ldw) -> Wt3 [3][N][K] (row stride ldo): 64 x 64 tiles through LDS.  blockIdx.z = job: input and output advanced by
+// in_off[z] / out_off[z] elements (the per-tap [Cin][Cout] slices of a transposed-convolution weight, gathered into per-parity operands)
+struct X3TrJobs { long in_off[16], out_off[16]; };
+__global__ __launch_bounds__(256) void x3_split_transpose_kernel(const float* __restrict__ w, long ldw, unsigned short* __restrict__ o, int K, int N, long ldo, long cs,
+                                                                 const X3TrJobs jobs) {
     __shared__ float sm[64][65];
+    w += jobs.in_off[blockIdx.z]; o += jobs.out_off[blockIdx.z];
     const int tk = blockIdx.y * 64, tn = blockIdx.x * 64, t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = t / 16 + 16 * i, c = (t % 16) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tk + r < K && tn + c < N) v = *reinterpret_cast<const float4*>(w + (long)(tk + r) * N + tn + c);
+        if (tk + r < K && tn + c < N) v = *reinterpret_cast<const float4*>(w + (long)(tk + r) * ldw + tn + c);
         sm[r][c] = v.x; sm[r][c + 1] = v.y; sm[r][c + 2] = v.z; sm[r][c + 3] = v.w;
     }
     __syncthreads();
@@ -670,8 +727,10 @@ static int x3_deconv_mode() { return (pdf_internal_x3_mode() & 2) != 0; }
 // all start on the same L2 / HBM channel (without it p5's backward-data ran 1.57 ms against 1.29 of the native kernel: profiles/r06_x3_deconv.txt)
 static long x3_ld(long K) { return K + 64; }
 // floats of workspace the x3 form of this transposed convolution wants (backward = 0: forward, 1: backward-data, 2: weight gradient), 0 when it does not qualify
+static long x3_deconv_general_workspace(int N, int H, int W, int Cin, int Cout, int K, int stride, int pad, int backward);
 long pdf_internal_x3_deconv_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward) {
-    if (!x3_deconv_mode() || KH != stride || KW != stride || pad != 0 || stride < 2) return 0;
+    if (!x3_deconv_mode() || KH != KW || stride < 2) return 0;
+    if (KH != stride || pad != 0) return x3_deconv_general_workspace(N, H, W, Cin, Cout, KH, stride, pad, backward);
     const long M = (long)N * H * W, NT = (long)KH * KW * Cout;
     if (Cin % 32 != 0 || Cout % 32 != 0 || M < 1024 || 2.0 * M * NT * Cin < 3.0e10) return 0;      // (a long reduction over a large product: p4, p5)
     if (backward == 2 && (M % 32 != 0 || 3.0 * Cin * NT * 4.0 >= 4294967000.0)) return 0;
@@ -699,7 +758,7 @@ int pdf_internal_x3_deconv_fwd(const float* x, const float* w, const float* bias
     unsigned short* x3 = reinterpret_cast<unsigned short*>(ws + ((3 * NT * ld + 1) / 2 + 3) / 4 * 4);
     {
         KTimer kt("x3_split_transpose_kernel", 0.0, 10.0 * NT * Cin, s);
-        hipLaunchKernelGGL(x3_split_transpose_kernel, dim3((unsigned)cdiv(NT, 64), (unsigned)cdiv(Cin, 64)), dim3(256), 0, s, w, w3, Cin, (int)NT, ld, NT * ld);
+        hipLaunchKernelGGL(x3_split_transpose_kernel, dim3((unsigned)cdiv(NT, 64), (unsigned)cdiv(Cin, 64)), dim3(256), 0, s, w, NT, w3, Cin, (int)NT, ld, NT * ld, X3TrJobs{});
     }
     hipLaunchKernelGGL(x3_split_rows_kernel, dim3(grid_for(M * Cin / 8, 256, 256 * 16)), dim3(256), 0, s, x, (long)Cin, x3, ld, M * ld, M, Cin / 8);
     PDF_LAUNCH_CHECK();
@@ -746,4 +805,163 @@ int pdf_internal_x3_deconv_bwd_weight(const float* x, const float* dy, float* dw
     g.csA = M * ldx3; g.csB = M * ldd; g.lda = (int)ldx3; g.ldb = (int)ldd;
     g.M = Cin; g.N = (int)NT; g.K = (int)M; g.batch = 1; g.splits = 1; g.rows_per_split = (int)M; g.accum = accumulate;
     return x3_launch_tn<2, 2, 2, 2, 3>(g, 6, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Transposed convolutions whose kernel is a multiple of the stride (the pyramid's p3: 512 -> 256, k = 4, s = 2, pad = 1; intaghand_encoder.py:602):
+//   forward        s x s parity classes of output pixels, each an implicit GEMM over its (k / s)^2 taps: rows = the class's pixels (qy, qx), A = x at
+//                  (qy + dy[t], qx + dx[t]) (zero outside the map), B = the class's taps of w gathered and transposed by the pre-pass, output scattered
+//                  to (qy s + py, qx s + px);
+//   backward-data  ONE implicit GEMM: rows = input pixels (iy, ix), A = dy at (iy s - pad + ky, ix s - pad + kx) over all k^2 taps, B = w as it lies.
+// Same x3gemm_nt kernel (template IM): the tap's pixel offset is applied per lane when the tap changes, its channels advance by the scalar offset.
+static bool x3_general_ok(int Cin, int Cout, int K, int stride, int pad) {
+    return K % stride == 0 && K * K <= 16 && K > stride && pad >= 0 && pad < K && Cin % 32 == 0 && Cout % 32 == 0;
+}
+static int x3_general_wgrad_splits(long M, int NI, long NJ) {      // ~2 blocks per CU, at least 64 K-steps per block
+    const long tiles = (long)cdiv(NI, 128) * cdiv(NJ, 128);
+    long sp = (512 + tiles - 1) / tiles;
+    if (sp > M / 2048) sp = M / 2048;
+    return (int)(sp < 1 ? 1 : sp);
+}
+static long x3_deconv_general_workspace(int N, int H, int W, int Cin, int Cout, int K, int stride, int pad, int backward) {
+    if (!x3_general_ok(Cin, Cout, K, stride, pad)) return 0;
+    const int OH = (H - 1) * stride - 2 * pad + K, OW = (W - 1) * stride - 2 * pad + K;
+    if (OH % stride != 0 || OW % stride != 0) return 0;
+    const long Min = (long)N * H * W, Mout = (long)N * OH * OW, T = (long)(K / stride) * (K / stride);
+    if (2.0 * Min * K * K * Cin * Cout < 3.0e10) return 0;
+    long ael, bel;
+    if (backward == 2) {                                     // P = x, Q = dy (+ zero row), slabs of the split reduction
+        if ((H & (H - 1)) || (W & (W - 1)) || Min % 32 != 0 || Cout % 128 != 0) return 0;
+        const long pel = Min * x3_ld(Cin), qel = (Mout + 1) * x3_ld(Cout);
+        if (3.0 * pel >= 2147483000.0 || 3.0 * qel >= 2147483000.0) return 0;
+        return ((3 * pel + 1) / 2 + 3) / 4 * 4 + ((3 * qel + 1) / 2 + 3) / 4 * 4 + (long)x3_general_wgrad_splits(Min, Cin, (long)K * K * Cout) * Cin * K * K * Cout + 64;
+    }
+    if (backward == 0) { ael = (Min + 1) * x3_ld(Cin); bel = (long)stride * stride * Cout * x3_ld(T * Cin); }
+    else { ael = (Mout + 1) * x3_ld(Cout); bel = (long)Cin * x3_ld((long)K * K * Cout); }
+    if (3.0 * ael >= 2147483000.0 || 3.0 * bel >= 2147483000.0) return 0;
+    return ((3 * bel + 1) / 2 + 3) / 4 * 4 + ((3 * ael + 1) / 2 + 3) / 4 * 4 + 64;
+}
+static int x3_zero_rows(unsigned short* a3, long rows, long ld, hipStream_t s) {      // the zero row behind each component plane
+    for (int c = 0; c < 3; ++c)
+        if (hipMemsetAsync(a3 + c * (rows + 1) * ld + rows * ld, 0, (size_t)ld * 2, s) != hipSuccess) return PDF_E_BADARG;
+    return 0;
+}
+int pdf_internal_x3_deconv_general_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin, int Cout,
+                                       int K, int stride, int pad, int OH, int OW, int ldy, hipStream_t s) {
+    const long Min = (long)N * H * W;
+    const int kk = K / stride, T = kk * kk, P = stride * stride;
+    const long ldA = x3_ld(Cin), ldB = x3_ld((long)T * Cin);
+    unsigned short* b3 = reinterpret_cast<unsigned short*>(ws);
+    unsigned short* a3 = reinterpret_cast<unsigned short*>(ws + ((3 * P * Cout * ldB + 1) / 2 + 3) / 4 * 4);
+    // taps of parity class (py, px), in the order both operands use
+    int tky[4][16], tkx[4][16];
+    X3TrJobs jobs = {};
+    if (P > 4 || P * T > 16) return PDF_E_BADARG;
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            int n = 0;
+            for (int ky = 0; ky < K; ++ky) {
+                if (((py + pad - ky) % stride + stride) % stride != 0) continue;
+                for (int kx = 0; kx < K; ++kx) {
+                    if (((px + pad - kx) % stride + stride) % stride != 0) continue;
+                    const int pc = py * stride + px;
+                    tky[pc][n] = ky; tkx[pc][n] = kx;
+                    jobs.in_off[pc * T + n] = (long)(ky * K + kx) * Cout;
+                    jobs.out_off[pc * T + n] = (long)pc * Cout * ldB + (long)n * Cin;
+                    ++n;
+                }
+            }
+            if (n != T) return PDF_E_BADARG;
+        }
+    {
+        KTimer kt("x3_split_transpose_kernel", 0.0, 10.0 * K * K * Cout * Cin, s);
+        hipLaunchKernelGGL(x3_split_transpose_kernel, dim3((unsigned)cdiv(Cout, 64), (unsigned)cdiv(Cin, 64), (unsigned)(P * T)), dim3(256), 0, s,
+                           w, (long)K * K * Cout, b3, Cin, Cout, ldB, (long)P * Cout * ldB, jobs);
+    }
+    hipLaunchKernelGGL(x3_split_rows_kernel, dim3(grid_for(Min * Cin / 8, 256, 256 * 16)), dim3(256), 0, s, x, (long)Cin, a3, ldA, (Min + 1) * ldA, Min, Cin / 8);
+    if (int rc = x3_zero_rows(a3, Min, ldA, s)) return rc;
+    PDF_LAUNCH_CHECK();
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            const int pc = py * stride + px, QH = (OH - py + stride - 1) / stride, QW = (OW - px + stride - 1) / stride;
+            X3Gemm g;
+            x3_gemm_desc(g, a3, (Min + 1) * ldA, ldA, b3 + (long)pc * Cout * ldB, (long)P * Cout * ldB, ldB, y, N * QH * QW, Cout, T * Cin, ldy);
+            g.ps_cout = Cout; g.ps_kw = 1; g.ps_s = stride; g.QH = QH; g.QW = QW; g.OH = OH; g.OW = OW; g.ooy = py; g.oox = px; g.bias = bias;
+            g.AH = H; g.AW = W; g.sy = 1; g.sx = 1; g.T = T; g.Cc = Cin; g.zrow = Min * ldA;
+            for (int n = 0; n < T; ++n) {                      // iy = qy + (py + pad - ky) / stride (exact division: the tap belongs to the class)
+                g.tdy[n] = (py + pad - tky[pc][n]) / stride; g.tdx[n] = (px + pad - tkx[pc][n]) / stride;
+            }
+            if (int rc = x3_launch_auto(g, s)) return rc;
+        }
+    return 0;
+}
+int pdf_internal_x3_deconv_general_bwd_data(const float* dy, const float* w, float* dx, float* ws, int N, int H, int W, int Cin, int lddx, int Cout,
+                                            int K, int stride, int pad, int OH, int OW, int lddy, hipStream_t s) {
+    const long Mout = (long)N * OH * OW, M = (long)N * H * W, NT = (long)K * K * Cout;
+    const long ldA = x3_ld(Cout), ldB = x3_ld(NT);
+    unsigned short* b3 = reinterpret_cast<unsigned short*>(ws);
+    unsigned short* a3 = reinterpret_cast<unsigned short*>(ws + ((3 * Cin * ldB + 1) / 2 + 3) / 4 * 4);
+    {
+        KTimer kt("x3_split_rows_kernel", 0.0, 10.0 * NT * Cin, s);
+        hipLaunchKernelGGL(x3_split_rows_kernel, dim3(grid_for(NT * Cin / 8, 256, 256 * 16)), dim3(256), 0, s, w, NT, b3, ldB, Cin * ldB, (long)Cin, (int)(NT / 8));
+    }
+    {
+        KTimer kt("x3_split_rows_kernel", 0.0, 10.0 * Mout * Cout, s);
+        hipLaunchKernelGGL(x3_split_rows_kernel, dim3(grid_for(Mout * Cout / 8, 256, 256 * 16)), dim3(256), 0, s, dy, (long)lddy, a3, ldA, (Mout + 1) * ldA, Mout, Cout / 8);
+    }
+    if (int rc = x3_zero_rows(a3, Mout, ldA, s)) return rc;
+    PDF_LAUNCH_CHECK();
+    X3Gemm g;
+    x3_gemm_desc(g, a3, (Mout + 1) * ldA, ldA, b3, Cin * ldB, ldB, dx, (int)M, Cin, (int)NT, lddx);
+    g.QH = H; g.QW = W; g.AH = OH; g.AW = OW; g.sy = stride; g.sx = stride; g.T = K * K; g.Cc = Cout; g.zrow = Mout * ldA;
+    for (int ky = 0; ky < K; ++ky)
+        for (int kx = 0; kx < K; ++kx) { g.tdy[ky * K + kx] = ky - pad; g.tdx[ky * K + kx] = kx - pad; }
+    return x3_launch_auto(g, s);
+}
+
+// slab [splits][n] summed in split order into dw [n] (+= when accumulate)
+__global__ __launch_bounds__(256) void x3_slab_reduce_kernel(const float* __restrict__ slab, int splits, long n4, float* __restrict__ dw, int accumulate) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(slab)[i];
+        for (int y = 1; y < splits; ++y) { const float4 u = reinterpret_cast<const float4*>(slab)[(long)y * n4 + i]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        if (accumulate) { const float4 u = reinterpret_cast<const float4*>(dw)[i]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        reinterpret_cast<float4*>(dw)[i] = v;
+    }
+}
+// dw [Cin][K][K][Cout] (+)= the weight gradient of the general form: sum over input pixels m of x[m][ci] dy[pixel(m, tap)][co] -- x3gemm_tn with the Q operand
+// gathered per tap (template IQ), the reduction split over the chip, the splits summed into dw
+int pdf_internal_x3_deconv_general_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int N, int H, int W, int Cin, int Cout,
+                                              int K, int stride, int pad, int OH, int OW, int lddy, int accumulate, hipStream_t s) {
+    const long Min = (long)N * H * W, Mout = (long)N * OH * OW, NT = (long)K * K * Cout;
+    const long ldP = x3_ld(Cin), ldQ = x3_ld(Cout);
+    unsigned short* p3 = reinterpret_cast<unsigned short*>(ws);
+    float* wq = ws + ((3 * Min * ldP + 1) / 2 + 3) / 4 * 4;
+    unsigned short* q3 = reinterpret_cast<unsigned short*>(wq);
+    float* slab = wq + ((3 * (Mout + 1) * ldQ + 1) / 2 + 3) / 4 * 4;
+    hipLaunchKernelGGL(x3_split_rows_kernel, dim3(grid_for(Min * Cin / 8, 256, 256 * 16)), dim3(256), 0, s, x, (long)Cin, p3, ldP, Min * ldP, Min, Cin / 8);
+    {
+        KTimer kt("x3_split_rows_kernel", 0.0, 10.0 * Mout * Cout, s);
+        hipLaunchKernelGGL(x3_split_rows_kernel, dim3(grid_for(Mout * Cout / 8, 256, 256 * 16)), dim3(256), 0, s, dy, (long)lddy, q3, ldQ, (Mout + 1) * ldQ, Mout, Cout / 8);
+    }
+    if (int rc = x3_zero_rows(q3, Mout, ldQ, s)) return rc;
+    PDF_LAUNCH_CHECK();
+    const int splits = x3_general_wgrad_splits(Min, Cin, NT);
+    X3Gemm g = {};
+    g.A = p3; g.B = q3; g.C = splits > 1 ? slab : dw;
+    g.csA = Min * ldP; g.csB = (Mout + 1) * ldQ; g.lda = (int)ldP; g.ldb = (int)ldQ;
+    g.M = Cin; g.N = (int)NT; g.K = (int)Min; g.batch = 1;
+    g.rows_per_split = cdiv(cdiv(Min, splits), 32) * 32; g.splits = cdiv(Min, g.rows_per_split);
+    g.accum = (g.splits == 1) ? accumulate : 0;
+    g.QH = H; g.QW = W; g.AH = OH; g.AW = OW; g.sy = stride; g.sx = stride; g.T = K * K; g.Cc = Cout; g.zrow = Mout * ldQ;
+    g.lw = __builtin_ctz(W); g.lhw = __builtin_ctz(H * W);
+    for (int ky = 0; ky < K; ++ky)
+        for (int kx = 0; kx < K; ++kx) { g.tdy[ky * K + kx] = ky - pad; g.tdx[ky * K + kx] = kx - pad; }
+    if (g.splits == 1) g.C = dw;
+    if (int rc = x3_launch_tn<2, 2, 2, 2, 3>(g, 6, s)) return rc;
+    if (g.splits > 1) {
+        KTimer kt("x3_slab_reduce_kernel", 0.0, 4.0 * (g.splits + 1) * Cin * NT, s);
+        hipLaunchKernelGGL(x3_slab_reduce_kernel, dim3(grid_for((long)Cin * NT / 4)), dim3(256), 0, s, slab, g.splits, (long)Cin * NT / 4, dw, accumulate);
+        PDF_LAUNCH_CHECK();
+    }
+    return 0;
 }

@@ -256,9 +256,9 @@ def set_x3(mode):
 
 
 def _x3_deconv_ws(N, H, W, Cin, Cout, KH, KW, stride, pad, backward, dev):
-    if not X3_DECONV or _GEMM_BF16 or KH != stride or KW != stride or pad != 0:
+    if not X3_DECONV or _GEMM_BF16 or KH != KW or stride < 2:
         return None, None
-    key = (N, H, W, Cin, Cout, KH, stride, backward)
+    key = (N, H, W, Cin, Cout, KH, stride, pad, backward)
     n = _x3d_cache.get(key)
     if n is None:
         n = _x3d_cache[key] = _L().pdf_deconv2d_x3_workspace_floats(N, H, W, Cin, Cout, KH, KW, stride, pad, backward)

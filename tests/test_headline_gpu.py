@@ -380,16 +380,15 @@ def test_heads_reading_one_feature_map_share_its_transformed_input():
 @pytest.mark.parametrize("x3", [True, False])
 @pytest.mark.parametrize("cfg", [(32, 512, 32, 32, 256, 4, 2, 1), (32, 1024, 16, 16, 256, 4, 4, 0), (32, 2048, 8, 8, 256, 8, 8, 0)])
 def test_pyramid_transposed_convolutions_at_their_real_size(cfg, x3, monkeypatch):
-    """p3 / p4 / p5 (intaghand_encoder.py:602-605): p5's weight is the largest tensor of the model (33.5 M elements).  x3: the kernel == stride
-    layers (p4, p5) run forward and backward-data as x3 GEMMs by default (csrc/gemm_x3.hip: six bf16 MFMAs per fp32 product on 3-way split
-    operands); False keeps the native fp32-MFMA implicit GEMM value-checked at the same bars."""
+    """p3 / p4 / p5 (intaghand_encoder.py:602-605): p5's weight is the largest tensor of the model (33.5 M elements).  x3: the three layers run
+    as x3 GEMMs by default (csrc/gemm_x3.hip: six bf16 MFMAs per fp32 product on 3-way split operands; p4 / p5 plain GEMMs + pixel shuffle, p3
+    implicit GEMMs over its taps); False keeps the native fp32-MFMA implicit GEMM value-checked at the same bars."""
     from pdfnet_amd import functional as F
     N, Cin, H, W, Cout, k, s, p = cfg
-    if not x3 and k != s:
-        pytest.skip("not an x3 layer: one run is enough")
     monkeypatch.setattr(F, "X3_DECONV", x3)
-    if x3 and k == s:
+    if x3:                                                      # all three qualify: p4 / p5 as plain GEMMs (+ their weight gradients), p3 as implicit GEMMs over its taps
         assert F._x3_deconv_ws(N, H, W, Cin, Cout, k, k, s, p, 0, 'cuda')[1] > 0 and F._x3_deconv_ws(N, H, W, Cin, Cout, k, k, s, p, 1, 'cuda')[1] > 0
+        assert F._x3_deconv_ws(N, H, W, Cin, Cout, k, k, s, p, 2, 'cuda')[1] > 0
     torch.set_num_threads(_threads())
     x = _rnd(N, Cin, H, W, seed=1)
     w = _rnd(Cin, Cout, k, k, seed=2, scale=Cin ** -0.5)

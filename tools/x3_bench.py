@@ -58,7 +58,8 @@ def wino_like(shape, dev, scale):
 def deconvs():
     """The pyramid's transposed convolutions through the Python op (forward, backward-data + weight gradient), x3 form off / on."""
     from pdfnet_amd import functional as F
-    for name, Cin, H, Cout, k, s, p in (("p5 2048->256 k8s8 @8", 2048, 8, 256, 8, 8, 0), ("p4 1024->256 k4s4 @16", 1024, 16, 256, 4, 4, 0)):
+    for name, Cin, H, Cout, k, s, p in (("p5 2048->256 k8s8 @8", 2048, 8, 256, 8, 8, 0), ("p4 1024->256 k4s4 @16", 1024, 16, 256, 4, 4, 0),
+                                        ("p3 512->256 k4s2p1 @32", 512, 32, 256, 4, 2, 1)):
         x = torch.randn(32, Cin, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
         w = (torch.randn(Cin, Cout, k, k, device="cuda") * Cin ** -0.5).contiguous(memory_format=torch.channels_last)
         b = torch.randn(Cout, device="cuda")
