@@ -750,6 +750,7 @@ def main():
     ap.add_argument('--check-grads', action='store_true', help='(default for --gpus > 1) verify the reduced gradient against an all_gather of the rank-local ones')
     ap.add_argument('--no-check-grads', action='store_true')
     ap.add_argument('--no-collective-path', action='store_true', help='skip the one-rank RCCL measurement of the reduction path (config.collective_path_ms)')
+    ap.add_argument('--no-native-leg', action='store_true', help='skip the all-native-fp32-MFMA steps timed beside the shipped (x3) step (arithmetic.native_fp32_mfma_step)')
     ap.add_argument('--no-bf16-legs', action='store_true', help='skip the bf16 B=32 / B=64 per-GPU legs (bf16_per_gpu) of the default fp32 run')
     ap.add_argument('--gemm-shapes', default=None, help='write the per-shape table of the instrumented step to this file')
     ap.add_argument('--hbm-shapes', default=None, help='the same for the HBM-bound entry points (integer arguments, algorithmic MB, ms, GB/s)')
@@ -849,7 +850,7 @@ def main():
                 (["p3 / p4 / p5 transposed convolutions (forward, backward-data, weight gradient)"] if x3_mode & 2 else [])),
             "everything_else": "native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
             "error_vs_float64": "x3 products 0.80-0.89x the native kernel's rms error, max error <= native (profiles/r06_x3_bench.txt)"}
-        if world == 1 and not args.graph:
+        if world == 1 and not args.graph and not args.no_native_leg:
             try:
                 F.set_x3(0)
                 kn = max(5, args.steps // 3)

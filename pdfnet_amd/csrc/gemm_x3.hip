@@ -345,6 +345,18 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
     }
 }
 
+// tile choice (profiles/r06_x3_kernel_ab.txt, ms with 256 x 128 / 8 waves : 128 x 128 / 8 waves): a narrow output over a long reduction runs best on
+// the 128 x 128 tile with the 3-stage ring (`feat` forward, N = 256, K = 1,024: 0.95 : 0.84; p3 forward 0.80 : 0.78); wide outputs re-read less B
+// per flop on the 256 x 128 tile (p5 forward, N = 16,384: 0.76 : 0.84; p3 backward-data 0.66 : 0.72) and short reductions are prologue-bound and
+// prefer its fewer blocks (256 -> 256 at 64x64: 0.245 : 0.267) -- as long as those still fill the chip twice over
+static int x3_nt_variant(long M, long N, long K, long batch) {
+    static const int rule = getenv("PDF_X3_TILE_RULE") ? atoi(getenv("PDF_X3_TILE_RULE")) : 2;      // (A/B switch: 0 = round-6 first rule, 1 = K >= 512 -> 8-wave 128 x 128)
+    const bool fills = (long)cdiv(M, 256) * cdiv(N, 128) * batch >= 512;
+    if (rule == 0) return fills ? 0 : 1;
+    if (rule == 1) return K >= 512 ? 5 : (fills ? 0 : 5);
+    if (N <= 256 && K >= 1024) return 5;
+    return fills ? 0 : 5;
+}
 template <int WM, int WN, int TM, int TN, int ST>
 static int x3_launch_nt(const X3Gemm& g, int nprod, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -371,12 +383,12 @@ int pdf_internal_x3_batched_gemm(const void* A3, long csA, const void* B3, long 
     g.csA = csA; g.csB = csB; g.gsA = gsA; g.gsB = gsB; g.gsC = gsC;
     g.M = M; g.N = N; g.K = K; g.batch = batch; g.ldc = N; g.lda = K; g.ldb = K;
     g.col_major_tiles = cdiv(N, 128) > 4 * cdiv(M, 128);
-    if (variant < 0) {                                     // auto (tools/x3_bench.py): the 256-row tile where its row blocks fill the chip
-        variant = (long)cdiv(M, 256) * cdiv(N, 128) * batch >= 512 ? 0 : 1;
-    }
+    if (variant < 0) variant = x3_nt_variant(M, N, K, batch);
     if (variant == 1) return x3_launch_nt<2, 2, 2, 2, 3>(g, nprod, s);
     if (variant == 2) return x3_launch_nt<2, 2, 2, 1, 3>(g, nprod, s);
     if (variant == 3) return x3_launch_nt<2, 2, 1, 1, 2>(g, nprod, s);     // 64 x 64, 48 KB of LDS
+    if (variant == 4) return x3_launch_nt<4, 2, 1, 2, 3>(g, nprod, s);     // 128 x 128 on 8 waves (two per SIMD), 3-stage ring
+    if (variant == 5) return x3_launch_nt<2, 4, 2, 1, 3>(g, nprod, s);     // the same, waves 2 x 4
     return x3_launch_nt<4, 2, 2, 2, 2>(g, nprod, s);
 }
 PDF_API int pdf_x3_batched_gemm_nt(const void* A3, long csA, const void* B3, long csB, float* C, int batch, long gsA, long gsB, long gsC,
@@ -627,7 +639,8 @@ int pdf_internal_x3_batched_wgemm(const void* P3, long csP, const void* Q3, long
     g.rows_per_split = cdiv(cdiv(M, splits < 1 ? 1 : splits), 32) * 32;
     int rc;
     if (variant < 0) variant = (NI % 256 == 0 && (long)(NI / 256) * cdiv(NJ, 128) * g.splits * batch >= 512) ? 2 : 0;
-    if (variant == 1) rc = x3_launch_tn<2, 2, 2, 1, 3>(g, nprod, s);
+    if (variant == 3) rc = x3_launch_tn<2, 4, 2, 1, 3>(g, nprod, s);          // 128 x 128 on 8 waves
+    else if (variant == 1) rc = x3_launch_tn<2, 2, 2, 1, 3>(g, nprod, s);
     else if (variant == 2) rc = x3_launch_tn<4, 2, 2, 2, 2>(g, nprod, s);
     else rc = x3_launch_tn<2, 2, 2, 2, 3>(g, nprod, s);
     return rc != 0 ? (rc < 0 ? rc : -rc) : g.splits;
@@ -744,11 +757,11 @@ static void x3_gemm_desc(X3Gemm& g, const void* A3, long csA, long lda, const vo
     g.csA = csA; g.csB = csB; g.M = M; g.N = N; g.K = K; g.batch = 1; g.ldc = ldc; g.lda = (int)lda; g.ldb = (int)ldb;
     g.col_major_tiles = cdiv(N, 128) > 4 * cdiv(M, 128);
 }
-// the 256 x 128 tile (8 waves) where its blocks fill the chip twice over, else 128 x 128 (p5's backward-data is 2,048 x 2,048 over a 16,384-long
-// reduction: 128 of the wide tiles would leave half the CUs idle -- 1.54 ms against 1.29 of the native kernel, profiles/r06_x3_deconv.txt)
 static int x3_launch_auto(const X3Gemm& g, hipStream_t s) {
-    if ((long)cdiv(g.M, 256) * cdiv(g.N, 128) * g.batch >= 512) return x3_launch_nt<4, 2, 2, 2, 2>(g, 6, s);
-    return x3_launch_nt<2, 2, 2, 2, 3>(g, 6, s);
+    const int v = x3_nt_variant(g.M, g.N, g.K, g.batch);
+    if (v == 0) return x3_launch_nt<4, 2, 2, 2, 2>(g, 6, s);
+    if (v == 1) return x3_launch_nt<2, 2, 2, 2, 3>(g, 6, s);
+    return x3_launch_nt<2, 4, 2, 1, 3>(g, 6, s);
 }
 // y [N][OH][OW][Cout] (row stride ldy) = ConvTranspose2d(x [N][H][W][Cin] dense, w [Cin][KH][KW][Cout]) + bias, kernel == stride, pad 0
 int pdf_internal_x3_deconv_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin, int Cout,

@@ -411,13 +411,18 @@ static int x3_nprod() {
     return v;
 }
 static int x3_minc() {
-    static const int v = getenv("PDF_X3_MINC") ? atoi(getenv("PDF_X3_MINC")) : 512;
+    static const int v = getenv("PDF_X3_MINC") ? atoi(getenv("PDF_X3_MINC")) : 256;
     return v;
 }
 // (T, C) of a transformed tensor that SEVERAL launches read (the forward's V: heads sharing it, the weight gradient): x3 where the products it
-// feeds are long enough reductions to be bound by the matrix pipe -- C >= PDF_X3_MINC (512: `feat`; the 128- / 256-channel layers gain 0-25 % on
-// the product and lose as much on the 1.5x larger transform writes: profiles/r06_x3_step_ab.txt)
-static bool wino_x3(long T, int C) { return x3_mode() != 0 && C >= x3_minc() && C % 32 == 0 && T % 32 == 0 && 73.0 * (double)T * C < 2147483000.0; }
+// feeds are long enough reductions over enough tiles to be bound by the matrix pipe -- C >= PDF_X3_MINC (256) and T >= PDF_X3_MINT (2,048 tiles): `feat`
+// and the 256-channel layers on the 32x32 / 64x64 maps.  The 128-channel layers and ResNet layer 3 (T = 512) gain 0-25 % on the product and lose as
+// much on the 1.5x larger transform writes (profiles/r06_x3_step_ab.txt, r06_x3_minc_ab.txt: 512 / 0 -> 45.38 ms, 256 / 8192 -> 45.0, 256 / 2048 -> 44.87).
+static long x3_mint() {
+    static const long v = getenv("PDF_X3_MINT") ? atol(getenv("PDF_X3_MINT")) : 2048;
+    return v;
+}
+static bool wino_x3(long T, int C) { return x3_mode() != 0 && C >= x3_minc() && T >= x3_mint() && C % 32 == 0 && T % 32 == 0 && 73.0 * (double)T * C < 2147483000.0; }
 // a transformed tensor PRIVATE to one launch (backward-data's V of dy; the weight gradient's Yh): its format follows the launch
 static bool wino_x3_fits(long T, int C) { return x3_mode() != 0 && C % 32 == 0 && T % 32 == 0 && 73.0 * (double)T * C < 2147483000.0; }
 int pdf_internal_colsum(const float* g, int ldg, int C, long R, float* out, int accumulate, float* ws, hipStream_t s);

@@ -5,7 +5,7 @@
 tag=${1:-prof}
 root=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-run="python3 $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-mpjpe --no-bf16-legs --no-collective-path"
+run="python3 $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-mpjpe --no-bf16-legs --no-native-leg --no-collective-path"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/$tag.kt -o p -- $run > /tmp/$tag.kt.log 2>&1 < /dev/null
 cp /tmp/$tag.kt/p_kernel_stats.csv $root/gpurun_out/${tag}_kernel_stats.csv
 timeout 120 python3 $root/tools/gap_analysis.py /tmp/$tag.kt/p_kernel_trace.csv > $root/gpurun_out/${tag}_gaps.txt 2>&1 < /dev/null
@@ -14,7 +14,7 @@ timeout 120 python3 $root/tools/stream_timeline.py /tmp/$tag.kt/p_kernel_trace.c
 PDFNET_SIDE_STREAMS=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/$tag.kx -o p -- $run > /tmp/$tag.kx.log 2>&1 < /dev/null
 cp /tmp/$tag.kx/p_kernel_stats.csv $root/gpurun_out/${tag}_kernel_stats_exclusive.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  PDFNET_SIDE_STREAMS=0 timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/$tag.$c -o p -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-mpjpe --no-bf16-legs --no-collective-path > /tmp/$tag.$c.log 2>&1 < /dev/null
+  PDFNET_SIDE_STREAMS=0 timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/$tag.$c -o p -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-mpjpe --no-bf16-legs --no-native-leg --no-collective-path > /tmp/$tag.$c.log 2>&1 < /dev/null
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/$tag.fps.$c -o p -- python3 $root/tools/hbm_bench.py fps > /tmp/$tag.fps.$c.log 2>&1 < /dev/null
 done
 timeout 120 python3 $root/tools/pmc_traffic.py /tmp/$tag.FETCH_SIZE /tmp/$tag.WRITE_SIZE 3 $root/gpurun_out/${tag}_pmc_traffic.json $tag < /dev/null | cut -c1-400
