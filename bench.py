@@ -362,9 +362,11 @@ def pmc_traffic():
     p = files[-1]
     try:
         d = json.load(open(p))
-        cur = hashlib.sha256(open(os.path.join(ROOT, "pdfnet_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
-        if d.get("gemm_hip_sha256") != cur:
-            return None, None, "%s is older than csrc/gemm.hip (withheld)" % os.path.basename(p)
+        h = hashlib.sha256()
+        for f in ("gemm.hip", "gemm_x3.hip"):
+            h.update(open(os.path.join(ROOT, "pdfnet_amd", "csrc", f), "rb").read())
+        if d.get("gemm_hip_sha256") != h.hexdigest():
+            return None, None, "%s is older than csrc/gemm.hip / gemm_x3.hip (withheld)" % os.path.basename(p)
         per_symbol = {k: round(v["bytes_per_launch"]) for k, v in d.get("symbols", {}).items()}
         return (per_symbol, round(d["gemm_family"]["bytes_per_launch"]),
                 "%s (rocprofv3 --pmc, %s)" % (os.path.basename(p), d.get("tag", "")))

@@ -483,7 +483,8 @@ int pdf_x3_split(const float* x, void* out, long n, long cs, void* stream);
 long pdf_deconv2d_x3_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward);
 /* which launches take the x3 form: bit 0 = the wide Winograd-domain products, bit 1 = the kernel == stride transposed convolutions (default 3; env PDF_X3=0 /
  * PDF_X3_DECONV=0); -1 = back to the environment's choice.  Workspace sizes (pdf_conv2d_winograd_workspace_floats, _v_offset, pdf_deconv2d_x3_workspace_floats)
- * depend on it: query them again after a change. */
+ * depend on it: query them again after a change, and change it BETWEEN steps only (a forward's transformed input kept for its weight gradient is in the
+ * format of the mode it was written under). */
 int pdf_set_x3_mode(int mode);
 int pdf_debug_x3_mode(void);
 int pdf_debug_x3_stamps(unsigned long long* out);       /* diagnostic builds (-DX3_STAMPS=1) only: phase clocks of block 0 of the last x3gemm_nt launch; 0 otherwise */

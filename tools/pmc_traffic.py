@@ -172,7 +172,10 @@ def main():
                              "bytes_per_launch": (rb + wb) / max(n, 1)}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res["tag"] = sys.argv[5] if len(sys.argv) > 5 else ""
-    res["gemm_hip_sha256"] = hashlib.sha256(open(os.path.join(root, "pdfnet_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
+    h = hashlib.sha256()                                       # (round 6: gemm.hip + gemm_x3.hip, the two files the fp32-mode GEMM symbols come from)
+    for f in ("gemm.hip", "gemm_x3.hip"):
+        h.update(open(os.path.join(root, "pdfnet_amd", "csrc", f), "rb").read())
+    res["gemm_hip_sha256"] = h.hexdigest()
     h = hashlib.sha256()
     for f in ("pointops.hip", "norm.hip"):
         h.update(open(os.path.join(root, "pdfnet_amd", "csrc", f), "rb").read())
