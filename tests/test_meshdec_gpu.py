@@ -88,29 +88,41 @@ def test_fused_level_backward_equals_the_unfused_chain(level, drop):
     V, cin = (63, 126, 252)[level], (512, 256, 128)[level]
     x0 = torch.randn(2, B, V, cin, generator=torch.Generator().manual_seed(level + 3)).cuda()
     gy = torch.randn(2, B, V, cin // 2, generator=torch.Generator().manual_seed(level + 4)).cuda()
-    res = {}
-    for fused in (False, True):
-        layer.zero_grad(set_to_none=True)
-        x = x0.clone().requires_grad_()
-        F.manual_seed(99)
-        F.MESH_FUSED = fused
-        try:
-            out = layer(x) if fused else _unfused(layer, x)
-        finally:
-            F.MESH_FUSED = True
-        out.backward(gy)
-        F.join_wgrad()
-        torch.cuda.synchronize()
-        res[fused] = (out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None})
-    (o0, dx0, g0), (o1, dx1, g1) = res[False], res[True]
+    def both(gy):
+        res = {}
+        for fused in (False, True):
+            layer.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_()
+            F.manual_seed(99)
+            F.MESH_FUSED = fused
+            try:
+                out = layer(x) if fused else _unfused(layer, x)
+            finally:
+                F.MESH_FUSED = True
+            out.backward(gy)
+            F.join_wgrad()
+            torch.cuda.synchronize()
+            res[fused] = (out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None})
+        return res[False], res[True]
+    (o0, dx0, g0), (o1, dx1, g1) = both(gy)
     assert float((o0 - o1).abs().max()) <= 5e-5 * max(1.0, float(o0.abs().max()))
     # Two correct fp32 implementations round LayerNorm differently, so a ReLU input within ~1e-7 of zero can fall on opposite sides in the two
-    # forwards (one element per ~10^6): that (hand, sample)'s data gradient then differs by a few per cent and every parameter gradient by ~1e-2 of
-    # its size.  So: all but at most one (hand, sample) agree tightly, the odd one loosely; parameter gradients tight unless such a flip occurred.
+    # forwards (one element per ~10^6): that (hand, sample)'s data gradient then differs by a few per cent.  Such a sample is a COUNTED exception
+    # (at most one, printed): its sample's output gradient is zeroed and both paths run again, so that every other sample and EVERY parameter gradient is
+    # held to the tight bar -- no loose bar anywhere.
     top = float(dx0.abs().max())
     per = (dx0 - dx1).abs().amax((2, 3)) / top                              # [2, B]
     flipped = int((per > 1e-4).sum())
     assert flipped <= 1 and float(per.max()) <= 0.2, per
+    if flipped:
+        h, b = [int(v) for v in (per > 1e-4).nonzero()[0]]
+        print("level %d p %.1f: ReLU flip in (hand %d, sample %d), data gradient off by %.1e of the largest: excluded and re-run" % (level, drop, h, b, float(per.max())))
+        gy2 = gy.clone()
+        gy2[:, b] = 0                                                       # both hands of the sample: they exchange keys / values in the cross-hand attention
+        (o0, dx0, g0), (o1, dx1, g1) = both(gy2)
+        top = float(dx0.abs().max())
+        per = (dx0 - dx1).abs().amax((2, 3)) / top
+    assert int((per > 1e-4).sum()) == 0, per
     assert set(g0) == set(g1), set(g0) ^ set(g1)
     worst = []
     for n in g0:
@@ -119,9 +131,9 @@ def test_fused_level_backward_equals_the_unfused_chain(level, drop):
             topg = float(g0[n[:-4] + 'weight'].abs().max())
         err = float((g0[n] - g1[n]).abs().max())
         worst.append((err / (topg + 1e-30), n))
-        assert err <= (1e-1 if flipped else 2e-4) * topg + 1e-6, (n, err, topg)
+        assert err <= 2e-4 * topg + 1e-6, (n, err, topg)
     worst.sort(reverse=True)
-    print("level %d p %.1f: %d parameter gradients, %d flipped ReLU sample(s), worst relative deviations %s" % (level, drop, len(g0), flipped, ["%s %.1e" % (n, e) for e, n in worst[:3]]))
+    print("level %d p %.1f: %d parameter gradients, %d excluded ReLU-flip sample(s), worst relative deviations %s" % (level, drop, len(g0), flipped, ["%s %.1e" % (n, e) for e, n in worst[:3]]))
 
 
 @pytest.mark.parametrize("level", [0, 1, 2])
