@@ -453,13 +453,17 @@ def cpu_baseline(R, threads, B=4, steps=3):
     b = synthetic_train_batch(B, R, seed=1, consts=consts)
     o.train()
     times = []
-    for _ in range(steps + 1):
+    t_all = time.time()
+    for i in range(steps + 1):
         t0 = time.time()
         opt.zero_grad()
         loss, _ = run(b, 'train', 0)
         loss.mean().backward()
         opt.step()
         times.append(time.time() - t0)
+        if i >= 1 and time.time() - t_all + times[-1] > 45.0:       # bounded: ~10-30 s of CPU work on a fast host; a slow host (33 s per step seen) stops after one timed step
+            break
+    steps = len(times) - 1
     med = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": round(B / med, 4), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": "CPU oracle (oracle/pdfnet_cpu.py + oracle/loss_cpu.py, PyTorch fp32): B=%d %dx%d RGB-D, full train step "
