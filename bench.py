@@ -199,6 +199,14 @@ def symbol_roofline(sym, peak, traffic_by_symbol=None, traffic_src=None):
             "launches_per_step": dom[0], "ms_per_step": round(dom[3] * 1e3, 3),
             "algorithmic_gflop_per_launch": round(dom[1] / max(dom[0], 1) / 1e9, 2), "avg_launch_ms": round(dom[3] / max(dom[0], 1) * 1e3, 4),
             "algorithmic_bytes_per_launch": round(dom[2] / max(dom[0], 1)), "traffic": tr, "traffic_source": traffic_src}
+    if name.startswith('x3gemm'):
+        # an x3 kernel runs on the bf16 matrix pipe (six MFMAs per fp32 product): its roofline is that pipe's -- achieved = the bf16 FLOPs it executes,
+        # peak = 2.5 PFLOP/s; the fp32-equivalent rate stays beside it
+        head["achieved_fp32_equivalent"] = head["achieved"]
+        head["achieved"] = round(6.0 * dom[1] / dom[3] / 1e12, 2)
+        head["peak"] = PEAK_BF16_MFMA_TFLOPS
+        head["frac"] = round(head["achieved"] / PEAK_BF16_MFMA_TFLOPS, 4)
+        head["arithmetic"] = "x3: six bf16 MFMAs per fp32 product (fp32-exact to ~2^-24), bf16 matrix pipe"
     # the kernel TEMPLATE with the most time when its instantiations are summed (two boolean instantiations of one
     # igemm_nt<64, 64, ...> loop were the largest pool of the step while `kernel` named a smaller single symbol)
     fam = {}
