@@ -877,6 +877,8 @@ def main():
                 barrier()
                 dtn = time.time() - tn0
                 out["arithmetic"]["native_fp32_mfma_step"] = {"images_per_s": round(B * kn / dtn, 2), "ms_per_step": round(dtn / kn * 1e3, 3), "steps": kn}
+            except Exception as e:                             # noqa: BLE001 -- the headline line must still be printed
+                out["arithmetic"]["native_fp32_mfma_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
             finally:
                 F.set_x3(None)
                 for _ in range(2):
