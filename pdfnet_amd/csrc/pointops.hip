@@ -329,15 +329,21 @@ PDF_API int pdf_invert_index(const int* idx, int Bc, int N, int E, int* start, i
     PDF_LAUNCH_CHECK();
     return 0;
 }
-// du[b, n, :] = sum over the slots of point n, in list order, of dy[b, slot, :]      (one wave per point; lanes over channels)
+// du[b, n, :] = sum over the slots of point n, in list order, of dy[b, slot, :].  CL lanes (one float4 each) cover a point's C <= 4 CL channels and a
+// wave takes 64 / CL points at once: with one wave per point the 64-channel level ran 16 of its 64 lanes (2.0 TB/s).  The
+// summation order per element is unchanged (list order, four rows in flight), so the results are bit-identical to the one-wave-per-point form.
+template <int CL>
 __global__ __launch_bounds__(256) void gather_sub_bwd_du_kernel(const float* __restrict__ dy, int lddy, const int* __restrict__ start,
                                                                 const int* __restrict__ list, float* __restrict__ du, int ldu,
                                                                 int N, int E, int C, long total_points) {
-    const int lane = threadIdx.x & 63;
+    constexpr int PPW = 64 / CL;
+    const int lane = threadIdx.x & 63, sub = lane / CL;
     const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
     const long nw = ((long)gridDim.x * blockDim.x) >> 6;
-    const int c4 = lane * 4;                                 // C <= 256: one float4 per lane
-    for (long pt = w0; pt < total_points; pt += nw) {
+    const int c4 = (lane % CL) * 4;
+    for (long p0 = w0 * PPW; p0 < total_points; p0 += nw * PPW) {
+        const long pt = p0 + sub;
+        if (pt >= total_points || c4 >= C) continue;
         const long b = pt / N;
         const int n = (int)(pt - b * N);
         const int* st = start + b * (N + 1);
@@ -345,33 +351,34 @@ __global__ __launch_bounds__(256) void gather_sub_bwd_du_kernel(const float* __r
         const int* lst = list + b * E;
         const float* g = dy + b * E * lddy;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c4 < C) {
-            int j = s0;
-            for (; j + 4 <= s1; j += 4) {                    // four rows in flight; summed in list order
-                const float4 x0 = *reinterpret_cast<const float4*>(g + (long)lst[j] * lddy + c4);
-                const float4 x1 = *reinterpret_cast<const float4*>(g + (long)lst[j + 1] * lddy + c4);
-                const float4 x2 = *reinterpret_cast<const float4*>(g + (long)lst[j + 2] * lddy + c4);
-                const float4 x3 = *reinterpret_cast<const float4*>(g + (long)lst[j + 3] * lddy + c4);
-                acc.x = ((((acc.x + x0.x) + x1.x) + x2.x) + x3.x); acc.y = ((((acc.y + x0.y) + x1.y) + x2.y) + x3.y);
-                acc.z = ((((acc.z + x0.z) + x1.z) + x2.z) + x3.z); acc.w = ((((acc.w + x0.w) + x1.w) + x2.w) + x3.w);
-            }
-            for (; j < s1; ++j) {
-                const float4 x = *reinterpret_cast<const float4*>(g + (long)lst[j] * lddy + c4);
-                acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-            }
-            *reinterpret_cast<float4*>(du + pt * ldu + c4) = acc;
+        int j = s0;
+        for (; j + 4 <= s1; j += 4) {                        // four rows in flight; summed in list order
+            const float4 x0 = *reinterpret_cast<const float4*>(g + (long)lst[j] * lddy + c4);
+            const float4 x1 = *reinterpret_cast<const float4*>(g + (long)lst[j + 1] * lddy + c4);
+            const float4 x2 = *reinterpret_cast<const float4*>(g + (long)lst[j + 2] * lddy + c4);
+            const float4 x3 = *reinterpret_cast<const float4*>(g + (long)lst[j + 3] * lddy + c4);
+            acc.x = ((((acc.x + x0.x) + x1.x) + x2.x) + x3.x); acc.y = ((((acc.y + x0.y) + x1.y) + x2.y) + x3.y);
+            acc.z = ((((acc.z + x0.z) + x1.z) + x2.z) + x3.z); acc.w = ((((acc.w + x0.w) + x1.w) + x2.w) + x3.w);
         }
+        for (; j < s1; ++j) {
+            const float4 x = *reinterpret_cast<const float4*>(g + (long)lst[j] * lddy + c4);
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        *reinterpret_cast<float4*>(du + pt * ldu + c4) = acc;
     }
 }
-// dv[b, s, :] = -sum_k dy[b, s, k, :]   (one wave per centroid, k in order)
+// dv[b, s, :] = -sum_k dy[b, s, k, :]   (CL lanes per centroid, 64 / CL centroids per wave; k in order)
+template <int CL>
 __global__ __launch_bounds__(256) void gather_sub_bwd_dv_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dv, int ldv,
                                                                 int K, int C, long total_rows) {
-    const int lane = threadIdx.x & 63;
+    constexpr int PPW = 64 / CL;
+    const int lane = threadIdx.x & 63, sub = lane / CL;
     const long w0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
     const long nw = ((long)gridDim.x * blockDim.x) >> 6;
-    const int c4 = lane * 4;
-    for (long row = w0; row < total_rows; row += nw) {
-        if (c4 >= C) continue;
+    const int c4 = (lane % CL) * 4;
+    for (long r0 = w0 * PPW; r0 < total_rows; r0 += nw * PPW) {
+        const long row = r0 + sub;
+        if (row >= total_rows || c4 >= C) continue;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* g = dy + row * K * lddy + c4;
 #pragma unroll 4
@@ -387,8 +394,16 @@ PDF_API int pdf_gather_sub_bwd_sorted(const float* dy, int lddy, const int* star
     if (C > 256 || C % 4 != 0 || lddy % 4 != 0 || ldu % 4 != 0 || ldv % 4 != 0) return PDF_E_BADARG;
     const long pts = (long)Bc * N, rows = (long)Bc * S;
     if (pts == 0 || rows == 0) return 0;
-    hipLaunchKernelGGL(gather_sub_bwd_du_kernel, dim3(grid_for(pts * 64)), dim3(256), 0, s, dy, lddy, start, list, du, ldu, N, S * K, C, pts);
-    hipLaunchKernelGGL(gather_sub_bwd_dv_kernel, dim3(grid_for(rows * 64)), dim3(256), 0, s, dy, lddy, dv, ldv, K, C, rows);
+    if (C <= 64) {
+        hipLaunchKernelGGL((gather_sub_bwd_du_kernel<16>), dim3(grid_for(pts * 16)), dim3(256), 0, s, dy, lddy, start, list, du, ldu, N, S * K, C, pts);
+        hipLaunchKernelGGL((gather_sub_bwd_dv_kernel<16>), dim3(grid_for(rows * 16)), dim3(256), 0, s, dy, lddy, dv, ldv, K, C, rows);
+    } else if (C <= 128) {
+        hipLaunchKernelGGL((gather_sub_bwd_du_kernel<32>), dim3(grid_for(pts * 32)), dim3(256), 0, s, dy, lddy, start, list, du, ldu, N, S * K, C, pts);
+        hipLaunchKernelGGL((gather_sub_bwd_dv_kernel<32>), dim3(grid_for(rows * 32)), dim3(256), 0, s, dy, lddy, dv, ldv, K, C, rows);
+    } else {
+        hipLaunchKernelGGL((gather_sub_bwd_du_kernel<64>), dim3(grid_for(pts * 64)), dim3(256), 0, s, dy, lddy, start, list, du, ldu, N, S * K, C, pts);
+        hipLaunchKernelGGL((gather_sub_bwd_dv_kernel<64>), dim3(grid_for(rows * 64)), dim3(256), 0, s, dy, lddy, dv, ldv, K, C, rows);
+    }
     PDF_LAUNCH_CHECK();
     return 0;
 }
