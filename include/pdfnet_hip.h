@@ -486,6 +486,8 @@ long pdf_deconv2d_x3_workspace_floats(int N, int H, int W, int Cin, int Cout, in
  * depend on it: query them again after a change, and change it BETWEEN steps only (a forward's transformed input kept for its weight gradient is in the
  * format of the mode it was written under). */
 int pdf_set_x3_mode(int mode);
+/* a HIP stream of the given priority (clamped to the device's range, returned in *lo (least) / *hi (greatest) when not NULL; out == NULL: only the range) */
+int pdf_stream_create(void** out, int priority, int* lo, int* hi);
 int pdf_debug_x3_mode(void);
 int pdf_debug_x3_stamps(unsigned long long* out);       /* diagnostic builds (-DX3_STAMPS=1) only: phase clocks of block 0 of the last x3gemm_nt launch; 0 otherwise */
 int pdf_x3_batched_gemm_nt(const void* A3, long csA, const void* B3, long csB, float* C, int batch, long gsA, long gsB, long gsC, int M, int N, int K, int variant, int nprod, void* stream);

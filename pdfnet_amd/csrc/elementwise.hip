@@ -696,6 +696,23 @@ PDF_API int pdf_stream_wait(hipStream_t waiter, hipStream_t signaler) {
     return 0;
 }
 
+// A stream of the given HIP priority (hipDeviceGetStreamPriorityRange: -1 high ... 1 low on this runtime; torch.cuda.Stream offers only -1 / 0): the
+// weight-gradient side streams can be created BELOW the main chain's priority (round 6 experiment, profiles/r06_wgrad_priority.txt).
+// *lo / *hi (optional) receive the range.  The caller owns the stream (torch.cuda.ExternalStream) for the life of the process.
+PDF_API int pdf_stream_create(void** out, int priority, int* lo, int* hi) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return PDF_E_WORKSPACE;
+    if (lo) *lo = least;
+    if (hi) *hi = greatest;
+    if (out == nullptr) return 0;
+    if (priority > least) priority = least;
+    if (priority < greatest) priority = greatest;
+    hipStream_t s = nullptr;
+    if (hipError_t rc = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority)) return (int)rc;
+    *out = (void*)s;
+    return 0;
+}
+
 // The rings (ticket counters, split-K scratch, events) are process-wide and live on the device that was current at the first
 // call: one process drives one GPU (one rank per GPU).  A later call from another current device is refused instead of handing
 // kernels on GPU n the memory and events of GPU m.

@@ -460,7 +460,13 @@ class wgrad_stream:
         key = (dev, cur_raw)
         ent = _wg_streams.get(key)
         if ent is None:
-            s = torch.cuda.Stream(priority=WGRAD_STREAM_PRIORITY)
+            if WGRAD_STREAM_PRIORITY > 0:                    # below normal: only the HIP API offers it (pdf_stream_create)
+                import ctypes as _ct
+                raw = _ct.c_void_p()
+                _L().pdf_stream_create(_ct.byref(raw), WGRAD_STREAM_PRIORITY, None, None)
+                s = torch.cuda.ExternalStream(raw.value)
+            else:
+                s = torch.cuda.Stream(priority=WGRAD_STREAM_PRIORITY)
             ent = _wg_streams[key] = (s, s.cuda_stream, s.stream_id, s.device_index, s.device_type)
         side, side_raw = ent[0], ent[1]
         wait = _L().pdf_stream_wait
