@@ -1513,7 +1513,7 @@ static int launch_igemm(IGemm& g, hipStream_t s, int groups = 1, long stat_cap =
         // (a deep-ring form for the mesh decoder's latency-bound products -- the whole reduction in flight before the first MFMA, 4-8 stages
         // of the LDS-DMA kernel on <= 512 / 1024 tiles -- was measured: the pair entry points unchanged, the step 0.5-3 % slower;
         // profiles/r04_igemm_dma_ab.txt)
-        if (dma > 0 && fast && launch_igemm_dma(g, 64, dma - 1, groups, 0, s)) {}
+        if (dma > 0 && fast && g.batch == 0 && launch_igemm_dma(g, 64, dma - 1, groups, 0, s)) {}      // (batch == 0: igemm_dma reads blockIdx.y as the pair index, not as a plane of a batched launch -- it faulted on the Winograd products, round 6)
         else if (fast && g.Cin % 32 == 0 && env_int(ENV_IG_BK32, 1)) launch_igemm_tile<64, 64, 2, 2, 32>(g, fast, grid, s);
         else launch_igemm_tile<64, 64, 2, 2>(g, fast, grid, s);
         g_last_tile = 64064;
