@@ -860,10 +860,11 @@ def main():
         out["arithmetic"] = {
             "x3_mode": x3_mode,
             "x3_layers": "fp32 via 3 x bf16 split (six bf16 MFMAs per fp32 product), fp32 accumulate: " + ", ".join(
-                (["`feat` 3x3 1024 -> 256 Winograd F(4x4)-domain products (forward, backward-data, weight gradient)"] if x3_mode & 1 else []) +
+                (["the Winograd F(4x4)-domain products of the stride-1 3x3 layers with >= 256 channels on >= 2,048 tiles -- at B = 32: `feat` 1024 -> 256, p2 and the "
+                  "hm / wh / params head convolutions 256 -> 256, all on the 64x64 map (forward, backward-data, weight gradient)"] if x3_mode & 1 else []) +
                 (["p3 / p4 / p5 transposed convolutions (forward, backward-data, weight gradient)"] if x3_mode & 2 else [])),
             "everything_else": "native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-            "error_vs_float64": "x3 products 0.80-0.89x the native kernel's rms error, max error <= native (profiles/r06_x3_bench.txt)"}
+            "error_vs_float64": "x3 products 0.31-0.37x the native kernel's rms error, max error 0.35-0.45x (profiles/r06_x3_bench.txt; enforced by tests/test_x3_gpu.py)"}
         if world == 1 and not args.graph and not args.no_native_leg:
             try:
                 F.set_x3(0)

@@ -468,7 +468,8 @@ int pdf_debug_callopts_size(void);
 /* ---- x3 arithmetic (round 6, csrc/gemm_x3.hip): fp32 products on the bf16 matrix pipe ------------------------------------------
  * gfx950 has no TF32 and its fp32 MFMA runs at 1/16 of the bf16 MFMA rate.  A fp32 value is exactly h + m + l with three bf16 values
  * (8 + 8 + 8 significand bits), so six bf16 MFMAs with fp32 accumulation (hh', hm', mh', mm', hl', lh') reproduce the fp32 product to
- * ~2^-24 relative -- the order of the native instruction's own rounding -- in 6/16 of the matrix-pipe time.  Operands are "x3 planes":
+ * ~2^-24 relative -- the order of the native instruction's own rounding -- in 6/16 of the matrix-pipe time (hh' accumulates in a register set of its
+ * own, the five small products in a second: measured rms error against float64 0.31-0.37x the native fp32-MFMA kernel's).  Operands are "x3 planes":
  * three bf16 tensors of the operand's shape, component c at base + c * cs elements.  Used by the Winograd-domain products of the stride-1
  * 3x3 convolutions (nn.Conv2d sites intaghand_encoder.py:602,617,675-693 and ResNet layers 2-3; PDF_X3=0 keeps the native fp32 MFMA).
  *   pdf_x3_split            x [n] fp32 -> out: 3 planes of n bf16 (n % 8 == 0, cs % 8 == 0, 16-byte aligned)

@@ -104,6 +104,12 @@ struct X3Gemm {
 };
 
 // the NPROD products of one (A fragment set, B fragment set) pair as (component of A, component of B), smallest terms first
+// X3_SPLIT_ACC = 1: the leading product hh' goes to one accumulator set and the five small ones (2^-8 .. 2^-16 of it) to a second, added once after
+// the K loop.  The fp32 accumulator that carries the full magnitude then takes ONE rounding per 16 k instead of six (the small set's roundings are
+// 2^-8 of those): rms error against float64 0.8-0.9x -> ~0.4x the native fp32-MFMA kernel's (which rounds once per 2 k) -- tests/test_x3_gpu.py.
+#ifndef X3_SPLIT_ACC
+#define X3_SPLIT_ACC 1
+#endif
 template <int NPROD> struct X3Prod;
 template <> struct X3Prod<3> { static constexpr int a[3] = {1, 0, 0}, b[3] = {0, 1, 0}; };
 template <> struct X3Prod<6> { static constexpr int a[6] = {2, 0, 1, 1, 0, 0}, b[6] = {0, 2, 1, 0, 1, 0}; };
@@ -210,12 +216,20 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
     };
 
     f32x16 acc[TM][TN];
+#if X3_SPLIT_ACC
+    f32x16 acc2[TM][TN];                                     // the small products (see X3_SPLIT_ACC)
+#endif
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int c = 0; c < TN; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[a][c][r] = 0.f;
+#if X3_SPLIT_ACC
+                acc2[a][c][r] = 0.f;
+#endif
+            }
 
     const int h = lane >> 5;
     int arow[TM], acx[TM], brow[TN], bcx[TN];
@@ -233,6 +247,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
     int st = 0, stn = ST - 1;
     constexpr int NG = 2 * TM * TN, NP = NIA + NIB, NR = (TM + TN) * 3;      // tile visits, DMA pieces, fragment reads of one k-sub-step
     constexpr int NSLOT = NG * NPROD / 2;
+    constexpr int RSL = NSLOT / 2 - 1 > 0 ? NSLOT / 2 - 1 : 1;              // slots that carry the second sub-step's fragment reads (one-tile waves with three products: all in slot 0)
     using PR = X3Prod<NPROD>;
 #if X3_STAMPS
     unsigned long long tw = 0, tr = 0, tm = 0, t0 = X3_T(), rt0 = __builtin_amdgcn_s_memrealtime();
@@ -265,14 +280,18 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
         for (int q = 0; q < NG * NPROD; ++q) {
             const int gi = q / NPROD, pr = q % NPROD;
             const int ks = gi / (TM * TN), i = (gi / TN) % TM, j = gi % TN;
+#if X3_SPLIT_ACC
+            if (PR::a[pr] + PR::b[pr] != 0) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PR::a[pr]], bf[ks][j][PR::b[pr]], acc2[i][j], 0, 0, 0);
+            else
+#endif
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PR::a[pr]], bf[ks][j][PR::b[pr]], acc[i][j], 0, 0, 0);
             if (q % 2 == 1 || q == NG * NPROD - 1) {
                 const int slot = q / 2;
                 __builtin_amdgcn_sched_barrier(0);
                 // second sub-step's reads in the first slots (they are needed from slot NSLOT / 2 on), the DMA pieces on every other slot
 #pragma unroll
-                for (int r = slot * NR / (NSLOT / 2 - 1); r < (slot + 1) * NR / (NSLOT / 2 - 1) && r < NR; ++r)
-                    if (slot < NSLOT / 2 - 1) read1(1, r);
+                for (int r = slot * NR / RSL; r < (slot + 1) * NR / RSL && r < NR; ++r)
+                    if (slot < RSL) read1(1, r);
                 if (slot % 2 == 0 && slot / 2 < NP) piece(slot / 2);
                 if (slot == NSLOT - 1) {
 #pragma unroll
@@ -294,6 +313,12 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_nt(const X3Gemm g) {
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#if X3_SPLIT_ACC
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c) acc[a][c] += acc2[a][c];
+#endif
 
     if (g.ps_cout > 0) {                                     // pixel-shuffled output (+ bias): 32 lanes of a store = 32 consecutive channels of one output pixel
 #pragma unroll
@@ -495,12 +520,20 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
     };
 
     f32x16 acc[TM][TN];
+#if X3_SPLIT_ACC
+    f32x16 acc2[TM][TN];                                     // the small products (see X3_SPLIT_ACC)
+#endif
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int c = 0; c < TN; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[a][c][r] = 0.f;
+#if X3_SPLIT_ACC
+                acc2[a][c][r] = 0.f;
+#endif
+            }
 
     // transposing fragment reads: lane (g, q, p) = (lane >> 4, (lane & 15) >> 2, lane & 3) reads k-row 8 (g >> 1) + q (and + 4), columns c0 + 16 (g & 1) + 4 p ...
     const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
@@ -533,6 +566,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
     int st = 0, stn = ST - 1;
     constexpr int NG = 2 * TM * TN, NP = NIP + NIQ, NR = (TM + TN) * 3;
     constexpr int NSLOT = NG * NPROD / 2;
+    constexpr int RSL = NSLOT / 2 - 1 > 0 ? NSLOT / 2 - 1 : 1;              // slots that carry the second sub-step's fragment reads (one-tile waves with three products: all in slot 0)
     using PR = X3Prod<NPROD>;
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * (NIP + NIQ)) : "memory");
@@ -551,13 +585,17 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
         for (int q = 0; q < NG * NPROD; ++q) {               // (schedule: see above x3gemm_nt)
             const int gi = q / NPROD, pr = q % NPROD;
             const int ks = gi / (TM * TN), i = (gi / TN) % TM, j = gi % TN;
+#if X3_SPLIT_ACC
+            if (PR::a[pr] + PR::b[pr] != 0) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PR::a[pr]], bf[ks][j][PR::b[pr]], acc2[i][j], 0, 0, 0);
+            else
+#endif
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PR::a[pr]], bf[ks][j][PR::b[pr]], acc[i][j], 0, 0, 0);
             if (q % 2 == 1 || q == NG * NPROD - 1) {
                 const int slot = q / 2;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = slot * NR / (NSLOT / 2 - 1); r < (slot + 1) * NR / (NSLOT / 2 - 1) && r < NR; ++r)
-                    if (slot < NSLOT / 2 - 1) read1(1, r);
+                for (int r = slot * NR / RSL; r < (slot + 1) * NR / RSL && r < NR; ++r)
+                    if (slot < RSL) read1(1, r);
                 if (slot % 2 == 0 && slot / 2 < NP) piece(slot / 2);
                 if (slot == NSLOT - 1) {
 #pragma unroll
@@ -570,6 +608,12 @@ __global__ __launch_bounds__(WM * WN * 64) void x3gemm_tn(const X3Gemm g) {
         stn = stn == ST - 1 ? 0 : stn + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#if X3_SPLIT_ACC
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c) acc[a][c] += acc2[a][c];
+#endif
 
     const int h = lane >> 5;
     const bool whole = i0 + BI <= NI && (double)NI * NJ * 4.0 < 4294967000.0;
