@@ -15,7 +15,9 @@
 //   (One launch per direction was the first form: it spilled -- 64-bit dropout index chains, tape offsets in scratch, three accumulator
 //   sets live -- and ran slower than the split form; the splits are at points where nothing is live in registers.)
 //
-// One 256-thread workgroup per (hand, sample) keeps that hand's [V][C] features of the sample on ONE CU for a whole kernel:
+// One 512-thread workgroup per (hand, sample) -- eight waves, two per SIMD, two accumulator tiles each (round 6: the chain is latency-bound, and a second
+// wave per SIMD hides what one cannot: every kernel 1.05-1.6x faster than with four waves of four tiles, forward 2.28 -> 1.80 ms at B = 32, the step
+// +1.8 %; profiles/r06_mesh_w8.txt; -DMD_WAVES=4 builds the old form) -- keeps that hand's [V][C] features of the sample on ONE CU for a whole kernel:
 // V x C = 63 x 256 = 126 x 128 = 252 x 64 = 16,128 floats at every level, so two [V][C + 4] staging buffers (<= 139 KB) fit the
 // 160 KB LDS.  Every matrix product is "activation-stationary": the A operand (this hand's rows) is read from LDS by
 // ds_read_b128 -- lane l takes row l & 31 and the four k of chunk l >> 5, which feeds four v_mfma_f32_32x32x2_f32 (fp32 in, exact
@@ -40,7 +42,16 @@ namespace md_bf16_build {                      // the second compilation of this
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define MD_THREADS 256
+// MD_WAVES waves per workgroup: 8 (two per SIMD, two accumulator tiles each) or 4 (the form of round 5: four tiles each).  Sixteen -- one tile each,
+// 128 registers -- was measured too: the attention kernels spill hundreds of registers and run 0.4-0.8x, the rest gains less than with eight
+// (profiles/r06_mesh_waves.txt).
+#if defined(MD_WAVES) && MD_WAVES != 4 && MD_WAVES != 8
+#error "meshdec.hip: MD_WAVES must be 4 or 8"
+#endif
+#ifndef MD_WAVES
+#define MD_WAVES 8
+#endif
+#define MD_THREADS (64 * MD_WAVES)
 // MD_BF16 = 1 (csrc/meshdec_bf16.hip compiles this file a second time): the LINEAR products run on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32
 // accumulate) -- a lane holds 8 consecutive k of its activation row and of its weight row anyway, which is exactly one bf16 MFMA's operand pair
 // instead of eight fp32 ones; operands are rounded (RNE) as they are fed, like the library's bf16 GEMM mode does.  Attention, LayerNorm, the graph
@@ -106,7 +117,11 @@ struct PdfMeshLevel {
 template <int LV> struct Cfg {
     static constexpr int V = 63 << LV, VP = 64 << LV, C = 256 >> LV, LD = C + 4, DH = C / 4, H = 4;
     static constexpr int MT = VP / 32, NT = C / 32;
+#if MD_WAVES == 8
+    static constexpr int WMT = 2, WNT = 1;                                     // accumulator tiles per wave: always 2
+#else
     static constexpr int WMT = LV == 0 ? 2 : 4, WNT = LV == 0 ? 2 : 1;         // accumulator tiles per wave: always 4
+#endif
     static constexpr int BUF = VP * LD;                                        // floats per LDS staging buffer
 };
 
@@ -177,11 +192,19 @@ template <int LV> struct Geo {
     int mt0, nt0;                                 // first M-tile / N-tile of this wave
     __device__ Geo() {
         lane = threadIdx.x & 63; wave = threadIdx.x >> 6; half = lane >> 5; l31 = lane & 31;
+#if MD_WAVES == 8
+        mt0 = LV == 0 ? 0 : LV == 1 ? 2 * (wave >> 2) : 2 * (wave >> 1);
+        nt0 = LV == 0 ? wave : LV == 1 ? (wave & 3) : (wave & 1);
+#else
         mt0 = LV == 2 ? 4 * (wave >> 1) : 0;
         nt0 = LV == 0 ? 2 * wave : LV == 1 ? wave : (wave & 1);
+#endif
     }
 };
 
+// waves of a workgroup that take (head, tile) items of an attention pass when `parts` workgroups share `items` of them (level 0: 8 items over 2
+// workgroups -- four waves each, the other four only help with the staging)
+__host__ __device__ inline int md_active_waves(int items, int parts) { const int w = items / (parts < 1 ? 1 : parts); return w < 1 ? 1 : (w < MD_WAVES ? w : MD_WAVES); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -422,7 +445,7 @@ __device__ __forceinline__ float md_drop(float v, float p, float sc, uint32_t ke
 template <int LV>
 __device__ __forceinline__ void load_rows_scaled(float* __restrict__ dst, const float* __restrict__ src, int ld, int c0, float scale) {
     using G = Cfg<LV>;
-    constexpr int C4 = G::C / 4, NI = G::VP * C4 / MD_THREADS, NB = 8;
+    constexpr int C4 = G::C / 4, NI = G::VP * C4 / MD_THREADS, NB = NI < 8 ? NI : 8;
     if (MD_WHATIF == 6) return;
 #pragma unroll
     for (int k0 = 0; k0 < NI; k0 += NB) {                               // two batches of 8 loads (32 registers)
@@ -1057,7 +1080,7 @@ template <int LV>
 __device__ __forceinline__ void drop_rows(const float* __restrict__ src, bool from_global, float* __restrict__ dstt, float* __restrict__ dstu,
                                           float* __restrict__ save, float p, float sc, uint32_t key, uint32_t i0) {
     using G = Cfg<LV>;
-    constexpr int C = G::C, C4 = C / 4, NI = G::VP * C4 / MD_THREADS, NB = 8;
+    constexpr int C = G::C, C4 = C / 4, NI = G::VP * C4 / MD_THREADS, NB = NI < 8 ? NI : 8;
 #pragma unroll
     for (int k0 = 0; k0 < NI; k0 += NB) {
         f32x4 t[NB];
@@ -1096,8 +1119,9 @@ __device__ __forceinline__ void attention_bwd_q(const Geo<LV>& g, const float* _
     constexpr int MT = G::MT, DH = G::DH, DT = DH >= 32 ? DH / 32 : 1, MTC = MT < 4 ? MT : 4;
     const float inv_norm = 1.f / sqrtf((float)DH), sc = 1.f / (1.f - p);
     const uint32_t dkey = md_key(seed);
-    // (head, query tile) items: independent; `parts` workgroups share them (part = this one's share)
-    for (int item = g.wave + part * (MD_THREADS / 64); item < G::H * MT; item += parts * (MD_THREADS / 64)) {
+    // (head, query tile) items: independent; `parts` workgroups share them (part = this one's share), `aw` waves of each take one at a time
+    const int aw = md_active_waves(G::H * MT, parts);
+    for (int item = g.wave + part * aw; g.wave < aw && item < G::H * MT; item += parts * aw) {
         const int h = item / MT, qt = item - h * MT;
         const int qi = qt * 32 + g.l31, qrow = min(qi, G::V - 1);
         f32x4 qf[DH / 8], gf[DH / 8];
@@ -1186,7 +1210,8 @@ __device__ __forceinline__ void attention_bwd_kv(const Geo<LV>& g, const float* 
     constexpr int MT = G::MT, DH = G::DH, DT = DH >= 32 ? DH / 32 : 1, HV = G::H * G::VP, MTC = MT < 4 ? MT : 4;
     const float sc = 1.f / (1.f - p);
     const uint32_t dkey = md_key(seed);
-    for (int item = g.wave + part * (MD_THREADS / 64); item < G::H * MT; item += parts * (MD_THREADS / 64)) {
+    const int aw = md_active_waves(G::H * MT, parts);
+    for (int item = g.wave + part * aw; g.wave < aw && item < G::H * MT; item += parts * aw) {
         const int h = item / MT, kt = item - h * MT;
         const int key = kt * 32 + g.l31, krow = min(key, G::V - 1);
         f32x4 kf[DH / 8], vf[DH / 8];
@@ -1584,7 +1609,7 @@ static int mesh_bwd_launch(const PdfMeshLevel& a, hipStream_t s, hipStream_t sid
     PDF_LAUNCH_CHECK();
     static const int att_split = getenv("PDF_MESH_ATT_SPLIT") ? atoi(getenv("PDF_MESH_ATT_SPLIT")) : 7;      // bit LV: the split form at that level
     const bool split = (att_split >> LV) & 1;
-    // workgroups per attention pass: the (head, tile) items are 8 / 16 / 32 at level 0 / 1 / 2, four waves take four at a time
+    // workgroups per attention pass: the (head, tile) items are 8 / 16 / 32 at level 0 / 1 / 2, a workgroup's waves take one each at a time (md_active_waves)
     static const int att_parts_env = getenv("PDF_MESH_ATT_PARTS") ? atoi(getenv("PDF_MESH_ATT_PARTS")) : 0;      // e.g. 124 = 1 / 2 / 4 at level 0 / 1 / 2
     const int parts_default[3] = {2, 2, 4};                 // (measured, profiles/r05_att_split.txt: 1-1-1 49.4, 1-2-2 49.4, 1-2-4 49.3, 2-2-4 49.05, 2-4-8 49.4 ms per step; one workgroup for everything: 50.0)
     int parts = att_parts_env > 0 ? (LV == 0 ? att_parts_env / 100 : LV == 1 ? (att_parts_env / 10) % 10 : att_parts_env % 10) : parts_default[LV];
