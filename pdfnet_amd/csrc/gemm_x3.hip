@@ -664,6 +664,17 @@ static int x3_launch_tn(const X3Gemm& g, int nprod, hipStream_t s) {
     return 0;
 }
 
+// the transposed convolutions' weight gradients: tile of the TN kernel (PDF_X3_TN_DECONV: 0 = 128 x 128 on 4 waves, 3 = on 8 waves, 2 = 256 x 128 on 8 waves;
+// default: the wide tile when it still makes >= 256 blocks, else 128 x 128 on 8 waves -- isolated p5 0.77 -> 0.63 ms, p3 0.78 -> 0.70, p4 0.38 -> 0.37; the
+// step does not notice, these run beside the main chain: profiles/r06_tn_deconv.txt)
+static int x3_launch_tn_deconv(const X3Gemm& g, hipStream_t s) {
+    static const int env = getenv("PDF_X3_TN_DECONV") ? atoi(getenv("PDF_X3_TN_DECONV")) : -1;
+    int v = env;
+    if (v < 0) v = (g.M % 256 == 0 && (long)(g.M / 256) * cdiv(g.N, 128) * g.splits * g.batch >= 256) ? 2 : 3;
+    if (v == 3) return x3_launch_tn<2, 4, 2, 1, 3>(g, 6, s);
+    if (v == 2 && g.M % 256 == 0) return x3_launch_tn<4, 2, 2, 2, 2>(g, 6, s);
+    return x3_launch_tn<2, 2, 2, 2, 3>(g, 6, s);
+}
 // rows of the reduction per split and the split count actually used (rows per split a multiple of 32)
 int pdf_internal_x3_tn_splits(int M, int splits) {
     const int rps = cdiv(cdiv(M, splits < 1 ? 1 : splits), 32) * 32;
@@ -861,7 +872,7 @@ int pdf_internal_x3_deconv_bwd_weight(const float* x, const float* dy, float* dw
     g.A = x3; g.B = d3; g.C = dw;
     g.csA = M * ldx3; g.csB = M * ldd; g.lda = (int)ldx3; g.ldb = (int)ldd;
     g.M = Cin; g.N = (int)NT; g.K = (int)M; g.batch = 1; g.splits = 1; g.rows_per_split = (int)M; g.accum = accumulate;
-    return x3_launch_tn<2, 2, 2, 2, 3>(g, 6, s);
+    return x3_launch_tn_deconv(g, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -1014,7 +1025,7 @@ int pdf_internal_x3_deconv_general_bwd_weight(const float* x, const float* dy, f
     for (int ky = 0; ky < K; ++ky)
         for (int kx = 0; kx < K; ++kx) { g.tdy[ky * K + kx] = ky - pad; g.tdx[ky * K + kx] = kx - pad; }
     if (g.splits == 1) g.C = dw;
-    if (int rc = x3_launch_tn<2, 2, 2, 2, 3>(g, 6, s)) return rc;
+    if (int rc = x3_launch_tn_deconv(g, s)) return rc;
     if (g.splits > 1) {
         KTimer kt("x3_slab_reduce_kernel", 0.0, 4.0 * (g.splits + 1) * Cin * NT, s);
         hipLaunchKernelGGL(x3_slab_reduce_kernel, dim3(grid_for((long)Cin * NT / 4)), dim3(256), 0, s, slab, g.splits, (long)Cin * NT / 4, dw, accumulate);

@@ -11,6 +11,20 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm /*[4]*/) {
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
+// the same for a block of ML_T threads (sm [ML_T / 64]): the wave partials summed in a fixed order
+template <int NW>
+__device__ __forceinline__ float block_sum_waves(float v, float* sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += sm[w];
+    return s;
+}
+
 // out[r] = mean_i f(pred[r][i] - tgt[r][i]),  f = |.| (mode 0: F.l1_loss(reduction='none').mean(-1)) or (.)^2 (mode 1: F.mse_loss)
 __global__ __launch_bounds__(256) void rowloss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, long n, int mode,
                                                           float* __restrict__ out) {
@@ -312,6 +326,9 @@ PDF_API int pdf_point_dist_sum(const float* pred, const float* gt, int rows, int
 // part[(g * B + b) * MLP + k]: k = 0 sum (v2p - v2gt)^2, 1 mean |vp - vgt_off|, 2 mean |jp_off - jg_off|, 3 normal sum, 4 edge sum,
 // 5 mean |hd3 - g3|, 6 sum (hd2 - g2)^2, 7 mean |root_pred - root_gt|, 8 mean |jp - jgt|, 9 mean |vpred - vgt|, 10 sum (lms - lmsgt)^2, 11 bone term
 #define MLP 12
+// threads per (hand, sample) block: 1,024 -- the 126 length-778 dot products of the joint regression take one wave-turn each, a dependent chain per
+// turn: 16 waves make 8 turns of what 4 waves made 32 (round 6: forward 133 -> 88 us, backward 140 -> 76 us; profiles/r06_mesh_loss_threads.txt)
+#define ML_T 1024
 #define ML_V 778
 #define ML_VG 252
 #define ML_J 21
@@ -345,7 +362,7 @@ __device__ __forceinline__ void ml_common(const MeshLoss& a, int g, int b, MlSha
     __syncthreads();
     // joints = reg . verts: (21 x 3) x 2 dot products of length 778, one per wave-turn
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = wave; o < ML_J * 3 * 2; o += 4) {
+    for (int o = wave; o < ML_J * 3 * 2; o += ML_T / 64) {
         const int which = o / (ML_J * 3), jk = o - which * ML_J * 3, j = jk / 3, k = jk - 3 * j;
         const float* rg = a.reg[g] + (long)j * ML_V;
         const float* src = which ? vg : vp;
@@ -381,9 +398,9 @@ __device__ __forceinline__ void ml_common(const MeshLoss& a, int g, int b, MlSha
 // ground truth of the GCN-level terms: node i of the 252 = mean of mean of GCN nodes 4i .. 4i + 3 (two pair-averagings, :117-122)
 __device__ __forceinline__ float ml_pool4(float x0, float x1, float x2, float x3) { return ((x0 + x1) * 0.5f + (x2 + x3) * 0.5f) * 0.5f; }
 
-__global__ __launch_bounds__(256) void mesh_loss_fwd_kernel(const MeshLoss a) {
+__global__ __launch_bounds__(ML_T) void mesh_loss_fwd_kernel(const MeshLoss a) {
     __shared__ MlShared S;
-    __shared__ float sm[4];
+    __shared__ float sm[ML_T / 64];
     const int g = blockIdx.x / a.B, b = blockIdx.x - g * a.B;
     const long gb = blockIdx.x;
     ml_common(a, g, b, S);
@@ -393,8 +410,8 @@ __global__ __launch_bounds__(256) void mesh_loss_fwd_kernel(const MeshLoss a) {
     {
         const float* v2p = a.v2p + gb * ML_V * 2;
         const float* v2g = a.v2gt[g] + (long)b * ML_V * 2;
-        for (int i = threadIdx.x; i < ML_V * 2; i += 256) { const float d = v2p[i] - v2g[i]; s0 += d * d; }
-        for (int i = threadIdx.x; i < ML_V * 3; i += 256) {
+        for (int i = threadIdx.x; i < ML_V * 2; i += ML_T) { const float d = v2p[i] - v2g[i]; s0 += d * d; }
+        for (int i = threadIdx.x; i < ML_V * 3; i += ML_T) {
             const int k = i % 3;
             s1 += fabsf(vp[i] - (vg[i] - S.root_gt[k]));
             s9 += fabsf((vp[i] + S.root_pred[k]) - vg[i]);
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(256) void mesh_loss_fwd_kernel(const MeshLoss a) {
     float s3 = 0.f, s4 = 0.f;
     {
         const long long* fc = a.faces + (long)g * a.Fc * 3;
-        for (int f = threadIdx.x; f < a.Fc; f += 256) {
+        for (int f = threadIdx.x; f < a.Fc; f += ML_T) {
             const long i0 = fc[3 * f], i1 = fc[3 * f + 1], i2 = fc[3 * f + 2];
             const V3 p0 = ld3(vp, i0), p1 = ld3(vp, i1), p2 = ld3(vp, i2);
             const V3 r = {S.root_gt[0], S.root_gt[1], S.root_gt[2]};
@@ -442,12 +459,12 @@ __global__ __launch_bounds__(256) void mesh_loss_fwd_kernel(const MeshLoss a) {
         const float* rl = a.jgt[0] + (long)b * ML_J * 3 + 9 * 3;
         const float* v2g = a.v2gt[g] + (long)b * ML_V * 2;
         const long long* pm = a.perm[g];
-        for (int i = threadIdx.x; i < ML_VG * 3; i += 256) {
+        for (int i = threadIdx.x; i < ML_VG * 3; i += ML_T) {
             const int n = i / 3, k = i - 3 * n;
             const float t = ml_pool4(vl[pm[4 * n] * 3 + k] - rl[k], vl[pm[4 * n + 1] * 3 + k] - rl[k], vl[pm[4 * n + 2] * 3 + k] - rl[k], vl[pm[4 * n + 3] * 3 + k] - rl[k]);
             s5 += fabsf(hd3[i] - t);
         }
-        for (int i = threadIdx.x; i < ML_VG * 2; i += 256) {
+        for (int i = threadIdx.x; i < ML_VG * 2; i += ML_T) {
             const int n = i / 2, k = i - 2 * n;
             const float t = ml_pool4(v2g[pm[4 * n] * 2 + k], v2g[pm[4 * n + 1] * 2 + k], v2g[pm[4 * n + 2] * 2 + k], v2g[pm[4 * n + 3] * 2 + k]);
             const float d = hd2[i] - t;
@@ -457,7 +474,7 @@ __global__ __launch_bounds__(256) void mesh_loss_fwd_kernel(const MeshLoss a) {
     float v[MLP] = {s0, s1 / (ML_V * 3), s2 / (ML_J * 3), s3, s4, s5 / (ML_VG * 3), s6, s7 / 3.f, s8 / (ML_J * 3), s9 / (ML_V * 3), s10, s11 / 20.f};
 #pragma unroll
     for (int k = 0; k < MLP; ++k) {
-        const float t = block_sum_256(v[k], sm);
+        const float t = block_sum_waves<ML_T / 64>(v[k], sm);
         if (threadIdx.x == 0) a.part[gb * MLP + k] = t;
     }
 }
@@ -505,14 +522,14 @@ __global__ __launch_bounds__(64) void mesh_loss_finalize_kernel(const MeshLoss a
 }
 PDF_API int pdf_mesh_loss_fwd(const MeshLoss* a, hipStream_t s) {
     if (a == nullptr || a->B < 1 || a->part == nullptr || a->out == nullptr || a->Fc < 1) return PDF_E_BADARG;
-    hipLaunchKernelGGL(mesh_loss_fwd_kernel, dim3(2 * a->B), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(mesh_loss_fwd_kernel, dim3(2 * a->B), dim3(ML_T), 0, s, *a);
     hipLaunchKernelGGL(mesh_loss_finalize_kernel, dim3(1), dim3(64), 0, s, *a);
     PDF_LAUNCH_CHECK();
     return 0;
 }
 
 // backward: gradients of sum_k gout[k] * out[k] with respect to vp, v2p, hd3, hd2, r
-__global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
+__global__ __launch_bounds__(ML_T) void mesh_loss_bwd_kernel(const MeshLoss a) {
     __shared__ MlShared S;
     __shared__ float acc[ML_V * 3];                                       // d vp of this (hand, sample)
     __shared__ float djp[ML_J * 3], dlms[ML_J * 2], droot[3], gsum[2];
@@ -553,11 +570,11 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
         const float* v2p = a.v2p + gb * ML_V * 2;
         const float* v2g = a.v2gt[g] + (long)b * ML_V * 2;
         float* d = a.dv2p + gb * ML_V * 2;
-        for (int i = threadIdx.x; i < ML_V * 2; i += 256) d[i] = c0 * 2.f * (v2p[i] - v2g[i]);
+        for (int i = threadIdx.x; i < ML_V * 2; i += ML_T) d[i] = c0 * 2.f * (v2p[i] - v2g[i]);
     }
     // vertex L1 terms -> acc; the absolute term also feeds the root
     float dr0 = 0.f, dr1 = 0.f, dr2 = 0.f;
-    for (int i = threadIdx.x; i < ML_V * 3; i += 256) {
+    for (int i = threadIdx.x; i < ML_V * 3; i += ML_T) {
         const int k = i % 3;
         const float e1 = vp[i] - (vg[i] - S.root_gt[k]), e9 = (vp[i] + S.root_pred[k]) - vg[i];
         const float s1 = e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f), s9 = e9 > 0.f ? 1.f : (e9 < 0.f ? -1.f : 0.f);
@@ -611,7 +628,7 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
     // d vp += reg^T d jp_off
     {
         const float* rg = a.reg[g];
-        for (int v = threadIdx.x; v < ML_V; v += 256) {
+        for (int v = threadIdx.x; v < ML_V; v += ML_T) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int j = 0; j < ML_J; ++j) { const float w = rg[(long)j * ML_V + v]; s0 += w * djp[j * 3]; s1 += w * djp[j * 3 + 1]; s2 += w * djp[j * 3 + 2]; }
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
     // faces (face_loss_bwd_kernel's arithmetic)
     if (c3 != 0.f || c4 != 0.f) {
         const long long* fc = a.faces + (long)g * a.Fc * 3;
-        for (int f = threadIdx.x; f < a.Fc; f += 256) {
+        for (int f = threadIdx.x; f < a.Fc; f += ML_T) {
             const long idx[3] = {(long)fc[3 * f], (long)fc[3 * f + 1], (long)fc[3 * f + 2]};
             const V3 pv[3] = {ld3(vp, idx[0]), ld3(vp, idx[1]), ld3(vp, idx[2])};
             const V3 g0 = ld3(vg, idx[0]), g1 = ld3(vg, idx[1]), g2 = ld3(vg, idx[2]);
@@ -659,13 +676,13 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
         const long long* pm = a.perm[g];
         float* d3 = a.dhd3 + gb * ML_VG * 3;
         float* d2 = a.dhd2 + gb * ML_VG * 2;
-        for (int i = threadIdx.x; i < ML_VG * 3; i += 256) {
+        for (int i = threadIdx.x; i < ML_VG * 3; i += ML_T) {
             const int n = i / 3, k = i - 3 * n;
             const float t = ml_pool4(vl[pm[4 * n] * 3 + k] - rl[k], vl[pm[4 * n + 1] * 3 + k] - rl[k], vl[pm[4 * n + 2] * 3 + k] - rl[k], vl[pm[4 * n + 3] * 3 + k] - rl[k]);
             const float e = hd3[i] - t;
             d3[i] = c5 * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
         }
-        for (int i = threadIdx.x; i < ML_VG * 2; i += 256) {
+        for (int i = threadIdx.x; i < ML_VG * 2; i += ML_T) {
             const int n = i / 2, k = i - 2 * n;
             const float t = ml_pool4(v2g[pm[4 * n] * 2 + k], v2g[pm[4 * n + 1] * 2 + k], v2g[pm[4 * n + 2] * 2 + k], v2g[pm[4 * n + 3] * 2 + k]);
             d2[i] = c6 * 2.f * (hd2[i] - t);
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
     __syncthreads();
     {
         float* o = a.dvp + gb * ML_V * 3;
-        for (int i = threadIdx.x; i < ML_V * 3; i += 256) o[i] = acc[i];
+        for (int i = threadIdx.x; i < ML_V * 3; i += ML_T) o[i] = acc[i];
     }
     if (threadIdx.x == 0) {
         // root_pred = (z ax, z ay, z), z = 0.4 + r0 / 100, ax = (r1 / 100 + cx - K02) / (K00 + eps)
@@ -687,7 +704,7 @@ __global__ __launch_bounds__(256) void mesh_loss_bwd_kernel(const MeshLoss a) {
 }
 PDF_API int pdf_mesh_loss_bwd(const MeshLoss* a, hipStream_t s) {
     if (a == nullptr || a->B < 1 || a->gmp == nullptr || a->dvp == nullptr || a->dv2p == nullptr || a->dhd3 == nullptr || a->dhd2 == nullptr || a->dr == nullptr) return PDF_E_BADARG;
-    hipLaunchKernelGGL(mesh_loss_bwd_kernel, dim3(2 * a->B), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(mesh_loss_bwd_kernel, dim3(2 * a->B), dim3(ML_T), 0, s, *a);
     PDF_LAUNCH_CHECK();
     return 0;
 }
