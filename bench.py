@@ -862,7 +862,8 @@ def main():
             "x3_layers": "fp32 via 3 x bf16 split (six bf16 MFMAs per fp32 product), fp32 accumulate: " + ", ".join(
                 (["the Winograd F(4x4)-domain products of the stride-1 3x3 layers with >= 256 channels on >= 2,048 tiles -- at B = 32: `feat` 1024 -> 256, p2 and the "
                   "hm / wh / params head convolutions 256 -> 256, all on the 64x64 map (forward, backward-data, weight gradient)"] if x3_mode & 1 else []) +
-                (["p3 / p4 / p5 transposed convolutions (forward, backward-data, weight gradient)"] if x3_mode & 2 else [])),
+                (["p3 / p4 / p5 transposed convolutions (forward, backward-data, weight gradient)"] if x3_mode & 2 else []) +
+                (["the linear products of the fused mesh decoder (GCN blocks, attention projections and MLPs, forward and data gradients; operands split in registers)"] if x3_mode & 4 else [])),
             "everything_else": "native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
             "error_vs_float64": "x3 products 0.31-0.37x the native kernel's rms error, max error 0.35-0.45x (profiles/r06_x3_bench.txt; enforced by tests/test_x3_gpu.py)"}
         if world == 1 and not args.graph and not args.no_native_leg:

@@ -482,8 +482,8 @@ int pdf_x3_split(const float* x, void* out, long n, long cs, void* stream);
  * workspace (PdfCallOpts::ws of pdf_deconv2d_fwd_x, backward = 0, pdf_deconv2d_bwd_data_x, backward = 1, and pdf_deconv2d_bwd_weight_x, backward = 2) with which
  * the call runs as a plain x3 GEMM (+ pixel shuffle); 0 when the layer does not qualify (PDF_X3_DECONV=0 / PDF_X3=0: never). */
 long pdf_deconv2d_x3_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int backward);
-/* which launches take the x3 form: bit 0 = the wide Winograd-domain products, bit 1 = the kernel == stride transposed convolutions (default 3; env PDF_X3=0 /
- * PDF_X3_DECONV=0); -1 = back to the environment's choice.  Workspace sizes (pdf_conv2d_winograd_workspace_floats, _v_offset, pdf_deconv2d_x3_workspace_floats)
+/* which launches take the x3 form: bit 0 = the wide Winograd-domain products, bit 1 = the transposed convolutions, bit 2 = the fused mesh decoder's linear
+ * products (pdf_mesh_level_*_x3: the caller's choice of entry point) (default 7; env PDF_X3=0 / PDF_X3_DECONV=0 / PDF_X3_MESH=0); -1 = back to the environment's choice.  Workspace sizes (pdf_conv2d_winograd_workspace_floats, _v_offset, pdf_deconv2d_x3_workspace_floats)
  * depend on it: query them again after a change, and change it BETWEEN steps only (a forward's transformed input kept for its weight gradient is in the
  * format of the mode it was written under). */
 int pdf_set_x3_mode(int mode);
@@ -544,6 +544,10 @@ int pdf_mesh_level_bwd(const PdfMeshLevel* a, void* stream, void* side_stream);
  * graph product in fp32): for the library's bf16 mode (BASELINE configs 4-5).  Same argument block and tape layout. */
 int pdf_mesh_level_fwd_bf16(const PdfMeshLevel* a, void* stream);
 int pdf_mesh_level_bwd_bf16(const PdfMeshLevel* a, void* stream, void* side_stream);
+/* ... and with its linear products as x3 arithmetic (both operands split into three bf16 values as they are fed, six bf16 MFMAs per product: fp32-grade
+ * results, see "x3 arithmetic" above): what the fp32 mode runs when bit 2 of pdf_debug_x3_mode() is set.  Same argument block and tape layout. */
+int pdf_mesh_level_fwd_x3(const PdfMeshLevel* a, void* stream);
+int pdf_mesh_level_bwd_x3(const PdfMeshLevel* a, void* stream, void* side_stream);
 int pdf_debug_mesh_level_size(void);
 
 /* ---- fused mesh loss (round 5, csrc/loss.hip) --------------------------------------------------------------------------------

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpdfnet_hip.so")
-SOURCES = ["gemm.hip", "gemm_dma.hip", "gemm_x3.hip", "winograd.hip", "gemm_bf16.hip", "pointops.hip", "norm.hip", "elementwise.hip", "graph.hip", "meshdec.hip", "meshdec_bf16.hip", "mano.hip", "frontend.hip", "loss.hip"]
+SOURCES = ["gemm.hip", "gemm_dma.hip", "gemm_x3.hip", "winograd.hip", "gemm_bf16.hip", "pointops.hip", "norm.hip", "elementwise.hip", "graph.hip", "meshdec.hip", "meshdec_bf16.hip", "meshdec_x3.hip", "mano.hip", "frontend.hip", "loss.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wno-unused-result"]
 
 
@@ -26,7 +26,7 @@ def build(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
-        deps = [src] + hdrs + ([os.path.join(CSRC, "meshdec.hip")] if s == "meshdec_bf16.hip" else [])     # (it #includes meshdec.hip)
+        deps = [src] + hdrs + ([os.path.join(CSRC, "meshdec.hip")] if s in ("meshdec_bf16.hip", "meshdec_x3.hip") else [])     # (it #includes meshdec.hip)
         if force or _stale(obj, deps):
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
 

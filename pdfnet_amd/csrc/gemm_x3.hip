@@ -777,18 +777,20 @@ __global__ __launch_bounds__(256) void x3_split_unshuffle_kernel(const float* __
     }
 }
 // Which launches take the x3 form: bit 0 = the wide Winograd-domain products (winograd.hip), bit 1 = the kernel == stride transposed convolutions.
-// Default 3 (PDF_X3=0: none; PDF_X3_DECONV=0: not the transposed convolutions); pdf_set_x3_mode changes it at run time (bench.py times the native
+// Default 7 (PDF_X3=0: none; PDF_X3_DECONV=0: not the transposed convolutions; PDF_X3_MESH=0: not the fused mesh decoder's linear products -- bit 2, the
+// caller picks pdf_mesh_level_*_x3 by it); pdf_set_x3_mode changes it at run time (bench.py times the native
 // fp32-MFMA step beside the shipped one).  Workspace sizes depend on it: a caller that caches them (functional.py) drops its cache on a change.
 static int g_x3_mode = -1;
 int pdf_internal_x3_mode() {
     if (g_x3_mode < 0) {
-        int v = getenv("PDF_X3") ? (atoi(getenv("PDF_X3")) ? 3 : 0) : 3;
+        int v = getenv("PDF_X3") ? (atoi(getenv("PDF_X3")) ? 7 : 0) : 7;
         if (getenv("PDF_X3_DECONV") && !atoi(getenv("PDF_X3_DECONV"))) v &= ~2;
+        if (getenv("PDF_X3_MESH") && !atoi(getenv("PDF_X3_MESH"))) v &= ~4;
         g_x3_mode = v;
     }
     return g_x3_mode;
 }
-PDF_API int pdf_set_x3_mode(int mode) { g_x3_mode = mode < 0 ? -1 : (mode & 3); return 0; }
+PDF_API int pdf_set_x3_mode(int mode) { g_x3_mode = mode < 0 ? -1 : (mode & 7); return 0; }
 PDF_API int pdf_debug_x3_mode(void) { return pdf_internal_x3_mode(); }
 static int x3_deconv_mode() { return (pdf_internal_x3_mode() & 2) != 0; }
 // row stride (elements) of a pre-split operand with K columns: one 128-byte line of padding, so that rows of 2^k bytes (p5: 4 KB and 32 KB) do not

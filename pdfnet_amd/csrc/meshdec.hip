@@ -35,7 +35,16 @@
 #ifndef MD_BF16
 #define MD_BF16 0
 #endif
-#if MD_BF16
+// MD_X3 = 1 (csrc/meshdec_x3.hip, a third compilation, with MD_BF16 = 1): the linear products as x3 arithmetic -- both operands split into three bf16
+// values as they are fed (a = h + m + l exactly) and six bf16 MFMAs per product instead of one: fp32-grade results (gemm_x3.hip) in
+// 6/16 of the fp32 MFMA's matrix-pipe time.  Round 6: with two waves per SIMD the level-0 products run at 80-90 % of the CU's fp32 MFMA rate
+// (profiles/r06_mesh_stamps.txt), so the pipe is what bounds them.  Entry points pdf_mesh_level_fwd_x3 / _bwd_x3.
+#ifndef MD_X3
+#define MD_X3 0
+#endif
+#if MD_X3
+namespace md_x3_build {
+#elif MD_BF16
 namespace md_bf16_build {                      // the second compilation of this file: its kernels need names of their own
 #endif
 
@@ -66,6 +75,28 @@ __device__ __forceinline__ md_bf16x8 md_pack8(float a, float b, float c, float d
     x.u[0] = pdf_pk_bf16(a, b); x.u[1] = pdf_pk_bf16(c, d); x.u[2] = pdf_pk_bf16(e, f); x.u[3] = pdf_pk_bf16(g_, h);
     return x.v;
 }
+#if MD_X3
+// eight floats -> their three bf16 components (o[0] + o[1] + o[2] == the floats exactly), packed like md_pack8
+struct md_x3x8 { md_bf16x8 c[3]; };
+__device__ __forceinline__ md_x3x8 md_split8(float a, float b, float c, float d, float e, float f, float g_, float h) {
+    union { unsigned u[4]; md_bf16x8 v; } x0, x1, x2;
+    pdf_x3_split2(a, b, x0.u[0], x1.u[0], x2.u[0]); pdf_x3_split2(c, d, x0.u[1], x1.u[1], x2.u[1]);
+    pdf_x3_split2(e, f, x0.u[2], x1.u[2], x2.u[2]); pdf_x3_split2(g_, h, x0.u[3], x1.u[3], x2.u[3]);
+    md_x3x8 o;
+    o.c[0] = x0.v; o.c[1] = x1.v; o.c[2] = x2.v;
+    return o;
+}
+// acc += a . b as six bf16 MFMAs, smallest products first (l h', h l', m m', m h', h m', h h')
+__device__ __forceinline__ f32x16 md_mma_x3(const md_x3x8& a, const md_x3x8& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.c[2], b.c[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.c[0], b.c[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.c[1], b.c[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.c[1], b.c[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.c[0], b.c[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.c[0], b.c[0], acc, 0, 0, 0);
+    return acc;
+}
+#endif
 #endif
 #ifndef MD_WHATIF
 #define MD_WHATIF 0
@@ -263,17 +294,29 @@ __device__ __forceinline__ void gemm_nt(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT
         }
 #if MD_BF16
         {
+#if MD_X3
+#define MD_PK8 md_split8
+            md_x3x8 a8[WMT], b8[WNT];
+#else
+#define MD_PK8 md_pack8
             md_bf16x8 a8[WMT], b8[WNT];
+#endif
 #pragma unroll
             for (int i = 0; i < WMT; ++i)                        // CHEBY: (x, L x) pairs interleaved like the weight row's (even, odd) columns
-                a8[i] = CHEBY ? md_pack8(a0[i][0], a1[i][0], a0[i][1], a1[i][1], a0[i][2], a1[i][2], a0[i][3], a1[i][3])
-                              : md_pack8(a0[i][0], a0[i][1], a0[i][2], a0[i][3], a1[i][0], a1[i][1], a1[i][2], a1[i][3]);
+                a8[i] = CHEBY ? MD_PK8(a0[i][0], a1[i][0], a0[i][1], a1[i][1], a0[i][2], a1[i][2], a0[i][3], a1[i][3])
+                              : MD_PK8(a0[i][0], a0[i][1], a0[i][2], a0[i][3], a1[i][0], a1[i][1], a1[i][2], a1[i][3]);
 #pragma unroll
-            for (int j = 0; j < WNT; ++j) b8[j] = md_pack8(b[j][0][0], b[j][0][1], b[j][0][2], b[j][0][3], b[j][1][0], b[j][1][1], b[j][1][2], b[j][1][3]);
+            for (int j = 0; j < WNT; ++j) b8[j] = MD_PK8(b[j][0][0], b[j][0][1], b[j][0][2], b[j][0][3], b[j][1][0], b[j][1][1], b[j][1][2], b[j][1][3]);
 #pragma unroll
             for (int i = 0; i < WMT; ++i)
 #pragma unroll
-                for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WNT; ++j) {
+#if MD_X3
+                    acc[i][j] = md_mma_x3(a8[i], b8[j], acc[i][j]);
+#else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+#endif
+                }
         }
         if constexpr (false) {
 #else
@@ -369,12 +412,24 @@ __device__ __forceinline__ void gemm_nn(f32x16 (&acc)[Cfg<LV>::WMT][Cfg<LV>::WNT
 #pragma unroll
                     for (int e = 0; e < 4; ++e) be[j][e] = b[j][e];
             } else {
+#if MD_X3
+                md_x3x8 a8[WMT], b8[WNT];
+#pragma unroll
+                for (int i = 0; i < WMT; ++i) a8[i] = md_split8(ae[i][0], ae[i][1], ae[i][2], ae[i][3], a0[i][0], a0[i][1], a0[i][2], a0[i][3]);
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) b8[j] = md_split8(be[j][0], be[j][1], be[j][2], be[j][3], b[j][0], b[j][1], b[j][2], b[j][3]);
+#pragma unroll
+                for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WNT; ++j) acc[i][j] = md_mma_x3(a8[i], b8[j], acc[i][j]);
+#else
 #pragma unroll
                 for (int i = 0; i < WMT; ++i)
 #pragma unroll
                     for (int j = 0; j < WNT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(md_pack8(ae[i][0], ae[i][1], ae[i][2], ae[i][3], a0[i][0], a0[i][1], a0[i][2], a0[i][3]),
                                                                             md_pack8(be[j][0], be[j][1], be[j][2], be[j][3], b[j][0], b[j][1], b[j][2], b[j][3]), acc[i][j], 0, 0, 0);
+#endif
             }
 #else
 #pragma unroll
@@ -973,7 +1028,10 @@ static int mesh_check(const PdfMeshLevel* a) {
 }
 
 // One DualGraphLayer forward (position embedding already added to x).  Launches three kernels on `stream`; allocates nothing, synchronises nothing.
-#if MD_BF16
+#if MD_X3
+#define pdf_mesh_level_fwd pdf_mesh_level_fwd_x3
+#define pdf_mesh_level_bwd pdf_mesh_level_bwd_x3
+#elif MD_BF16
 #define pdf_mesh_level_fwd pdf_mesh_level_fwd_bf16
 #define pdf_mesh_level_bwd pdf_mesh_level_bwd_bf16
 #endif
@@ -1700,5 +1758,5 @@ PDF_API int pdf_debug_mesh_stamps(unsigned long long* out) {
 #endif
 }
 #else
-}   // namespace md_bf16_build
+}   // namespace md_bf16_build / md_x3_build
 #endif

@@ -248,7 +248,8 @@ _x3d_cache = {}
 
 def set_x3(mode):
     """Which launches run as x3 products (include/pdfnet_hip.h pdf_set_x3_mode: bit 0 Winograd-domain products of the wide layers, bit 1 the
-    kernel == stride transposed convolutions; None = the environment's choice).  Drops the cached workspace sizes, which depend on it."""
+    transposed convolutions, bit 2 the fused mesh decoder's linear products; None = the environment's choice).  Drops the cached workspace sizes, which
+    depend on it."""
     _L().pdf_set_x3_mode(-1 if mode is None else int(mode))
     _wino_cache.clear()
     _wino_voff.clear()
@@ -2266,6 +2267,19 @@ def mesh_bf16_mfma():
     return _GEMM_BF16 and MESH_BF16_MFMA
 
 
+def mesh_x3():
+    """fp32 mode: the fused levels' linear products as x3 arithmetic (bit 2 of the library's x3 mode; PDF_X3_MESH=0 / set_x3 keep the native fp32 MFMA)."""
+    return (not _GEMM_BF16) and (_L().pdf_debug_x3_mode() & 4) != 0
+
+
+def _mesh_entry(L, which):
+    if mesh_bf16_mfma():
+        return getattr(L, 'pdf_mesh_level_%s_bf16' % which)
+    if mesh_x3():
+        return getattr(L, 'pdf_mesh_level_%s_x3' % which)
+    return getattr(L, 'pdf_mesh_level_%s' % which)
+
+
 def _pair(dst, l, r):
     dst[0], dst[1] = ptr(l), ptr(r)
 
@@ -2333,7 +2347,7 @@ def mesh_level_forward(layer, x, training=False, save=False):
     qkv = torch.empty((3, 2, B, V, C), dtype=torch.float32, device=x.device)
     a = _mesh_args(layer, x, save or training, float(layer.attn.p) if training else 0.0, out, tape, qkv)
     # bf16 mode: the build of the same kernels whose linear products run on the bf16 MFMA (csrc/meshdec_bf16.hip); same tape
-    (_L().pdf_mesh_level_fwd_bf16 if mesh_bf16_mfma() else _L().pdf_mesh_level_fwd)(_byref(a), stream())
+    _mesh_entry(_L(), 'fwd')(_byref(a), stream())
     return out, a, tape, qkv
 
 
@@ -2408,7 +2422,7 @@ class _MeshLevel(Function):
         # bucket copy): they are produced on it too.
         direct = all(g is None for g in grads)
         with wgrad_stream(direct, x, tape, qkv, gtape, ws, dout, params=tensors):
-            (L.pdf_mesh_level_bwd_bf16 if mesh_bf16_mfma() else L.pdf_mesh_level_bwd)(_byref(a), cur, stream())
+            _mesh_entry(L, 'bwd')(_byref(a), cur, stream())
         ctx.keep = ctx.args = None
         return (dx, None, None) + tuple(grads)
 

@@ -14,6 +14,17 @@ from tests.util import gold, T
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["x3", "native"])
+def _mesh_arithmetic(request):
+    """Every test of this file runs twice: with the fused levels' linear products as x3 arithmetic (the shipped default, csrc/meshdec_x3.hip) and on the
+    native fp32 MFMA (x3 mode bit 2 off)."""
+    from pdfnet_amd import functional as F
+    F.set_x3(7 if request.param == "x3" else 3)
+    assert F.mesh_x3() == (request.param == "x3")
+    yield
+    F.set_x3(None)
+
+
 def _layer(level):
     from oracle import synth
     from pdfnet_amd.networks import intaghand_decoder as D

@@ -360,4 +360,4 @@ def test_committed_bench_line_keeps_the_drivers_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "images/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     a = d["arithmetic"]                                                                                 # x3 is disclosed, with the all-native step beside it
-    assert a["x3_mode"] in (1, 2, 3) and a["native_fp32_mfma_step"]["images_per_s"] > 0 and "native fp32 MFMA" in a["everything_else"]
+    assert 1 <= a["x3_mode"] <= 7 and a["native_fp32_mfma_step"]["images_per_s"] > 0 and "native fp32 MFMA" in a["everything_else"]
