@@ -41,7 +41,10 @@ def make_opt(R):
 def _with_explicit_form(lib, name):
     """-> [name, name + '_x'] when the library has the explicit-options form of the entry point (include/pdfnet_hip.h PdfCallOpts):
     same positional arguments, the options structure appended -- the argument positions the profilers read are unchanged."""
-    return [name, name + '_x'] if (name + '_x') in lib.protos else [name]
+    names = [name, name + '_x'] if (name + '_x') in lib.protos else [name]
+    if name.startswith('pdf_mesh_level'):                    # the x3 and bf16 builds of the fused mesh decoder: same call, same contraction
+        names += [name + s for s in ('_x3', '_bf16') if (name + s) in lib.protos]
+    return names
 
 
 class GemmProfiler:
