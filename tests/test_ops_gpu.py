@@ -1218,3 +1218,21 @@ def test_statistics_epilogue_survives_a_large_common_offset(F):
     close(rv, y64.var(0, unbiased=True).float(), 1e-6, rtol=1e-4, what="var")
     ref = ((y64 - y64.mean(0)) / (y64.var(0, unbiased=False) + 1e-5).sqrt()).float()
     close(out.permute(0, 2, 3, 1).reshape(-1, Cout), ref, 2e-3, what="normalised")          # (fp32 spacing at 1000 is 6e-5: y itself carries it)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 16, 16), (3, 128, 64, 64), (2, 256, 8, 8), (2, 64, 32, 32), (1, 128, 5, 7), (2, 16, 13, 14)])
+def test_upsample2x_backward_at_the_decoders_shapes(F, shape):
+    """pdf_upsample2x_bwd (gather form, one thread per input pixel and channel quad) at the channel counts of the dense decoders (128) and the other
+    float4 cases, incl. odd sizes, against ATen's bilinear backward on the CPU.  (Round 6 tried an LDS-staged form of the gather -- a block stages the dy
+    rows and columns of its input row segment once: bit-identical, but 2.3x slower, 64 KB of LDS per block leave two blocks per CU and nothing to hide the
+    staging behind; profiles/r06_up2_lds.txt.)"""
+    x = rnd(*shape, seed=sum(shape))
+    xr = x.clone().requires_grad_()
+    ref = TF.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=True)
+    gy = rnd(*ref.shape, seed=7)
+    ref.backward(gy)
+    xd = dev(x).requires_grad_()
+    out = F.upsample2x(xd)
+    out.backward(dev(gy))
+    close(out, ref, 2e-6, what="upsample %s" % (shape,))
+    close(xd.grad, xr.grad, 1e-5, what="upsample dx %s" % (shape,))
