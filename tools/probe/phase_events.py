@@ -68,6 +68,16 @@ def dforward(*a, **k):
     mark('fwd: mesh decoder')
     return r
 dec.forward = dforward
+# round 6: where the loss's backward ends and the decoder tail's begins (the gradient of the level output's first consumers, the coordinate head and the
+# vertex-average head, leaves them last: the hook on the tail's INPUT fires above; this one fires when the gradient of verts3d leaves the loss)
+um = dec.unsample_layer
+um_fwd = um.forward
+def umforward(x):
+    r = um_fwd(x)
+    if r.requires_grad:
+        r.register_hook(lambda g: mark('bwd:   loss done, first tail gradient (grad of the up-sampled vertices)'))
+    return r
+um.forward = umforward
 # round 5: the three DualGraphLayers on their own (forward: in / out of dual_gcn; backward: gradient of its output = loss + decoder tail done,
 # gradient of its input = the levels done)
 dg = dec.dual_gcn
