@@ -9,6 +9,8 @@ the 20-bone direction term on [2,B,21,2]) is left to aten.  The step is sync-fre
 Differences from the reference are host-side only: no `.cpu()` debug dumps (simplified.py:527-596) and the
 focal loss' `if num_pos.sum() == 0` host branch (lib/models/losses.py:161) is a device-side select.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -71,6 +73,9 @@ def projection_batch(scale, trans2d, pts, img_size):
     return s * pts[..., :2] + t
 
 
+FORK_DENSE_LOSS = os.environ.get("PDFNET_FORK_DENSE_LOSS", "1") != "0"
+
+
 class CtdetLoss(nn.Module):
     """opt fields used: size_train, center_weight (200), reproj_weight (1), bone_dir_weight (200), down_ratio (4).
     `consts`: {'full_regressor_left/right' [21,778], 'faces_left/right' [1538,3] int64}."""
@@ -93,12 +98,15 @@ class CtdetLoss(nn.Module):
             ind = nms_top1_centers(sigmoid_clamped(otherInfo['ret']['hm']))                # :376-389
         else:
             ind = batch['ind']
+        # dense-map terms on a forked stream (round 6): two launches forward and one backward that neither feed nor need the mesh terms -- they and
+        # their backward (which hands its gradients to the dense decoders' own streams) leave the main chain (PDFNET_FORK_DENSE_LOSS=0: in line, last)
+        fd = F.fork(lambda: self.dense_terms(otherInfo, batch)) if (FORK_DENSE_LOSS and not test) else None
         t = self.mesh_terms(result, paramsDict, handDictList, otherInfo['converter_left'], otherInfo['converter_right'],
                             batch, ind, test, epoch)
         if test:
             return t
-        # dense-map terms (created last: their backward is issued first, ahead of the launch-bound mesh terms)
-        t.update(self.dense_terms(otherInfo, batch))
+        # (in line: created last, so that their backward is issued first, ahead of the launch-bound mesh terms)
+        t.update(fd.join() if fd is not None else self.dense_terms(otherInfo, batch))
         mp = t.pop('_mesh_part', None)
         if mp is not None:                                   # fused mesh terms: their weighted sum came out of the kernel
             loss = mp + self.dense_part(t)
